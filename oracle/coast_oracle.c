@@ -1,0 +1,688 @@
+/*
+ * coast_oracle.c -- CPU ORACLE (test infrastructure only, see coast_oracle.h).
+ *
+ * Restates, in plain C, (1) the arithmetic of the four COAST benchmark kernels and
+ * (2) the replicate / vote / count semantics that the dataflowProtection pass gives them,
+ * in the reference mode the GPU engine instantiates: `-TMR -noMemReplication -countErrors
+ * -countSyncs` (single memory copy, every register value replicated, store data voted:
+ * synchronization.cpp:197-224, cloning.cpp:90-95; docs/source/passes.rst:331) and `-DWC`.
+ *
+ * Sync-point schedules frozen here (SURVEY.md section 8 a'):
+ *   mm     : r[i][j] voted once before the store (mm_common_tmr.c:16); with sync_every=V also the
+ *            accumulator after every V-th k step (loop-condition sync, mm_common_tmr.c:12).
+ *   sha256 : the 8 ctx_state words after every compression (sha256_common_tmr.c:90-97 are stores),
+ *            the 8 digest words before they are written out (:169-178).
+ *   aes    : the 4 state dwords and 4 round-key dwords at the end (in-place stores, TI_aes_128.c:145,
+ *            211,228); with sync_every=1 also after every main-loop round.
+ *   crc16  : the returned crc (crc16.c:30); with sync_every=V also crc after every V-th byte.
+ * Wave-uniform control values (loop counters, lengths) are single-copy, i.e. __NO_xMR
+ * (tests/COAST.h:11) -- they are outside the sphere of replication on the GPU and here.
+ */
+#include "coast_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* voter / comparator                                                                         */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct {
+    unsigned nrep;
+    unsigned sync_every;
+    orc_stats *st;
+    int detected; /* DWC mismatch seen on the current item */
+} sync_ctx;
+
+/* One sync point on a 32-bit value.  TMR: synchronization.cpp:934-938 (cmp orig,clone1 ; select) and
+ * :1391-1443 (second compare, AND, conditional TMR_ERROR_CNT+1); afterwards all three replicas continue
+ * from the voted value (:527-529).  DWC: :1117-1192 -- a mismatch branches to the error block; here it is
+ * recorded per item and the replicas keep their own values. */
+static void sync32(sync_ctx *c, uint32_t v[3])
+{
+    if (c->nrep == 3) {
+        const int e01 = (v[0] == v[1]);
+        const int e02 = (v[0] == v[2]);
+        c->st->sync_count += 1;
+        if (!(e01 && e02))
+            c->st->errors_corrected += 1;
+        const uint32_t voted = e01 ? v[0] : v[2];
+        v[0] = v[1] = v[2] = voted;
+    } else if (c->nrep == 2) {
+        c->st->sync_count += 1;
+        if (v[0] != v[1])
+            c->detected = 1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fault list handling                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+static int fault_cmp(const void *a, const void *b)
+{
+    const orc_fault *x = (const orc_fault *)a, *y = (const orc_fault *)b;
+    if (x->item != y->item)
+        return x->item < y->item ? -1 : 1;
+    if (x->step != y->step)
+        return x->step < y->step ? -1 : 1;
+    return 0;
+}
+
+static orc_fault *sorted_faults(const orc_fault *f, size_t n)
+{
+    orc_fault *s = (orc_fault *)malloc((n ? n : 1) * sizeof(orc_fault));
+    if (n)
+        memcpy(s, f, n * sizeof(orc_fault));
+    qsort(s, n, sizeof(orc_fault), fault_cmp);
+    return s;
+}
+
+/* first index with item >= key */
+static size_t fault_lower(const orc_fault *s, size_t n, uint64_t key)
+{
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t mid = (lo + hi) / 2;
+        if (s[mid].item < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+/* flipOneBit, injector.py:202-207: new = old XOR (1 << bit), on the 32-bit register; `mask` is the live width */
+static inline uint32_t flip(uint32_t v, unsigned bit, uint32_t mask)
+{
+    return v ^ ((1u << (bit & 31)) & mask);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* matrix multiply                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+
+/* mm_common_tmr.c:3-20: r[i][j] = (mm_t) sum_k f[i][k]*s[k][j]; product is a 32-bit wrapping multiply, the
+ * sum is truncated on the store, so only the low 32 bits ever matter. */
+void orc_mm_plain(const uint32_t *f, const uint32_t *s, uint32_t *r, int n)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            unsigned long sum = 0;
+            for (int k = 0; k < n; ++k)
+                sum += (uint32_t)(f[(size_t)i * n + k] * s[(size_t)k * n + j]);
+            r[(size_t)i * n + j] = (uint32_t)sum;
+        }
+}
+
+uint32_t orc_mm_xor(const uint32_t *r, int n)
+{
+    uint32_t x = 0;
+    for (size_t e = 0; e < (size_t)n * n; ++e)
+        x ^= r[e];
+    return x;
+}
+
+/* one protected output element; fl[0..nf) are the faults of this item */
+static uint32_t mm_item(const uint32_t *f, const uint32_t *s, int n, int i, int j, sync_ctx *c, const orc_fault *fl,
+                        size_t nf)
+{
+    uint32_t acc[3] = {0, 0, 0};
+    const unsigned R = c->nrep;
+    for (int k = 0; k < n; ++k) {
+        for (unsigned r = 0; r < R; ++r) {
+            uint32_t a = f[(size_t)i * n + k]; /* loads repeated from the same address: cloning.cpp:2247-2255 */
+            uint32_t b = s[(size_t)k * n + j];
+            for (size_t q = 0; q < nf; ++q) {
+                if (fl[q].step != (uint32_t)k || fl[q].replica != r)
+                    continue;
+                if (fl[q].site == ORC_SITE_MM_ACC)
+                    acc[r] = flip(acc[r], fl[q].bit, 0xffffffffu);
+                else if (fl[q].site == ORC_SITE_MM_OPA)
+                    a = flip(a, fl[q].bit, 0xffffffffu);
+                else if (fl[q].site == ORC_SITE_MM_OPB)
+                    b = flip(b, fl[q].bit, 0xffffffffu);
+            }
+            acc[r] += a * b;
+        }
+        if (c->sync_every && ((k + 1) % (int)c->sync_every) == 0 && (k + 1) < n)
+            sync32(c, acc);
+    }
+    for (size_t q = 0; q < nf; ++q)
+        if (fl[q].step == (uint32_t)n && fl[q].site == ORC_SITE_MM_ACC && fl[q].replica < R)
+            acc[fl[q].replica] = flip(acc[fl[q].replica], fl[q].bit, 0xffffffffu);
+    sync32(c, acc); /* store-data sync, synchronization.cpp:476-561 */
+    return acc[0];
+}
+
+void orc_mm_xmr(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, size_t batch, const orc_cfg *cfg,
+                const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
+{
+    orc_fault *fs = sorted_faults(faults, nfaults);
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0};
+    const size_t nn = (size_t)n * n;
+    size_t fp = 0;
+    for (size_t b = 0; b < batch; ++b)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                const uint64_t item = (uint64_t)b * nn + (uint64_t)i * n + j;
+                while (fp < nfaults && fs[fp].item < item)
+                    ++fp;
+                size_t fe = fp;
+                while (fe < nfaults && fs[fe].item == item)
+                    ++fe;
+                c.detected = 0;
+                r[item] = mm_item(f + b * nn, s + b * nn, n, i, j, &c, fs + fp, fe - fp);
+                if (c.detected) {
+                    st->dwc_detected += 1;
+                    if (detected)
+                        detected[item] = 1;
+                }
+                fp = fe;
+            }
+    free(fs);
+}
+
+void orc_mm_xmr_items(const uint32_t *f, const uint32_t *s, int n, const uint64_t *items, size_t nitems,
+                      uint32_t *out, const orc_cfg *cfg, const orc_fault *faults, size_t nfaults, orc_stats *st,
+                      uint8_t *detected)
+{
+    orc_fault *fs = sorted_faults(faults, nfaults);
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0};
+    const size_t nn = (size_t)n * n;
+    for (size_t q = 0; q < nitems; ++q) {
+        const uint64_t item = items[q];
+        const size_t b = item / nn;
+        const int i = (int)((item % nn) / n), j = (int)(item % n);
+        size_t fp = fault_lower(fs, nfaults, item), fe = fp;
+        while (fe < nfaults && fs[fe].item == item)
+            ++fe;
+        c.detected = 0;
+        out[q] = mm_item(f + b * nn, s + b * nn, n, i, j, &c, fs + fp, fe - fp);
+        if (c.detected) {
+            st->dwc_detected += 1;
+            if (detected)
+                detected[q] = 1;
+        }
+    }
+    free(fs);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* sha256                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+static const uint32_t SHA_K[64] = { /* FIPS 180-4 round constants; sha256_common_tmr.c:8-19 */
+    0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u,
+    0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u,
+    0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+    0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u,
+    0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,
+    0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+    0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
+    0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+
+static const uint32_t SHA_IV[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
+                                   0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+
+static inline uint32_t rotr(uint32_t x, unsigned n) { return (x >> n) | (x << (32 - n)); }
+
+/* sha256_transform (sha256_common_tmr.c:27-98) on nrep register copies; `blk` is the single memory copy of the
+ * 64-byte block.  `cidx` numbers the compressions of this message for the fault steps. */
+static void sha_compress(uint32_t st[3][8], const uint8_t *blk, unsigned nrep, uint32_t cidx, const orc_fault *fl,
+                         size_t nf)
+{
+    for (unsigned r = 0; r < nrep; ++r) {
+        uint32_t m[64], v[8];
+        for (unsigned t = 0; t < 64; ++t) {
+            if (t < 16) {
+                m[t] = ((uint32_t)blk[4 * t] << 24) | ((uint32_t)blk[4 * t + 1] << 16) |
+                       ((uint32_t)blk[4 * t + 2] << 8) | (uint32_t)blk[4 * t + 3];
+            } else {
+                const uint32_t x = m[t - 2], y = m[t - 15];
+                const uint32_t s1 = rotr(x, 17) ^ rotr(x, 19) ^ (x >> 10);
+                const uint32_t s0 = rotr(y, 7) ^ rotr(y, 18) ^ (y >> 3);
+                m[t] = s1 + m[t - 7] + s0 + m[t - 16];
+            }
+            for (size_t q = 0; q < nf; ++q)
+                if (fl[q].site == ORC_SITE_SHA_M && fl[q].replica == r && fl[q].step == cidx * 64 + t)
+                    m[t] = flip(m[t], fl[q].bit, 0xffffffffu);
+        }
+        for (unsigned w = 0; w < 8; ++w)
+            v[w] = st[r][w];
+        for (unsigned t = 0; t < 64; ++t) {
+            for (size_t q = 0; q < nf; ++q)
+                if (fl[q].site == ORC_SITE_SHA_WV && fl[q].replica == r && fl[q].step == cidx * 64 + t)
+                    v[fl[q].index & 7] = flip(v[fl[q].index & 7], fl[q].bit, 0xffffffffu);
+            const uint32_t a = v[0], b = v[1], cc = v[2], e = v[4], ff = v[5], g = v[6];
+            const uint32_t ep0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+            const uint32_t ep1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+            const uint32_t ch = (e & ff) ^ (~e & g);
+            const uint32_t maj = (a & b) ^ (a & cc) ^ (b & cc);
+            const uint32_t t1 = v[7] + ep1 + ch + SHA_K[t] + m[t];
+            const uint32_t t2 = ep0 + maj;
+            v[7] = g;
+            v[6] = ff;
+            v[5] = e;
+            v[4] = v[3] + t1;
+            v[3] = cc;
+            v[2] = b;
+            v[1] = a;
+            v[0] = t1 + t2;
+        }
+        for (unsigned w = 0; w < 8; ++w)
+            st[r][w] += v[w];
+    }
+}
+
+static void sha_state_faults(uint32_t st[3][8], unsigned nrep, uint32_t cidx, const orc_fault *fl, size_t nf)
+{
+    for (size_t q = 0; q < nf; ++q)
+        if (fl[q].site == ORC_SITE_SHA_STATE && fl[q].step == cidx && fl[q].replica < nrep)
+            st[fl[q].replica][fl[q].index & 7] = flip(st[fl[q].replica][fl[q].index & 7], fl[q].bit, 0xffffffffu);
+}
+
+static void sha_sync_state(sync_ctx *c, uint32_t st[3][8])
+{
+    for (unsigned w = 0; w < 8; ++w) {
+        uint32_t v[3] = {st[0][w], st[1][w], st[2][w]};
+        sync32(c, v);
+        st[0][w] = v[0];
+        st[1][w] = v[1];
+        st[2][w] = v[2];
+    }
+}
+
+/* sha256_hash (sha256_common_tmr.c:100-179): one-shot hash of `len` bytes incl. padding; the bit length is
+ * kept as two u32 exactly like DBL_INT_ADD (:2-5). */
+static void sha_item(const uint8_t *data, uint32_t len, uint8_t hash[32], sync_ctx *c, const orc_fault *fl,
+                     size_t nf)
+{
+    uint32_t st[3][8];
+    uint8_t buf[64];
+    uint32_t bitlen[2] = {0, 0};
+    uint32_t datalen = 0, cidx = 0;
+    const unsigned R = c->nrep;
+    for (unsigned r = 0; r < 3; ++r)
+        for (unsigned w = 0; w < 8; ++w)
+            st[r][w] = SHA_IV[w];
+
+    for (uint32_t i = 0; i < len; ++i) {
+        buf[datalen++] = data[i];
+        if (datalen == 64) {
+            sha_state_faults(st, R, cidx, fl, nf);
+            sha_compress(st, buf, R, cidx, fl, nf);
+            sha_sync_state(c, st);
+            ++cidx;
+            if (bitlen[0] > 0xffffffffu - 512u)
+                ++bitlen[1];
+            bitlen[0] += 512u;
+            datalen = 0;
+        }
+    }
+    uint32_t i = datalen;
+    if (datalen < 56) {
+        buf[i++] = 0x80;
+        while (i < 56)
+            buf[i++] = 0;
+    } else {
+        buf[i++] = 0x80;
+        while (i < 64)
+            buf[i++] = 0;
+        sha_state_faults(st, R, cidx, fl, nf);
+        sha_compress(st, buf, R, cidx, fl, nf);
+        sha_sync_state(c, st);
+        ++cidx;
+        memset(buf, 0, 56);
+    }
+    if (bitlen[0] > 0xffffffffu - datalen * 8u)
+        ++bitlen[1];
+    bitlen[0] += datalen * 8u;
+    for (unsigned b = 0; b < 4; ++b) {
+        buf[63 - b] = (uint8_t)(bitlen[0] >> (8 * b));
+        buf[59 - b] = (uint8_t)(bitlen[1] >> (8 * b));
+    }
+    sha_state_faults(st, R, cidx, fl, nf);
+    sha_compress(st, buf, R, cidx, fl, nf);
+    sha_sync_state(c, st);
+    ++cidx;
+
+    sha_state_faults(st, R, cidx, fl, nf); /* step == ncompress: between the last compression and the digest */
+    sha_sync_state(c, st);                 /* digest words voted before the store, :169-178 */
+    for (unsigned w = 0; w < 8; ++w)
+        for (unsigned b = 0; b < 4; ++b)
+            hash[4 * w + b] = (uint8_t)(st[0][w] >> (24 - 8 * b));
+}
+
+void orc_sha256_plain(const uint8_t *data, uint32_t len, uint8_t hash[32])
+{
+    orc_stats st = {0, 0, 0, 0};
+    sync_ctx c = {1, 0, &st, 0};
+    sha_item(data, len, hash, &c, NULL, 0);
+}
+
+void orc_sha256_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nmsgs, uint8_t *digests,
+                    const orc_cfg *cfg, const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
+{
+    orc_fault *fs = sorted_faults(faults, nfaults);
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0};
+    size_t fp = 0;
+    for (size_t m = 0; m < nmsgs; ++m) {
+        while (fp < nfaults && fs[fp].item < m)
+            ++fp;
+        size_t fe = fp;
+        while (fe < nfaults && fs[fe].item == m)
+            ++fe;
+        c.detected = 0;
+        sha_item(msgs + m * stride, len, digests + 32 * m, &c, fs + fp, fe - fp);
+        if (c.detected) {
+            st->dwc_detected += 1;
+            if (detected)
+                detected[m] = 1;
+        }
+        fp = fe;
+    }
+    free(fs);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* aes-128                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+static uint8_t AES_S[256], AES_RS[256];
+static int aes_tables_ready = 0;
+
+/* FIPS-197 S-box computed from its definition (GF(2^8) inverse + affine map) instead of a pasted table;
+ * tests/ check it against the reference's sbox/rsbox (TI_aes_128.c:44,64) through oracle/_ref. */
+static uint8_t gf_mul(uint8_t a, uint8_t b)
+{
+    uint8_t p = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (b & 1)
+            p ^= a;
+        const uint8_t hi = a & 0x80;
+        a = (uint8_t)(a << 1);
+        if (hi)
+            a ^= 0x1b;
+        b >>= 1;
+    }
+    return p;
+}
+
+static void aes_tables(void)
+{
+    if (aes_tables_ready)
+        return;
+    for (int x = 0; x < 256; ++x) {
+        uint8_t inv = 0;
+        if (x)
+            for (int y = 1; y < 256; ++y)
+                if (gf_mul((uint8_t)x, (uint8_t)y) == 1) {
+                    inv = (uint8_t)y;
+                    break;
+                }
+        uint8_t s = inv;
+        for (int k = 1; k <= 4; ++k)
+            s ^= (uint8_t)((inv << k) | (inv >> (8 - k)));
+        s ^= 0x63;
+        AES_S[x] = s;
+        AES_RS[s] = (uint8_t)x;
+    }
+    aes_tables_ready = 1;
+}
+
+const uint8_t *orc_aes_sbox(void)
+{
+    aes_tables();
+    return AES_S;
+}
+const uint8_t *orc_aes_rsbox(void)
+{
+    aes_tables();
+    return AES_RS;
+}
+
+static const uint8_t AES_RCON[10] = {0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80, 0x1b, 0x36};
+
+static inline uint8_t xtime(uint8_t v) { return (uint8_t)((v << 1) ^ ((v & 0x80) ? 0x1b : 0)); } /* galois_mul2 :88-99 */
+
+static void aes_key_fwd(uint8_t k[16], int rd) /* TI_aes_128.c:115-121, 220-226 */
+{
+    k[0] ^= AES_S[k[13]] ^ AES_RCON[rd];
+    k[1] ^= AES_S[k[14]];
+    k[2] ^= AES_S[k[15]];
+    k[3] ^= AES_S[k[12]];
+    for (int i = 4; i < 16; ++i)
+        k[i] ^= k[i - 4];
+}
+
+static void aes_key_inv(uint8_t k[16], int rd) /* :134-141 */
+{
+    for (int i = 15; i > 3; --i)
+        k[i] ^= k[i - 4];
+    k[0] ^= AES_S[k[13]] ^ AES_RCON[rd];
+    k[1] ^= AES_S[k[14]];
+    k[2] ^= AES_S[k[15]];
+    k[3] ^= AES_S[k[12]];
+}
+
+static void aes_mix_col(uint8_t *c, int inverse) /* :168-185 */
+{
+    if (inverse) {
+        const uint8_t u = xtime(xtime(c[0] ^ c[2])), v = xtime(xtime(c[1] ^ c[3]));
+        c[0] ^= u;
+        c[1] ^= v;
+        c[2] ^= u;
+        c[3] ^= v;
+    }
+    const uint8_t t = c[0] ^ c[1] ^ c[2] ^ c[3], c0 = c[0];
+    c[0] ^= xtime(c[0] ^ c[1]) ^ t;
+    c[1] ^= xtime(c[1] ^ c[2]) ^ t;
+    c[2] ^= xtime(c[2] ^ c[3]) ^ t;
+    c[3] ^= xtime(c[3] ^ c0) ^ t;
+}
+
+/* one main-loop iteration of aes_enc_dec (TI_aes_128.c:131-227) on one replica */
+static void aes_round(uint8_t s[16], uint8_t k[16], int dir, int rd)
+{
+    uint8_t t[16];
+    if (dir) {
+        aes_key_inv(k, 9 - rd);
+        if (rd > 0)
+            for (int c = 0; c < 4; ++c)
+                aes_mix_col(s + 4 * c, 1);
+        for (int c = 0; c < 4; ++c) /* inverse shift rows: row r rotates right by r columns */
+            for (int r = 0; r < 4; ++r)
+                t[4 * ((c + r) & 3) + r] = s[4 * c + r];
+        for (int i = 0; i < 16; ++i)
+            s[i] = AES_RS[t[i]] ^ k[i];
+    } else {
+        for (int i = 0; i < 16; ++i)
+            t[i] = AES_S[s[i] ^ k[i]];
+        for (int c = 0; c < 4; ++c) /* shift rows: row r rotates left by r columns */
+            for (int r = 0; r < 4; ++r)
+                s[4 * c + r] = t[4 * ((c + r) & 3) + r];
+        if (rd < 9)
+            for (int c = 0; c < 4; ++c)
+                aes_mix_col(s + 4 * c, 0);
+        aes_key_fwd(k, rd);
+    }
+}
+
+static inline uint32_t ld32(const uint8_t *p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+static inline void st32(uint8_t *p, uint32_t v)
+{
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+    p[2] = (uint8_t)(v >> 16);
+    p[3] = (uint8_t)(v >> 24);
+}
+
+static void aes_faults(uint8_t s[3][16], uint8_t k[3][16], unsigned nrep, uint32_t step, const orc_fault *fl,
+                       size_t nf)
+{
+    for (size_t q = 0; q < nf; ++q) {
+        if (fl[q].step != step || fl[q].replica >= nrep)
+            continue;
+        uint8_t *p = NULL;
+        if (fl[q].site == ORC_SITE_AES_STATE)
+            p = s[fl[q].replica] + 4 * (fl[q].index & 3);
+        else if (fl[q].site == ORC_SITE_AES_KEY)
+            p = k[fl[q].replica] + 4 * (fl[q].index & 3);
+        if (p)
+            st32(p, flip(ld32(p), fl[q].bit, 0xffffffffu));
+    }
+}
+
+static void aes_sync(sync_ctx *c, uint8_t s[3][16], uint8_t k[3][16])
+{
+    for (int half = 0; half < 2; ++half)
+        for (int w = 0; w < 4; ++w) {
+            uint8_t(*a)[16] = half ? k : s;
+            uint32_t v[3] = {ld32(a[0] + 4 * w), ld32(a[1] + 4 * w), ld32(a[2] + 4 * w)};
+            sync32(c, v);
+            for (int r = 0; r < 3; ++r)
+                st32(a[r] + 4 * w, v[r]);
+        }
+}
+
+static void aes_item(uint8_t state[16], uint8_t key[16], int dir, sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    uint8_t s[3][16], k[3][16];
+    const unsigned R = c->nrep;
+    aes_tables();
+    for (unsigned r = 0; r < 3; ++r) {
+        memcpy(s[r], state, 16);
+        memcpy(k[r], key, 16);
+    }
+    if (dir)
+        for (unsigned r = 0; r < R; ++r) { /* :110-128 last encryption key, first AddRoundKey */
+            for (int rd = 0; rd < 10; ++rd)
+                aes_key_fwd(k[r], rd);
+            for (int i = 0; i < 16; ++i)
+                s[r][i] ^= k[r][i];
+        }
+    for (int rd = 0; rd < 10; ++rd) {
+        aes_faults(s, k, R, (uint32_t)rd, fl, nf);
+        for (unsigned r = 0; r < R; ++r)
+            aes_round(s[r], k[r], dir, rd);
+        if (c->sync_every && rd < 9)
+            aes_sync(c, s, k);
+    }
+    aes_faults(s, k, R, 10u, fl, nf);
+    if (!dir)
+        for (unsigned r = 0; r < R; ++r) /* :228-233 last AddRoundKey */
+            for (int i = 0; i < 16; ++i)
+                s[r][i] ^= k[r][i];
+    aes_sync(c, s, k);
+    memcpy(state, s[0], 16);
+    memcpy(key, k[0], 16);
+}
+
+void orc_aes128_plain(uint8_t state[16], uint8_t key[16], uint8_t dir)
+{
+    orc_stats st = {0, 0, 0, 0};
+    sync_ctx c = {1, 0, &st, 0};
+    aes_item(state, key, dir ? 1 : 0, &c, NULL, 0);
+}
+
+void orc_aes128_xmr(uint8_t *states, uint8_t *keys, size_t nblocks, int dir, const orc_cfg *cfg,
+                    const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
+{
+    orc_fault *fs = sorted_faults(faults, nfaults);
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0};
+    size_t fp = 0;
+    for (size_t b = 0; b < nblocks; ++b) {
+        while (fp < nfaults && fs[fp].item < b)
+            ++fp;
+        size_t fe = fp;
+        while (fe < nfaults && fs[fe].item == b)
+            ++fe;
+        c.detected = 0;
+        aes_item(states + 16 * b, keys + 16 * b, dir ? 1 : 0, &c, fs + fp, fe - fp);
+        if (c.detected) {
+            st->dwc_detected += 1;
+            if (detected)
+                detected[b] = 1;
+        }
+        fp = fe;
+    }
+    free(fs);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* crc16                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* crc16.c:21-31, all truncations as written (x is unsigned char, crc unsigned short) */
+static inline uint16_t crc_step(uint16_t crc, uint8_t byte, uint8_t *xout)
+{
+    uint8_t x = (uint8_t)((crc >> 8) ^ byte);
+    x ^= (uint8_t)(x >> 4);
+    if (xout)
+        *xout = x;
+    return (uint16_t)((uint16_t)(crc << 8) ^ (uint16_t)((uint16_t)x << 12) ^ (uint16_t)((uint16_t)x << 5) ^
+                      (uint16_t)x);
+}
+
+uint16_t orc_crc16_plain(const uint8_t *data, uint32_t length)
+{
+    uint16_t crc = 0xFFFF;
+    for (uint32_t t = 0; t < length; ++t)
+        crc = crc_step(crc, data[t], NULL);
+    return crc;
+}
+
+static uint16_t crc_item(const uint8_t *data, uint32_t len, sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    uint32_t crc[3] = {0xFFFF, 0xFFFF, 0xFFFF};
+    const unsigned R = c->nrep;
+    for (uint32_t t = 0; t < len; ++t) {
+        for (unsigned r = 0; r < R; ++r) {
+            for (size_t q = 0; q < nf; ++q)
+                if (fl[q].site == ORC_SITE_CRC_CRC && fl[q].step == t && fl[q].replica == r)
+                    crc[r] = flip(crc[r], fl[q].bit, 0xffffu);
+            uint8_t x = (uint8_t)((crc[r] >> 8) ^ data[t]);
+            x ^= (uint8_t)(x >> 4);
+            for (size_t q = 0; q < nf; ++q)
+                if (fl[q].site == ORC_SITE_CRC_X && fl[q].step == t && fl[q].replica == r)
+                    x = (uint8_t)flip(x, fl[q].bit, 0xffu);
+            crc[r] = (uint16_t)((uint16_t)(crc[r] << 8) ^ (uint16_t)((uint16_t)x << 12) ^
+                                (uint16_t)((uint16_t)x << 5) ^ (uint16_t)x);
+        }
+        if (c->sync_every && ((t + 1) % c->sync_every) == 0 && (t + 1) < len)
+            sync32(c, crc);
+    }
+    for (size_t q = 0; q < nf; ++q)
+        if (fl[q].site == ORC_SITE_CRC_CRC && fl[q].step == len && fl[q].replica < R)
+            crc[fl[q].replica] = flip(crc[fl[q].replica], fl[q].bit, 0xffffu);
+    sync32(c, crc); /* return-value sync, synchronization.cpp:741-949 (ReturnInst) */
+    return (uint16_t)crc[0];
+}
+
+void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint16_t *crcs, const orc_cfg *cfg,
+                   const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
+{
+    orc_fault *fs = sorted_faults(faults, nfaults);
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0};
+    size_t fp = 0;
+    for (size_t b = 0; b < nblocks; ++b) {
+        while (fp < nfaults && fs[fp].item < b)
+            ++fp;
+        size_t fe = fp;
+        while (fe < nfaults && fs[fe].item == b)
+            ++fe;
+        c.detected = 0;
+        crcs[b] = crc_item(data + (size_t)b * block_len, block_len, &c, fs + fp, fe - fp);
+        if (c.detected) {
+            st->dwc_detected += 1;
+            if (detected)
+                detected[b] = 1;
+        }
+        fp = fe;
+    }
+    free(fs);
+}

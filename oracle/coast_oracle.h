@@ -1,0 +1,111 @@
+/*
+ * coast_oracle.h -- CPU ORACLE for the COAST dataflowProtection hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (libcoast_hip.so) never
+ * links, imports or falls back to anything in this directory.
+ *
+ * What it restates (all paths relative to the reference checkout):
+ *   - the four benchmark kernels' arithmetic
+ *       matrix_multiply   tests/mm_common/mm_common_tmr.c:3-20
+ *       sha256_hash       tests/sha256_common/sha256_common_tmr.c:27-179
+ *       aes_enc_dec       tests/aes/TI_aes_128.c:107-231
+ *       crc16             tests/crc16/crc16.c:21-31
+ *   - the TMR voter / corrected-fault counter / DWC comparator that the
+ *     dataflowProtection pass inserts
+ *       voter   vote(a,b,c) = (a==b) ? a : c      projects/dataflowProtection/synchronization.cpp:934-938, 512-522
+ *       counter cnt += !((a==b)&&(a==c))          synchronization.cpp:1391-1443
+ *       syncs   __SYNC_COUNT += 1 per counted vote synchronization.cpp:1415-1425
+ *       DWC     a != b -> FAULT_DETECTED_DWC()    synchronization.cpp:1117-1192, 1299-1302
+ *   - the fault model: one single-bit flip of a 32-bit datum
+ *       flipOneBit  simulation/platform/resources/injector.py:202-207
+ *
+ * Parity pins: kernel arithmetic is pinned by the reference's own golden vectors
+ * (mm xor_golden x3 sizes, sha256 x2 lengths, 568 AES KATs) and by oracle/_ref (the
+ * reference C compiled unmodified).  Vote outcomes under faults and TMR_ERROR_CNT
+ * values are "parity unpinned" by the reference (no reference test injects a fault and
+ * asserts a count); they are pinned by the voter/counter rules above.
+ */
+#ifndef COAST_ORACLE_H
+#define COAST_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* fault sites (kernel specific).  Same numeric values as include/coast_hip.h. */
+enum {
+    ORC_SITE_MM_ACC = 0,   /* accumulator, before the MAC of k == step (step == n: after the loop) */
+    ORC_SITE_MM_OPA = 1,   /* loaded f[i][k] of k == step */
+    ORC_SITE_MM_OPB = 2,   /* loaded s[k][j] of k == step */
+
+    ORC_SITE_SHA_M = 8,    /* schedule word m[step%64] of compression step/64, right after it is produced */
+    ORC_SITE_SHA_WV = 9,   /* working variable a..h (index 0..7) before round step%64 of compression step/64 */
+    ORC_SITE_SHA_STATE = 10, /* ctx_state[index] before compression `step` (step == ncompress: before the digest) */
+
+    ORC_SITE_AES_STATE = 16, /* dword `index` (0..3) of the state at the start of main-loop round `step` (10: after loop) */
+    ORC_SITE_AES_KEY = 17,   /* dword `index` (0..3) of the running round key, same timing */
+
+    ORC_SITE_CRC_CRC = 24, /* crc register before byte `step` (step == length: after the loop) */
+    ORC_SITE_CRC_X = 25    /* temporary x of byte `step`, after x ^= x>>4 */
+};
+
+/* One single-bit flip.  16 bytes; identical layout to coast_fault in include/coast_hip.h. */
+typedef struct {
+    uint64_t item;    /* logical work item: mm b*n*n+i*n+j ; sha message ; aes block ; crc block */
+    uint32_t step;    /* see site */
+    uint8_t replica;  /* 0..nrep-1 */
+    uint8_t site;     /* ORC_SITE_* */
+    uint8_t bit;      /* 0..31, bit of the 32-bit register holding the value */
+    uint8_t index;    /* word / variable index where the site has several */
+} orc_fault;
+
+typedef struct {
+    uint64_t errors_corrected; /* TMR_ERROR_CNT analogue */
+    uint64_t sync_count;       /* __SYNC_COUNT analogue */
+    uint64_t dwc_detected;     /* items on which a DWC compare failed */
+    uint64_t reserved;
+} orc_stats;
+
+typedef struct {
+    uint32_t replicas;   /* 1 = unprotected, 2 = DWC, 3 = TMR */
+    uint32_t sync_every; /* 0 = only at the mandatory sync points; V>0 = also every V steps (kernel specific) */
+} orc_cfg;
+
+/* ---- plain (unprotected) restatements of the reference kernels ---- */
+void orc_mm_plain(const uint32_t *f, const uint32_t *s, uint32_t *r, int n);
+uint32_t orc_mm_xor(const uint32_t *r, int n); /* checkGolden's XOR reduce, mm_common_tmr.c:22-32 */
+void orc_sha256_plain(const uint8_t *data, uint32_t len, uint8_t hash[32]);
+void orc_aes128_plain(uint8_t state[16], uint8_t key[16], uint8_t dir);
+uint16_t orc_crc16_plain(const uint8_t *data, uint32_t length);
+const uint8_t *orc_aes_sbox(void);
+const uint8_t *orc_aes_rsbox(void);
+
+/* ---- replicated (TMR / DWC) semantic model with fault list ---- */
+/* faults need not be sorted; `detected` (may be NULL) gets one byte per item, 1 = DWC mismatch seen. */
+void orc_mm_xmr(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, size_t batch, const orc_cfg *cfg,
+                const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
+void orc_sha256_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nmsgs, uint8_t *digests,
+                    const orc_cfg *cfg, const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
+void orc_aes128_xmr(uint8_t *states, uint8_t *keys, size_t nblocks, int dir, const orc_cfg *cfg,
+                    const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
+void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint16_t *crcs, const orc_cfg *cfg,
+                   const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
+
+/* sparse variants: evaluate only the listed items (used to check huge batches) */
+void orc_mm_xmr_items(const uint32_t *f, const uint32_t *s, int n, const uint64_t *items, size_t nitems,
+                      uint32_t *out, const orc_cfg *cfg, const orc_fault *faults, size_t nfaults, orc_stats *st,
+                      uint8_t *detected);
+
+/* ---- CPU-TMR baseline: default COAST mode (memory x3, loop-condition votes, -countErrors) ---- */
+/* returns XOR-golden mismatch flag like checkGolden; *cnt gets TMR_ERROR_CNT, *syncs the dynamic vote count */
+int orc_cpu_tmr_mm(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, uint32_t xor_golden, uint32_t *cnt,
+                   uint64_t *syncs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,277 @@
+"""ctypes front-end to the CPU oracle (oracle/liboracle.so) and, when present, to the reference's own C
+kernels compiled unmodified (oracle/_ref/libcoast_ref.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg;
+never from coast_amd/ (the product fails loudly without its HIP library instead of falling back to this).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+SITE_MM_ACC, SITE_MM_OPA, SITE_MM_OPB = 0, 1, 2
+SITE_SHA_M, SITE_SHA_WV, SITE_SHA_STATE = 8, 9, 10
+SITE_AES_STATE, SITE_AES_KEY = 16, 17
+SITE_CRC_CRC, SITE_CRC_X = 24, 25
+
+# identical layout to orc_fault / coast_fault (16 bytes)
+FAULT_DTYPE = np.dtype(
+    [("item", "<u8"), ("step", "<u4"), ("replica", "u1"), ("site", "u1"), ("bit", "u1"), ("index", "u1")]
+)
+assert FAULT_DTYPE.itemsize == 16
+
+
+class Cfg(C.Structure):
+    _fields_ = [("replicas", C.c_uint32), ("sync_every", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("errors_corrected", C.c_uint64),
+        ("sync_count", C.c_uint64),
+        ("dwc_detected", C.c_uint64),
+        ("reserved", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {
+            "errors_corrected": int(self.errors_corrected),
+            "sync_count": int(self.sync_count),
+            "dwc_detected": int(self.dwc_detected),
+        }
+
+
+def build(force: bool = False) -> None:
+    """make -C oracle (compiles liboracle.so; also oracle/_ref when /root/reference is present)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(so)
+        for f in ("coast_oracle.c", "coast_oracle.h", "cpu_tmr_baseline.c")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/tests"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref = None
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        L.orc_mm_xor.restype = C.c_uint32
+        L.orc_crc16_plain.restype = C.c_uint16
+        L.orc_cpu_tmr_mm.restype = C.c_int
+        L.orc_aes_sbox.restype = C.POINTER(C.c_uint8)
+        L.orc_aes_rsbox.restype = C.POINTER(C.c_uint8)
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The reference's own kernels (None when oracle/_ref was never built)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libcoast_ref.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.ref_crc16.restype = C.c_uint16
+        R.ref_crc16.argtypes = [C.c_char_p, C.c_ubyte]
+        _ref = R
+    return _ref
+
+
+def _faults(faults):
+    if faults is None:
+        return np.zeros(0, dtype=FAULT_DTYPE)
+    f = np.ascontiguousarray(faults, dtype=FAULT_DTYPE)
+    return f
+
+
+def make_faults(rows):
+    """rows: iterable of (item, replica, site, step, bit[, index])"""
+    rows = list(rows)
+    f = np.zeros(len(rows), dtype=FAULT_DTYPE)
+    for q, row in enumerate(rows):
+        item, replica, site, step, bit = row[:5]
+        f[q] = (item, step, replica, site, bit, row[5] if len(row) > 5 else 0)
+    return f
+
+
+# ---------------------------------------------------------------- plain kernels
+def mm_plain(f, s):
+    f = np.ascontiguousarray(f, dtype=np.uint32)
+    s = np.ascontiguousarray(s, dtype=np.uint32)
+    n = f.shape[-1]
+    r = np.empty((n, n), dtype=np.uint32)
+    lib().orc_mm_plain(_p(f, C.c_uint32), _p(s, C.c_uint32), _p(r, C.c_uint32), C.c_int(n))
+    return r
+
+
+def mm_xor(r):
+    r = np.ascontiguousarray(r, dtype=np.uint32)
+    return int(lib().orc_mm_xor(_p(r, C.c_uint32), C.c_int(r.shape[-1])))
+
+
+def sha256_plain(data: bytes) -> bytes:
+    buf = np.frombuffer(bytes(data) + b"\0", dtype=np.uint8).copy()
+    out = np.empty(32, dtype=np.uint8)
+    lib().orc_sha256_plain(_p(buf, C.c_uint8), C.c_uint32(len(data)), _p(out, C.c_uint8))
+    return out.tobytes()
+
+
+def aes128_plain(state: bytes, key: bytes, direction: int):
+    s = np.frombuffer(bytes(state), dtype=np.uint8).copy()
+    k = np.frombuffer(bytes(key), dtype=np.uint8).copy()
+    lib().orc_aes128_plain(_p(s, C.c_uint8), _p(k, C.c_uint8), C.c_uint8(direction))
+    return s.tobytes(), k.tobytes()
+
+
+def crc16_plain(data: bytes) -> int:
+    buf = np.frombuffer(bytes(data) + b"\0", dtype=np.uint8).copy()
+    return int(lib().orc_crc16_plain(_p(buf, C.c_uint8), C.c_uint32(len(data))))
+
+
+# ---------------------------------------------------------------- replicated model
+def mm_xmr(f, s, replicas=3, sync_every=0, faults=None):
+    """f, s: (batch, n, n) uint32.  Returns (r, stats dict, detected per item)."""
+    f = np.ascontiguousarray(f, dtype=np.uint32)
+    s = np.ascontiguousarray(s, dtype=np.uint32)
+    if f.ndim == 2:
+        f, s = f[None], s[None]
+    batch, n, _ = f.shape
+    r = np.empty_like(f)
+    fl = _faults(faults)
+    st = Stats()
+    det = np.zeros(batch * n * n, dtype=np.uint8)
+    cfg = Cfg(replicas, sync_every)
+    lib().orc_mm_xmr(_p(f, C.c_uint32), _p(s, C.c_uint32), _p(r, C.c_uint32), C.c_int(n), C.c_size_t(batch),
+                     C.byref(cfg), fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st),
+                     _p(det, C.c_uint8))
+    return r, st.as_dict(), det
+
+
+def mm_xmr_items(f, s, items, replicas=3, sync_every=0, faults=None):
+    f = np.ascontiguousarray(f, dtype=np.uint32)
+    s = np.ascontiguousarray(s, dtype=np.uint32)
+    n = f.shape[-1]
+    items = np.ascontiguousarray(items, dtype=np.uint64)
+    out = np.empty(len(items), dtype=np.uint32)
+    fl = _faults(faults)
+    st = Stats()
+    det = np.zeros(len(items), dtype=np.uint8)
+    cfg = Cfg(replicas, sync_every)
+    lib().orc_mm_xmr_items(_p(f, C.c_uint32), _p(s, C.c_uint32), C.c_int(n), _p(items, C.c_uint64),
+                           C.c_size_t(len(items)), _p(out, C.c_uint32), C.byref(cfg),
+                           fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st), _p(det, C.c_uint8))
+    return out, st.as_dict(), det
+
+
+def sha256_xmr(msgs, length, replicas=3, faults=None):
+    """msgs: (nmsgs, stride) uint8, each message = first `length` bytes of its row."""
+    msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+    nm, stride = msgs.shape
+    dig = np.empty((nm, 32), dtype=np.uint8)
+    fl = _faults(faults)
+    st = Stats()
+    det = np.zeros(nm, dtype=np.uint8)
+    cfg = Cfg(replicas, 0)
+    pad = np.concatenate([msgs.reshape(-1), np.zeros(8, np.uint8)])  # keep 0-length rows addressable
+    lib().orc_sha256_xmr(_p(pad, C.c_uint8), C.c_size_t(stride), C.c_uint32(length), C.c_size_t(nm),
+                         _p(dig, C.c_uint8), C.byref(cfg), fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)),
+                         C.byref(st), _p(det, C.c_uint8))
+    return dig, st.as_dict(), det
+
+
+def aes128_xmr(states, keys, direction, replicas=2, sync_every=0, faults=None):
+    """states, keys: (n, 16) uint8; returns new (states, keys, stats, detected) -- inputs untouched."""
+    s = np.array(states, dtype=np.uint8, copy=True, order="C")
+    k = np.array(keys, dtype=np.uint8, copy=True, order="C")
+    n = s.shape[0]
+    fl = _faults(faults)
+    st = Stats()
+    det = np.zeros(n, dtype=np.uint8)
+    cfg = Cfg(replicas, sync_every)
+    lib().orc_aes128_xmr(_p(s, C.c_uint8), _p(k, C.c_uint8), C.c_size_t(n), C.c_int(direction), C.byref(cfg),
+                         fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st), _p(det, C.c_uint8))
+    return s, k, st.as_dict(), det
+
+
+def crc16_xmr(data, block_len, replicas=3, sync_every=0, faults=None):
+    """data: (nblocks, block_len) uint8."""
+    data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, max(block_len, 1))[:, :block_len]
+    data = np.ascontiguousarray(data)
+    nb = data.shape[0]
+    crcs = np.empty(nb, dtype=np.uint16)
+    fl = _faults(faults)
+    st = Stats()
+    det = np.zeros(nb, dtype=np.uint8)
+    cfg = Cfg(replicas, sync_every)
+    pad = np.concatenate([data.reshape(-1), np.zeros(8, np.uint8)])
+    lib().orc_crc16_xmr(_p(pad, C.c_uint8), C.c_uint32(block_len), C.c_size_t(nb), _p(crcs, C.c_uint16),
+                        C.byref(cfg), fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st),
+                        _p(det, C.c_uint8))
+    return crcs, st.as_dict(), det
+
+
+def cpu_tmr_mm(f, s, xor_golden):
+    """Default-mode CPU-TMR restatement (timing baseline).  Returns (r, error_flag, TMR_ERROR_CNT, syncs)."""
+    f = np.ascontiguousarray(f, dtype=np.uint32)
+    s = np.ascontiguousarray(s, dtype=np.uint32)
+    n = f.shape[-1]
+    r = np.empty((n, n), dtype=np.uint32)
+    cnt = C.c_uint32(0)
+    syncs = C.c_uint64(0)
+    err = lib().orc_cpu_tmr_mm(_p(f, C.c_uint32), _p(s, C.c_uint32), _p(r, C.c_uint32), C.c_int(n),
+                               C.c_uint32(xor_golden), C.byref(cnt), C.byref(syncs))
+    return r, int(err), int(cnt.value), int(syncs.value)
+
+
+# ---------------------------------------------------------------- the reference itself (oracle/_ref)
+def ref_mm(f, s, golden):
+    R = ref()
+    n = f.shape[-1]
+    fn = getattr(R, "ref_mm%d_run" % n)
+    f = np.ascontiguousarray(f, dtype=np.uint32)
+    s = np.ascontiguousarray(s, dtype=np.uint32)
+    r = np.empty((n, n), dtype=np.uint32)
+    err = fn(_p(f, C.c_uint32), _p(s, C.c_uint32), _p(r, C.c_uint32), C.c_uint32(golden))
+    return r, int(err)
+
+
+def ref_sha256(data: bytes) -> bytes:
+    R = ref()
+    ctx_data = np.zeros(64, np.uint8)
+    bitlen = np.zeros(2, np.uint32)
+    state = np.zeros(8, np.uint32)
+    buf = np.frombuffer(bytes(data) + b"\0", dtype=np.uint8).copy()
+    out = np.empty(32, np.uint8)
+    R.ref_sha256_hash(_p(ctx_data, C.c_uint8), _p(bitlen, C.c_uint32), _p(state, C.c_uint32), _p(buf, C.c_uint8),
+                      C.c_uint32(len(data)), _p(out, C.c_uint8))
+    return out.tobytes()
+
+
+def ref_aes(state: bytes, key: bytes, direction: int):
+    R = ref()
+    s = np.frombuffer(bytes(state), dtype=np.uint8).copy()
+    k = np.frombuffer(bytes(key), dtype=np.uint8).copy()
+    R.ref_aes_enc_dec(_p(s, C.c_uint8), _p(k, C.c_uint8), C.c_ubyte(direction))
+    return s.tobytes(), k.tobytes()
+
+
+def ref_crc16(data: bytes) -> int:
+    assert len(data) <= 255
+    return int(ref().ref_crc16(bytes(data), len(data)))

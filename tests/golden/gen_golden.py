@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the reference checkout.  Run ONLY where /root/reference exists (the build
+container); the GPU box just reads the committed fixtures.
+
+Sources (relative to /root/reference):
+  mm     tests/mm_common/mm_tmr.c (side 9), tests/hifive1/matrixMultiply.tmr/mm.inc (19),
+         tests/pynq/matrixMultiply.tmr/mm.inc (30): input matrices + xor_golden, parsed from the C initialisers;
+         re-generated with mm_generator.py's algorithm (random.seed(0); randint(0, 2**32-1), tests/mm_common/
+         mm_generator.py:42-51) to prove the generator equivalence, which then extends the set to side 32 and 256;
+         result matrices come from the reference's own matrix_multiply (oracle/_ref).
+  sha256 tests/sha256_common/sha_data.inc (LEN 10), tests/hifive1/sha256.tmr/sha_data.inc (LEN 4000).
+  aes    tests/aes/ECB{GFSbox,KeySbox,VarKey,VarTxt}128.h: 568 NIST AESAVS vectors, 80 bytes each
+         (key, key, ciphertext, plaintext, plaintext -- tests/aes/aes.c:62-66).
+  crc16  no golden in the tree; vectors are outputs of the reference's crc16() (tests/crc16/crc16.c:21-31)
+         compiled unmodified (oracle/_ref), incl. its own "Automated TMR" case (crc16.c:14,40).
+"""
+import hashlib
+import json
+import os
+import random
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/tests"
+
+from oracle import oracle as orc  # noqa: E402
+
+
+def gen_mm(n, seed=0):
+    """mm_generator.py:42-51 -- first matrix row-major, then second, from one seeded stream."""
+    random.seed(seed)
+    m1 = [[random.randint(0, 2**32 - 1) for _ in range(n)] for _ in range(n)]
+    m2 = [[random.randint(0, 2**32 - 1) for _ in range(n)] for _ in range(n)]
+    return np.array(m1, dtype=np.uint32), np.array(m2, dtype=np.uint32)
+
+
+def parse_mm(path):
+    txt = open(path).read()
+    side = int(re.search(r"#define\s+side\s+(\d+)", txt).group(1))
+    mats = []
+    for name in ("first_matrix", "second_matrix"):
+        body = re.search(name + r"\[\w+\]\[\w+\]\s*=\s*\{(.*?)\};", txt, re.S).group(1)
+        vals = [int(v) for v in re.findall(r"\d+", body)]
+        assert len(vals) == side * side, (name, len(vals))
+        mats.append(np.array(vals, dtype=np.uint32).reshape(side, side))
+    gold = int(re.search(r"xor_golden\s*=\s*(\d+)", txt).group(1))
+    return side, mats[0], mats[1], gold
+
+
+def parse_bytes(txt, name):
+    body = re.search(name + r"\s*\[\w*\]\s*=\s*\{(.*?)\}", txt, re.S).group(1)
+    return bytes(int(v, 16) for v in re.findall(r"0x[0-9a-fA-F]+", body))
+
+
+def main():
+    orc.build()
+    assert orc.ref() is not None, "oracle/_ref not built"
+    out = {}
+
+    # ---------------- mm
+    mm = {}
+    for path in ("mm_common/mm_tmr.c", "hifive1/matrixMultiply.tmr/mm.inc", "pynq/matrixMultiply.tmr/mm.inc"):
+        side, f, s, gold = parse_mm(os.path.join(REF, path))
+        gf, gs = gen_mm(side)
+        assert (gf == f).all() and (gs == s).all(), "generator mismatch for side %d" % side
+        r, err = orc.ref_mm(f, s, gold)
+        assert err == 0
+        mm["f%d" % side], mm["s%d" % side], mm["r%d" % side] = f, s, r
+        out["mm_xor_golden_%d" % side] = gold
+        out["mm_source_%d" % side] = path
+    for side in (32, 256):
+        f, s = gen_mm(side)
+        gold = orc.mm_xor(orc.mm_plain(f, s))
+        r, err = orc.ref_mm(f, s, gold)
+        assert err == 0 and orc.mm_xor(r) == gold
+        out["mm_xor_golden_%d" % side] = gold
+        out["mm_inputs_sha256_%d" % side] = hashlib.sha256(f.tobytes() + s.tobytes()).hexdigest()
+        out["mm_result_sha256_%d" % side] = hashlib.sha256(r.tobytes()).hexdigest()
+        if side == 32:
+            mm["f32"], mm["s32"], mm["r32"] = f, s, r
+    # LANL variant (tests/matrixMultiply/matrixMultiply.c:80-81: both inputs i*j), run at side 32 through
+    # the reference's mm_common matrix_multiply (identical loop nest, matrixMultiply.c:95-112)
+    ij = np.fromfunction(lambda i, j: i * j, (32, 32), dtype=np.int64).astype(np.uint32)
+    r, _ = orc.ref_mm(ij, ij, 0)
+    mm["lanl_r32"] = r
+    np.savez_compressed(os.path.join(HERE, "mm_fixtures.npz"), **mm)
+
+    # ---------------- sha256
+    sha = {}
+    for tag, path in (("10", "sha256_common/sha_data.inc"), ("4000", "hifive1/sha256.tmr/sha_data.inc")):
+        txt = open(os.path.join(REF, path)).read()
+        data, gold = parse_bytes(txt, "hash_data"), parse_bytes(txt, "golden")
+        assert len(data) == int(tag) and len(gold) == 32
+        random.seed(0)  # sha_generator.py:44-50
+        assert bytes(random.randint(0, 255) for _ in range(len(data))) == data
+        assert hashlib.sha256(data).digest() == gold and orc.ref_sha256(data) == gold
+        sha["data" + tag] = np.frombuffer(data, np.uint8)
+        sha["golden" + tag] = np.frombuffer(gold, np.uint8)
+    np.savez_compressed(os.path.join(HERE, "sha_fixtures.npz"), **sha)
+
+    # ---------------- aes
+    kat = []
+    counts = {}
+    for name in ("ECBGFSbox128", "ECBKeySbox128", "ECBVarKey128", "ECBVarTxt128"):
+        txt = open(os.path.join(REF, "aes", name + ".h")).read()
+        cnt = int(re.search(name + r"_count\s*=\s*(\d+)", txt).group(1))
+        body = re.search(name + r"\[\]\s*=\s*\{(.*?)\};", txt, re.S).group(1)
+        vals = bytes(int(v, 16) for v in re.findall(r"0x[0-9a-fA-F]+", body))
+        assert len(vals) >= cnt * 80, (name, len(vals), cnt)
+        kat.append(np.frombuffer(vals[: cnt * 80], np.uint8).reshape(cnt, 80))
+        counts[name] = cnt
+    kat = np.concatenate(kat)
+    assert kat.shape == (568, 80)
+    for row in kat[::37]:  # spot check through the reference's aes_enc_dec
+        key, key2, ct, pt, inp = (row[16 * q:16 * q + 16].tobytes() for q in range(5))
+        enc, _ = orc.ref_aes(inp, key, 0)
+        dec, _ = orc.ref_aes(enc, key2, 1)
+        assert enc == ct and dec == pt
+    np.savez_compressed(os.path.join(HERE, "aes_kat.npz"), kat=kat)
+    out["aes_counts"] = counts
+    sb = np.ctypeslib.as_array(orc.lib().orc_aes_sbox(), (256,))
+    import ctypes as C
+    rsb = (C.c_ubyte * 256).in_dll(orc.ref(), "ref_aes_rsbox")
+    rs = (C.c_ubyte * 256).in_dll(orc.ref(), "ref_aes_sbox")
+    assert bytes(rs) == sb.tobytes(), "oracle S-box differs from the reference's"
+    assert bytes(rsb) == np.ctypeslib.as_array(orc.lib().orc_aes_rsbox(), (256,)).tobytes()
+    out["aes_sbox_sha256"] = hashlib.sha256(sb.tobytes()).hexdigest()
+
+    # ---------------- crc16 (outputs of the reference run here)
+    vec = [{"data": b"Automated TMR".hex(), "crc": orc.ref_crc16(b"Automated TMR")}]
+    assert vec[0]["crc"] == 0x5BA3
+    rng = random.Random(16)
+    for ln in list(range(0, 20)) + [63, 64, 65, 127, 128, 129, 200, 254, 255]:
+        d = bytes(rng.randrange(256) for _ in range(ln))
+        vec.append({"data": d.hex(), "crc": orc.ref_crc16(d)})
+    vec.append({"data": b"123456789".hex(), "crc": orc.ref_crc16(b"123456789")})
+    out["crc16_vectors"] = vec
+
+    with open(os.path.join(HERE, "golden.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("wrote", sorted(os.listdir(HERE)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+"""CPU tests: the oracle against every golden vector the reference's tests hold for the hot path
+(SURVEY.md section 8c), against the reference itself (oracle/_ref, when built), and the voter/counter rules."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import gen_mm
+
+
+@pytest.mark.parametrize("n", [9, 19, 30, 32])
+def test_mm_plain_matches_reference_fixtures(orc, golden, n):
+    f, s, r = golden["mm"]["f%d" % n], golden["mm"]["s%d" % n], golden["mm"]["r%d" % n]
+    got = orc.mm_plain(f, s)
+    assert (got == r).all()
+    assert orc.mm_xor(got) == golden["mm_xor_golden_%d" % n]  # mm_tmr.c:31, mm.inc:43, mm.inc:65
+
+
+def test_mm_generator_equivalence_and_256(orc, golden):
+    for n in (9, 19, 30):
+        f, s = gen_mm(n)
+        assert (f == golden["mm"]["f%d" % n]).all() and (s == golden["mm"]["s%d" % n]).all()
+    f, s = gen_mm(256)
+    assert hashlib.sha256(f.tobytes() + s.tobytes()).hexdigest() == golden["mm_inputs_sha256_256"]
+    r = orc.mm_plain(f, s)
+    assert orc.mm_xor(r) == golden["mm_xor_golden_256"] == 458951617
+    assert hashlib.sha256(r.tobytes()).hexdigest() == golden["mm_result_sha256_256"]
+
+
+def test_mm_lanl_variant(orc, golden):
+    ij = np.fromfunction(lambda i, j: i * j, (32, 32), dtype=np.int64).astype(np.uint32)
+    assert (orc.mm_plain(ij, ij) == golden["mm"]["lanl_r32"]).all()
+
+
+@pytest.mark.parametrize("tag", ["10", "4000"])
+def test_sha256_fixtures(orc, golden, tag):
+    data = golden["sha"]["data" + tag].tobytes()
+    assert orc.sha256_plain(data) == golden["sha"]["golden" + tag].tobytes()
+
+
+def test_sha256_lengths_vs_hashlib(orc):
+    rng = np.random.default_rng(1)
+    for ln in list(range(0, 130)) + [255, 256, 1000]:
+        d = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+        assert orc.sha256_plain(d) == hashlib.sha256(d).digest(), ln
+
+
+def test_aes_kat(orc, golden):
+    # tests/aes/aes.c:91-99: enc(input,key)==ciphertext, dec(.,key2)==plaintext
+    errors = 0
+    for row in golden["aes_kat"]:
+        key, key2, ct, pt, inp = (row[16 * q:16 * q + 16].tobytes() for q in range(5))
+        enc, k_after = orc.aes128_plain(inp, key, 0)
+        dec, k2_after = orc.aes128_plain(enc, key2, 1)
+        errors += (inp != pt) + (enc != ct) + (dec != pt)
+        assert k2_after == key2  # decrypt walks the key schedule back to the cipher key
+    assert errors == 0
+    assert hashlib.sha256(bytes(np.ctypeslib.as_array(orc.lib().orc_aes_sbox(), (256,)))).hexdigest() == golden[
+        "aes_sbox_sha256"]
+
+
+def test_crc16_vectors(orc, golden):
+    for v in golden["crc16_vectors"]:
+        assert orc.crc16_plain(bytes.fromhex(v["data"])) == v["crc"]
+    assert orc.crc16_plain(b"Automated TMR") == 0x5BA3  # tests/crc16/crc16.c:14,40 compiled unmodified
+
+
+def test_against_reference_build(orc, golden):
+    if orc.ref() is None:
+        pytest.skip("oracle/_ref not built (no reference checkout on this box)")
+    rng = np.random.default_rng(7)
+    for ln in (0, 1, 55, 56, 63, 64, 65, 119, 120, 300):
+        d = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+        assert orc.sha256_plain(d) == orc.ref_sha256(d)
+    for _ in range(64):
+        st, key = rng.integers(0, 256, 16, dtype=np.uint8).tobytes(), rng.integers(0, 256, 16, dtype=np.uint8).tobytes()
+        for d in (0, 1):
+            assert orc.aes128_plain(st, key, d) == orc.ref_aes(st, key, d)
+    for ln in range(0, 256, 5):
+        d = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+        assert orc.crc16_plain(d) == orc.ref_crc16(d)
+    f, s = gen_mm(32, seed=3)
+    assert (orc.mm_plain(f, s) == orc.ref_mm(f, s, 0)[0]).all()
+
+
+# ------------------------------------------------------------------ voter / counter semantics
+def test_tmr_clean_run_counts(orc, golden):
+    f, s = golden["mm"]["f9"], golden["mm"]["s9"]
+    r, st, _ = orc.mm_xmr(f, s, replicas=3)
+    assert (r[0] == golden["mm"]["r9"]).all()
+    assert st == {"errors_corrected": 0, "sync_count": 81, "dwc_detected": 0}
+    r, st, _ = orc.mm_xmr(f, s, replicas=3, sync_every=4)  # + votes after k=4,8 (k+1<n)
+    assert st["sync_count"] == 81 * 3 and st["errors_corrected"] == 0
+    r, st, _ = orc.mm_xmr(f, s, replicas=1)
+    assert st["sync_count"] == 0 and (r[0] == golden["mm"]["r9"]).all()
+
+
+def test_tmr_voter_is_select_not_bitwise_majority(orc, golden):
+    """synchronization.cpp:934-938: vote = (a==b) ? a : c on the whole value."""
+    f, s, good = golden["mm"]["f9"], golden["mm"]["s9"], golden["mm"]["r9"]
+    item = 9 * 4 + 5
+    # single fault in any one replica: corrected, +1
+    for rep in range(3):
+        r, st, _ = orc.mm_xmr(f, s, faults=orc.make_faults([(item, rep, orc.SITE_MM_ACC, 3, 7)]))
+        assert (r[0] == good).all() and st["errors_corrected"] == 1
+    # replicas 0 and 1 corrupted identically: the corrupted value wins, counted once (replica 2 differs)
+    fl = orc.make_faults([(item, 0, orc.SITE_MM_ACC, 9, 7), (item, 1, orc.SITE_MM_ACC, 9, 7)])
+    r, st, _ = orc.mm_xmr(f, s, faults=fl)
+    assert r[0].reshape(-1)[item] == good.reshape(-1)[item] ^ (1 << 7) and st["errors_corrected"] == 1
+    # replicas 0 and 2 corrupted identically (0 != 1): replica 2 is taken unconditionally -> corrupted output;
+    # a bitwise-majority voter would ALSO give the corrupted value here, but for different bits it differs:
+    fl = orc.make_faults([(item, 0, orc.SITE_MM_ACC, 9, 3), (item, 2, orc.SITE_MM_ACC, 9, 12)])
+    r, st, _ = orc.mm_xmr(f, s, faults=fl)
+    assert r[0].reshape(-1)[item] == good.reshape(-1)[item] ^ (1 << 12)  # bitwise majority would give `good`
+    assert st["errors_corrected"] == 1
+    # never more than +1 per voted value
+    fl = orc.make_faults([(item, 0, orc.SITE_MM_ACC, 9, 3), (item, 1, orc.SITE_MM_ACC, 9, 4),
+                          (item, 2, orc.SITE_MM_ACC, 9, 5)])
+    _, st, _ = orc.mm_xmr(f, s, faults=fl)
+    assert st["errors_corrected"] == 1
+
+
+def test_dwc_detects_and_keeps_replica0(orc, golden):
+    f, s, good = golden["mm"]["f9"], golden["mm"]["s9"], golden["mm"]["r9"]
+    item = 17
+    r, st, det = orc.mm_xmr(f, s, replicas=2, faults=orc.make_faults([(item, 1, orc.SITE_MM_OPA, 2, 31)]))
+    assert (r[0] == good).all() and st["dwc_detected"] == 1 and det[item] == 1 and det.sum() == 1
+    r, st, det = orc.mm_xmr(f, s, replicas=2, faults=orc.make_faults([(item, 0, orc.SITE_MM_ACC, 9, 0)]))
+    assert r[0].reshape(-1)[item] == good.reshape(-1)[item] ^ 1 and st["dwc_detected"] == 1
+
+
+def test_fault_sites_other_kernels(orc, golden):
+    rng = np.random.default_rng(3)
+    # sha256: any single replica-private flip is corrected; digest unchanged
+    msgs = rng.integers(0, 256, (6, 64), dtype=np.uint8)
+    clean, st0, _ = orc.sha256_xmr(msgs, 64)
+    assert st0["sync_count"] == 6 * (8 * 2 + 8) and st0["errors_corrected"] == 0
+    for m in range(6):
+        assert clean[m].tobytes() == hashlib.sha256(msgs[m].tobytes()).digest()
+    fl = orc.make_faults([(0, 0, orc.SITE_SHA_M, 5, 1), (1, 1, orc.SITE_SHA_M, 64 + 40, 31),
+                          (2, 2, orc.SITE_SHA_WV, 63, 9, 4), (3, 1, orc.SITE_SHA_STATE, 1, 0, 7),
+                          (4, 0, orc.SITE_SHA_STATE, 2, 13, 3)])
+    d, st, _ = orc.sha256_xmr(msgs, 64, faults=fl)
+    assert (d == clean).all() and st["errors_corrected"] >= 5
+    # aes DWC: flip detected, clean otherwise
+    stt, key = rng.integers(0, 256, (4, 16), dtype=np.uint8), rng.integers(0, 256, (4, 16), dtype=np.uint8)
+    c, k, st, det = orc.aes128_xmr(stt, key, 0)
+    assert st["dwc_detected"] == 0 and st["sync_count"] == 4 * 8
+    c2, k2, st, det = orc.aes128_xmr(stt, key, 0, faults=orc.make_faults([(2, 1, orc.SITE_AES_STATE, 4, 17, 2)]))
+    assert st["dwc_detected"] == 1 and list(det) == [0, 0, 1, 0] and (c2 == c).all()
+    # aes TMR corrects
+    c3, k3, st, _ = orc.aes128_xmr(stt, key, 0, replicas=3, faults=orc.make_faults([(2, 0, orc.SITE_AES_KEY, 4, 17, 2)]))
+    assert (c3 == c).all() and (k3 == k).all() and st["errors_corrected"] >= 1
+    # crc16: bits >= 16 of the crc register are dead (legal no-effect hit, injector.py:202-207 flips any of 32)
+    data = rng.integers(0, 256, (5, 64), dtype=np.uint8)
+    crc, st, _ = orc.crc16_xmr(data, 64)
+    assert st["sync_count"] == 5 and [orc.crc16_plain(r.tobytes()) for r in data] == list(crc)
+    crc2, st, _ = orc.crc16_xmr(data, 64, faults=orc.make_faults([(1, 2, orc.SITE_CRC_CRC, 10, 20),
+                                                                   (3, 0, orc.SITE_CRC_X, 63, 2)]))
+    assert (crc2 == crc).all() and st["errors_corrected"] == 1
+
+
+def test_cpu_tmr_baseline_matches(orc, golden):
+    for n in (9, 30):
+        f, s = golden["mm"]["f%d" % n], golden["mm"]["s%d" % n]
+        r, err, cnt, syncs = orc.cpu_tmr_mm(f, s, golden["mm_xor_golden_%d" % n])
+        assert (r == golden["mm"]["r%d" % n]).all() and err == 0 and cnt == 0
+        # (n+1)(n^2+n+1) loop-condition votes in matrix_multiply + checkGolden's n^2+1 + return
+        assert syncs == (n + 1) * (n * n + n + 1) + n * n + 1 + 1
