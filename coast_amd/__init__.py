@@ -1,0 +1,16 @@
+"""coast_amd -- MI355X-native redundant-execution engine for COAST's dataflowProtection hot path.
+
+The product is libcoast_hip.so (hand-written gfx950 kernels behind the C ABI of include/coast_hip.h).  This package is
+the thin host-side mirror of the reference's interface for that path: the protected kernels under their reference
+names (matrix_multiply, sha256_hash, aes_enc_dec, crc16), the batch engine, the fault injector and the multi-GPU
+counter reduction.  Nothing here computes on the CPU.
+"""
+from .engine import DWC, TMR, UNPROTECTED, Engine, XmrConfig, make_faults  # noqa: F401
+from .hostapi import (FaultDetectedDWC, aes_enc_dec, crc16, host_stats, matrix_multiply,  # noqa: F401
+                      sha256_hash)
+from ._lib import FAULT_DTYPE, CoastLibraryError  # noqa: F401
+
+SITE_MM_ACC, SITE_MM_OPA, SITE_MM_OPB = 0, 1, 2
+SITE_SHA_M, SITE_SHA_WV, SITE_SHA_STATE = 8, 9, 10
+SITE_AES_STATE, SITE_AES_KEY = 16, 17
+SITE_CRC_CRC, SITE_CRC_X = 24, 25

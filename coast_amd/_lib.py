@@ -1,0 +1,86 @@
+"""ctypes binding of include/coast_hip.h.  Fails loudly when the HIP library is missing: there is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+FAULT_DTYPE = np.dtype(
+    [("item", "<u8"), ("step", "<u4"), ("replica", "u1"), ("site", "u1"), ("bit", "u1"), ("index", "u1")]
+)
+assert FAULT_DTYPE.itemsize == 16
+
+
+class CoastCfg(C.Structure):
+    _fields_ = [("replicas", C.c_uint32), ("sync_every", C.c_uint32)]
+
+
+class CoastStats(C.Structure):
+    _fields_ = [("errors_corrected", C.c_uint64), ("sync_count", C.c_uint64), ("dwc_detected", C.c_uint64),
+                ("launches", C.c_uint64)]
+
+
+# every symbol include/coast_hip.h declares (tests check the library exports all of them)
+SYMBOLS = {
+    "coast_abi_version": (C.c_int, []),
+    "coast_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "coast_destroy": (None, [C.c_void_p]),
+    "coast_last_error": (C.c_char_p, [C.c_void_p]),
+    "coast_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "coast_bind_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "coast_reduce_counters": (C.c_int, [C.c_void_p]),
+    "coast_read_stats": (C.c_int, [C.c_void_p, C.POINTER(CoastStats)]),
+    "coast_reset_stats": (C.c_int, [C.c_void_p]),
+    "coast_inject_faults": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "coast_mm_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t,
+                                 C.POINTER(CoastCfg), C.c_void_p]),
+    "coast_sha256_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_void_p,
+                                     C.POINTER(CoastCfg), C.c_void_p]),
+    "coast_aes128_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(CoastCfg),
+                                     C.c_void_p]),
+    "coast_crc16_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.POINTER(CoastCfg),
+                                    C.c_void_p]),
+    "coast_matrix_multiply_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(CoastCfg)]),
+    "coast_sha256_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(CoastCfg)]),
+    "coast_aes_enc_dec_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint8, C.POINTER(CoastCfg)]),
+    "coast_crc16_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(CoastCfg)]),
+    "coast_host_stats": (C.c_int, [C.POINTER(CoastStats), C.c_int]),
+}
+
+_lib = None
+
+
+class CoastLibraryError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """dlopen libcoast_hip.so (built in-tree).  Raises CoastLibraryError when it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise CoastLibraryError(
+            "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "coast_amd has no CPU fallback." % path)
+    try:
+        L = C.CDLL(path)
+    except OSError as e:
+        raise CoastLibraryError("cannot load %s: %s" % (path, e)) from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise CoastLibraryError("%s does not export %s" % (path, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L

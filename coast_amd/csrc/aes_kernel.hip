@@ -1,0 +1,253 @@
+// aes_kernel.hip -- protected aes_enc_dec (AES-128, one block, on-the-fly key schedule) for gfx950.
+//
+// Replaces: the DWC/TMR-transformed aes_enc_dec of tests/aes/TI_aes_128.c:107-231, including its data contract: the
+// 16-byte state AND the 16-byte key are updated in place (encrypt leaves the last round key, decrypt first rolls the key
+// forward 10 rounds, :110-123, then walks it back to the cipher key).
+// Logical work item = one 16-byte block; lane NREP*q + r holds replica r of the wave's q-th block: state and running
+// round key as 16 + 16 byte values in VGPRs.  S-box / inverse S-box (:44,:64) sit in LDS -- a single shared copy, i.e.
+// read-only memory outside the sphere of replication, like the reference's const tables under -noMemReplication.
+// Sync points (frozen in oracle/coast_oracle.c): the 4 state dwords and 4 key dwords at the end (they are stored back),
+// and with sync_every != 0 also after every main-loop round.
+#include "xmr.hpp"
+
+namespace coast {
+
+enum { SITE_AES_STATE = 16, SITE_AES_KEY = 17 };
+
+__constant__ uint8_t kAesRcon[10] = {0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80, 0x1b, 0x36}; // :83
+
+// FIPS-197 S-box generated from its definition at load time by aes_tables_kernel (no pasted table)
+__device__ uint8_t gAesSbox[256];
+__device__ uint8_t gAesRsbox[256];
+
+__device__ __forceinline__ uint32_t gf_mul_dev(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (b & 1u)
+            p ^= a;
+        const uint32_t hi = a & 0x80u;
+        a = (a << 1) & 0xffu;
+        if (hi)
+            a ^= 0x1bu;
+        b >>= 1;
+    }
+    return p;
+}
+
+__global__ void aes_tables_kernel()
+{
+    const uint32_t x = threadIdx.x; // 256 threads
+    uint32_t inv = 0;
+    if (x)
+        for (uint32_t y = 1; y < 256; ++y)
+            if (gf_mul_dev(x, y) == 1u) {
+                inv = y;
+                break;
+            }
+    uint32_t s = inv;
+    for (int k = 1; k <= 4; ++k)
+        s ^= ((inv << k) | (inv >> (8 - k))) & 0xffu;
+    s ^= 0x63u;
+    gAesSbox[x] = (uint8_t)s;
+    gAesRsbox[s] = (uint8_t)x;
+}
+
+__device__ __forceinline__ uint32_t xtime(uint32_t v) { return ((v << 1) ^ ((v & 0x80u) ? 0x1bu : 0u)) & 0xffu; } // :88-99
+
+__device__ __forceinline__ void aes_mix_col(uint32_t *c, bool inverse) // :168-185
+{
+    if (inverse) {
+        const uint32_t u = xtime(xtime(c[0] ^ c[2])), v = xtime(xtime(c[1] ^ c[3]));
+        c[0] ^= u;
+        c[1] ^= v;
+        c[2] ^= u;
+        c[3] ^= v;
+    }
+    const uint32_t t = c[0] ^ c[1] ^ c[2] ^ c[3], c0 = c[0];
+    c[0] ^= xtime(c[0] ^ c[1]) ^ t;
+    c[1] ^= xtime(c[1] ^ c[2]) ^ t;
+    c[2] ^= xtime(c[2] ^ c[3]) ^ t;
+    c[3] ^= xtime(c[3] ^ c0) ^ t;
+}
+
+__device__ __forceinline__ void aes_key_fwd(uint32_t k[16], const uint8_t *sb, int rd) // :115-121, :220-226
+{
+    k[0] ^= (uint32_t)sb[k[13]] ^ (uint32_t)kAesRcon[rd];
+    k[1] ^= sb[k[14]];
+    k[2] ^= sb[k[15]];
+    k[3] ^= sb[k[12]];
+#pragma unroll
+    for (int i = 4; i < 16; ++i)
+        k[i] ^= k[i - 4];
+}
+
+__device__ __forceinline__ void aes_key_inv(uint32_t k[16], const uint8_t *sb, int rd) // :134-141
+{
+#pragma unroll
+    for (int i = 15; i > 3; --i)
+        k[i] ^= k[i - 4];
+    k[0] ^= (uint32_t)sb[k[13]] ^ (uint32_t)kAesRcon[rd];
+    k[1] ^= sb[k[14]];
+    k[2] ^= sb[k[15]];
+    k[3] ^= sb[k[12]];
+}
+
+// one main-loop iteration (:131-227) on one replica
+__device__ __forceinline__ void aes_round(uint32_t s[16], uint32_t k[16], const uint8_t *sb, const uint8_t *rsb,
+                                          bool dir, int rd)
+{
+    uint32_t t[16];
+    if (dir) {
+        aes_key_inv(k, sb, 9 - rd);
+        if (rd > 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                aes_mix_col(s + 4 * c, true);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                t[4 * ((c + r) & 3) + r] = s[4 * c + r]; // inverse shift rows
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            s[i] = (uint32_t)rsb[t[i]] ^ k[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            t[i] = sb[s[i] ^ k[i]];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                s[4 * c + r] = t[4 * ((c + r) & 3) + r]; // shift rows
+        if (rd < 9) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                aes_mix_col(s + 4 * c, false);
+        }
+        aes_key_fwd(k, sb, rd);
+    }
+}
+
+__device__ __forceinline__ uint32_t pack4(const uint32_t *b) { return b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24); }
+__device__ __forceinline__ void unpack4(uint32_t w, uint32_t *b)
+{
+    b[0] = w & 0xffu;
+    b[1] = (w >> 8) & 0xffu;
+    b[2] = (w >> 16) & 0xffu;
+    b[3] = w >> 24;
+}
+
+template <int NREP>
+__device__ __forceinline__ void aes_sync(uint32_t s[16], uint32_t k[16], const LaneMap<NREP> &lm, bool cnt, Tally &tl)
+{
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        unpack4(xmr_sync<NREP>(pack4(s + 4 * w), lm, cnt, tl), s + 4 * w);
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        unpack4(xmr_sync<NREP>(pack4(k + 4 * w), lm, cnt, tl), k + 4 * w);
+}
+
+template <int NREP>
+__global__ __launch_bounds__(256) void aes128_xmr_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
+                                                         uint64_t nblocksData, int dirFlag, uint32_t syncEvery,
+                                                         Counters ctr, FaultTab ft, int haveFaults,
+                                                         uint8_t *__restrict__ detected)
+{
+    __shared__ uint8_t sSb[256];
+    __shared__ uint8_t sRsb[256];
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    constexpr int IPB = 4 * IPW;
+    const LaneMap<NREP> lm;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lb = blockIdx.x;
+    const int slot = wave * IPW + lm.q;
+    const uint64_t item = (uint64_t)lb * IPB + (uint64_t)slot;
+    const bool live = lm.live && item < nblocksData;
+    const bool dir = dirFlag != 0;
+
+    sSb[threadIdx.x] = gAesSbox[threadIdx.x];
+    sRsb[threadIdx.x] = gAesRsbox[threadIdx.x];
+    if (threadIdx.x < 4)
+        sCnt[threadIdx.x] = 0;
+    __syncthreads();
+
+    uint2 fr = make_uint2(0u, 0u);
+    if (haveFaults)
+        fr = ft.range[lb];
+    const bool cnt = live && lm.r == 0;
+    Tally tl;
+
+    // one 16-byte load per array feeds the replica's 16 byte registers (buffers are 16-byte aligned by contract)
+    const uint64_t it = live ? item : 0;
+    const uint4 sv = reinterpret_cast<const uint4 *>(states)[it];
+    const uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
+    uint32_t s[16], k[16];
+    unpack4(sv.x, s + 0);
+    unpack4(sv.y, s + 4);
+    unpack4(sv.z, s + 8);
+    unpack4(sv.w, s + 12);
+    unpack4(kv.x, k + 0);
+    unpack4(kv.y, k + 4);
+    unpack4(kv.z, k + 8);
+    unpack4(kv.w, k + 12);
+
+    if (dir) { // :110-128 last encryption key, then the first AddRoundKey
+#pragma unroll 1
+        for (int rd = 0; rd < 10; ++rd)
+            aes_key_fwd(k, sSb, rd);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            s[i] ^= k[i];
+    }
+#pragma unroll 1
+    for (int rd = 0; rd <= 10; ++rd) {
+        if (fr.y) { // injector hook at the start of round rd (rd == 10: after the loop)
+            for (uint32_t q = 0; q < fr.y; ++q) {
+                const DevFault df = ft.list[fr.x + q];
+                if (df.step != (uint32_t)rd || (int)df.local != slot || (int)df.replica != lm.r || !lm.live)
+                    continue;
+                const uint32_t m = 1u << (df.bit & 31u);
+                const int byteIdx = 4 * (df.index & 3) + (int)((df.bit & 31u) >> 3);
+                const uint32_t bm = (m >> (8 * ((df.bit & 31u) >> 3))) & 0xffu;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i == byteIdx) {
+                        if (df.site == SITE_AES_STATE)
+                            s[i] ^= bm;
+                        else if (df.site == SITE_AES_KEY)
+                            k[i] ^= bm;
+                    }
+            }
+        }
+        if (rd == 10)
+            break;
+        aes_round(s, k, sSb, sRsb, dir, rd);
+        if (syncEvery && rd < 9)
+            aes_sync<NREP>(s, k, lm, cnt, tl);
+    }
+    if (!dir) { // :228-233 last AddRoundKey
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            s[i] ^= k[i];
+    }
+    aes_sync<NREP>(s, k, lm, cnt, tl); // in-place stores of state and key: store-data sync
+
+    uint32_t detItems = 0;
+    if (cnt) {
+        reinterpret_cast<uint4 *>(states)[item] = make_uint4(pack4(s), pack4(s + 4), pack4(s + 8), pack4(s + 12));
+        reinterpret_cast<uint4 *>(keys)[item] = make_uint4(pack4(k), pack4(k + 4), pack4(k + 8), pack4(k + 12));
+        if (NREP == 2 && tl.det) {
+            detItems = 1;
+            if (detected)
+                detected[item] = 1;
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, lb);
+}
+
+} // namespace coast

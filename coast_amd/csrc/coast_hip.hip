@@ -1,0 +1,384 @@
+// coast_hip.hip -- C ABI of libcoast_hip.so (declared in include/coast_hip.h) and the host side of every launch.
+// Unity build: the kernels are included so that one hipcc invocation produces the whole gfx950 code object.
+#include "../../include/coast_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "xmr.hpp"
+#include "injector.hip"
+#include "mm_kernel.hip"
+#include "sha256_kernel.hip"
+#include "aes_kernel.hip"
+#include "crc16_kernel.hip"
+
+using namespace coast;
+
+static_assert(sizeof(coast_fault) == 16, "coast_fault layout");
+static_assert(sizeof(DevFault) == 16, "DevFault layout");
+
+struct coast_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr; // protected kernels
+    hipStream_t side = nullptr;   // injector: descriptor upload + indexing
+    hipEvent_t evArmed = nullptr;    // side -> main: fault table ready
+    hipEvent_t evConsumed = nullptr; // main -> side: previous table no longer read
+    bool consumedPending = false;
+
+    unsigned long long *dSlots = nullptr;  // [kCounterSlots][kSlotStride]
+    unsigned long long *dTotals = nullptr; // internal totals
+    unsigned long long *dBound = nullptr;  // caller-owned totals (optional)
+    unsigned long long pendingLaunches = 0;
+
+    std::vector<coast_fault> armed; // host copy of the faults waiting for the next launch
+    DevFault *hPinned = nullptr;
+    size_t pinnedCap = 0;
+    DevFault *dList = nullptr;
+    size_t listCap = 0;
+    uint2 *dRange = nullptr;
+    size_t rangeCap = 0;
+
+    std::string err;
+};
+
+namespace {
+
+int fail(coast_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                                    \
+    do {                                                                                                      \
+        hipError_t e__ = (call);                                                                              \
+        if (e__ != hipSuccess)                                                                                \
+            return fail((ctx), COAST_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,  \
+                        __LINE__);                                                                            \
+    } while (0)
+
+unsigned long long *totals_of(coast_ctx *c) { return c->dBound ? c->dBound : c->dTotals; }
+
+int check_cfg(coast_ctx *ctx, const coast_cfg *cfg)
+{
+    if (!ctx)
+        return COAST_EINVAL;
+    if (!cfg || cfg->replicas < 1 || cfg->replicas > 3)
+        return fail(ctx, COAST_EINVAL, "coast_cfg.replicas must be 1 (none), 2 (DWC) or 3 (TMR)");
+    return COAST_OK;
+}
+
+// Kernel-specific decode of one armed fault: returns false when the fault addresses nothing in this launch
+// (item out of range, replica >= replicas) -- such a fault is dropped exactly as the oracle ignores it.
+typedef bool (*decode_fn)(const coast_fault &, const void *geom, DevFault &);
+
+// Upload the armed faults for a launch of `nblocks` workgroups.  Runs entirely on the side stream; the main stream
+// waits on evArmed.  Returns haveFaults (0/1) through *have.
+int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, FaultTab *ft, int *have)
+{
+    *have = 0;
+    ft->list = nullptr;
+    ft->range = nullptr;
+    if (c->armed.empty())
+        return COAST_OK;
+    std::vector<DevFault> dv;
+    dv.reserve(c->armed.size());
+    for (const coast_fault &f : c->armed) {
+        DevFault d;
+        if (dec(f, geom, d))
+            dv.push_back(d);
+    }
+    c->armed.clear(); // consumed by exactly one launch
+    if (dv.empty())
+        return COAST_OK;
+    std::stable_sort(dv.begin(), dv.end(), [](const DevFault &a, const DevFault &b) { return a.block < b.block; });
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->side)); // pinned staging buffer free again
+    if (dv.size() > c->pinnedCap) {
+        if (c->hPinned)
+            HIP_TRY(c, hipHostFree(c->hPinned));
+        c->pinnedCap = std::max<size_t>(dv.size() * 2, 1024);
+        HIP_TRY(c, hipHostMalloc((void **)&c->hPinned, c->pinnedCap * sizeof(DevFault), hipHostMallocDefault));
+    }
+    if (c->consumedPending) { // the previous table may still be read by a kernel on the main stream
+        HIP_TRY(c, hipStreamWaitEvent(c->side, c->evConsumed, 0));
+        c->consumedPending = false;
+    }
+    if (dv.size() > c->listCap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->dList)
+            HIP_TRY(c, hipFree(c->dList));
+        c->listCap = std::max<size_t>(dv.size() * 2, 1024);
+        HIP_TRY(c, hipMalloc((void **)&c->dList, c->listCap * sizeof(DevFault)));
+    }
+    if ((size_t)nblocks > c->rangeCap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->dRange)
+            HIP_TRY(c, hipFree(c->dRange));
+        c->rangeCap = std::max<size_t>((size_t)nblocks * 2, 4096);
+        HIP_TRY(c, hipMalloc((void **)&c->dRange, c->rangeCap * sizeof(uint2)));
+    }
+    memcpy(c->hPinned, dv.data(), dv.size() * sizeof(DevFault));
+    HIP_TRY(c, hipMemcpyAsync(c->dList, c->hPinned, dv.size() * sizeof(DevFault), hipMemcpyHostToDevice, c->side));
+    HIP_TRY(c, hipMemsetAsync(c->dRange, 0, (size_t)nblocks * sizeof(uint2), c->side));
+    const uint32_t k = (uint32_t)dv.size();
+    hipLaunchKernelGGL(fault_range_kernel, dim3((k + 255) / 256), dim3(256), 0, c->side, c->dList, k, c->dRange);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->evArmed, c->side));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evArmed, 0));
+    ft->list = c->dList;
+    ft->range = c->dRange;
+    *have = 1;
+    return COAST_OK;
+}
+
+int after_launch(coast_ctx *c, int haveFaults)
+{
+    HIP_TRY(c, hipGetLastError());
+    c->pendingLaunches += 1;
+    if (haveFaults) {
+        HIP_TRY(c, hipEventRecord(c->evConsumed, c->stream));
+        c->consumedPending = true;
+    }
+    return COAST_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ context
+extern "C" int coast_abi_version(void) { return COAST_HIP_ABI_VERSION; }
+
+extern "C" int coast_create(coast_ctx **out, int device)
+{
+    if (!out)
+        return COAST_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return COAST_ENODEV;
+    coast_ctx *c = new coast_ctx();
+    c->device = device;
+    auto bail = [&](hipError_t e) {
+        if (e == hipSuccess)
+            return false;
+        delete c;
+        return true;
+    };
+    if (bail(hipSetDevice(device)) || bail(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) ||
+        bail(hipEventCreateWithFlags(&c->evArmed, hipEventDisableTiming)) ||
+        bail(hipEventCreateWithFlags(&c->evConsumed, hipEventDisableTiming)) ||
+        bail(hipMalloc((void **)&c->dSlots, sizeof(unsigned long long) * kCounterSlots * kSlotStride)) ||
+        bail(hipMalloc((void **)&c->dTotals, sizeof(unsigned long long) * 4)) ||
+        bail(hipMemset(c->dSlots, 0, sizeof(unsigned long long) * kCounterSlots * kSlotStride)) ||
+        bail(hipMemset(c->dTotals, 0, sizeof(unsigned long long) * 4)))
+        return COAST_EHIP;
+    *out = c;
+    return COAST_OK;
+}
+
+extern "C" void coast_destroy(coast_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->side);
+    if (c->hPinned)
+        (void)hipHostFree(c->hPinned);
+    if (c->dList)
+        (void)hipFree(c->dList);
+    if (c->dRange)
+        (void)hipFree(c->dRange);
+    (void)hipFree(c->dSlots);
+    (void)hipFree(c->dTotals);
+    (void)hipEventDestroy(c->evArmed);
+    (void)hipEventDestroy(c->evConsumed);
+    (void)hipStreamDestroy(c->side);
+    delete c;
+}
+
+extern "C" const char *coast_last_error(const coast_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int coast_set_stream(coast_ctx *c, void *hip_stream)
+{
+    if (!c)
+        return COAST_EINVAL;
+    c->stream = (hipStream_t)hip_stream;
+    return COAST_OK;
+}
+
+extern "C" int coast_bind_counters(coast_ctx *c, uint64_t *d_totals)
+{
+    if (!c)
+        return COAST_EINVAL;
+    c->dBound = (unsigned long long *)d_totals;
+    return COAST_OK;
+}
+
+extern "C" int coast_reduce_counters(coast_ctx *c)
+{
+    if (!c)
+        return COAST_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(kCounterSlots), 0, c->stream, c->dSlots, totals_of(c),
+                       c->pendingLaunches);
+    HIP_TRY(c, hipGetLastError());
+    c->pendingLaunches = 0;
+    return COAST_OK;
+}
+
+extern "C" int coast_read_stats(coast_ctx *c, coast_stats *out)
+{
+    if (!c || !out)
+        return COAST_EINVAL;
+    int rc = coast_reduce_counters(c);
+    if (rc)
+        return rc;
+    unsigned long long h[4];
+    HIP_TRY(c, hipMemcpyAsync(h, totals_of(c), sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->errors_corrected = h[0];
+    out->sync_count = h[1];
+    out->dwc_detected = h[2];
+    out->launches = h[3];
+    return COAST_OK;
+}
+
+extern "C" int coast_reset_stats(coast_ctx *c)
+{
+    if (!c)
+        return COAST_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->dSlots, 0, sizeof(unsigned long long) * kCounterSlots * kSlotStride, c->stream));
+    HIP_TRY(c, hipMemsetAsync(totals_of(c), 0, sizeof(unsigned long long) * 4, c->stream));
+    c->pendingLaunches = 0;
+    return COAST_OK;
+}
+
+extern "C" int coast_inject_faults(coast_ctx *c, const coast_fault *faults, size_t k)
+{
+    if (!c || (k && !faults))
+        return COAST_EINVAL;
+    c->armed.insert(c->armed.end(), faults, faults + k);
+    return COAST_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ mm
+namespace {
+
+struct MmHostGeom {
+    MmGeom g;
+    size_t batch;
+    int replicas;
+    int tpb;
+};
+
+bool decode_mm(const coast_fault &f, const void *gp, DevFault &d)
+{
+    const MmHostGeom &h = *(const MmHostGeom *)gp;
+    const uint64_t nn = (uint64_t)h.g.n * h.g.n;
+    if (f.item >= nn * h.batch || f.replica >= h.replicas)
+        return false;
+    if (f.site > COAST_SITE_MM_OPB || f.step > (uint32_t)h.g.n)
+        return false;
+    const uint64_t mat = f.item / nn, e = f.item % nn;
+    const int i = (int)(e / h.g.n), j = (int)(e % h.g.n);
+    const int tile = (i / 4) * h.g.tc + (j / 4);
+    const int bim = tile / h.tpb, tb = tile % h.tpb;
+    d.block = (uint32_t)(mat * h.g.bpm + bim);
+    d.local = ((uint32_t)tb << 4) | (uint32_t)((i & 3) << 2) | (uint32_t)(j & 3);
+    d.step = f.step;
+    d.replica = f.replica;
+    d.site = f.site;
+    d.bit = f.bit;
+    d.index = f.index;
+    return true;
+}
+
+} // namespace
+
+extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t *d_s, uint32_t *d_r, int n,
+                              size_t batch, const coast_cfg *cfg, uint8_t *d_detected)
+{
+    int rc = check_cfg(c, cfg);
+    if (rc)
+        return rc;
+    if (!d_f || !d_s || !d_r || n < 1 || n > 4096)
+        return fail(c, COAST_EINVAL, "coast_mm_batch: bad pointers or side %d (1..4096)", n);
+    if (batch == 0)
+        return COAST_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    MmHostGeom h;
+    MmGeom &g = h.g;
+    const int ipw = 64 / (int)cfg->replicas;
+    h.tpb = 4 * ipw;
+    h.batch = batch;
+    h.replicas = (int)cfg->replicas;
+    g.n = n;
+    g.tc = (n + 3) / 4;
+    g.tiles = g.tc * g.tc;
+    g.bpm = (g.tiles + h.tpb - 1) / h.tpb;
+    g.npad = 4 * g.tc;
+    int maxTileRows = 1;
+    for (int b = 0; b < g.bpm; ++b) {
+        const int t0 = b * h.tpb, t1 = std::min(t0 + h.tpb, g.tiles) - 1;
+        maxTileRows = std::max(maxTileRows, t1 / g.tc - t0 / g.tc + 1);
+    }
+    g.rs = 4 * maxTileRows;
+    // k-chunk: largest power of two <= 16 whose panels fit 48 KiB (>= 3 workgroups per CU)
+    g.kt = 16;
+    while (g.kt > 1 && (size_t)g.kt * (g.rs + g.npad) * 4 > 48 * 1024)
+        g.kt >>= 1;
+    g.ktLog2 = 0;
+    while ((1 << g.ktLog2) < g.kt)
+        ++g.ktLog2;
+    const size_t lds = (size_t)g.kt * (g.rs + g.npad) * 4 + 16;
+    if (lds > 160 * 1024)
+        return fail(c, COAST_EINVAL, "coast_mm_batch: side %d needs %zu B of LDS", n, lds);
+    const uint64_t nb = (uint64_t)g.bpm * batch;
+    if (nb > 0x7fffffffull)
+        return fail(c, COAST_EINVAL, "coast_mm_batch: %llu workgroups exceed the grid limit", (unsigned long long)nb);
+    g.nblocks = (uint32_t)nb;
+
+    FaultTab ft;
+    int have = 0;
+    rc = arm_faults(c, g.nblocks, decode_mm, &h, &ft, &have);
+    if (rc)
+        return rc;
+    Counters ctr{c->dSlots};
+    const dim3 grid(g.nblocks), block(256);
+#define LAUNCH_MM(R)                                                                                           \
+    do {                                                                                                       \
+        if (lds > 64 * 1024)                                                                                   \
+            HIP_TRY(c, hipFuncSetAttribute((const void *)mm_xmr_kernel<R>,                                     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
+        hipLaunchKernelGGL(mm_xmr_kernel<R>, grid, block, lds, c->stream, d_f, d_s, d_r, g, cfg->sync_every,   \
+                           ctr, ft, have, d_detected);                                                         \
+    } while (0)
+    if (cfg->replicas == 3)
+        LAUNCH_MM(3);
+    else if (cfg->replicas == 2)
+        LAUNCH_MM(2);
+    else
+        LAUNCH_MM(1);
+#undef LAUNCH_MM
+    return after_launch(c, have);
+}
+
+#include "launch_others.inc"
+#include "host_shims.inc"

@@ -1,0 +1,138 @@
+// xmr.hpp -- lane-replicated execution primitives for gfx950 (wave64).
+//
+// The reference replicates every instruction of a protected region 2 or 3 times in the IR of a single CPU thread
+// (cloning.cpp:2187-2209) and inserts voters at sync points (synchronization.cpp:741-949).  Here the replicas of one
+// logical work item are NREP ADJACENT LANES of a wavefront: lane = NREP*q + r holds replica r of the wave's q-th item,
+// a wave carries 64/NREP items (21 for TMR + one idle lane, 32 for DWC), and a sync point is a cross-lane exchange.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace coast {
+
+constexpr int kWave = 64;
+constexpr int kCounterSlots = 256; // per-workgroup counter slots, one 64-byte line each
+constexpr int kSlotStride = 8;     // uint64 per slot: {errors, syncs, dwc_items, pad...}
+
+// decoded fault descriptor written by the injector (side stream), sorted by workgroup
+struct DevFault {
+    uint32_t block;   // workgroup (logical id) that owns the item
+    uint32_t local;   // kernel specific: item slot inside the workgroup (+ element inside a register tile)
+    uint32_t step;
+    uint8_t replica, site, bit, index;
+};
+
+struct FaultTab {
+    const DevFault *list;   // sorted by block
+    const uint2 *range;     // per logical block: {first index, count}
+};
+
+struct Counters {
+    unsigned long long *slots; // [kCounterSlots][kSlotStride]
+};
+
+template <int NREP> struct LaneMap {
+    static constexpr int kItemsPerWave = kWave / NREP;
+    int lane;  // 0..63
+    int q;     // item slot in the wave
+    int r;     // replica id
+    bool live; // false for the idle lane(s) when 64 % NREP != 0
+    int base4; // byte address (lane*4) of replica 0 of this item, for ds_bpermute
+    __device__ __forceinline__ LaneMap()
+    {
+        lane = threadIdx.x & (kWave - 1);
+        q = lane / NREP;
+        r = lane - q * NREP;
+        live = q < kItemsPerWave;
+        base4 = (lane - r) * 4;
+    }
+};
+
+// Running tallies of one lane; only replica 0 of a live item tallies, so every sync point counts once.
+struct Tally {
+    uint32_t miss = 0;  // voted values whose copies were not all equal      (TMR_ERROR_CNT)
+    uint32_t syncs = 0; // sync points executed                               (__SYNC_COUNT)
+    uint32_t det = 0;   // DWC: a compare failed on the current item
+};
+
+// One sync point on a 32-bit value.
+//   TMR  vote = (a == b) ? a : c, whole-value compare (synchronization.cpp:934-938); miss = !((a==b)&&(a==c))
+//        (:1391-1400); all three replicas continue from the voted value (:527-529).
+//   DWC  mismatch = (a != b) (:1117-1192); replicas keep their own value, the item is flagged.
+// `count` gates the tallies (false for padding elements and idle lanes); the exchange itself is wave-wide.
+template <int NREP>
+__device__ __forceinline__ uint32_t xmr_sync(uint32_t v, const LaneMap<NREP> &lm, bool count, Tally &t)
+{
+    if constexpr (NREP == 3) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(lm.base4, (int)v);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(lm.base4 + 4, (int)v);
+        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(lm.base4 + 8, (int)v);
+        const bool e01 = (a == b), e02 = (a == c);
+        if (count) {
+            t.syncs += 1;
+            t.miss += (e01 && e02) ? 0u : 1u;
+        }
+        return e01 ? a : c;
+    } else if constexpr (NREP == 2) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(lm.base4, (int)v);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(lm.base4 + 4, (int)v);
+        if (count) {
+            t.syncs += 1;
+            t.det |= (a != b) ? 1u : 0u;
+        }
+        return v;
+    } else {
+        return v;
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += (uint32_t)__shfl_xor((int)v, o, kWave);
+    return v;
+}
+
+// Mismatch / sync / detected-item counters: lane -> wave (shuffle) -> LDS (one atomic per wave) -> one global
+// atomic per workgroup into the workgroup's slot.  `s_cnt` is 3 x uint32 of LDS, zeroed by the caller before a barrier.
+__device__ __forceinline__ void block_tally(uint32_t miss, uint32_t syncs, uint32_t detItems, uint32_t *s_cnt,
+                                            const Counters &ctr, uint32_t slotKey)
+{
+    const uint32_t wm = wave_sum(miss), ws = wave_sum(syncs), wd = wave_sum(detItems);
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        if (wm)
+            atomicAdd(&s_cnt[0], wm);
+        if (ws)
+            atomicAdd(&s_cnt[1], ws);
+        if (wd)
+            atomicAdd(&s_cnt[2], wd);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long *slot = ctr.slots + (size_t)(slotKey % kCounterSlots) * kSlotStride;
+        if (s_cnt[0])
+            atomicAdd(slot + 0, (unsigned long long)s_cnt[0]);
+        if (s_cnt[1])
+            atomicAdd(slot + 1, (unsigned long long)s_cnt[1]);
+        if (s_cnt[2])
+            atomicAdd(slot + 2, (unsigned long long)s_cnt[2]);
+    }
+}
+
+// XCD-aware logical block id: the dispatcher places hardware block b on XCD b % 8 (each XCD has a private L2), so
+// give every XCD one contiguous range of logical blocks -- neighbours that share inputs then share an L2.
+__device__ __forceinline__ uint32_t xcd_logical_block(uint32_t hw, uint32_t nblocks)
+{
+    constexpr uint32_t X = 8;
+    const uint32_t per = nblocks / X, rem = nblocks % X; // XCD x owns per + (x < rem) blocks
+    const uint32_t x = hw % X, i = hw / X;
+    return x * per + (x < rem ? x : rem) + i;
+}
+
+__device__ __forceinline__ uint32_t flip_bit(uint32_t v, uint32_t bit, uint32_t liveMask)
+{
+    return v ^ ((1u << (bit & 31u)) & liveMask); // flipOneBit, injector.py:202-207
+}
+
+} // namespace coast

@@ -1,0 +1,144 @@
+"""Batch engine: device-resident inputs -> protected kernels -> device-resident outputs + fault counters.
+
+Mirrors the reference's user-facing controls for the hot path: -TMR / -DWC select the replica count
+(projects/TMR/TMR.cpp:33, projects/DWC/DWC.cpp:33), -countErrors / -countSyncs expose TMR_ERROR_CNT / __SYNC_COUNT
+(projects/dataflowProtection/dataflowProtection.cpp:37,46).  torch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+
+TMR, DWC, UNPROTECTED = 3, 2, 1
+
+
+@dataclass(frozen=True)
+class XmrConfig:
+    replicas: int = TMR   # 3 = -TMR, 2 = -DWC, 1 = no protection
+    sync_every: int = 0   # extra loop-condition sync points every V steps (0 = mandatory sync points only)
+
+    def c(self):
+        return _lib.CoastCfg(self.replicas, self.sync_every)
+
+
+def make_faults(rows):
+    """rows: iterable of (item, replica, site, step, bit[, index]) -> structured array of coast_fault."""
+    rows = list(rows)
+    f = np.zeros(len(rows), dtype=_lib.FAULT_DTYPE)
+    for q, row in enumerate(rows):
+        item, replica, site, step, bit = row[:5]
+        f[q] = (item, step, replica, site, bit, row[5] if len(row) > 5 else 0)
+    return f
+
+
+def _ptr(t: torch.Tensor):
+    return C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One context per GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device: int | None = None):
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.CoastLibraryError("no GPU visible: coast_amd only runs on an MI355X (no CPU fallback)")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        h = C.c_void_p()
+        rc = self._lib.coast_create(C.byref(h), self.device)
+        if rc != 0:
+            raise RuntimeError("coast_create failed with %d" % rc)
+        self._h = h
+        # totals live in a torch tensor so that torch.distributed (RCCL) can all-reduce them in place
+        self.counters = torch.zeros(4, dtype=torch.int64, device="cuda:%d" % self.device)
+        self._check(self._lib.coast_bind_counters(self._h, _ptr(self.counters)))
+        self.use_stream(torch.cuda.current_stream(self.device))
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("libcoast_hip: %s (code %d)" % (self._lib.coast_last_error(self._h).decode(), rc))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.coast_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_stream(self, stream: torch.cuda.Stream):
+        self._stream = stream
+        self._check(self._lib.coast_set_stream(self._h, C.c_void_p(stream.cuda_stream)))
+
+    # -- fault injector
+    def inject_faults(self, faults):
+        """Arm single-bit flips (structured array of FAULT_DTYPE) for the next protected launch."""
+        f = np.ascontiguousarray(faults, dtype=_lib.FAULT_DTYPE)
+        self._check(self._lib.coast_inject_faults(self._h, f.ctypes.data_as(C.c_void_p), len(f)))
+
+    # -- counters
+    def reduce_counters(self):
+        """Fold the per-workgroup slots into self.counters (async, on the engine's stream)."""
+        self._check(self._lib.coast_reduce_counters(self._h))
+        return self.counters
+
+    def stats(self) -> dict:
+        st = _lib.CoastStats()
+        self._check(self._lib.coast_read_stats(self._h, C.byref(st)))
+        return {"errors_corrected": int(st.errors_corrected), "sync_count": int(st.sync_count),
+                "dwc_detected": int(st.dwc_detected), "launches": int(st.launches)}
+
+    def reset_stats(self):
+        self._check(self._lib.coast_reset_stats(self._h))
+
+    # -- protected regions
+    def mm_batch(self, f, s, out=None, cfg: XmrConfig = XmrConfig(), detected=None):
+        """f, s: (batch, n, n) int32/uint32-bit-pattern tensors on the GPU.  Returns r with the same layout."""
+        assert f.is_cuda and s.is_cuda and f.is_contiguous() and s.is_contiguous()
+        assert f.dtype in (torch.int32, torch.uint32) and f.shape == s.shape and f.dim() == 3
+        batch, n, _ = f.shape
+        if out is None:
+            out = torch.empty_like(f)
+        cc = cfg.c()
+        self._check(self._lib.coast_mm_batch(self._h, _ptr(f), _ptr(s), _ptr(out), n, batch, C.byref(cc),
+                                             _ptr(detected) if detected is not None else None))
+        return out
+
+    def sha256_batch(self, msgs, length, out=None, cfg: XmrConfig = XmrConfig(), detected=None):
+        """msgs: (n_msgs, stride) uint8 on the GPU; message m = first `length` bytes of row m."""
+        assert msgs.is_cuda and msgs.dtype == torch.uint8 and msgs.dim() == 2 and msgs.is_contiguous()
+        n, stride = msgs.shape
+        if out is None:
+            out = torch.empty((n, 32), dtype=torch.uint8, device=msgs.device)
+        cc = cfg.c()
+        self._check(self._lib.coast_sha256_batch(self._h, _ptr(msgs), stride, length, n, _ptr(out), C.byref(cc),
+                                                 _ptr(detected) if detected is not None else None))
+        return out
+
+    def aes128_batch(self, states, keys, direction, cfg: XmrConfig = XmrConfig(DWC), detected=None):
+        """states, keys: (n, 16) uint8 on the GPU, both updated IN PLACE (reference contract)."""
+        assert states.is_cuda and keys.is_cuda and states.dtype == torch.uint8 and keys.dtype == torch.uint8
+        assert states.shape == keys.shape and states.shape[1] == 16 and states.is_contiguous() and keys.is_contiguous()
+        cc = cfg.c()
+        self._check(self._lib.coast_aes128_batch(self._h, _ptr(states), _ptr(keys), states.shape[0], int(direction),
+                                                 C.byref(cc), _ptr(detected) if detected is not None else None))
+        return states, keys
+
+    def crc16_batch(self, data, block_len, out=None, cfg: XmrConfig = XmrConfig(), detected=None):
+        """data: uint8 tensor holding n_blocks * block_len bytes.  Returns (n_blocks,) crcs as int16 bit patterns."""
+        assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
+        nb = data.numel() // block_len if block_len else data.shape[0]
+        if out is None:
+            out = torch.empty(nb, dtype=torch.int16, device=data.device)
+        cc = cfg.c()
+        self._check(self._lib.coast_crc16_batch(self._h, _ptr(data), block_len, nb, _ptr(out), C.byref(cc),
+                                                _ptr(detected) if detected is not None else None))
+        return out

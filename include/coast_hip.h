@@ -1,0 +1,139 @@
+/*
+ * coast_hip.h -- C ABI of libcoast_hip.so: the MI355X (gfx950) redundant-execution engine that replaces
+ * COAST's dataflowProtection passes (-TMR / -DWC) for the four benchmark kernels of the hot path.
+ *
+ * The reference has no run-time FFI: its boundary is source + symbol conventions.
+ * Each entry point below names the reference interface it replaces (paths relative to the reference checkout).
+ * All pointers named d_* are DEVICE pointers (HBM); everything else is host memory.  Calls are asynchronous
+ * on the context's stream unless stated; only coast_read_stats() and the single-call shims synchronise.
+ * Every function returns 0 on success or a negative COAST_E* code; coast_last_error() has the text.
+ * There is no CPU fallback anywhere behind this interface.
+ */
+#ifndef COAST_HIP_H
+#define COAST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COAST_HIP_ABI_VERSION 1
+
+enum {
+    COAST_OK = 0,
+    COAST_EINVAL = -1, /* bad argument (NULL pointer, replicas not in {1,2,3}, size overflow ...) */
+    COAST_EHIP = -2,   /* a HIP runtime call failed */
+    COAST_ENODEV = -3, /* no gfx950 device */
+    COAST_ENOMEM = -4
+};
+
+/* Protection mode.  replicas = 3 is what `opt -TMR` selects (projects/TMR/TMR.cpp:33, DP.run(M,3)),
+ * replicas = 2 is `opt -DWC` (projects/DWC/DWC.cpp:33), replicas = 1 runs the region unprotected.
+ * The engine instantiates the reference's `-noMemReplication -countErrors -countSyncs` rule set
+ * (dataflowProtection.cpp:14-18,37,46): one memory copy, every register value replicated across adjacent
+ * lanes, store data and return values voted.  sync_every adds the reference's loop-condition sync points at a
+ * chosen granularity (synchronization.cpp:146-155): mm = every V k-steps, crc16 = every V bytes,
+ * aes = 1 -> after every round; 0 = mandatory sync points only. */
+typedef struct coast_cfg {
+    uint32_t replicas;
+    uint32_t sync_every;
+} coast_cfg;
+
+/* Counters.  errors_corrected is TMR_ERROR_CNT (synchronization.cpp:269-294,1391-1443: +1 per voted value whose
+ * copies are not all equal); sync_count is __SYNC_COUNT (:103-121,1415-1425); dwc_detected counts the work items on
+ * which a DWC compare failed (each would have called FAULT_DETECTED_DWC(), :1299-1302). */
+typedef struct coast_stats {
+    uint64_t errors_corrected;
+    uint64_t sync_count;
+    uint64_t dwc_detected;
+    uint64_t launches;
+} coast_stats;
+
+/* Fault sites, replacing the QEMU/GDB injector's "random register" targets
+ * (simulation/platform/resources/injector.py:163-167,237-260). */
+enum {
+    COAST_SITE_MM_ACC = 0, /* accumulator before the MAC of k == step (step == n: after the loop) */
+    COAST_SITE_MM_OPA = 1, /* loaded f[i][k], k == step */
+    COAST_SITE_MM_OPB = 2, /* loaded s[k][j], k == step */
+    COAST_SITE_SHA_M = 8,  /* schedule word m[step%64] of compression step/64, right after it is produced */
+    COAST_SITE_SHA_WV = 9, /* working variable index 0..7 (a..h) before round step%64 of compression step/64 */
+    COAST_SITE_SHA_STATE = 10, /* ctx_state[index] before compression `step` (== ncompress: before the digest) */
+    COAST_SITE_AES_STATE = 16, /* state dword `index` at the start of main-loop round `step` (10: after the loop) */
+    COAST_SITE_AES_KEY = 17,   /* running round-key dword `index`, same timing */
+    COAST_SITE_CRC_CRC = 24,   /* crc register before byte `step` (== length: after the loop) */
+    COAST_SITE_CRC_X = 25      /* temporary x of byte `step` after x ^= x>>4 */
+};
+
+/* One single-event upset: new = old XOR (1 << bit) on the 32-bit register holding the value
+ * (FaultInjector.flipOneBit, injector.py:202-207).  Only replica-private state can be hit. */
+typedef struct coast_fault {
+    uint64_t item;   /* mm: b*n*n + i*n + j ; sha256: message ; aes: block ; crc16: block */
+    uint32_t step;
+    uint8_t replica; /* 0 .. replicas-1 */
+    uint8_t site;    /* COAST_SITE_* */
+    uint8_t bit;     /* 0..31 */
+    uint8_t index;
+} coast_fault;
+
+typedef struct coast_ctx coast_ctx;
+
+/* ---- context ---- */
+int coast_create(coast_ctx **out, int device);
+void coast_destroy(coast_ctx *ctx);
+const char *coast_last_error(const coast_ctx *ctx);
+int coast_abi_version(void);
+/* protected kernels run on `hip_stream` (a hipStream_t; NULL = the null stream) */
+int coast_set_stream(coast_ctx *ctx, void *hip_stream);
+/* Optional: totals are accumulated into the caller's device buffer of 4 x uint64
+ * {errors_corrected, sync_count, dwc_detected, launches} (e.g. a tensor that RCCL all-reduces across GPUs,
+ * replacing the single global TMR_ERROR_CNT of synchronization.cpp:1428-1431).  NULL restores the internal one. */
+int coast_bind_counters(coast_ctx *ctx, uint64_t *d_totals);
+/* fold the per-workgroup counter slots into the totals (async; coast_read_stats does it implicitly) */
+int coast_reduce_counters(coast_ctx *ctx);
+int coast_read_stats(coast_ctx *ctx, coast_stats *out); /* synchronises the stream */
+int coast_reset_stats(coast_ctx *ctx);
+
+/* ---- on-device fault injector (replaces simulation/platform/supervisor.py + injector.py) ----
+ * Arms `k` single-bit flips for the NEXT protected launch on this context.  The descriptor table is written on
+ * a side stream and event-ordered before the consuming kernel; it is consumed by exactly one launch. */
+int coast_inject_faults(coast_ctx *ctx, const coast_fault *faults, size_t k);
+
+/* ---- protected regions (batch entry points) ---- */
+
+/* matrix_multiply (tests/mm_common/mm_common_tmr.c:3-20; LANL variant tests/matrixMultiply/matrixMultiply.c:95-112):
+ * `batch` independent n x n row-major uint32 products, r = (uint32) sum_k f[i][k]*s[k][j].
+ * d_detected: optional, one byte per output element, set to 1 where a DWC compare failed. */
+int coast_mm_batch(coast_ctx *ctx, const uint32_t *d_f, const uint32_t *d_s, uint32_t *d_r, int n, size_t batch,
+                   const coast_cfg *cfg, uint8_t *d_detected);
+
+/* sha256_hash (tests/sha256_common/sha256_common_tmr.c:100-179): n_msgs messages of `len` bytes, message m at
+ * d_msgs + m*stride; digests big-endian, 32 bytes each. */
+int coast_sha256_batch(coast_ctx *ctx, const uint8_t *d_msgs, size_t stride, uint32_t len, size_t n_msgs,
+                       uint8_t *d_digests, const coast_cfg *cfg, uint8_t *d_detected);
+
+/* aes_enc_dec (tests/aes/TI_aes_128.c:107-231): n blocks, 16-byte state and 16-byte key each, both updated IN PLACE
+ * exactly like the reference (encrypt leaves the last round key in `key`, decrypt restores the cipher key).
+ * dir = 0 encrypt, != 0 decrypt. */
+int coast_aes128_batch(coast_ctx *ctx, uint8_t *d_states, uint8_t *d_keys, size_t n, int dir, const coast_cfg *cfg,
+                       uint8_t *d_detected);
+
+/* crc16 (tests/crc16/crc16.c:21-31): n_blocks independent blocks of block_len bytes (the reference's `length` is an
+ * unsigned char, so one call covers <= 255 bytes; larger streams are batches of blocks), crc per block. */
+int coast_crc16_batch(coast_ctx *ctx, const uint8_t *d_data, uint32_t block_len, size_t n_blocks, uint16_t *d_crcs,
+                      const coast_cfg *cfg, uint8_t *d_detected);
+
+/* ---- single-call host shims with the reference's data contract (host pointers, synchronous) ---- */
+/* matrix_multiply's `side` is a macro in the reference (mm_tmr.c:10), so the glue TU passes it explicitly */
+int coast_matrix_multiply_host(const uint32_t *f, const uint32_t *s, uint32_t *r, int side, const coast_cfg *cfg);
+int coast_sha256_host(const uint8_t *data, uint32_t len, uint8_t hash[32], uint32_t state_out[8], const coast_cfg *cfg);
+int coast_aes_enc_dec_host(uint8_t *state, uint8_t *key, uint8_t dir, const coast_cfg *cfg);
+int coast_crc16_host(const uint8_t *data, uint32_t length, uint16_t *crc, const coast_cfg *cfg);
+/* counters accumulated by the host shims since the last call (what TMR_ERROR_CNT / __SYNC_COUNT expose) */
+int coast_host_stats(coast_stats *out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COAST_HIP_H */

@@ -1,0 +1,338 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI of libcoast_hip.so, against the CPU oracle on the
+same seeded inputs and fault lists, against the committed golden fixtures, and through size-independent properties.
+Bit-exact everywhere (integer kernels)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import gen_mm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    import coast_amd
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    e = coast_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def _dev(a):
+    import torch
+
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        return torch.from_numpy(a.view(np.int32)).cuda()
+    if a.dtype == np.uint16:
+        return torch.from_numpy(a.view(np.int16)).cuda()
+    return torch.from_numpy(a).cuda()
+
+
+def _host(t, dtype):
+    return t.cpu().numpy().view(dtype)
+
+
+def _stats3(st):
+    return {k: st[k] for k in ("errors_corrected", "sync_count", "dwc_detected")}
+
+
+def _rand_faults(rng, k, nitems, nrep, sites, max_step, max_index=1):
+    import coast_amd
+
+    rows = []
+    for _ in range(k):
+        site = int(rng.choice(sites))
+        rows.append((int(rng.integers(0, nitems)), int(rng.integers(0, nrep)), site,
+                     int(rng.integers(0, max_step + 1)), int(rng.integers(0, 32)), int(rng.integers(0, max_index))))
+    return coast_amd.make_faults(rows)
+
+
+# ------------------------------------------------------------------------------------------------ mm
+@pytest.mark.parametrize("n", [9, 19, 30, 32])
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+def test_mm_golden_fixtures(eng, orc, golden, n, replicas):
+    import coast_amd
+
+    f, s, r = golden["mm"]["f%d" % n], golden["mm"]["s%d" % n], golden["mm"]["r%d" % n]
+    eng.reset_stats()
+    got = _host(eng.mm_batch(_dev(f[None]), _dev(s[None]), cfg=coast_amd.XmrConfig(replicas)), np.uint32)[0]
+    assert (got == r).all()
+    assert int(np.bitwise_xor.reduce(got.reshape(-1))) == golden["mm_xor_golden_%d" % n]
+    st = eng.stats()
+    assert st["errors_corrected"] == 0 and st["dwc_detected"] == 0
+    assert st["sync_count"] == (n * n if replicas > 1 else 0)
+
+
+def test_mm_256_golden(eng, golden):
+    f, s = gen_mm(256)
+    assert hashlib.sha256(f.tobytes() + s.tobytes()).hexdigest() == golden["mm_inputs_sha256_256"]
+    eng.reset_stats()
+    got = _host(eng.mm_batch(_dev(f[None]), _dev(s[None])), np.uint32)[0]
+    assert int(np.bitwise_xor.reduce(got.reshape(-1))) == golden["mm_xor_golden_256"]
+    assert hashlib.sha256(got.tobytes()).hexdigest() == golden["mm_result_sha256_256"]
+    assert _stats3(eng.stats()) == {"errors_corrected": 0, "sync_count": 65536, "dwc_detected": 0}
+
+
+def test_mm_lanl_variant(eng, golden):
+    ij = np.fromfunction(lambda i, j: i * j, (32, 32), dtype=np.int64).astype(np.uint32)
+    got = _host(eng.mm_batch(_dev(ij[None]), _dev(ij[None])), np.uint32)[0]
+    assert (got == golden["mm"]["lanl_r32"]).all()
+
+
+@pytest.mark.parametrize("n,batch", [(1, 5), (3, 7), (9, 11), (17, 3), (32, 4), (33, 2), (64, 2), (100, 1)])
+@pytest.mark.parametrize("replicas,sync_every", [(3, 0), (3, 5), (2, 0), (2, 3), (1, 0)])
+def test_mm_faults_vs_oracle(eng, orc, n, batch, replicas, sync_every):
+    import coast_amd
+
+    rng = np.random.default_rng(1000 * n + 10 * replicas + sync_every)
+    f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    k = 0 if replicas == 1 else 40
+    fl = _rand_faults(rng, k, batch * n * n, replicas, [0, 1, 2], n)
+    exp_r, exp_st, exp_det = orc.mm_xmr(f, s, replicas=replicas, sync_every=sync_every, faults=fl)
+    import torch
+
+    det = torch.zeros(batch * n * n, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    got = _host(eng.mm_batch(_dev(f), _dev(s), cfg=coast_amd.XmrConfig(replicas, sync_every), detected=det), np.uint32)
+    assert (got == exp_r).all()
+    assert _stats3(eng.stats()) == exp_st
+    assert (det.cpu().numpy() == exp_det).all()
+    # the table is consumed by exactly one launch: the next one is clean
+    eng.reset_stats()
+    got = _host(eng.mm_batch(_dev(f), _dev(s), cfg=coast_amd.XmrConfig(replicas, sync_every)), np.uint32)
+    clean, clean_st, _ = orc.mm_xmr(f, s, replicas=replicas, sync_every=sync_every)
+    assert (got == clean).all() and _stats3(eng.stats()) == clean_st
+
+
+def test_mm_voter_select_semantics(eng, orc, golden):
+    """synchronization.cpp:934-938 -- two replicas hit: (a==b)?a:c differs from a bitwise majority."""
+    import coast_amd
+
+    f, s = golden["mm"]["f9"][None], golden["mm"]["s9"][None]
+    item = 9 * 4 + 5
+    for rows in ([(item, 0, 0, 9, 3), (item, 2, 0, 9, 12)], [(item, 0, 0, 9, 7), (item, 1, 0, 9, 7)],
+                 [(item, 0, 0, 9, 3), (item, 1, 0, 9, 4), (item, 2, 0, 9, 5)], [(item, 1, 2, 4, 31)]):
+        fl = coast_amd.make_faults(rows)
+        exp_r, exp_st, _ = orc.mm_xmr(f, s, faults=fl)
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        got = _host(eng.mm_batch(_dev(f), _dev(s)), np.uint32)
+        assert (got == exp_r).all() and _stats3(eng.stats()) == exp_st
+
+
+def test_mm_256_batch_properties(eng, orc):
+    """Full-size config: linearity mod 2^32 (r(f1+f2, s) == r(f1,s)+r(f2,s)), sparse oracle check, exact fault count."""
+    import coast_amd
+
+    rng = np.random.default_rng(256)
+    batch, n = 6, 256
+    f1 = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    f2 = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    r1 = _host(eng.mm_batch(_dev(f1), _dev(s)), np.uint32)
+    r2 = _host(eng.mm_batch(_dev(f2), _dev(s)), np.uint32)
+    items = rng.choice(batch * n * n, 300, replace=False).astype(np.uint64)
+    fl = coast_amd.make_faults([(int(it), int(rng.integers(0, 3)), 0, int(rng.integers(0, n + 1)),
+                                 int(rng.integers(0, 32))) for it in items[:200]])
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    r12 = _host(eng.mm_batch(_dev(f1 + f2), _dev(s)), np.uint32)
+    assert (r12 == r1 + r2).all()
+    st = eng.stats()
+    assert st["errors_corrected"] == 200 and st["sync_count"] == batch * n * n  # one accumulator flip per item
+    exp, _, _ = orc.mm_xmr_items(f1 + f2, s, items)
+    assert (r12.reshape(-1)[items.astype(np.int64)] == exp).all()
+
+
+# ------------------------------------------------------------------------------------------------ sha256
+@pytest.mark.parametrize("tag", ["10", "4000"])
+def test_sha256_golden(eng, golden, tag):
+    import torch
+
+    data = golden["sha"]["data" + tag]
+    msgs = torch.from_numpy(np.ascontiguousarray(data[None])).cuda()
+    eng.reset_stats()
+    dig = eng.sha256_batch(msgs, len(data)).cpu().numpy()[0].tobytes()
+    assert dig == golden["sha"]["golden" + tag].tobytes()
+    ncomp = len(data) // 64 + (1 if len(data) % 64 < 56 else 2)
+    assert _stats3(eng.stats()) == {"errors_corrected": 0, "sync_count": 8 * ncomp + 8, "dwc_detected": 0}
+
+
+@pytest.mark.parametrize("length,stride", [(0, 4), (1, 1), (10, 10), (55, 55), (56, 56), (63, 64), (64, 64), (65, 68),
+                                           (119, 120), (120, 120), (200, 256), (1000, 1000)])
+def test_sha256_lengths_vs_hashlib(eng, length, stride):
+    import torch
+
+    rng = np.random.default_rng(length)
+    msgs = rng.integers(0, 256, (97, stride), dtype=np.uint8)
+    dig = eng.sha256_batch(torch.from_numpy(msgs).cuda(), length).cpu().numpy()
+    for m in range(97):
+        assert dig[m].tobytes() == hashlib.sha256(msgs[m, :length].tobytes()).digest()
+
+
+@pytest.mark.parametrize("replicas", [3, 2])
+@pytest.mark.parametrize("length", [10, 64, 150])
+def test_sha256_faults_vs_oracle(eng, orc, replicas, length):
+    import torch
+
+    import coast_amd
+
+    rng = np.random.default_rng(77 + length + replicas)
+    nm = 500
+    msgs = rng.integers(0, 256, (nm, ((length + 3) // 4) * 4), dtype=np.uint8)
+    ncomp = length // 64 + (1 if length % 64 < 56 else 2)
+    rows = []
+    for _ in range(120):
+        site = int(rng.choice([8, 9, 10]))
+        step = int(rng.integers(0, ncomp + 1)) if site == 10 else int(rng.integers(0, ncomp * 64))
+        rows.append((int(rng.integers(0, nm)), int(rng.integers(0, replicas)), site, step, int(rng.integers(0, 32)),
+                     int(rng.integers(0, 8))))
+    fl = coast_amd.make_faults(rows)
+    exp, exp_st, exp_det = orc.sha256_xmr(msgs, length, replicas=replicas, faults=fl)
+    det = torch.zeros(nm, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    got = eng.sha256_batch(torch.from_numpy(msgs).cuda(), length, cfg=coast_amd.XmrConfig(replicas),
+                           detected=det).cpu().numpy()
+    assert (got == exp).all()
+    assert _stats3(eng.stats()) == exp_st
+    assert (det.cpu().numpy() == exp_det).all()
+    if replicas == 3:  # single upsets are all masked: digests equal the clean run
+        for m in range(0, nm, 17):
+            assert got[m].tobytes() == hashlib.sha256(msgs[m, :length].tobytes()).digest()
+
+
+# ------------------------------------------------------------------------------------------------ aes
+def test_aes_kat(eng, golden):
+    """tests/aes/aes.c:91-99 on all 568 NIST vectors at once: enc == ciphertext, dec == plaintext, 0 errors."""
+    import torch
+
+    kat = golden["aes_kat"]
+    key, key2, ct, pt, inp = (np.ascontiguousarray(kat[:, 16 * q:16 * q + 16]) for q in range(5))
+    st, k1 = torch.from_numpy(inp.copy()).cuda(), torch.from_numpy(key.copy()).cuda()
+    eng.reset_stats()
+    eng.aes128_batch(st, k1, 0)
+    assert (st.cpu().numpy() == ct).all()
+    k2 = torch.from_numpy(key2.copy()).cuda()
+    eng.aes128_batch(st, k2, 1)
+    assert (st.cpu().numpy() == pt).all()
+    assert (k2.cpu().numpy() == key2).all()  # decrypt restores the cipher key
+    assert _stats3(eng.stats()) == {"errors_corrected": 0, "sync_count": 2 * 568 * 8, "dwc_detected": 0}
+
+
+@pytest.mark.parametrize("replicas,sync_every", [(2, 0), (2, 1), (3, 0), (3, 1), (1, 0)])
+@pytest.mark.parametrize("direction", [0, 1])
+def test_aes_faults_vs_oracle(eng, orc, replicas, sync_every, direction):
+    import torch
+
+    import coast_amd
+
+    rng = np.random.default_rng(5 + replicas * 4 + sync_every * 2 + direction)
+    n = 1000
+    st = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    key = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    fl = _rand_faults(rng, 0 if replicas == 1 else 150, n, replicas, [16, 17], 10, max_index=4)
+    es, ek, exp_st, exp_det = orc.aes128_xmr(st, key, direction, replicas=replicas, sync_every=sync_every, faults=fl)
+    ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(key.copy()).cuda()
+    det = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    eng.aes128_batch(ds, dk, direction, cfg=coast_amd.XmrConfig(replicas, sync_every), detected=det)
+    assert (ds.cpu().numpy() == es).all() and (dk.cpu().numpy() == ek).all()
+    assert _stats3(eng.stats()) == exp_st
+    assert (det.cpu().numpy() == exp_det).all()
+
+
+def test_aes_roundtrip_1M(eng):
+    """BASELINE config 3 size: 2^20 blocks with per-block keys, encrypt then decrypt must round-trip."""
+    import torch
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    n = 1 << 20
+    pt = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda", generator=g)
+    key = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda", generator=g)
+    st, k = pt.clone(), key.clone()
+    eng.reset_stats()
+    eng.aes128_batch(st, k, 0)
+    assert not torch.equal(st, pt)
+    k2 = key.clone()
+    eng.aes128_batch(st, k2, 1)
+    assert torch.equal(st, pt) and torch.equal(k2, key)
+    assert eng.stats()["dwc_detected"] == 0
+
+
+# ------------------------------------------------------------------------------------------------ crc16
+def test_crc16_vectors(eng, golden):
+    import coast_amd
+
+    for v in golden["crc16_vectors"]:
+        assert coast_amd.crc16(bytes.fromhex(v["data"])) == v["crc"]
+
+
+@pytest.mark.parametrize("block_len", [1, 13, 64, 255, 256])
+@pytest.mark.parametrize("replicas,sync_every", [(3, 0), (3, 7), (2, 0), (1, 0)])
+def test_crc16_faults_vs_oracle(eng, orc, block_len, replicas, sync_every):
+    import torch
+
+    import coast_amd
+
+    rng = np.random.default_rng(block_len * 7 + replicas + sync_every)
+    nb = 700
+    data = rng.integers(0, 256, (nb, block_len), dtype=np.uint8)
+    fl = _rand_faults(rng, 0 if replicas == 1 else 100, nb, replicas, [24, 25], block_len)
+    exp, exp_st, exp_det = orc.crc16_xmr(data, block_len, replicas=replicas, sync_every=sync_every, faults=fl)
+    det = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    got = _host(eng.crc16_batch(torch.from_numpy(data).cuda(), block_len, cfg=coast_amd.XmrConfig(replicas, sync_every),
+                                detected=det), np.uint16)
+    assert (got == exp).all()
+    assert _stats3(eng.stats()) == exp_st
+    assert (det.cpu().numpy() == exp_det).all()
+
+
+def test_crc16_stream_prefix_and_linearity(eng, orc):
+    """Stream config: parity on a 1 MiB prefix vs the oracle; CRC linearity crc(a^b) ^ crc(a) ^ crc(b) == crc(0)."""
+    import torch
+
+    g = torch.Generator(device="cuda").manual_seed(16)
+    nb, bl = 1 << 16, 256
+    a = torch.randint(0, 256, (nb * bl,), dtype=torch.uint8, device="cuda", generator=g)
+    b = torch.randint(0, 256, (nb * bl,), dtype=torch.uint8, device="cuda", generator=g)
+    ca = _host(eng.crc16_batch(a, bl), np.uint16)
+    cb = _host(eng.crc16_batch(b, bl), np.uint16)
+    cx = _host(eng.crc16_batch(a ^ b, bl), np.uint16)
+    c0 = orc.crc16_plain(bytes(bl))
+    assert ((cx ^ ca ^ cb) == c0).all()
+    pre = a[: 1 << 20].cpu().numpy().reshape(-1, bl)
+    exp, _, _ = orc.crc16_xmr(pre, bl)
+    assert (ca[: pre.shape[0]] == exp).all()
+
+
+# ------------------------------------------------------------------------------------------------ boundary
+def test_reference_named_host_calls(eng, orc, golden):
+    """The single-call shims carry the reference's data contract (host buffers, in-place key schedule)."""
+    import coast_amd
+
+    coast_amd.host_stats(reset=True)
+    f, s = golden["mm"]["f9"], golden["mm"]["s9"]
+    assert (coast_amd.matrix_multiply(f, s) == golden["mm"]["r9"]).all()
+    data = golden["sha"]["data10"].tobytes()
+    assert coast_amd.sha256_hash(data) == golden["sha"]["golden10"].tobytes()
+    row = golden["aes_kat"][100]
+    key, key2, ct, pt, inp = (row[16 * q:16 * q + 16].tobytes() for q in range(5))
+    enc, k_after = coast_amd.aes_enc_dec(inp, key, 0)
+    assert enc == ct and (enc, k_after) == orc.aes128_plain(inp, key, 0)
+    dec, k2_after = coast_amd.aes_enc_dec(enc, key2, 1)
+    assert dec == pt and k2_after == key2
+    assert coast_amd.crc16(b"Automated TMR") == 0x5BA3
+    st = coast_amd.host_stats()
+    assert st["errors_corrected"] == 0 and st["sync_count"] == 81 + 16 + 16 + 1 and st["launches"] == 5
