@@ -205,9 +205,13 @@ def test_sha256_faults_vs_oracle(eng, orc, replicas, length):
     assert (got == exp).all()
     assert _stats3(eng.stats()) == exp_st
     assert (det.cpu().numpy() == exp_det).all()
-    if replicas == 3:  # single upsets are all masked: digests equal the clean run
-        for m in range(0, nm, 17):
-            assert got[m].tobytes() == hashlib.sha256(msgs[m, :length].tobytes()).digest()
+    if replicas == 3:  # a message hit in ONE replica only is fully masked: digest equals the clean run
+        hit = {}
+        for row in rows:
+            hit.setdefault(row[0], set()).add(row[1])
+        for m in range(nm):
+            if len(hit.get(m, ())) <= 1:
+                assert got[m].tobytes() == hashlib.sha256(msgs[m, :length].tobytes()).digest()
 
 
 # ------------------------------------------------------------------------------------------------ aes

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Time every protected kernel at the BASELINE.json config sizes (1 GPU) with HIP events on the launch stream.
+Not the bench contract (that is bench.py) -- a development probe whose output goes under profiles/."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import coast_amd  # noqa: E402
+
+
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return min(ts), sum(ts) / len(ts)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    eng = coast_amd.Engine(0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    res = {}
+
+    def want(k):
+        return not a.only or k in a.only.split(",")
+
+    if want("mm"):
+        for rep in (3, 2, 1):
+            batch, n = 2048, 256
+            f = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device="cuda", generator=g)
+            s = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device="cuda", generator=g)
+            r = torch.empty_like(f)
+            cfg = coast_amd.XmrConfig(rep)
+            mn, av = timeit(lambda: eng.mm_batch(f, s, out=r, cfg=cfg))
+            res["mm256_rep%d" % rep] = {"ms": mn, "elems_per_s": batch * n * n / mn * 1e3,
+                                        "TMAC_alg": batch * n**3 / mn * 1e-9}
+            del f, s, r
+    if want("sha"):
+        nm = 1 << 22
+        msgs = torch.randint(0, 256, (nm, 64), dtype=torch.uint8, device="cuda", generator=g)
+        out = torch.empty((nm, 32), dtype=torch.uint8, device="cuda")
+        for rep in (3, 2, 1):
+            cfg = coast_amd.XmrConfig(rep)
+            mn, av = timeit(lambda: eng.sha256_batch(msgs, 64, out=out, cfg=cfg))
+            res["sha256_4Mx64B_rep%d" % rep] = {"ms": mn, "msgs_per_s": nm / mn * 1e3, "GBs_in": nm * 64 / mn * 1e-6}
+    if want("aes"):
+        n = 1 << 20
+        st = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda", generator=g)
+        key = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda", generator=g)
+        for rep in (2, 3, 1):
+            for d in (0, 1):
+                cfg = coast_amd.XmrConfig(rep)
+                mn, av = timeit(lambda: eng.aes128_batch(st, key, d, cfg=cfg))
+                res["aes128_1M_rep%d_dir%d" % (rep, d)] = {"ms": mn, "blocks_per_s": n / mn * 1e3,
+                                                          "GBs": n * 64 / mn * 1e-6}
+    if want("crc"):
+        nbytes = 1 << 30
+        data = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device="cuda", generator=g)
+        for bl in (256, 255):
+            nb = nbytes // bl
+            out = torch.empty(nb, dtype=torch.int16, device="cuda")
+            for rep in (3, 2, 1):
+                cfg = coast_amd.XmrConfig(rep)
+                mn, av = timeit(lambda: eng.crc16_batch(data[: nb * bl], bl, out=out, cfg=cfg), reps=3, warm=1)
+                res["crc16_1GiB_bl%d_rep%d" % (bl, rep)] = {"ms": mn, "GBs": nb * bl / mn * 1e-6,
+                                                            "frac_of_8TBs": nb * bl / mn * 1e-6 / 8000}
+    for k, v in res.items():
+        print(k, json.dumps(v))
+
+
+if __name__ == "__main__":
+    main()
