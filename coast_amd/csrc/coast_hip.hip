@@ -44,6 +44,9 @@ struct coast_ctx {
     size_t listCap = 0;
     uint2 *dRange = nullptr;
     size_t rangeCap = 0;
+    uint32_t *hBlocks = nullptr; // pinned: distinct workgroups that own >= 1 armed fault
+    uint32_t *dBlocks = nullptr;
+    size_t blocksCap = 0;
 
     std::string err;
 };
@@ -87,9 +90,14 @@ typedef bool (*decode_fn)(const coast_fault &, const void *geom, DevFault &);
 
 // Upload the armed faults for a launch of `nblocks` workgroups.  Runs entirely on the side stream; the main stream
 // waits on evArmed.  Returns haveFaults (0/1) through *have.
-int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, FaultTab *ft, int *have)
+int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, FaultTab *ft, int *have,
+               const uint32_t **dBlockList = nullptr, uint32_t *nFaultBlocks = nullptr)
 {
     *have = 0;
+    if (dBlockList)
+        *dBlockList = nullptr;
+    if (nFaultBlocks)
+        *nFaultBlocks = 0;
     ft->list = nullptr;
     ft->range = nullptr;
     if (c->armed.empty())
@@ -105,6 +113,10 @@ int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, 
     if (dv.empty())
         return COAST_OK;
     std::stable_sort(dv.begin(), dv.end(), [](const DevFault &a, const DevFault &b) { return a.block < b.block; });
+    std::vector<uint32_t> blocks;
+    for (const DevFault &d : dv)
+        if (blocks.empty() || blocks.back() != d.block)
+            blocks.push_back(d.block);
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->side)); // pinned staging buffer free again
@@ -113,6 +125,16 @@ int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, 
             HIP_TRY(c, hipHostFree(c->hPinned));
         c->pinnedCap = std::max<size_t>(dv.size() * 2, 1024);
         HIP_TRY(c, hipHostMalloc((void **)&c->hPinned, c->pinnedCap * sizeof(DevFault), hipHostMallocDefault));
+    }
+    if (blocks.size() > c->blocksCap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->hBlocks)
+            HIP_TRY(c, hipHostFree(c->hBlocks));
+        if (c->dBlocks)
+            HIP_TRY(c, hipFree(c->dBlocks));
+        c->blocksCap = std::max<size_t>(blocks.size() * 2, 1024);
+        HIP_TRY(c, hipHostMalloc((void **)&c->hBlocks, c->blocksCap * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc((void **)&c->dBlocks, c->blocksCap * sizeof(uint32_t)));
     }
     if (c->consumedPending) { // the previous table may still be read by a kernel on the main stream
         HIP_TRY(c, hipStreamWaitEvent(c->side, c->evConsumed, 0));
@@ -134,6 +156,8 @@ int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, 
     }
     memcpy(c->hPinned, dv.data(), dv.size() * sizeof(DevFault));
     HIP_TRY(c, hipMemcpyAsync(c->dList, c->hPinned, dv.size() * sizeof(DevFault), hipMemcpyHostToDevice, c->side));
+    memcpy(c->hBlocks, blocks.data(), blocks.size() * sizeof(uint32_t));
+    HIP_TRY(c, hipMemcpyAsync(c->dBlocks, c->hBlocks, blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->side));
     HIP_TRY(c, hipMemsetAsync(c->dRange, 0, (size_t)nblocks * sizeof(uint2), c->side));
     const uint32_t k = (uint32_t)dv.size();
     hipLaunchKernelGGL(fault_range_kernel, dim3((k + 255) / 256), dim3(256), 0, c->side, c->dList, k, c->dRange);
@@ -143,6 +167,10 @@ int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, 
     ft->list = c->dList;
     ft->range = c->dRange;
     *have = 1;
+    if (dBlockList)
+        *dBlockList = c->dBlocks;
+    if (nFaultBlocks)
+        *nFaultBlocks = (uint32_t)blocks.size();
     return COAST_OK;
 }
 
@@ -203,6 +231,10 @@ extern "C" void coast_destroy(coast_ctx *c)
         (void)hipFree(c->dList);
     if (c->dRange)
         (void)hipFree(c->dRange);
+    if (c->hBlocks)
+        (void)hipHostFree(c->hBlocks);
+    if (c->dBlocks)
+        (void)hipFree(c->dBlocks);
     (void)hipFree(c->dSlots);
     (void)hipFree(c->dTotals);
     (void)hipEventDestroy(c->evArmed);
@@ -340,16 +372,18 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
         maxTileRows = std::max(maxTileRows, t1 / g.tc - t0 / g.tc + 1);
     }
     g.rs = 4 * maxTileRows;
-    // k-chunk: largest power of two <= 16 whose panels fit 48 KiB (>= 3 workgroups per CU)
-    g.kt = 16;
-    while (g.kt > 1 && (size_t)g.kt * (g.rs + g.npad) * 4 > 48 * 1024)
-        g.kt >>= 1;
+    // k-chunk: largest power of two <= 16 whose panels a workgroup can stage with its fixed per-thread slots and
+    // whose two LDS buffers leave room for >= 3 workgroups per CU
+    g.kt = 16; // the fast kernel is instantiated for kt in {16, 4, 1}
+    while (g.kt > 1 && ((size_t)g.kt * (g.npad / 4) > 256u * kMmMaxB || (size_t)g.kt * g.rs > 256u * kMmMaxA ||
+                        (size_t)2 * g.kt * (g.rs + g.npad) * 4 > 52 * 1024))
+        g.kt >>= 2;
+    if ((size_t)g.kt * (g.npad / 4) > 256u * kMmMaxB || (size_t)g.kt * g.rs > 256u * kMmMaxA)
+        return fail(c, COAST_EINVAL, "coast_mm_batch: side %d exceeds the staging geometry", n);
     g.ktLog2 = 0;
     while ((1 << g.ktLog2) < g.kt)
         ++g.ktLog2;
-    const size_t lds = (size_t)g.kt * (g.rs + g.npad) * 4 + 16;
-    if (lds > 160 * 1024)
-        return fail(c, COAST_EINVAL, "coast_mm_batch: side %d needs %zu B of LDS", n, lds);
+    const size_t lds = (size_t)2 * g.kt * (g.rs + g.npad) * 4 + 16;
     const uint64_t nb = (uint64_t)g.bpm * batch;
     if (nb > 0x7fffffffull)
         return fail(c, COAST_EINVAL, "coast_mm_batch: %llu workgroups exceed the grid limit", (unsigned long long)nb);
@@ -357,18 +391,48 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
 
     FaultTab ft;
     int have = 0;
-    rc = arm_faults(c, g.nblocks, decode_mm, &h, &ft, &have);
+    const uint32_t *dBlockList = nullptr;
+    uint32_t nFaultBlocks = 0;
+    rc = arm_faults(c, g.nblocks, decode_mm, &h, &ft, &have, &dBlockList, &nFaultBlocks);
     if (rc)
         return rc;
     Counters ctr{c->dSlots};
-    const dim3 grid(g.nblocks), block(256);
-#define LAUNCH_MM(R)                                                                                           \
-    do {                                                                                                       \
-        if (lds > 64 * 1024)                                                                                   \
-            HIP_TRY(c, hipFuncSetAttribute((const void *)mm_xmr_kernel<R>,                                     \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        hipLaunchKernelGGL(mm_xmr_kernel<R>, grid, block, lds, c->stream, d_f, d_s, d_r, g, cfg->sync_every,   \
-                           ctr, ft, have, d_detected);                                                         \
+    const dim3 block(256);
+    const bool allGeneral = cfg->sync_every != 0; // extra sync points: every workgroup takes the stepwise kernel
+#define LAUNCH_FAST(R, V, K)                                                                                    \
+    do {                                                                                                        \
+        if (lds > 64 * 1024)                                                                                    \
+            HIP_TRY(c, hipFuncSetAttribute((const void *)mm_fast_kernel<R, V, K>,                               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        hipLaunchKernelGGL((mm_fast_kernel<R, V, K>), dim3(g.nblocks), block, lds, c->stream, d_f, d_s, d_r, g, \
+                           ctr, have ? ft.range : (const uint2 *)nullptr, d_detected);                          \
+    } while (0)
+#define LAUNCH_FAST_K(R, V)                                                                                     \
+    do {                                                                                                        \
+        if (g.kt == 16)                                                                                         \
+            LAUNCH_FAST(R, V, 16);                                                                              \
+        else if (g.kt == 4)                                                                                     \
+            LAUNCH_FAST(R, V, 4);                                                                               \
+        else                                                                                                    \
+            LAUNCH_FAST(R, V, 1);                                                                               \
+    } while (0)
+#define LAUNCH_MM(R)                                                                                            \
+    do {                                                                                                        \
+        if (lds > 64 * 1024)                                                                                    \
+            HIP_TRY(c, hipFuncSetAttribute((const void *)mm_general_kernel<R>,                                  \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        if (allGeneral) {                                                                                       \
+            hipLaunchKernelGGL(mm_general_kernel<R>, dim3(g.nblocks), block, lds, c->stream, d_f, d_s, d_r, g,  \
+                               cfg->sync_every, ctr, ft, (const uint32_t *)nullptr, d_detected);                \
+        } else {                                                                                                \
+            if ((n & 3) == 0)                                                                                   \
+                LAUNCH_FAST_K(R, true);                                                                         \
+            else                                                                                                \
+                LAUNCH_FAST_K(R, false);                                                                        \
+            if (have && nFaultBlocks)                                                                           \
+                hipLaunchKernelGGL(mm_general_kernel<R>, dim3(nFaultBlocks), block, lds, c->stream, d_f, d_s,   \
+                                   d_r, g, 0u, ctr, ft, dBlockList, d_detected);                                \
+        }                                                                                                       \
     } while (0)
     if (cfg->replicas == 3)
         LAUNCH_MM(3);
@@ -376,6 +440,8 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
         LAUNCH_MM(2);
     else
         LAUNCH_MM(1);
+#undef LAUNCH_FAST
+#undef LAUNCH_FAST_K
 #undef LAUNCH_MM
     return after_launch(c, have);
 }

@@ -8,9 +8,17 @@
 // 4*IPW consecutive tiles of ONE matrix in row-major tile order, so it needs a few rows of f and a full-width panel
 // of s per k-chunk: both are loaded from HBM/L2 once, coalesced, into LDS, and every replica lane reads the same LDS
 // word (broadcast) -- the reference's -noMemReplication rule: one memory copy, loads repeated from the same address
-// (cloning.cpp:2247-2255).  The k-loop is VALU bound (3x the integer MACs of the unprotected kernel); LDS traffic is
-// 2 ds_read_b128 per 16 MACs.  Before the store every element is voted across its replicas (store-data sync,
+// (cloning.cpp:2247-2255).  Before the store every element is voted across its replicas (store-data sync,
 // synchronization.cpp:476-561); only replica 0 writes the single output copy.
+//
+// Two kernels share the mapping:
+//   mm_fast_kernel     every workgroup no armed fault points at: double-buffered LDS panels, next chunk prefetched
+//                      into registers under the MACs, one v_mad_u64_u32 per MAC (the 64-bit accumulator is the
+//                      reference's `unsigned long sum`; only its low word is ever stored).  VALU bound: 3x the integer
+//                      MACs of the unprotected kernel, 2 ds_read_b128 per 16 MACs.
+//   mm_general_kernel  workgroups that own an armed fault, or every workgroup when sync_every != 0: one k step at a
+//                      time with the injector hooks (flip = old XOR 1<<bit on the named replica's register) and the
+//                      optional loop-condition sync points.
 #include "xmr.hpp"
 
 namespace coast {
@@ -20,7 +28,7 @@ struct MmGeom {
     int tc;       // tiles per tile-row = ceil(n/4)
     int tiles;    // tc*tc tiles per matrix
     int bpm;      // workgroups per matrix
-    int kt;       // k-chunk staged per barrier pair (power of two)
+    int kt;       // k-chunk staged per barrier (power of two)
     int ktLog2;
     int rs;       // LDS row stride of the f panel (rows, multiple of 4)
     int npad;     // 4*tc
@@ -29,64 +37,286 @@ struct MmGeom {
 
 enum { SITE_MM_ACC = 0, SITE_MM_OPA = 1, SITE_MM_OPB = 2 };
 
+constexpr int kMmMaxB = 4; // uint4 of the s panel a thread stages per chunk  (kt * npad/4 <= 256*kMmMaxB)
+constexpr int kMmMaxA = 4; // dwords of the f panel a thread stages per chunk (kt * rs     <= 256*kMmMaxA)
+
+// where this lane's tile sits
+template <int NREP> struct MmLane {
+    LaneMap<NREP> lm;
+    uint32_t lb, mat;
+    int t0, tb, row0, rows, aRow, i0, j0;
+    bool live;
+    __device__ __forceinline__ MmLane(const MmGeom &g, uint32_t logicalBlock)
+    {
+        constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+        constexpr int TPB = 4 * IPW;
+        lb = logicalBlock;
+        mat = lb / (uint32_t)g.bpm;
+        const int bim = (int)(lb - mat * (uint32_t)g.bpm);
+        t0 = bim * TPB;
+        tb = (int)(threadIdx.x >> 6) * IPW + lm.q;
+        live = lm.live && (t0 + tb) < g.tiles;
+        const int t = live ? (t0 + tb) : t0;
+        const int tr = t / g.tc, tcI = t - tr * g.tc;
+        row0 = (t0 / g.tc) * 4;
+        const int tLast = min(t0 + TPB, g.tiles) - 1;
+        rows = min((tLast / g.tc) * 4 + 4, g.n) - row0; // rows of f staged (<= rs)
+        aRow = tr * 4 - row0;
+        i0 = tr * 4;
+        j0 = tcI * 4;
+    }
+};
+
+// store-data sync + single-copy store + counters (shared epilogue)
 template <int NREP>
-__global__ __launch_bounds__(256) void mm_xmr_kernel(const uint32_t *__restrict__ F, const uint32_t *__restrict__ S,
-                                                     uint32_t *__restrict__ R, MmGeom g, uint32_t syncEvery,
-                                                     Counters ctr, FaultTab ft, int haveFaults,
-                                                     uint8_t *__restrict__ detected)
+__device__ __forceinline__ void mm_epilogue(const uint32_t acc[16], const MmLane<NREP> &L, const MmGeom &g,
+                                            uint32_t *__restrict__ r, Tally &tl, uint8_t *__restrict__ detected,
+                                            size_t matOff, uint32_t *sCnt, const Counters &ctr)
+{
+    const int n = g.n;
+    const bool vec = (n & 3) == 0;
+    uint32_t out[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const bool valid = L.live && (L.i0 + (e >> 2)) < n && (L.j0 + (e & 3)) < n;
+        Tally te = tl;
+        te.det = 0;
+        out[e] = xmr_sync<NREP>(acc[e], L.lm, valid && L.lm.r == 0, te);
+        tl.miss = te.miss;
+        tl.syncs = te.syncs;
+        tl.det |= te.det << e; // per-element DWC flags
+    }
+    uint32_t detItems = 0;
+    if (L.live && L.lm.r == 0) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = L.i0 + ii;
+            if (i >= n)
+                continue;
+            uint32_t *dst = r + (size_t)i * n + L.j0;
+            if (vec) {
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(out[ii * 4], out[ii * 4 + 1], out[ii * 4 + 2], out[ii * 4 + 3]);
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    if (L.j0 + jj < n)
+                        dst[jj] = out[ii * 4 + jj];
+            }
+        }
+        if (NREP == 2 && tl.det) {
+            detItems = (uint32_t)__builtin_popcount(tl.det);
+            if (detected) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if ((tl.det >> e) & 1u)
+                        detected[matOff + (size_t)(L.i0 + (e >> 2)) * n + (L.j0 + (e & 3))] = 1;
+            }
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, L.lb);
+}
+
+// One MAC = one v_mad_u64_u32 (measured 5.1 cycles/wave-instruction vs 4.5 + 2.1 for v_mul_lo_u32 + half a v_add3_u32,
+// tools/valu_microbench).  Written as asm because hipcc narrows a 64-bit accumulation whose high word is dead back to
+// v_mul_lo_u32 + add.  Pure register VALU: no memory operand, no hazard with its neighbours beyond the vcc clobber.
+__device__ __forceinline__ void mac_u64(unsigned long long &acc, uint32_t a, uint32_t b)
+{
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+
+// One k step of a lane's 4x4 tile as a single asm block: 16 back-to-back v_mad_u64_u32 with no compiler-inserted
+// boundary nops between them.  acc[4*i+j] += a[i] * b[j].
+__device__ __forceinline__ void mac16_u64(unsigned long long (&acc)[16], const uint4 &a, const uint4 &b)
+{
+    asm("v_mad_u64_u32 %0, vcc, %16, %20, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %16, %21, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %16, %22, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %16, %23, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %17, %20, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %17, %21, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %17, %22, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %17, %23, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %18, %20, %8\n\t"
+        "v_mad_u64_u32 %9, vcc, %18, %21, %9\n\t"
+        "v_mad_u64_u32 %10, vcc, %18, %22, %10\n\t"
+        "v_mad_u64_u32 %11, vcc, %18, %23, %11\n\t"
+        "v_mad_u64_u32 %12, vcc, %19, %20, %12\n\t"
+        "v_mad_u64_u32 %13, vcc, %19, %21, %13\n\t"
+        "v_mad_u64_u32 %14, vcc, %19, %22, %14\n\t"
+        "v_mad_u64_u32 %15, vcc, %19, %23, %15"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+          "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]),
+          "+v"(acc[14]), "+v"(acc[15])
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w)
+        : "vcc");
+}
+
+// ------------------------------------------------------------------------------------------------ fast path
+// VEC: n % 4 == 0, every panel row is 16-byte aligned (the bench shape); !VEC handles ragged sides (9, 19, 30 ...).
+// KT: the k-chunk as a compile-time constant so the MAC loop is fully unrolled and the LDS reads of step kk+1 are
+// issued under the 16 MACs of step kk.
+template <int NREP, bool VEC, int KT>
+__global__ __launch_bounds__(256) void mm_fast_kernel(const uint32_t *__restrict__ F, const uint32_t *__restrict__ S,
+                                                      uint32_t *__restrict__ R, MmGeom g, Counters ctr,
+                                                      const uint2 *__restrict__ faultRange,
+                                                      uint8_t *__restrict__ detected)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *As = smem;                  // [kt][rs]   f panel, k-major
-    uint32_t *Bs = smem + g.kt * g.rs;    // [kt][npad] s panel
-    uint32_t *sCnt = Bs + g.kt * g.npad;  // 4 counters
-
-    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
-    constexpr int TPB = 4 * IPW; // tiles per workgroup
-    const LaneMap<NREP> lm;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6;
-    const int n = g.n;
+    const int panel = g.kt * (g.rs + g.npad); // dwords per buffer: As[kt][rs] then Bs[kt][npad]
+    uint32_t *sCnt = smem + 2 * panel;
 
     const uint32_t lb = xcd_logical_block(blockIdx.x, g.nblocks);
-    const uint32_t mat = lb / (uint32_t)g.bpm;
-    const int bim = (int)(lb - mat * (uint32_t)g.bpm);
-    const int t0 = bim * TPB;
-    const int tb = wave * IPW + lm.q;
-    const bool live = lm.live && (t0 + tb) < g.tiles;
-    const int t = live ? (t0 + tb) : t0;
-    const int tr = t / g.tc, tcI = t - tr * g.tc;
-    const int row0 = (t0 / g.tc) * 4;
-    const int tLast = min(t0 + TPB, g.tiles) - 1;
-    const int rows = min((tLast / g.tc) * 4 + 4, n) - row0; // rows of f staged (<= rs)
-    const int aRow = tr * 4 - row0;
-    const int i0 = tr * 4, j0 = tcI * 4;
-
+    if (faultRange && faultRange[lb].y != 0u)
+        return; // an armed fault points into this workgroup: mm_general_kernel owns it
+    const MmLane<NREP> L(g, lb);
+    const int tid = threadIdx.x;
+    const int n = g.n;
     const size_t nn = (size_t)n * n;
-    const uint32_t *f = F + mat * nn;
-    const uint32_t *s = S + mat * nn;
-    uint32_t *r = R + mat * nn;
+    const uint32_t *f = F + L.mat * nn;
+    const uint32_t *s = S + L.mat * nn;
 
     if (tid < 4)
         sCnt[tid] = 0;
 
+    // per-thread staging slots (fixed for the whole k loop)
+    constexpr bool vec = VEC;
+    const int npad4 = g.npad >> 2;
+    int bKk[kMmMaxB], bCol[kMmMaxB];
+#pragma unroll
+    for (int u = 0; u < kMmMaxB; ++u) {
+        const int idx = tid + 256 * u;
+        bKk[u] = (idx < g.kt * npad4) ? idx / npad4 : -1;
+        bCol[u] = 4 * (idx - max(bKk[u], 0) * npad4);
+    }
+    int aKk[kMmMaxA], aRl[kMmMaxA];
+#pragma unroll
+    for (int u = 0; u < kMmMaxA; ++u) {
+        const int idx = tid + 256 * u;
+        aRl[u] = idx >> g.ktLog2;
+        aKk[u] = (aRl[u] < g.rs) ? (idx & (g.kt - 1)) : -1;
+    }
+    uint4 pb[kMmMaxB];
+    uint32_t pa[kMmMaxA];
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < kMmMaxB; ++u) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            const int k = k0 + bKk[u];
+            if (bKk[u] >= 0 && k < n) {
+                const uint32_t *src = s + (size_t)k * n + bCol[u];
+                if (vec) {
+                    v = *reinterpret_cast<const uint4 *>(src);
+                } else {
+                    v.x = (bCol[u] + 0 < n) ? src[0] : 0u;
+                    v.y = (bCol[u] + 1 < n) ? src[1] : 0u;
+                    v.z = (bCol[u] + 2 < n) ? src[2] : 0u;
+                    v.w = (bCol[u] + 3 < n) ? src[3] : 0u;
+                }
+            }
+            pb[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < kMmMaxA; ++u) {
+            uint32_t v = 0u;
+            const int k = k0 + aKk[u];
+            if (aKk[u] >= 0 && aRl[u] < L.rows && k < n)
+                v = f[(size_t)(L.row0 + aRl[u]) * n + k];
+            pa[u] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        uint32_t *As = smem + buf * panel;
+        uint32_t *Bs = As + g.kt * g.rs;
+#pragma unroll
+        for (int u = 0; u < kMmMaxB; ++u)
+            if (bKk[u] >= 0)
+                *reinterpret_cast<uint4 *>(Bs + bKk[u] * g.npad + bCol[u]) = pb[u];
+#pragma unroll
+        for (int u = 0; u < kMmMaxA; ++u)
+            if (aKk[u] >= 0)
+                As[aKk[u] * g.rs + aRl[u]] = pa[u];
+    };
+
+    unsigned long long acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        acc[e] = 0ull;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int nchunks = (n + g.kt - 1) >> g.ktLog2;
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = (c + 1) < nchunks;
+        if (more)
+            gload((c + 1) << g.ktLog2); // in flight under the MACs below
+        const uint32_t *As = smem + (c & 1) * panel + L.aRow;
+        const uint32_t *Bs = smem + (c & 1) * panel + KT * g.rs + L.j0;
+        uint4 a = *reinterpret_cast<const uint4 *>(As);
+        uint4 b = *reinterpret_cast<const uint4 *>(Bs);
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            uint4 an = a, bn = b;
+            if (kk + 1 < KT) {
+                an = *reinterpret_cast<const uint4 *>(As + (kk + 1) * g.rs);
+                bn = *reinterpret_cast<const uint4 *>(Bs + (kk + 1) * g.npad);
+            }
+            mac16_u64(acc, a, b);
+            a = an;
+            b = bn;
+        }
+        if (more)
+            lstore((c + 1) & 1); // the other buffer: every wave left it at the previous barrier
+        __syncthreads();
+    }
+
+    uint32_t lo[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        lo[e] = (uint32_t)acc[e]; // r_matrix[i][j] = sum truncates (mm_common_tmr.c:16)
+    Tally tl;
+    mm_epilogue<NREP>(lo, L, g, R + L.mat * nn, tl, detected, L.mat * nn, sCnt, ctr);
+}
+
+// ------------------------------------------------------------------------------------------------ general path
+template <int NREP>
+__global__ __launch_bounds__(256) void mm_general_kernel(const uint32_t *__restrict__ F, const uint32_t *__restrict__ S,
+                                                         uint32_t *__restrict__ R, MmGeom g, uint32_t syncEvery,
+                                                         Counters ctr, FaultTab ft,
+                                                         const uint32_t *__restrict__ blockList,
+                                                         uint8_t *__restrict__ detected)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *As = smem;                 // [kt][rs]   f panel, k-major
+    uint32_t *Bs = smem + g.kt * g.rs;   // [kt][npad] s panel
+    uint32_t *sCnt = smem + 2 * g.kt * (g.rs + g.npad);
+
+    const uint32_t lb = blockList ? blockList[blockIdx.x] : blockIdx.x;
+    const MmLane<NREP> L(g, lb);
+    const LaneMap<NREP> &lm = L.lm;
+    const int tid = threadIdx.x;
+    const int n = g.n;
+    const size_t nn = (size_t)n * n;
+    const uint32_t *f = F + L.mat * nn;
+    const uint32_t *s = S + L.mat * nn;
+
+    if (tid < 4)
+        sCnt[tid] = 0;
     uint2 fr = make_uint2(0u, 0u);
-    if (haveFaults)
+    if (ft.range)
         fr = ft.range[lb];
-    const bool general = (fr.y != 0u) || (syncEvery != 0u);
 
     uint32_t acc[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e)
         acc[e] = 0u;
     Tally tl;
-    uint32_t detItems = 0;
-
     const bool vec = (n & 3) == 0;
     const int npad4 = g.npad >> 2;
 
     for (int k0 = 0; k0 < n; k0 += g.kt) {
-        __syncthreads(); // previous chunk fully consumed
-        // ---- stage the s panel: rows k0..k0+kt-1, all columns (coalesced, 16 B/lane when n % 4 == 0)
+        __syncthreads();
         for (int idx = tid; idx < g.kt * npad4; idx += 256) {
             const int kk = idx / npad4, c4 = idx - kk * npad4;
             const int k = k0 + kk;
@@ -105,139 +335,79 @@ __global__ __launch_bounds__(256) void mm_xmr_kernel(const uint32_t *__restrict_
             }
             *reinterpret_cast<uint4 *>(Bs + kk * g.npad + 4 * c4) = v;
         }
-        // ---- stage the f panel transposed: As[kk][row]
         for (int idx = tid; idx < (g.rs << g.ktLog2); idx += 256) {
             const int rl = idx >> g.ktLog2, kk = idx & (g.kt - 1);
-            const int k = k0 + kk, row = row0 + rl;
+            const int k = k0 + kk;
             uint32_t v = 0u;
-            if (rl < rows && k < n)
-                v = f[(size_t)row * n + k];
+            if (rl < L.rows && k < n)
+                v = f[(size_t)(L.row0 + rl) * n + k];
             As[kk * g.rs + rl] = v;
         }
         __syncthreads();
 
-        if (!general) {
-            // ---- fast path: no fault targets this workgroup, mandatory sync points only
-#pragma unroll 4
-            for (int kk = 0; kk < g.kt; ++kk) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(As + kk * g.rs + aRow);
-                const uint4 b = *reinterpret_cast<const uint4 *>(Bs + kk * g.npad + j0);
+        const int kEnd = min(g.kt, n - k0);
+        for (int kk = 0; kk < kEnd; ++kk) {
+            const int k = k0 + kk;
+            const uint4 a = *reinterpret_cast<const uint4 *>(As + kk * g.rs + L.aRow);
+            const uint4 b = *reinterpret_cast<const uint4 *>(Bs + kk * g.npad + L.j0);
+            uint32_t ae[16], be[16]; // per-element operand copies: an operand upset hits ONE item's MAC
+            {
                 const uint32_t av[4] = {a.x, a.y, a.z, a.w};
                 const uint32_t bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        acc[ii * 4 + jj] += av[ii] * bv[jj];
+                for (int e = 0; e < 16; ++e) {
+                    ae[e] = av[e >> 2];
+                    be[e] = bv[e & 3];
+                }
             }
-        } else {
-            // ---- general path: per-step injector hooks and optional loop-condition sync points
-            const int kEnd = min(g.kt, n - k0);
-            for (int kk = 0; kk < kEnd; ++kk) {
-                const int k = k0 + kk;
-                const uint4 a = *reinterpret_cast<const uint4 *>(As + kk * g.rs + aRow);
-                const uint4 b = *reinterpret_cast<const uint4 *>(Bs + kk * g.npad + j0);
-                uint32_t ae[16], be[16];
-                {
-                    const uint32_t av[4] = {a.x, a.y, a.z, a.w};
-                    const uint32_t bv[4] = {b.x, b.y, b.z, b.w};
+            for (uint32_t q = 0; q < fr.y; ++q) {
+                const DevFault df = ft.list[fr.x + q];
+                if (df.step != (uint32_t)k || (int)(df.local >> 4) != L.tb || (int)df.replica != lm.r || !lm.live)
+                    continue;
+                const uint32_t m = 1u << (df.bit & 31u);
+                const int fe = (int)(df.local & 15u);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        ae[e] = av[e >> 2];
-                        be[e] = bv[e & 3];
-                    }
-                }
-                for (uint32_t q = 0; q < fr.y; ++q) {
-                    const DevFault df = ft.list[fr.x + q];
-                    if (df.step != (uint32_t)k || (int)(df.local >> 4) != tb || (int)df.replica != lm.r || !lm.live)
-                        continue;
-                    const uint32_t m = 1u << (df.bit & 31u);
-                    const int fe = (int)(df.local & 15u);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        if (e == fe) {
-                            if (df.site == SITE_MM_ACC)
-                                acc[e] ^= m;
-                            else if (df.site == SITE_MM_OPA)
-                                ae[e] ^= m;
-                            else if (df.site == SITE_MM_OPB)
-                                be[e] ^= m;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    acc[e] += ae[e] * be[e];
-                if (syncEvery && ((uint32_t)(k + 1) % syncEvery) == 0u && (k + 1) < n) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const bool valid = live && (i0 + (e >> 2)) < n && (j0 + (e & 3)) < n;
-                        Tally te = tl;
-                        te.det = 0;
-                        acc[e] = xmr_sync<NREP>(acc[e], lm, valid && lm.r == 0, te);
-                        tl.miss = te.miss;
-                        tl.syncs = te.syncs;
-                        tl.det |= te.det << e; // per-element DWC flags
+                for (int e = 0; e < 16; ++e) {
+                    if (e == fe) {
+                        if (df.site == SITE_MM_ACC)
+                            acc[e] ^= m;
+                        else if (df.site == SITE_MM_OPA)
+                            ae[e] ^= m;
+                        else if (df.site == SITE_MM_OPB)
+                            be[e] ^= m;
                     }
                 }
             }
-        }
-    }
-
-    // ---- injector hook after the loop (step == n hits the finished accumulator)
-    if (general) {
-        for (uint32_t q = 0; q < fr.y; ++q) {
-            const DevFault df = ft.list[fr.x + q];
-            if (df.step != (uint32_t)n || df.site != SITE_MM_ACC || (int)(df.local >> 4) != tb ||
-                (int)df.replica != lm.r || !lm.live)
-                continue;
-            const int fe = (int)(df.local & 15u);
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if (e == fe)
-                    acc[e] ^= 1u << (df.bit & 31u);
-        }
-    }
-
-    // ---- store-data sync: vote every element across its replicas, replica 0 writes the single copy
-    uint32_t out[16];
+                acc[e] += ae[e] * be[e];
+            if (syncEvery && ((uint32_t)(k + 1) % syncEvery) == 0u && (k + 1) < n) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const bool valid = live && (i0 + (e >> 2)) < n && (j0 + (e & 3)) < n;
-        Tally te = tl;
-        te.det = 0;
-        out[e] = xmr_sync<NREP>(acc[e], lm, valid && lm.r == 0, te);
-        tl.miss = te.miss;
-        tl.syncs = te.syncs;
-        tl.det |= te.det << e;
-    }
-    if (live && lm.r == 0) {
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = i0 + ii;
-            if (i >= n)
-                continue;
-            uint32_t *dst = r + (size_t)i * n + j0;
-            if (vec) {
-                *reinterpret_cast<uint4 *>(dst) = make_uint4(out[ii * 4], out[ii * 4 + 1], out[ii * 4 + 2], out[ii * 4 + 3]);
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    if (j0 + jj < n)
-                        dst[jj] = out[ii * 4 + jj];
-            }
-        }
-        if (NREP == 2 && tl.det) {
-            detItems = (uint32_t)__builtin_popcount(tl.det);
-            if (detected) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if ((tl.det >> e) & 1u)
-                        detected[mat * nn + (size_t)(i0 + (e >> 2)) * n + (j0 + (e & 3))] = 1;
+                for (int e = 0; e < 16; ++e) {
+                    const bool valid = L.live && (L.i0 + (e >> 2)) < n && (L.j0 + (e & 3)) < n;
+                    Tally te = tl;
+                    te.det = 0;
+                    acc[e] = xmr_sync<NREP>(acc[e], lm, valid && lm.r == 0, te);
+                    tl.miss = te.miss;
+                    tl.syncs = te.syncs;
+                    tl.det |= te.det << e;
+                }
             }
         }
     }
-    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, lb);
+    // injector hook after the loop (step == n hits the finished accumulator)
+    for (uint32_t q = 0; q < fr.y; ++q) {
+        const DevFault df = ft.list[fr.x + q];
+        if (df.step != (uint32_t)n || df.site != SITE_MM_ACC || (int)(df.local >> 4) != L.tb ||
+            (int)df.replica != lm.r || !lm.live)
+            continue;
+        const int fe = (int)(df.local & 15u);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (e == fe)
+                acc[e] ^= 1u << (df.bit & 31u);
+    }
+    mm_epilogue<NREP>(acc, L, g, R + L.mat * nn, tl, detected, L.mat * nn, sCnt, ctr);
 }
 
 } // namespace coast
