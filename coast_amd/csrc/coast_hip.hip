@@ -425,7 +425,10 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
             hipLaunchKernelGGL(mm_general_kernel<R>, dim3(g.nblocks), block, lds, c->stream, d_f, d_s, d_r, g,  \
                                cfg->sync_every, ctr, ft, (const uint32_t *)nullptr, d_detected);                \
         } else {                                                                                                \
-            if ((n & 3) == 0)                                                                                   \
+            if (n == 256 && g.kt == Mm256<R>::KT && g.rs == Mm256<R>::RS && g.bpm == Mm256<R>::BPM)            \
+                hipLaunchKernelGGL(mm_fast256_kernel<R>, dim3(g.nblocks), block, lds, c->stream, d_f, d_s, d_r,  \
+                                   g, ctr, have ? ft.range : (const uint2 *)nullptr, d_detected);               \
+            else if ((n & 3) == 0)                                                                              \
                 LAUNCH_FAST_K(R, true);                                                                         \
             else                                                                                                \
                 LAUNCH_FAST_K(R, false);                                                                        \

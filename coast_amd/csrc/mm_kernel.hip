@@ -20,6 +20,7 @@
 //                      time with the injector hooks (flip = old XOR 1<<bit on the named replica's register) and the
 //                      optional loop-condition sync points.
 #include "xmr.hpp"
+#include <type_traits>
 
 namespace coast {
 
@@ -275,6 +276,140 @@ __global__ __launch_bounds__(256) void mm_fast_kernel(const uint32_t *__restrict
 #pragma unroll
     for (int e = 0; e < 16; ++e)
         lo[e] = (uint32_t)acc[e]; // r_matrix[i][j] = sum truncates (mm_common_tmr.c:16)
+    Tally tl;
+    mm_epilogue<NREP>(lo, L, g, R + L.mat * nn, tl, detected, L.mat * nn, sCnt, ctr);
+}
+
+// ------------------------------------------------------------------------------------------------ fast path, side 256
+// The headline shape (BASELINE.json configs[1]) with its whole geometry as compile-time constants: panel loads are
+// buffer_load with one precomputed per-thread voffset and a scalar per-chunk soffset (no per-chunk address VALU, rows
+// past the matrix come back as 0 from the descriptor's bounds check), LDS reads carry immediate offsets, and the chunk
+// loop is unrolled by two so that both LDS buffers are addressed statically.  Same mapping and results as
+// mm_fast_kernel<NREP, true, 16>.
+template <int NREP> struct Mm256 {
+    static constexpr int N = 256, TC = 64, TILES = TC * TC, NPAD = 256, KT = 16;
+    static constexpr int IPW = kWave / NREP, TPB = 4 * IPW;
+    static constexpr int BPM = (TILES + TPB - 1) / TPB;
+    static constexpr int max_tile_rows()
+    {
+        int m = 1;
+        for (int b = 0; b < BPM; ++b) {
+            const int t0 = b * TPB, t1 = (t0 + TPB < TILES ? t0 + TPB : TILES) - 1;
+            const int r = t1 / TC - t0 / TC + 1;
+            m = r > m ? r : m;
+        }
+        return m;
+    }
+    static constexpr int RS = 4 * max_tile_rows();
+    static constexpr int PANEL = KT * (RS + NPAD); // dwords per LDS buffer
+    static constexpr size_t LDS_BYTES = (size_t)2 * PANEL * 4 + 16;
+    static_assert(RS * KT <= 256, "one f-panel dword per thread");
+};
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int NREP>
+__global__ __launch_bounds__(256) void mm_fast256_kernel(const uint32_t *__restrict__ F, const uint32_t *__restrict__ S,
+                                                         uint32_t *__restrict__ R, MmGeom g, Counters ctr,
+                                                         const uint2 *__restrict__ faultRange,
+                                                         uint8_t *__restrict__ detected)
+{
+    using G = Mm256<NREP>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *sCnt = smem + 2 * G::PANEL;
+
+    const uint32_t lb = xcd_logical_block(blockIdx.x, g.nblocks);
+    if (faultRange && faultRange[lb].y != 0u)
+        return; // an armed fault points into this workgroup: mm_general_kernel owns it
+    const MmLane<NREP> L(g, lb);
+    const int tid = threadIdx.x;
+    constexpr size_t nn = (size_t)G::N * G::N;
+    if (tid < 4)
+        sCnt[tid] = 0;
+
+    // descriptors from blockIdx-derived scalars only (provably wave-uniform: no waterfall loops)
+    const __amdgpu_buffer_rsrc_t rsS =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(S + L.mat * nn), 0, (int)(nn * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsF =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(F + L.mat * nn), 0, (int)(nn * 4), 0x00020000);
+
+    // s panel: 16 rows x 64 uint4 -> thread owns (kk = tid/64 + 4u, c4 = tid%64); byte offset inside the chunk is the
+    // same in HBM and in LDS.  f panel: RS rows x 16 k -> thread tid < 16*RS owns (rl = tid/16, kk = tid%16).
+    int voffB[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        voffB[u] = (((tid >> 6) + 4 * u) * G::NPAD + 4 * (tid & 63)) * 4;
+    const bool aOn = tid < G::RS * G::KT;
+    const int aRl = tid >> 4, aKk = tid & 15;
+    const int voffA = aOn ? ((L.row0 + aRl) * G::N + aKk) * 4 : -4; // -4 = 0xfffffffc: out of range -> 0
+    const int ldsA = (aKk * G::RS + aRl) * 4;
+
+    u32x4_t pb[4];
+    uint32_t pa;
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            pb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsS, voffB[u], c * (G::KT * G::N * 4), 0);
+        pa = __builtin_amdgcn_raw_buffer_load_b32(rsF, voffA, c * (G::KT * 4), 0);
+    };
+    auto lstore = [&](auto bufTag) {
+        constexpr int BUF = decltype(bufTag)::value;
+        char *base = reinterpret_cast<char *>(smem) + BUF * G::PANEL * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            *reinterpret_cast<u32x4_t *>(base + G::KT * G::RS * 4 + voffB[u]) = pb[u];
+        if (aOn)
+            *reinterpret_cast<uint32_t *>(base + ldsA) = pa;
+    };
+
+    unsigned long long acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        acc[e] = 0ull;
+    const char *rdA = reinterpret_cast<const char *>(smem) + L.aRow * 4;
+    const char *rdB = reinterpret_cast<const char *>(smem) + (G::KT * G::RS + L.j0) * 4;
+    auto compute = [&](auto bufTag) {
+        constexpr int BUF = decltype(bufTag)::value;
+        uint4 a = *reinterpret_cast<const uint4 *>(rdA + BUF * G::PANEL * 4);
+        uint4 b = *reinterpret_cast<const uint4 *>(rdB + BUF * G::PANEL * 4);
+#pragma unroll
+        for (int kk = 0; kk < G::KT; ++kk) {
+            uint4 an = a, bn = b;
+            if (kk + 1 < G::KT) {
+                an = *reinterpret_cast<const uint4 *>(rdA + (BUF * G::PANEL + (kk + 1) * G::RS) * 4);
+                bn = *reinterpret_cast<const uint4 *>(rdB + (BUF * G::PANEL + (kk + 1) * G::NPAD) * 4);
+            }
+            mac16_u64(acc, a, b);
+            a = an;
+            b = bn;
+        }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+
+    constexpr int NCHUNK = G::N / G::KT; // 16, even
+    gload(0);
+    lstore(B0{});
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < NCHUNK; c += 2) {
+        gload(c + 1); // in flight under the MACs
+        compute(B0{});
+        lstore(B1{});
+        __syncthreads();
+        const bool more = (c + 2) < NCHUNK;
+        if (more)
+            gload(c + 2);
+        compute(B1{});
+        if (more)
+            lstore(B0{});
+        __syncthreads();
+    }
+
+    uint32_t lo[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        lo[e] = (uint32_t)acc[e];
     Tally tl;
     mm_epilogue<NREP>(lo, L, g, R + L.mat * nn, tl, detected, L.mat * nn, sCnt, ctr);
 }

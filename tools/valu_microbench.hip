@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <cstdlib>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -78,12 +79,13 @@ __global__ __launch_bounds__(256) void k_dpp_wave_shl(uint32_t *out, uint32_t se
     if (r == 0x12345678u) out[threadIdx.x] = r;
 }
 
+static int gBlocksPerCu = 8;
 template <typename K> int run(const char *name, K kern, uint32_t *d, double extraPerIter = 1.0)
 {
     hipDeviceProp_t p;
     CHECK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
-    const int blocks = cus * 8; // 8 workgroups of 4 waves per CU = 8 waves per SIMD
+    const int blocks = cus * gBlocksPerCu; // N workgroups of 4 waves per CU = N waves per SIMD
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -107,8 +109,10 @@ template <typename K> int run(const char *name, K kern, uint32_t *d, double extr
     return 0;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1) gBlocksPerCu = atoi(argv[1]);
+    printf("waves per SIMD: %d\n", gBlocksPerCu);
     uint32_t *d;
     CHECK(hipMalloc(&d, 4096));
     run("v_add_u32", k_add, d);
