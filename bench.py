@@ -22,8 +22,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (= 157.3 TFLOP/s / 2)
-MAC_ISSUE_SLOTS = 4.0          # v_mad_u64_u32 / v_mul_lo_u32: quarter rate (tools/valu_microbench, profiles/)
+# Integer-MAC issue ceiling of the chip.  MI355X_MICROARCH.md gives the full-rate VALU figure (256 CU x 4 SIMD x 32 lanes
+# x 2.4 GHz = 78.6 T lane-ops/s = 157.3 TFLOP/s / 2) but no integer-multiply rates, so the MAC peak is the measured
+# issue rate of v_mad_u64_u32 -- the one-instruction 32-bit MAC the kernel is built from -- at 8 waves/SIMD:
+# 5.11 cycles per wave-instruction = 30.78 T lane-MAC/s (tools/valu_microbench, profiles/microbench_r01.txt).
+MAC_PEAK = 30.78e12
 
 
 def parse():
@@ -150,7 +153,7 @@ def main():
         elems = float(world) * batch * n * n * a.steps
         macs = float(batch) * n ** 3            # algorithmic MACs of one launch (N^3 per matrix)
         bytes_alg = float(batch) * 12 * n * n   # algorithmic HBM bytes of one launch (read f, s once; write r once)
-        mac_peak = VALU_LANE_OPS / MAC_ISSUE_SLOTS
+        mac_peak = MAC_PEAK
         out = {
             "metric": "protected elems/sec + corrected-fault count, matrixMultiply TMR",
             "value": elems / dt, "unit": "protected elems/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -162,7 +165,7 @@ def main():
             "corrected_faults": tot[0], "expected_corrected_faults": len(faults) * a.steps * world,
             "sync_count": tot[1], "outputs_match_unprotected": outputs_ok,
             "roofline": {
-                "bound": "valu", "kernel": "mm_xmr_kernel<3>",
+                "bound": "valu", "kernel": "mm_fast256_kernel<3>",
                 "achieved": macs / (kern_ms * 1e-3) * 1e-12, "peak": mac_peak * 1e-12, "unit": "T int32-MAC/s",
                 "frac": macs / (kern_ms * 1e-3) / mac_peak,
                 "executed_frac": 3.0 * macs / (kern_ms * 1e-3) / mac_peak,
@@ -170,8 +173,9 @@ def main():
                 "hbm_achieved_GBs": bytes_alg / (kern_ms * 1e-3) * 1e-9, "hbm_peak_GBs": HBM_PEAK_GBS,
                 "hbm_frac": bytes_alg / (kern_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS,
                 "traffic": None,
-                "note": "32-bit wrapping multiply has no MFMA form; bound = VALU integer multiply issue "
-                        "(78.6 T lane-ops/s / %g issue slots per MAC); TMR executes 3x the algorithmic MACs" % MAC_ISSUE_SLOTS,
+                "note": "32-bit wrapping multiply has no MFMA form; bound = VALU issue of v_mad_u64_u32 (measured "
+                        "30.78 T lane-MAC/s, profiles/microbench_r01.txt); achieved/frac count ALGORITHMIC MACs (N^3 per "
+                        "matrix), TMR executes 3x of them (executed_frac)",
             },
         }
         if not a.no_cpu_baseline:

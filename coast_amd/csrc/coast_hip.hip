@@ -30,6 +30,8 @@ struct coast_ctx {
     hipStream_t side = nullptr;   // injector: descriptor upload + indexing
     hipEvent_t evArmed = nullptr;    // side -> main: fault table ready
     hipEvent_t evConsumed = nullptr; // main -> side: previous table no longer read
+    hipEvent_t evMainReady = nullptr; // main -> side: inputs of this launch are complete
+    hipEvent_t evSideDone = nullptr;  // side -> main: stepwise (injector) kernel finished
     bool consumedPending = false;
 
     unsigned long long *dSlots = nullptr;  // [kCounterSlots][kSlotStride]
@@ -209,6 +211,8 @@ extern "C" int coast_create(coast_ctx **out, int device)
     if (bail(hipSetDevice(device)) || bail(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) ||
         bail(hipEventCreateWithFlags(&c->evArmed, hipEventDisableTiming)) ||
         bail(hipEventCreateWithFlags(&c->evConsumed, hipEventDisableTiming)) ||
+        bail(hipEventCreateWithFlags(&c->evMainReady, hipEventDisableTiming)) ||
+        bail(hipEventCreateWithFlags(&c->evSideDone, hipEventDisableTiming)) ||
         bail(hipMalloc((void **)&c->dSlots, sizeof(unsigned long long) * kCounterSlots * kSlotStride)) ||
         bail(hipMalloc((void **)&c->dTotals, sizeof(unsigned long long) * 4)) ||
         bail(hipMemset(c->dSlots, 0, sizeof(unsigned long long) * kCounterSlots * kSlotStride)) ||
@@ -239,6 +243,8 @@ extern "C" void coast_destroy(coast_ctx *c)
     (void)hipFree(c->dTotals);
     (void)hipEventDestroy(c->evArmed);
     (void)hipEventDestroy(c->evConsumed);
+    (void)hipEventDestroy(c->evMainReady);
+    (void)hipEventDestroy(c->evSideDone);
     (void)hipStreamDestroy(c->side);
     delete c;
 }
@@ -425,6 +431,14 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
             hipLaunchKernelGGL(mm_general_kernel<R>, dim3(g.nblocks), block, lds, c->stream, d_f, d_s, d_r, g,  \
                                cfg->sync_every, ctr, ft, (const uint32_t *)nullptr, d_detected);                \
         } else {                                                                                                \
+            const bool sideGeneral = have && nFaultBlocks;                                                      \
+            if (sideGeneral) { /* faulted workgroups: stepwise kernel on the side stream, beside the fast one */ \
+                HIP_TRY(c, hipEventRecord(c->evMainReady, c->stream));                                          \
+                HIP_TRY(c, hipStreamWaitEvent(c->side, c->evMainReady, 0));                                     \
+                hipLaunchKernelGGL(mm_general_kernel<R>, dim3(nFaultBlocks), block, lds, c->side, d_f, d_s,     \
+                                   d_r, g, 0u, ctr, ft, dBlockList, d_detected);                                \
+                HIP_TRY(c, hipEventRecord(c->evSideDone, c->side));                                             \
+            }                                                                                                   \
             if (n == 256 && g.kt == Mm256<R>::KT && g.rs == Mm256<R>::RS && g.bpm == Mm256<R>::BPM)            \
                 hipLaunchKernelGGL(mm_fast256_kernel<R>, dim3(g.nblocks), block, lds, c->stream, d_f, d_s, d_r,  \
                                    g, ctr, have ? ft.range : (const uint2 *)nullptr, d_detected);               \
@@ -432,9 +446,8 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
                 LAUNCH_FAST_K(R, true);                                                                         \
             else                                                                                                \
                 LAUNCH_FAST_K(R, false);                                                                        \
-            if (have && nFaultBlocks)                                                                           \
-                hipLaunchKernelGGL(mm_general_kernel<R>, dim3(nFaultBlocks), block, lds, c->stream, d_f, d_s,   \
-                                   d_r, g, 0u, ctr, ft, dBlockList, d_detected);                                \
+            if (sideGeneral)                                                                                    \
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSideDone, 0));                                    \
         }                                                                                                       \
     } while (0)
     if (cfg->replicas == 3)
