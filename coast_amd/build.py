@@ -13,6 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcoast_hip.so")
 DROPIN = os.path.join(LIBDIR, "libcoast_dropin.so")
+DROPIN_OBJ = os.path.join(LIBDIR, "coast_dropin.o")  # static object: link-time interposition needs a regular object
 ARCH = "gfx950"
 
 
@@ -54,6 +55,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=gnu11", "-I", os.path.join(HERE, "..", "include"), "-c",
+                               dropin_src, "-o", DROPIN_OBJ])
     return LIB
 
 

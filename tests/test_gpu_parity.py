@@ -340,3 +340,27 @@ def test_reference_named_host_calls(eng, orc, golden):
     assert coast_amd.crc16(b"Automated TMR") == 0x5BA3
     st = coast_amd.host_stats()
     assert st["errors_corrected"] == 0 and st["sync_count"] == 81 + 16 + 16 + 1 and st["launches"] == 5
+
+
+# ------------------------------------------------------------------------------------------------ drop-in boundary
+@pytest.mark.parametrize("binary,mode,expect", [
+    ("crc16_coast", "TMR", "result: 5ba3"),                 # tests/crc16/crc16.c:40
+    ("aes_coast", "DWC", "Number of errors: 0"),            # tests/aes/aes.c:114 (568 KATs x 3 checks)
+    ("sha256_coast", "TMR", "C:0 E:0 F:0 T:0us"),           # tests/sha256_common/sha256_tmr.c:30
+    ("mm_coast", "TMR", "Error?: 0"),                       # tests/mm_common/mm_tmr.c:40
+    ("matrixMultiply_coast", "TMR", "Number of errors: 0"),  # tests/matrixMultiply/matrixMultiply.c:157, unittest/cfg/full.yml:3
+])
+def test_unmodified_reference_drivers_on_gpu_backend(binary, mode, expect):
+    """The reference's own main()s, compiled unchanged from /root/reference in the build container and linked against
+    coast_dropin.o + libcoast_hip.so (oracle/Makefile `interpose`), run here on the GPU backend."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "bin", binary)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/bin not built (needs the reference checkout at build time)")
+    env = dict(os.environ, COAST_MODE=mode)
+    p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout[-500:], p.stderr[-500:])
+    assert expect in p.stdout
