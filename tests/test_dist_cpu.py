@@ -1,0 +1,67 @@
+"""Multi-GPU path on CPU: world_size-2 gloo run of the sharding + counter all-reduce that bench.py uses with RCCL."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _FakeEngine:  # stands in for coast_amd.Engine: only the counters tensor matters to the collective
+    def __init__(self, vals):
+        self.counters = torch.tensor(vals, dtype=torch.int64)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from coast_amd.dist import allreduce_counters, any_dwc_detected, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(1001, rank, world)
+    eng = _FakeEngine([10 * (rank + 1), hi - lo, rank, 1])
+    tot = allreduce_counters(eng, dist)
+    q.put((rank, lo, hi, tot.tolist(), eng.counters.tolist(), any_dwc_detected(eng, dist)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_counter_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, tot0, loc0, det0), (r1, lo1, hi1, tot1, loc1, det1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 501, 501, 1001)          # contiguous, no overlap, first rank takes the odd one
+    assert tot0 == tot1 == [30, 1001, 1, 2]                      # global sums on every rank
+    assert loc0 == [10, 501, 0, 1] and loc1 == [20, 500, 1, 1]   # local totals untouched
+    assert det0 and det1                                         # rank 1 saw a DWC mismatch -> the whole job knows
+
+
+def test_shard_range_partitions():
+    from coast_amd.dist import shard_range
+
+    for n in (0, 1, 7, 8, 1 << 20, (1 << 28) + 5):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_is_identity():
+    from coast_amd.dist import allreduce_counters
+
+    eng = _FakeEngine([1, 2, 3, 4])
+    assert allreduce_counters(eng, None).tolist() == [1, 2, 3, 4]
