@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -49,6 +50,9 @@ struct coast_ctx {
     uint32_t *hBlocks = nullptr; // pinned: distinct workgroups that own >= 1 armed fault
     uint32_t *dBlocks = nullptr;
     size_t blocksCap = 0;
+
+    uint16_t *dCrcTable = nullptr; // 64 Ki x u16 two-byte-step table of the crc16 stream kernel
+    int numCUs = 256;
 
     std::string err;
 };
@@ -218,6 +222,9 @@ extern "C" int coast_create(coast_ctx **out, int device)
         bail(hipMemset(c->dSlots, 0, sizeof(unsigned long long) * kCounterSlots * kSlotStride)) ||
         bail(hipMemset(c->dTotals, 0, sizeof(unsigned long long) * 4)))
         return COAST_EHIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        c->numCUs = prop.multiProcessorCount;
     *out = c;
     return COAST_OK;
 }
@@ -239,6 +246,8 @@ extern "C" void coast_destroy(coast_ctx *c)
         (void)hipHostFree(c->hBlocks);
     if (c->dBlocks)
         (void)hipFree(c->dBlocks);
+    if (c->dCrcTable)
+        (void)hipFree(c->dCrcTable);
     (void)hipFree(c->dSlots);
     (void)hipFree(c->dTotals);
     (void)hipEventDestroy(c->evArmed);

@@ -4,8 +4,24 @@
 //     x = crc >> 8 ^ *data_p++;  x ^= x >> 4;  crc = (crc << 8) ^ (x << 12) ^ (x << 5) ^ x;     (u8 / u16 truncations)
 // The reference's `length` is an unsigned char, so a stream is a batch of independent blocks (<= 255 bytes in the
 // reference; any block_len here).  Logical work item = one block; lane NREP*q + r holds replica r of the wave's q-th
-// block (crc and x in VGPRs).  Sync points: the returned crc (ReturnInst sync, synchronization.cpp:741-949) and, with
-// sync_every = V, crc after every V-th byte (the `while (length--)` loop-condition sync, crc16.c:25).
+// block (crc and x in VGPRs); a wave owns one TILE of IPW = 64/NREP consecutive blocks.  Sync points: the returned
+// crc (ReturnInst sync, synchronization.cpp:741-949) and, with sync_every = V, crc after every V-th byte (the
+// `while (length--)` loop-condition sync, crc16.c:25).
+//
+// Two kernels:
+//   crc16_stream_kernel   the HBM-streaming path (block_len % 64 == 0, no fault in the tile, mandatory sync only).
+//                         The byte-serial update costs ~9 VALU ops per byte per replica -- 3 replicas would cap the
+//                         chip near 2 TB/s -- so two update steps are folded into ONE lookup: for W = (b0<<8)|b1,
+//                         crc' = T16[crc ^ W] (both byte steps depend on crc and the data only through crc ^ W; derived
+//                         in crc16_table_kernel).  T16 is 64 Ki x u16 = 128 KiB: it fills the CU's LDS, so the kernel is
+//                         persistent (one 1024-thread workgroup per CU, waves grid-stride over tiles).  The table is a
+//                         single shared read-only copy (memory, outside the sphere of replication); crc stays
+//                         replica-private, the three replica lanes look up the same address (LDS broadcast).
+//                         Each lane streams its own block 64 bytes (4 x dwordx4) at a time, next batch in flight under
+//                         the current one; the replicas of a block issue the same addresses (one fetch).
+//   crc16_general_kernel  byte-serial, exactly as written in crc16.c, with the injector hooks and the optional
+//                         per-V-bytes votes; one wave per tile; runs the tiles that own an armed fault (side stream) or
+//                         every tile when the stream path does not apply.
 #include "xmr.hpp"
 
 namespace coast {
@@ -19,20 +35,140 @@ __device__ __forceinline__ uint32_t crc16_byte(uint32_t crc, uint32_t byte)
     return ((crc << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xffffu;
 }
 
+// T16[(u << 8) | v] = state after two byte steps from a state/data pair with crc ^ ((b0<<8)|b1) == (u<<8)|v.
+// Proof sketch: step 1 reads only u = (crc>>8)^b0 and produces s1 = ((crc&0xff)<<8) ^ T8[u]; step 2 reads
+// (s1>>8)^b1 = v ^ (T8[u]>>8), and its (s1<<8) term keeps only T8[u]&0xff -- crc and the bytes enter only via u, v.
+// Running the reference recurrence from crc = idx with both data bytes zero realises exactly that.
+__global__ void crc16_table_kernel(uint16_t *__restrict__ t16)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; // 65536 threads
+    t16[idx] = (uint16_t)crc16_byte(crc16_byte(idx, 0u), 0u);
+}
+
+constexpr int kCrcStreamThreads = 1024;
+constexpr int kCrcTableBytes = 65536 * 2;
+
+template <int NREP, int NT>
+__global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
+    const uint8_t *__restrict__ data, uint32_t blockLen, uint64_t nblocksData, uint16_t *__restrict__ crcs,
+    const uint16_t *__restrict__ t16g, uint64_t ntiles, Counters ctr, const uint2 *__restrict__ faultRange,
+    uint8_t *__restrict__ detected)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smemRaw[];
+    uint16_t *T = reinterpret_cast<uint16_t *>(smemRaw);
+    uint32_t *sCnt = reinterpret_cast<uint32_t *>(smemRaw + kCrcTableBytes);
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    const LaneMap<NREP> lm;
+    const int tid = threadIdx.x;
+
+    { // 128 KiB table: 1024 threads x 8 x 16 B, L2-resident after the first workgroup
+        const uint4 *src = reinterpret_cast<const uint4 *>(t16g);
+        uint4 *dst = reinterpret_cast<uint4 *>(T);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            dst[tid + u * kCrcStreamThreads] = src[tid + u * kCrcStreamThreads];
+    }
+    if (tid < 4)
+        sCnt[tid] = 0;
+    __syncthreads();
+
+    const uint64_t wavesTotal = (uint64_t)gridDim.x * (kCrcStreamThreads / kWave);
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (kCrcStreamThreads / kWave) + (tid >> 6);
+    Tally tl;
+    uint32_t detItems = 0;
+    const uint32_t nbatch = blockLen >> 6; // 64-byte batches per block
+
+    for (uint64_t tileBase = wave0 * NT; tileBase < ntiles; tileBase += wavesTotal * NT) {
+        // NT independent tiles per wave: NT dependent lookup chains in flight per lane
+        const uint8_t *p[NT];
+        bool liveT[NT], cntT[NT];
+        uint64_t itemT[NT];
+        uint32_t crc[NT];
+        uint4 cur[NT][4], nxt[NT][4];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const uint64_t tile = tileBase + j;
+            bool skip = tile >= ntiles;
+            if (!skip && faultRange)
+                skip = faultRange[tile].y != 0u; // crc16_general_kernel owns faulted tiles
+            itemT[j] = tile * IPW + (uint64_t)lm.q;
+            liveT[j] = !skip && lm.live && itemT[j] < nblocksData;
+            cntT[j] = liveT[j] && lm.r == 0;
+            p[j] = data + (liveT[j] ? itemT[j] : 0) * (uint64_t)blockLen;
+            crc[j] = 0xFFFFu;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                cur[j][v] = reinterpret_cast<const uint4 *>(p[j])[v];
+        }
+        for (uint32_t b = 0; b < nbatch; ++b) {
+            const bool more = (b + 1) < nbatch;
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        nxt[j][v] = reinterpret_cast<const uint4 *>(p[j] + (size_t)(b + 1) * 64)[v];
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    uint32_t e[NT];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const uint32_t d = (c == 0) ? cur[j][v].x : (c == 1) ? cur[j][v].y : (c == 2) ? cur[j][v].z : cur[j][v].w;
+                        e[j] = __builtin_bswap32(d); // (b0<<24)|(b1<<16)|(b2<<8)|b3
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        crc[j] = T[crc[j] ^ (e[j] >> 16)];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        crc[j] = T[crc[j] ^ (e[j] & 0xffffu)];
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        cur[j][v] = nxt[j][v];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            Tally te = tl;
+            te.det = 0;
+            const uint32_t voted = xmr_sync<NREP>(crc[j], lm, cntT[j], te); // return-value sync
+            tl.miss = te.miss;
+            tl.syncs = te.syncs;
+            if (cntT[j]) {
+                crcs[itemT[j]] = (uint16_t)voted;
+                if (NREP == 2 && te.det) {
+                    detItems += 1;
+                    if (detected)
+                        detected[itemT[j]] = 1;
+                }
+            }
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+// one wave (64-thread workgroup) per tile
 template <int NREP>
-__global__ __launch_bounds__(256) void crc16_xmr_kernel(const uint8_t *__restrict__ data, uint32_t blockLen,
-                                                        uint64_t nblocksData, uint16_t *__restrict__ crcs,
-                                                        uint32_t syncEvery, uint32_t nwg, Counters ctr, FaultTab ft,
-                                                        int haveFaults, uint8_t *__restrict__ detected)
+__global__ __launch_bounds__(64) void crc16_general_kernel(const uint8_t *__restrict__ data, uint32_t blockLen,
+                                                           uint64_t nblocksData, uint16_t *__restrict__ crcs,
+                                                           uint32_t syncEvery, Counters ctr, FaultTab ft,
+                                                           const uint32_t *__restrict__ tileList,
+                                                           uint8_t *__restrict__ detected)
 {
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
-    constexpr int IPB = 4 * IPW;
     const LaneMap<NREP> lm;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t lb = blockIdx.x;
-    const int slot = wave * IPW + lm.q;
-    const uint64_t item = (uint64_t)lb * IPB + (uint64_t)slot;
+    const uint32_t tile = tileList ? tileList[blockIdx.x] : blockIdx.x;
+    const int slot = lm.q;
+    const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
     const bool live = lm.live && item < nblocksData;
     const uint8_t *p = data + (live ? item : 0) * (uint64_t)blockLen;
     const bool aligned = ((blockLen & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(data) & 3u) == 0u);
@@ -42,14 +178,14 @@ __global__ __launch_bounds__(256) void crc16_xmr_kernel(const uint8_t *__restric
     __syncthreads();
 
     uint2 fr = make_uint2(0u, 0u);
-    if (haveFaults)
-        fr = ft.range[lb];
-    const bool general = (fr.y != 0u) || (syncEvery != 0u);
+    if (ft.range)
+        fr = ft.range[tile];
+    const bool stepwise = (fr.y != 0u) || (syncEvery != 0u);
     const bool cnt = live && lm.r == 0;
     Tally tl;
     uint32_t crc = 0xFFFFu;
 
-    if (!general) {
+    if (!stepwise) {
         uint32_t t = 0;
         if (aligned) {
             for (; t + 4u <= blockLen; t += 4u) {
@@ -98,8 +234,7 @@ __global__ __launch_bounds__(256) void crc16_xmr_kernel(const uint8_t *__restric
                 detected[item] = 1;
         }
     }
-    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, lb);
-    (void)nwg;
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, tile);
 }
 
 } // namespace coast
