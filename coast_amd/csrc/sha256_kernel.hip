@@ -4,10 +4,17 @@
 // Logical work item = one message; lane NREP*q + r holds replica r of the wave's q-th message: the eight ctx_state
 // words, the working variables a..h and a rolling 16-word window of the message schedule all live in that lane's
 // VGPRs (the reference's m[64] array is only ever read 16 words back, :49-63, so the window is the same dataflow).
-// The message bytes are the single memory copy (-noMemReplication): the replicas of a message load the same
-// addresses, which the memory pipeline serves from one fetch.  Sync points (frozen in oracle/coast_oracle.c):
-// the 8 ctx_state words after every compression (they are stores, :90-97) and the 8 digest words before the
-// store (:169-178).  The kernel is VALU bound (~3000 integer ops per compression per replica).
+// A wave owns one TILE of IPW = 64/NREP consecutive messages.  The message bytes are the single memory copy
+// (-noMemReplication): the replicas of a message load the same addresses, which the memory pipeline serves from one
+// fetch.  Sync points (frozen in oracle/coast_oracle.c): the 8 ctx_state words after every compression (they are
+// stores, :90-97) and the 8 digest words before the store (:169-178).  VALU bound: ~1400 integer instructions per
+// compression per replica (rotates are v_alignbit_b32, 3-input xor / ch / maj are one v_bitop3_b32 each).
+//
+// Two kernels:
+//   sha256_fast_kernel     tiles no armed fault points at: 64 rounds fully unrolled with rotating register names,
+//                          whole 64-byte blocks loaded as 4 x dwordx4 per lane.
+//   sha256_general_kernel  tiles that own an armed fault (side stream), or every tile when the message array is not
+//                          4-byte aligned: round-at-a-time with the injector hooks.
 #include "xmr.hpp"
 
 namespace coast {
@@ -24,8 +31,31 @@ __constant__ uint32_t kShaK[64] = { // FIPS 180-4 section 4.2.2; sha256_common_t
     0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
     0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
 
+// the same constants as compile-time values for the unrolled kernel (they become SGPR/literal operands)
+#define SHA_K_LIST                                                                                               \
+    0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u,      \
+    0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u,      \
+    0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,      \
+    0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u,      \
+    0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,      \
+    0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,      \
+    0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,      \
+    0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u
+
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); // a ^ b ^ c in one VALU op
+}
+__device__ __forceinline__ uint32_t sha_ch(uint32_t e, uint32_t f, uint32_t g)
+{
+    return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); // (e & f) ^ (~e & g)  == e ? f : g
+}
+__device__ __forceinline__ uint32_t sha_maj(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); // (a & b) ^ (a & c) ^ (b & c)
+}
 
 // word t (big-endian) of padded block c of a `len`-byte message (padding exactly as sha256_hash :129-164)
 __device__ __forceinline__ uint32_t sha_word(const uint8_t *msg, uint32_t len, uint32_t c, int t, bool aligned,
@@ -59,144 +89,114 @@ __device__ __forceinline__ uint32_t sha_word(const uint8_t *msg, uint32_t len, u
     return w;
 }
 
-#define SHA_ROUND(T, MW)                                                                                        \
-    do {                                                                                                        \
-        const uint32_t ep0_ = rotr32(v[0], 2) ^ rotr32(v[0], 13) ^ rotr32(v[0], 22);                            \
-        const uint32_t ep1_ = rotr32(v[4], 6) ^ rotr32(v[4], 11) ^ rotr32(v[4], 25);                            \
-        const uint32_t ch_ = (v[4] & v[5]) ^ (~v[4] & v[6]);                                                    \
-        const uint32_t maj_ = (v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]);                                    \
-        const uint32_t t1_ = v[7] + ep1_ + ch_ + kShaK[(T)] + (MW);                                             \
-        const uint32_t t2_ = ep0_ + maj_;                                                                       \
-        v[7] = v[6];                                                                                            \
-        v[6] = v[5];                                                                                            \
-        v[5] = v[4];                                                                                            \
-        v[4] = v[3] + t1_;                                                                                      \
-        v[3] = v[2];                                                                                            \
-        v[2] = v[1];                                                                                            \
-        v[1] = v[0];                                                                                            \
-        v[0] = t1_ + t2_;                                                                                       \
-    } while (0)
-
-// sha256_transform (:27-98).  CHECKED adds the injector hooks of the general path.
-template <bool CHECKED>
-__device__ __forceinline__ void sha_compress(uint32_t st[8], uint32_t m[16], uint32_t cidx, const FaultTab &ft,
-                                             uint2 fr, int slot, int rep, bool laneLive)
+// ------------------------------------------------------------------------------------------------ fast path
+// sha256_transform (:27-98), 64 rounds unrolled; the working variables rotate by renaming, not by moves.
+__device__ __forceinline__ void sha_compress_unrolled(uint32_t st[8], uint32_t m[16])
 {
-    uint32_t v[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w)
-        v[w] = st[w];
-#pragma unroll 1
-    for (int t16 = 0; t16 < 64; t16 += 16) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int t = t16 + u;
-            if (t16 > 0) { // schedule expansion :49-63 on the rolling window
-                const uint32_t x = m[(u + 14) & 15], y = m[(u + 1) & 15];
-                const uint32_t s1 = rotr32(x, 17) ^ rotr32(x, 19) ^ (x >> 10);
-                const uint32_t s0 = rotr32(y, 7) ^ rotr32(y, 18) ^ (y >> 3);
-                m[u] = s1 + m[(u + 9) & 15] + s0 + m[u];
-            }
-            if (CHECKED) {
-                for (uint32_t q = 0; q < fr.y; ++q) {
-                    const DevFault df = ft.list[fr.x + q];
-                    if ((int)df.local != slot || (int)df.replica != rep || !laneLive ||
-                        df.step != cidx * 64u + (uint32_t)t)
-                        continue;
-                    const uint32_t mask = 1u << (df.bit & 31u);
-                    if (df.site == SITE_SHA_M) {
-                        m[u] ^= mask;
-                    } else if (df.site == SITE_SHA_WV) {
-#pragma unroll
-                        for (int w = 0; w < 8; ++w)
-                            if (w == (df.index & 7))
-                                v[w] ^= mask;
-                    }
-                }
-            }
-            SHA_ROUND(t, m[u]);
-        }
-    }
-#pragma unroll
-    for (int w = 0; w < 8; ++w)
-        st[w] += v[w];
+    constexpr uint32_t K[64] = {SHA_K_LIST};
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#define SHA_STEP(A, B, C, D, E, F, G, H, T)                                                                      \
+    do {                                                                                                        \
+        if ((T) >= 16) { /* schedule expansion :49-63 on the rolling window */                                  \
+            const uint32_t x_ = m[((T) + 14) & 15], y_ = m[((T) + 1) & 15];                                     \
+            const uint32_t s1_ = xor3(rotr32(x_, 17), rotr32(x_, 19), x_ >> 10);                                \
+            const uint32_t s0_ = xor3(rotr32(y_, 7), rotr32(y_, 18), y_ >> 3);                                  \
+            m[(T) & 15] = m[(T) & 15] + s0_ + (m[((T) + 9) & 15] + s1_);                                        \
+        }                                                                                                       \
+        const uint32_t ep1_ = xor3(rotr32(E, 6), rotr32(E, 11), rotr32(E, 25));                                 \
+        const uint32_t t1_ = (H + ep1_ + sha_ch(E, F, G)) + (K[(T)] + m[(T) & 15]);                             \
+        const uint32_t ep0_ = xor3(rotr32(A, 2), rotr32(A, 13), rotr32(A, 22));                                 \
+        D += t1_;                                                                                               \
+        H = t1_ + ep0_ + sha_maj(A, B, C);                                                                      \
+    } while (0)
+#define SHA_STEP8(T)                                                                                             \
+    SHA_STEP(a, b, c, d, e, f, g, h, (T) + 0);                                                                  \
+    SHA_STEP(h, a, b, c, d, e, f, g, (T) + 1);                                                                  \
+    SHA_STEP(g, h, a, b, c, d, e, f, (T) + 2);                                                                  \
+    SHA_STEP(f, g, h, a, b, c, d, e, (T) + 3);                                                                  \
+    SHA_STEP(e, f, g, h, a, b, c, d, (T) + 4);                                                                  \
+    SHA_STEP(d, e, f, g, h, a, b, c, (T) + 5);                                                                  \
+    SHA_STEP(c, d, e, f, g, h, a, b, (T) + 6);                                                                  \
+    SHA_STEP(b, c, d, e, f, g, h, a, (T) + 7)
+    SHA_STEP8(0);
+    SHA_STEP8(8);
+    SHA_STEP8(16);
+    SHA_STEP8(24);
+    SHA_STEP8(32);
+    SHA_STEP8(40);
+    SHA_STEP8(48);
+    SHA_STEP8(56);
+#undef SHA_STEP8
+#undef SHA_STEP
+    st[0] += a;
+    st[1] += b;
+    st[2] += c;
+    st[3] += d;
+    st[4] += e;
+    st[5] += f;
+    st[6] += g;
+    st[7] += h;
 }
 
-// Note: the reference produces ALL 64 schedule words before round 0, so a flip of m[t] lands before any round runs,
-// and a working-variable flip "before round t" lands after m[t..63] exist.  In the interleaved form above the M hook
-// of step t runs right after m[t] is produced and before round t, and the WV hook before round t: every value that
-// depends on the flipped word is computed after the flip in both orders, so the dataflow is identical.
-
-template <int NREP>
-__global__ __launch_bounds__(256) void sha256_xmr_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
-                                                         uint64_t nmsgs, uint8_t *__restrict__ digests,
-                                                         uint32_t nblocks, Counters ctr, FaultTab ft, int haveFaults,
-                                                         uint8_t *__restrict__ detected)
+// one wave per tile; requires 4-byte aligned message rows (stride % 4 == 0, base % 4 == 0); VEC16: rows 16-byte aligned
+template <int NREP, bool VEC16>
+__global__ __launch_bounds__(256) void sha256_fast_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
+                                                          uint64_t nmsgs, uint8_t *__restrict__ digests,
+                                                          uint64_t ntiles, Counters ctr,
+                                                          const uint2 *__restrict__ faultRange,
+                                                          uint8_t *__restrict__ detected)
 {
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
-    constexpr int IPB = 4 * IPW;
     const LaneMap<NREP> lm;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t lb = blockIdx.x; // messages are independent and read once: no XCD remap needed
-    const int slot = wave * IPW + lm.q;
-    const uint64_t item = (uint64_t)lb * IPB + (uint64_t)slot;
-    const bool live = lm.live && item < nmsgs;
-    const uint8_t *msg = msgs + (live ? item : 0) * stride;
-    const bool aligned = ((stride & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(msgs) & 3u) == 0u);
-
     if (threadIdx.x < 4)
         sCnt[threadIdx.x] = 0;
     __syncthreads();
 
-    uint2 fr = make_uint2(0u, 0u);
-    if (haveFaults)
-        fr = ft.range[lb];
-    const bool general = fr.y != 0u;
+    const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    bool skip = tile >= ntiles;
+    if (!skip && faultRange)
+        skip = faultRange[tile].y != 0u; // sha256_general_kernel owns faulted tiles
+    const uint64_t item = tile * IPW + (uint64_t)lm.q;
+    const bool live = !skip && lm.live && item < nmsgs;
+    const bool cnt = live && lm.r == 0;
+    const uint8_t *msg = msgs + (live ? item : 0) * stride;
 
     uint32_t st[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
                       0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u}; // :107-114
     Tally tl;
-    const bool cnt = live && lm.r == 0;
-    const uint32_t rem = len & 63u;
-    const uint32_t ncomp = (len >> 6) + (rem < 56u ? 1u : 2u);
+    const uint32_t nfull = len >> 6, rem = len & 63u;
+    const uint32_t ncomp = nfull + (rem < 56u ? 1u : 2u);
 
     for (uint32_t c = 0; c < ncomp; ++c) {
         uint32_t m[16];
-        const bool last = (c + 1u == ncomp);
+        if (c < nfull) { // a whole data block
+            if (VEC16) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(msg + (size_t)c * 64);
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-            m[t] = sha_word(msg, len, c, t, aligned, last);
-        if (general) {
-            for (uint32_t q = 0; q < fr.y; ++q) { // ctx_state hook before compression c
-                const DevFault df = ft.list[fr.x + q];
-                if (df.site != SITE_SHA_STATE || df.step != c || (int)df.local != slot || (int)df.replica != lm.r ||
-                    !lm.live)
-                    continue;
+                for (int v = 0; v < 4; ++v) {
+                    const uint4 q = src[v];
+                    m[4 * v + 0] = bswap32(q.x);
+                    m[4 * v + 1] = bswap32(q.y);
+                    m[4 * v + 2] = bswap32(q.z);
+                    m[4 * v + 3] = bswap32(q.w);
+                }
+            } else {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(msg + (size_t)c * 64);
 #pragma unroll
-                for (int w = 0; w < 8; ++w)
-                    if (w == (df.index & 7))
-                        st[w] ^= 1u << (df.bit & 31u);
+                for (int t = 0; t < 16; ++t)
+                    m[t] = bswap32(src[t]);
             }
-            sha_compress<true>(st, m, c, ft, fr, slot, lm.r, lm.live);
-        } else {
-            sha_compress<false>(st, m, c, ft, fr, slot, lm.r, lm.live);
+        } else { // tail / padding blocks (:129-164)
+            const bool last = (c + 1u == ncomp);
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                m[t] = sha_word(msg, len, c, t, true, last);
         }
+        sha_compress_unrolled(st, m);
 #pragma unroll
         for (int w = 0; w < 8; ++w) // ctx_state[w] += ... are stores: store-data sync
             st[w] = xmr_sync<NREP>(st[w], lm, cnt, tl);
-    }
-    if (general) {
-        for (uint32_t q = 0; q < fr.y; ++q) { // step == ncompress: between the last compression and the digest
-            const DevFault df = ft.list[fr.x + q];
-            if (df.site != SITE_SHA_STATE || df.step != ncomp || (int)df.local != slot || (int)df.replica != lm.r ||
-                !lm.live)
-                continue;
-#pragma unroll
-            for (int w = 0; w < 8; ++w)
-                if (w == (df.index & 7))
-                    st[w] ^= 1u << (df.bit & 31u);
-        }
     }
     uint32_t dg[8];
 #pragma unroll
@@ -222,7 +222,159 @@ __global__ __launch_bounds__(256) void sha256_xmr_kernel(const uint8_t *__restri
                 detected[item] = 1;
         }
     }
-    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, lb);
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------ general path
+#define SHA_ROUND(T, MW)                                                                                        \
+    do {                                                                                                        \
+        const uint32_t ep0_ = rotr32(v[0], 2) ^ rotr32(v[0], 13) ^ rotr32(v[0], 22);                            \
+        const uint32_t ep1_ = rotr32(v[4], 6) ^ rotr32(v[4], 11) ^ rotr32(v[4], 25);                            \
+        const uint32_t ch_ = (v[4] & v[5]) ^ (~v[4] & v[6]);                                                    \
+        const uint32_t maj_ = (v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]);                                    \
+        const uint32_t t1_ = v[7] + ep1_ + ch_ + kShaK[(T)] + (MW);                                             \
+        const uint32_t t2_ = ep0_ + maj_;                                                                       \
+        v[7] = v[6];                                                                                            \
+        v[6] = v[5];                                                                                            \
+        v[5] = v[4];                                                                                            \
+        v[4] = v[3] + t1_;                                                                                      \
+        v[3] = v[2];                                                                                            \
+        v[2] = v[1];                                                                                            \
+        v[1] = v[0];                                                                                            \
+        v[0] = t1_ + t2_;                                                                                       \
+    } while (0)
+
+// sha256_transform (:27-98), a round at a time with the injector hooks.  The reference produces all 64 schedule words
+// before round 0; here word t is produced (and an M hook of step t applied) right before round t, and a working-variable
+// hook is applied before round t: every value that depends on a flipped word is computed after the flip in both
+// orders, so the dataflow is identical to the oracle's.
+__device__ __forceinline__ void sha_compress_hooked(uint32_t st[8], uint32_t m[16], uint32_t cidx, const FaultTab &ft,
+                                                    uint2 fr, int slot, int rep, bool laneLive)
+{
+    uint32_t v[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+        v[w] = st[w];
+#pragma unroll 1
+    for (int t16 = 0; t16 < 64; t16 += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int t = t16 + u;
+            if (t16 > 0) {
+                const uint32_t x = m[(u + 14) & 15], y = m[(u + 1) & 15];
+                const uint32_t s1 = rotr32(x, 17) ^ rotr32(x, 19) ^ (x >> 10);
+                const uint32_t s0 = rotr32(y, 7) ^ rotr32(y, 18) ^ (y >> 3);
+                m[u] = s1 + m[(u + 9) & 15] + s0 + m[u];
+            }
+            for (uint32_t q = 0; q < fr.y; ++q) {
+                const DevFault df = ft.list[fr.x + q];
+                if ((int)df.local != slot || (int)df.replica != rep || !laneLive ||
+                    df.step != cidx * 64u + (uint32_t)t)
+                    continue;
+                const uint32_t mask = 1u << (df.bit & 31u);
+                if (df.site == SITE_SHA_M) {
+                    m[u] ^= mask;
+                } else if (df.site == SITE_SHA_WV) {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w)
+                        if (w == (df.index & 7))
+                            v[w] ^= mask;
+                }
+            }
+            SHA_ROUND(t, m[u]);
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+        st[w] += v[w];
+}
+
+__device__ __forceinline__ void sha_state_hook(uint32_t st[8], uint32_t step, const FaultTab &ft, uint2 fr, int slot,
+                                               int rep, bool laneLive)
+{
+    for (uint32_t q = 0; q < fr.y; ++q) {
+        const DevFault df = ft.list[fr.x + q];
+        if (df.site != SITE_SHA_STATE || df.step != step || (int)df.local != slot || (int)df.replica != rep ||
+            !laneLive)
+            continue;
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+            if (w == (df.index & 7))
+                st[w] ^= 1u << (df.bit & 31u);
+    }
+}
+
+// one wave (64-thread workgroup) per tile
+template <int NREP>
+__global__ __launch_bounds__(64) void sha256_general_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
+                                                            uint64_t nmsgs, uint8_t *__restrict__ digests,
+                                                            Counters ctr, FaultTab ft,
+                                                            const uint32_t *__restrict__ tileList,
+                                                            uint8_t *__restrict__ detected)
+{
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    const LaneMap<NREP> lm;
+    const uint32_t tile = tileList ? tileList[blockIdx.x] : blockIdx.x;
+    const int slot = lm.q;
+    const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
+    const bool live = lm.live && item < nmsgs;
+    const uint8_t *msg = msgs + (live ? item : 0) * stride;
+    const bool aligned = ((stride & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(msgs) & 3u) == 0u);
+
+    if (threadIdx.x < 4)
+        sCnt[threadIdx.x] = 0;
+    __syncthreads();
+
+    uint2 fr = make_uint2(0u, 0u);
+    if (ft.range)
+        fr = ft.range[tile];
+
+    uint32_t st[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
+                      0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    Tally tl;
+    const bool cnt = live && lm.r == 0;
+    const uint32_t rem = len & 63u;
+    const uint32_t ncomp = (len >> 6) + (rem < 56u ? 1u : 2u);
+
+    for (uint32_t c = 0; c < ncomp; ++c) {
+        uint32_t m[16];
+        const bool last = (c + 1u == ncomp);
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            m[t] = sha_word(msg, len, c, t, aligned, last);
+        sha_state_hook(st, c, ft, fr, slot, lm.r, lm.live); // ctx_state hook before compression c
+        sha_compress_hooked(st, m, c, ft, fr, slot, lm.r, lm.live);
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+            st[w] = xmr_sync<NREP>(st[w], lm, cnt, tl);
+    }
+    sha_state_hook(st, ncomp, ft, fr, slot, lm.r, lm.live); // step == ncompress: before the digest
+    uint32_t dg[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+        dg[w] = bswap32(xmr_sync<NREP>(st[w], lm, cnt, tl));
+
+    uint32_t detItems = 0;
+    if (cnt) {
+        uint8_t *out = digests + item * 32u;
+        if ((reinterpret_cast<uintptr_t>(digests) & 15u) == 0u) {
+            reinterpret_cast<uint4 *>(out)[0] = make_uint4(dg[0], dg[1], dg[2], dg[3]);
+            reinterpret_cast<uint4 *>(out)[1] = make_uint4(dg[4], dg[5], dg[6], dg[7]);
+        } else {
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    out[4 * w + b] = (uint8_t)(dg[w] >> (8 * b));
+        }
+        if (NREP == 2 && tl.det) {
+            detItems = 1;
+            if (detected)
+                detected[item] = 1;
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, tile);
 }
 
 } // namespace coast

@@ -37,6 +37,11 @@ KERNEL(k_bfi, "v_bfi_b32 %0, %1, %2, %0")
 KERNEL(k_add3, "v_add3_u32 %0, %0, %1, %2")
 KERNEL(k_perm, "v_perm_b32 %0, %0, %1, %2")
 KERNEL(k_lshl_add, "v_lshl_add_u32 %0, %0, 1, %1")
+KERNEL(k_add_e64, "v_add_u32_e64 %0, %0, %1")
+KERNEL(k_xor_lit, "v_xor_b32_e32 %0, 0x12345678, %0")
+KERNEL(k_bitop3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+KERNEL(k_lshr, "v_lshrrev_b32_e32 %0, 3, %0")
+KERNEL(k_and_or, "v_and_or_b32 %0, %0, %1, %2")
 
 __global__ __launch_bounds__(256) void k_mad_u64_u32(uint32_t *out, uint32_t seed)
 {
@@ -128,6 +133,11 @@ int main(int argc, char **argv)
     run("v_add3_u32", k_add3, d);
     run("v_perm_b32", k_perm, d);
     run("v_lshl_add_u32", k_lshl_add, d);
+    run("v_add_u32_e64", k_add_e64, d);
+    run("v_xor_b32 literal", k_xor_lit, d);
+    run("v_bitop3_b32", k_bitop3, d);
+    run("v_lshrrev_b32", k_lshr, d);
+    run("v_and_or_b32", k_and_or, d);
     run("ds_bpermute_b32", k_bpermute, d);
     run("dpp wave_shl:1", k_dpp_wave_shl, d);
     return 0;
