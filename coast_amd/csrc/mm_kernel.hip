@@ -370,18 +370,23 @@ __global__ __launch_bounds__(256) void mm_fast256_kernel(const uint32_t *__restr
     const char *rdB = reinterpret_cast<const char *>(smem) + (G::KT * G::RS + L.j0) * 4;
     auto compute = [&](auto bufTag) {
         constexpr int BUF = decltype(bufTag)::value;
-        uint4 a = *reinterpret_cast<const uint4 *>(rdA + BUF * G::PANEL * 4);
-        uint4 b = *reinterpret_cast<const uint4 *>(rdB + BUF * G::PANEL * 4);
+        // LDS reads run two k steps ahead of the MACs that consume them
+        uint4 a0 = *reinterpret_cast<const uint4 *>(rdA + BUF * G::PANEL * 4);
+        uint4 b0 = *reinterpret_cast<const uint4 *>(rdB + BUF * G::PANEL * 4);
+        uint4 a1 = *reinterpret_cast<const uint4 *>(rdA + (BUF * G::PANEL + G::RS) * 4);
+        uint4 b1 = *reinterpret_cast<const uint4 *>(rdB + (BUF * G::PANEL + G::NPAD) * 4);
 #pragma unroll
         for (int kk = 0; kk < G::KT; ++kk) {
-            uint4 an = a, bn = b;
-            if (kk + 1 < G::KT) {
-                an = *reinterpret_cast<const uint4 *>(rdA + (BUF * G::PANEL + (kk + 1) * G::RS) * 4);
-                bn = *reinterpret_cast<const uint4 *>(rdB + (BUF * G::PANEL + (kk + 1) * G::NPAD) * 4);
+            uint4 an = a1, bn = b1;
+            if (kk + 2 < G::KT) {
+                an = *reinterpret_cast<const uint4 *>(rdA + (BUF * G::PANEL + (kk + 2) * G::RS) * 4);
+                bn = *reinterpret_cast<const uint4 *>(rdB + (BUF * G::PANEL + (kk + 2) * G::NPAD) * 4);
             }
-            mac16_u64(acc, a, b);
-            a = an;
-            b = bn;
+            mac16_u64(acc, a0, b0);
+            a0 = a1;
+            b0 = b1;
+            a1 = an;
+            b1 = bn;
         }
     };
     using B0 = std::integral_constant<int, 0>;
