@@ -332,12 +332,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    ndev = max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        torch.cuda.set_device(local % ndev)  # one process per GPU; the modulo only matters for single-GPU dry runs
+        backend = os.environ.get("COAST_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo for 1-GPU dry runs
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
