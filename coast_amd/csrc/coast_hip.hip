@@ -364,10 +364,10 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     int rc = check_cfg(c, cfg);
     if (rc)
         return rc;
+    if (batch == 0)
+        return COAST_OK; // an empty batch is a no-op (armed faults stay armed for the next real launch)
     if (!d_f || !d_s || !d_r || n < 1 || n > 4096)
         return fail(c, COAST_EINVAL, "coast_mm_batch: bad pointers or side %d (1..4096)", n);
-    if (batch == 0)
-        return COAST_OK;
     HIP_TRY(c, hipSetDevice(c->device));
 
     MmHostGeom h;

@@ -364,3 +364,70 @@ def test_unmodified_reference_drivers_on_gpu_backend(binary, mode, expect):
     p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, (p.returncode, p.stdout[-500:], p.stderr[-500:])
     assert expect in p.stdout
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("n", [512, 1100, 2048])
+def test_mm_large_sides_generic_kernels(eng, orc, n):
+    """Sides beyond the specialised 256 path: k-chunk 4 (n=512), ragged + k-chunk 1 (n=1100), n=2048."""
+    import coast_amd
+
+    rng = np.random.default_rng(n)
+    f = rng.integers(0, 2**32, (1, n, n), dtype=np.uint32)
+    s = rng.integers(0, 2**32, (1, n, n), dtype=np.uint32)
+    items = rng.choice(n * n, 64, replace=False).astype(np.uint64)
+    fl = coast_amd.make_faults([(int(it), int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, n)),
+                                 int(rng.integers(0, 32))) for it in items[:32]])
+    exp_items, exp_st, _ = orc.mm_xmr_items(f[0], s[0], items, faults=fl)
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    got = _host(eng.mm_batch(_dev(f), _dev(s)), np.uint32)[0]
+    st = eng.stats()
+    assert (got.reshape(-1)[items.astype(np.int64)] == exp_items).all()
+    assert st["errors_corrected"] == exp_st["errors_corrected"] and st["sync_count"] == n * n
+    if n <= 1100:  # full-matrix check against the plain restatement (all single faults are out-voted)
+        assert (got == orc.mm_plain(f[0], s[0])).all()
+    else:
+        clean = _host(eng.mm_batch(_dev(f), _dev(s), cfg=coast_amd.XmrConfig(1)), np.uint32)[0]
+        assert (got == clean).all()
+
+
+def test_empty_batches_are_noops(eng):
+    import torch
+
+    import coast_amd
+
+    eng.reset_stats()
+    z32 = torch.empty((0, 8, 8), dtype=torch.int32, device="cuda")
+    assert eng.mm_batch(z32, z32).shape == (0, 8, 8)
+    assert eng.sha256_batch(torch.empty((0, 64), dtype=torch.uint8, device="cuda"), 64).shape == (0, 32)
+    zs = torch.empty((0, 16), dtype=torch.uint8, device="cuda")
+    eng.aes128_batch(zs, zs.clone(), 0)
+    assert eng.crc16_batch(torch.empty((0,), dtype=torch.uint8, device="cuda"), 256).shape == (0,)
+    st = eng.stats()
+    assert st["sync_count"] == 0 and st["errors_corrected"] == 0
+    # a fault list that addresses nothing (out-of-range item, replica >= replicas) is dropped, like the oracle does
+    eng.inject_faults(coast_amd.make_faults([(10**12, 0, 0, 0, 0), (0, 2, 0, 0, 0)]))
+    f = torch.ones((1, 4, 4), dtype=torch.int32, device="cuda")
+    out = eng.mm_batch(f, f, cfg=coast_amd.XmrConfig(coast_amd.DWC))
+    assert (out == 4).all() and eng.stats()["dwc_detected"] == 0
+
+
+def test_bad_arguments_are_rejected(eng):
+    import ctypes as C
+
+    import torch
+
+    import coast_amd
+    from coast_amd import _lib
+
+    f = torch.ones((1, 4, 4), dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError):
+        eng.mm_batch(f, f, cfg=coast_amd.XmrConfig(4))
+    with pytest.raises(RuntimeError):
+        eng.mm_batch(f, f, cfg=coast_amd.XmrConfig(0))
+    L = _lib.load()
+    assert L.coast_mm_batch(None, None, None, None, 4, 1, None, None) != 0
+    st = torch.zeros(17, dtype=torch.uint8, device="cuda")[1:]  # misaligned aes state array
+    cfg = _lib.CoastCfg(2, 0)
+    assert L.coast_aes128_batch(eng._h, C.c_void_p(st.data_ptr()), C.c_void_p(st.data_ptr()), 1, 0, C.byref(cfg), None) != 0
