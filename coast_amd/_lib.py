@@ -68,9 +68,13 @@ def load():
         return _lib
     path = lib_path()
     if not os.path.exists(path):
-        raise CoastLibraryError(
-            "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
-            "coast_amd has no CPU fallback." % path)
+        # a fresh checkout: compile the HIP library in-tree (still the native path -- there is nothing to fall back to)
+        try:
+            _build.build()
+        except Exception as e:  # no hipcc, compile error ...
+            raise CoastLibraryError(
+                "%s is missing and could not be built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "coast_amd has no CPU fallback." % (path, e)) from e
     try:
         L = C.CDLL(path)
     except OSError as e:

@@ -8,6 +8,14 @@
 // read-only memory outside the sphere of replication, like the reference's const tables under -noMemReplication.
 // Sync points (frozen in oracle/coast_oracle.c): the 4 state dwords and 4 key dwords at the end (they are stored back),
 // and with sync_every != 0 also after every main-loop round.
+//
+// Two kernels, one wave per tile of IPW blocks:
+//   aes128_enc_fast_kernel  encryption, tiles without an armed fault, mandatory sync points only: state and key as four
+//                           little-endian column dwords; SubBytes + ShiftRows + MixColumns of one round are 16 lookups in
+//                           four 1-KiB LDS tables (Te_r[v] = MixColumns column r scaled by S[v]) folded with v_bitop3
+//                           xors -- the same bytes as TI_aes_128.c:142-185 computes one at a time.
+//   aes128_xmr_kernel       byte-at-a-time exactly as written in the reference, both directions, injector hooks and
+//                           per-round sync points; runs faulted tiles (side stream), decryption, and sync_every != 0.
 #include "xmr.hpp"
 
 namespace coast {
@@ -19,6 +27,7 @@ __constant__ uint8_t kAesRcon[10] = {0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0
 // FIPS-197 S-box generated from its definition at load time by aes_tables_kernel (no pasted table)
 __device__ uint8_t gAesSbox[256];
 __device__ uint8_t gAesRsbox[256];
+__device__ uint32_t gAesTe[4][256]; // Te_r[v]: bytes (out row 0..3) = MixColumns matrix column r times S[v]
 
 __device__ __forceinline__ uint32_t gf_mul_dev(uint32_t a, uint32_t b)
 {
@@ -51,6 +60,12 @@ __global__ void aes_tables_kernel()
     s ^= 0x63u;
     gAesSbox[x] = (uint8_t)s;
     gAesRsbox[s] = (uint8_t)x;
+    const uint32_t s2 = ((s << 1) ^ ((s & 0x80u) ? 0x1bu : 0u)) & 0xffu, s3 = s2 ^ s;
+    // matrix [2 3 1 1; 1 2 3 1; 1 1 2 3; 3 1 1 2] (TI_aes_128.c:176-185): column r lists the weights of input row r
+    gAesTe[0][x] = s2 | (s << 8) | (s << 16) | (s3 << 24);
+    gAesTe[1][x] = s3 | (s2 << 8) | (s << 16) | (s << 24);
+    gAesTe[2][x] = s | (s3 << 8) | (s2 << 16) | (s << 24);
+    gAesTe[3][x] = s | (s << 8) | (s3 << 16) | (s2 << 24);
 }
 
 __device__ __forceinline__ uint32_t xtime(uint32_t v) { return ((v << 1) ^ ((v & 0x80u) ? 0x1bu : 0u)) & 0xffu; } // :88-99
@@ -151,33 +166,134 @@ __device__ __forceinline__ void aes_sync(uint32_t s[16], uint32_t k[16], const L
         unpack4(xmr_sync<NREP>(pack4(k + 4 * w), lm, cnt, tl), k + 4 * w);
 }
 
-template <int NREP>
-__global__ __launch_bounds__(256) void aes128_xmr_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
-                                                         uint64_t nblocksData, int dirFlag, uint32_t syncEvery,
-                                                         Counters ctr, FaultTab ft, int haveFaults,
-                                                         uint8_t *__restrict__ detected)
+// ------------------------------------------------------------------------------------------------ fast encryption
+__device__ __forceinline__ uint32_t aes_xor3(uint32_t a, uint32_t b, uint32_t c)
 {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
+template <int NREP>
+__global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
+                                                              uint64_t nblocksData, uint64_t ntiles, Counters ctr,
+                                                              const uint2 *__restrict__ faultRange,
+                                                              uint8_t *__restrict__ detected)
+{
+    __shared__ uint32_t sTe[4][256];
     __shared__ uint8_t sSb[256];
-    __shared__ uint8_t sRsb[256];
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
-    constexpr int IPB = 4 * IPW;
     const LaneMap<NREP> lm;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t lb = blockIdx.x;
-    const int slot = wave * IPW + lm.q;
-    const uint64_t item = (uint64_t)lb * IPB + (uint64_t)slot;
-    const bool live = lm.live && item < nblocksData;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        sTe[r][tid] = gAesTe[r][tid];
+    sSb[tid] = gAesSbox[tid];
+    if (tid < 4)
+        sCnt[tid] = 0;
+    __syncthreads();
+
+    const uint64_t tile = (uint64_t)blockIdx.x * 4 + (tid >> 6);
+    bool skip = tile >= ntiles;
+    if (!skip && faultRange)
+        skip = faultRange[tile].y != 0u; // aes128_xmr_kernel owns faulted tiles
+    const uint64_t item = tile * IPW + (uint64_t)lm.q;
+    const bool live = !skip && lm.live && item < nblocksData;
+    const bool cnt = live && lm.r == 0;
+    const uint64_t it = live ? item : 0;
+    uint4 sv = reinterpret_cast<const uint4 *>(states)[it];
+    uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
+    uint32_t s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w; // column c = state[4c..4c+3], row r in bits 8r
+    uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
+
+#define B0(x) ((x) & 0xffu)
+#define B1(x) (((x) >> 8) & 0xffu)
+#define B2(x) (((x) >> 16) & 0xffu)
+#define B3(x) ((x) >> 24)
+#pragma unroll
+    for (int rd = 0; rd < 10; ++rd) {
+        const uint32_t x0 = s0 ^ k0, x1 = s1 ^ k1, x2 = s2 ^ k2, x3 = s3 ^ k3; // state[i] ^ key[i]       (:144-146)
+        if (rd < 9) { // SubBytes, ShiftRows (row r of column j comes from column j+r, :148-166), MixColumns (:168-185)
+            s0 = aes_xor3(sTe[0][B0(x0)], sTe[1][B1(x1)], sTe[2][B2(x2)]) ^ sTe[3][B3(x3)];
+            s1 = aes_xor3(sTe[0][B0(x1)], sTe[1][B1(x2)], sTe[2][B2(x3)]) ^ sTe[3][B3(x0)];
+            s2 = aes_xor3(sTe[0][B0(x2)], sTe[1][B1(x3)], sTe[2][B2(x0)]) ^ sTe[3][B3(x1)];
+            s3 = aes_xor3(sTe[0][B0(x3)], sTe[1][B1(x0)], sTe[2][B2(x1)]) ^ sTe[3][B3(x2)];
+        } else { // last round: no MixColumns
+            s0 = (uint32_t)sSb[B0(x0)] | ((uint32_t)sSb[B1(x1)] << 8) | ((uint32_t)sSb[B2(x2)] << 16) | ((uint32_t)sSb[B3(x3)] << 24);
+            s1 = (uint32_t)sSb[B0(x1)] | ((uint32_t)sSb[B1(x2)] << 8) | ((uint32_t)sSb[B2(x3)] << 16) | ((uint32_t)sSb[B3(x0)] << 24);
+            s2 = (uint32_t)sSb[B0(x2)] | ((uint32_t)sSb[B1(x3)] << 8) | ((uint32_t)sSb[B2(x0)] << 16) | ((uint32_t)sSb[B3(x1)] << 24);
+            s3 = (uint32_t)sSb[B0(x3)] | ((uint32_t)sSb[B1(x0)] << 8) | ((uint32_t)sSb[B2(x1)] << 16) | ((uint32_t)sSb[B3(x2)] << 24);
+        }
+        // key schedule (:220-226): key[0..3] ^= sbox[key[13,14,15,12]] (^ Rcon on byte 0), then key[i] ^= key[i-4]
+        const uint32_t sw = (uint32_t)sSb[B1(k3)] | ((uint32_t)sSb[B2(k3)] << 8) | ((uint32_t)sSb[B3(k3)] << 16) |
+                            ((uint32_t)sSb[B0(k3)] << 24);
+        k0 = aes_xor3(k0, sw, (uint32_t)kAesRcon[rd]);
+        k1 ^= k0;
+        k2 ^= k1;
+        k3 ^= k2;
+    }
+#undef B0
+#undef B1
+#undef B2
+#undef B3
+    s0 ^= k0; // last AddRoundKey (:228-233)
+    s1 ^= k1;
+    s2 ^= k2;
+    s3 ^= k3;
+
+    Tally tl;
+    s0 = xmr_sync<NREP>(s0, lm, cnt, tl); // in-place stores of state and key: store-data sync
+    s1 = xmr_sync<NREP>(s1, lm, cnt, tl);
+    s2 = xmr_sync<NREP>(s2, lm, cnt, tl);
+    s3 = xmr_sync<NREP>(s3, lm, cnt, tl);
+    k0 = xmr_sync<NREP>(k0, lm, cnt, tl);
+    k1 = xmr_sync<NREP>(k1, lm, cnt, tl);
+    k2 = xmr_sync<NREP>(k2, lm, cnt, tl);
+    k3 = xmr_sync<NREP>(k3, lm, cnt, tl);
+    uint32_t detItems = 0;
+    if (cnt) {
+        reinterpret_cast<uint4 *>(states)[item] = make_uint4(s0, s1, s2, s3);
+        reinterpret_cast<uint4 *>(keys)[item] = make_uint4(k0, k1, k2, k3);
+        if (NREP == 2 && tl.det) {
+            detItems = 1;
+            if (detected)
+                detected[item] = 1;
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------ general path
+template <int NREP>
+__global__ __launch_bounds__(256, 5) void aes128_xmr_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
+                                                        uint64_t nblocksData, int dirFlag, uint32_t syncEvery,
+                                                        Counters ctr, FaultTab ft,
+                                                        const uint32_t *__restrict__ tileList, uint32_t nslots,
+                                                        uint8_t *__restrict__ detected)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sSb[256];
+    __shared__ __attribute__((aligned(16))) uint8_t sRsb[256];
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    const LaneMap<NREP> lm;
+    // blockDim.x / 64 tiles per workgroup: 1 when walking the faulted-tile list, 4 when covering a whole batch
+    const uint32_t tslot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const bool slotOk = tslot < nslots; // the last workgroup of a whole-batch launch may hang over
+    const uint32_t lb = slotOk ? (tileList ? tileList[tslot] : tslot) : 0u; // tile
+    const int slot = lm.q;
+    const uint64_t item = (uint64_t)lb * IPW + (uint64_t)slot;
+    const bool live = slotOk && lm.live && item < nblocksData;
     const bool dir = dirFlag != 0;
 
-    sSb[threadIdx.x] = gAesSbox[threadIdx.x];
-    sRsb[threadIdx.x] = gAesRsbox[threadIdx.x];
+    if (threadIdx.x < 64) {
+        reinterpret_cast<uint32_t *>(sSb)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gAesSbox)[threadIdx.x];
+        reinterpret_cast<uint32_t *>(sRsb)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gAesRsbox)[threadIdx.x];
+    }
     if (threadIdx.x < 4)
         sCnt[threadIdx.x] = 0;
     __syncthreads();
 
     uint2 fr = make_uint2(0u, 0u);
-    if (haveFaults)
+    if (ft.range && slotOk)
         fr = ft.range[lb];
     const bool cnt = live && lm.r == 0;
     Tally tl;
