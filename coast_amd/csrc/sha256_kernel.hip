@@ -138,13 +138,62 @@ __device__ __forceinline__ void sha_compress_unrolled(uint32_t st[8], uint32_t m
     st[7] += h;
 }
 
+// The padding block of a message whose length is a multiple of 64 holds no data: its 16 words (0x80000000, 0 ..., the
+// bit length) and therefore its whole 64-word schedule depend on `len` alone -- a launch-uniform value like a loop bound,
+// outside the sphere of replication.  The host expands that schedule once and passes kw[t] = K[t] + W[t]; the replicated
+// part (the 64 rounds on the replica-private state) is unchanged.  Same digest bit for bit.
+struct ShaTail {
+    uint32_t kw[64];
+    uint32_t enabled;
+};
+
+__device__ __forceinline__ void sha_compress_const(uint32_t st[8], const ShaTail &tail)
+{
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#define SHA_CSTEP(A, B, C, D, E, F, G, H, T)                                                                     \
+    do {                                                                                                        \
+        const uint32_t ep1_ = xor3(rotr32(E, 6), rotr32(E, 11), rotr32(E, 25));                                 \
+        const uint32_t t1_ = (H + ep1_ + sha_ch(E, F, G)) + tail.kw[(T)];                                       \
+        const uint32_t ep0_ = xor3(rotr32(A, 2), rotr32(A, 13), rotr32(A, 22));                                 \
+        D += t1_;                                                                                               \
+        H = t1_ + ep0_ + sha_maj(A, B, C);                                                                      \
+    } while (0)
+#define SHA_CSTEP8(T)                                                                                            \
+    SHA_CSTEP(a, b, c, d, e, f, g, h, (T) + 0);                                                                 \
+    SHA_CSTEP(h, a, b, c, d, e, f, g, (T) + 1);                                                                 \
+    SHA_CSTEP(g, h, a, b, c, d, e, f, (T) + 2);                                                                 \
+    SHA_CSTEP(f, g, h, a, b, c, d, e, (T) + 3);                                                                 \
+    SHA_CSTEP(e, f, g, h, a, b, c, d, (T) + 4);                                                                 \
+    SHA_CSTEP(d, e, f, g, h, a, b, c, (T) + 5);                                                                 \
+    SHA_CSTEP(c, d, e, f, g, h, a, b, (T) + 6);                                                                 \
+    SHA_CSTEP(b, c, d, e, f, g, h, a, (T) + 7)
+    SHA_CSTEP8(0);
+    SHA_CSTEP8(8);
+    SHA_CSTEP8(16);
+    SHA_CSTEP8(24);
+    SHA_CSTEP8(32);
+    SHA_CSTEP8(40);
+    SHA_CSTEP8(48);
+    SHA_CSTEP8(56);
+#undef SHA_CSTEP8
+#undef SHA_CSTEP
+    st[0] += a;
+    st[1] += b;
+    st[2] += c;
+    st[3] += d;
+    st[4] += e;
+    st[5] += f;
+    st[6] += g;
+    st[7] += h;
+}
+
 // one wave per tile; requires 4-byte aligned message rows (stride % 4 == 0, base % 4 == 0); VEC16: rows 16-byte aligned
 template <int NREP, bool VEC16>
 __global__ __launch_bounds__(256) void sha256_fast_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
                                                           uint64_t nmsgs, uint8_t *__restrict__ digests,
                                                           uint64_t ntiles, Counters ctr,
                                                           const uint2 *__restrict__ faultRange,
-                                                          uint8_t *__restrict__ detected)
+                                                          uint8_t *__restrict__ detected, ShaTail tail)
 {
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
@@ -170,6 +219,13 @@ __global__ __launch_bounds__(256) void sha256_fast_kernel(const uint8_t *__restr
 
     for (uint32_t c = 0; c < ncomp; ++c) {
         uint32_t m[16];
+        if (tail.enabled && c == nfull) { // data-free padding block (len % 64 == 0): host-expanded schedule
+            sha_compress_const(st, tail);
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+                st[w] = xmr_sync<NREP>(st[w], lm, cnt, tl);
+            continue;
+        }
         if (c < nfull) { // a whole data block
             if (VEC16) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(msg + (size_t)c * 64);
