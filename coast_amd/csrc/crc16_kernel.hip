@@ -9,7 +9,7 @@
 // `while (length--)` loop-condition sync, crc16.c:25).
 //
 // Two kernels:
-//   crc16_stream_kernel   the HBM-streaming path (block_len % 64 == 0, no fault in the tile, mandatory sync only).
+//   crc16_stream_kernel   the HBM-streaming path (any block_len, no fault in the tile, mandatory sync only).
 //                         The byte-serial update costs ~9 VALU ops per byte per replica -- 3 replicas would cap the
 //                         chip near 2 TB/s -- so two update steps are folded into ONE lookup: for W = (b0<<8)|b1,
 //                         crc' = T16[crc ^ W] (both byte steps depend on crc and the data only through crc ^ W; derived
@@ -18,7 +18,10 @@
 //                         single shared read-only copy (memory, outside the sphere of replication); crc stays
 //                         replica-private, the three replica lanes look up the same address (LDS broadcast).
 //                         Each lane streams its own block 64 bytes (4 x dwordx4) at a time, next batch in flight under
-//                         the current one; the replicas of a block issue the same addresses (one fetch).
+//                         the current one; the replicas of a block issue the same addresses (one fetch).  Blocks that
+//                         are not 16-byte aligned (the reference's own maximum, 255 bytes) use byte-aligned wide loads;
+//                         a tail shorter than 64 bytes goes dword / byte-pair / last-byte (the odd byte is one
+//                         byte-serial step).
 //   crc16_general_kernel  byte-serial, exactly as written in crc16.c, with the injector hooks and the optional
 //                         per-V-bytes votes; one wave per tile; runs the tiles that own an armed fault (side stream) or
 //                         every tile when the stream path does not apply.
@@ -48,7 +51,21 @@ __global__ void crc16_table_kernel(uint16_t *__restrict__ t16)
 constexpr int kCrcStreamThreads = 1024;
 constexpr int kCrcTableBytes = 65536 * 2;
 
-template <int NREP, int NT>
+struct __attribute__((packed, aligned(1))) CrcU4 { // byte-aligned 16-byte load (global memory is in unaligned mode)
+    uint32_t x, y, z, w;
+};
+struct __attribute__((packed, aligned(1))) CrcU1 {
+    uint32_t x;
+};
+template <bool ALIGNED> __device__ __forceinline__ uint4 crc_load16(const uint8_t *p)
+{
+    if (ALIGNED)
+        return *reinterpret_cast<const uint4 *>(p);
+    const CrcU4 v = *reinterpret_cast<const CrcU4 *>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <int NREP, int NT, bool ALIGNED>
 __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
     const uint8_t *__restrict__ data, uint32_t blockLen, uint64_t nblocksData, uint16_t *__restrict__ crcs,
     const uint16_t *__restrict__ t16g, uint64_t ntiles, Counters ctr, const uint2 *__restrict__ faultRange,
@@ -77,6 +94,7 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
     Tally tl;
     uint32_t detItems = 0;
     const uint32_t nbatch = blockLen >> 6; // 64-byte batches per block
+    const uint32_t rem = blockLen & 63u;   // tail bytes
 
     for (uint64_t tileBase = wave0 * NT; tileBase < ntiles; tileBase += wavesTotal * NT) {
         // NT independent tiles per wave: NT dependent lookup chains in flight per lane
@@ -96,9 +114,11 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
             cntT[j] = liveT[j] && lm.r == 0;
             p[j] = data + (liveT[j] ? itemT[j] : 0) * (uint64_t)blockLen;
             crc[j] = 0xFFFFu;
+            if (nbatch) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                cur[j][v] = reinterpret_cast<const uint4 *>(p[j])[v];
+                for (int v = 0; v < 4; ++v)
+                    cur[j][v] = crc_load16<ALIGNED>(p[j] + 16 * v);
+            }
         }
         for (uint32_t b = 0; b < nbatch; ++b) {
             const bool more = (b + 1) < nbatch;
@@ -107,7 +127,7 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
-                        nxt[j][v] = reinterpret_cast<const uint4 *>(p[j] + (size_t)(b + 1) * 64)[v];
+                        nxt[j][v] = crc_load16<ALIGNED>(p[j] + (size_t)(b + 1) * 64 + 16 * v);
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -133,6 +153,29 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
                         cur[j][v] = nxt[j][v];
+            }
+        }
+        if (rem) { // tail shorter than one batch: dwords, then a byte pair, then the odd byte (one byte-serial step)
+            const size_t tb = (size_t)nbatch * 64;
+            uint32_t t = 0;
+            for (; t + 4u <= rem; t += 4u) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const uint32_t e = __builtin_bswap32(reinterpret_cast<const CrcU1 *>(p[j] + tb + t)->x);
+                    crc[j] = T[crc[j] ^ (e >> 16)];
+                    crc[j] = T[crc[j] ^ (e & 0xffffu)];
+                }
+            }
+            if (t + 2u <= rem) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    crc[j] = T[crc[j] ^ (((uint32_t)p[j][tb + t] << 8) | (uint32_t)p[j][tb + t + 1])];
+                t += 2u;
+            }
+            if (t < rem) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    crc[j] = crc16_byte(crc[j], p[j][tb + t]);
             }
         }
 #pragma unroll
