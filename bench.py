@@ -75,13 +75,20 @@ def cpu_baseline_mm(side, budget_s=12.0):
 
     reps, dt = _time_budget(one, budget_s)
     ureps, du = _time_budget(lambda: orc.mm_plain(f, s), 2.0)  # unprotected arithmetic, for the CPU TMR overhead
+    # all host cores over independent matrices (the reference itself is single-threaded; this is the generous bound)
+    ncpu = os.cpu_count() or 1
+    per_thread = max(1, int(round(4.0 * reps / dt)))  # ~4 s of work per thread
+    wall = orc.cpu_tmr_mm_threads(f, s, gold, ncpu, per_thread)
     return {
         "value": reps * side * side / dt, "unit": "protected elems/s", "cores": 1, "kind": "port",
         "sample": "%d x (%dx%d uint32 matrix_multiply + checkGolden), default-mode TMR restatement "
                   "(memory x3, loop-condition votes, -countErrors), gcc -O3, %.1f s" % (reps, side, side, dt),
         "unprotected_elems_per_s": ureps * side * side / du,
         "tmr_overhead_x": (dt / reps) / (du / ureps),
-        "host_cpus": os.cpu_count(),
+        "host_cpus": ncpu,
+        "all_cores": {"value": ncpu * per_thread * side * side / wall if wall > 0 else None, "cores": ncpu,
+                      "unit": "protected elems/s",
+                      "sample": "%d threads x %d matrices, %.1f s wall" % (ncpu, per_thread, wall)},
     }
 
 

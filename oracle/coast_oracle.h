@@ -104,6 +104,8 @@ void orc_mm_xmr_items(const uint32_t *f, const uint32_t *s, int n, const uint64_
 /* returns XOR-golden mismatch flag like checkGolden; *cnt gets TMR_ERROR_CNT, *syncs the dynamic vote count */
 int orc_cpu_tmr_mm(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, uint32_t xor_golden, uint32_t *cnt,
                    uint64_t *syncs);
+/* the same on nthreads host threads, reps independent matrices each; returns wall seconds (< 0 on a wrong result) */
+double orc_cpu_tmr_mm_threads(const uint32_t *f, const uint32_t *s, int n, uint32_t golden, int nthreads, int reps);
 
 #ifdef __cplusplus
 }

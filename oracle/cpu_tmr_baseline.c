@@ -97,3 +97,51 @@ int orc_cpu_tmr_mm(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, uin
         *syncs = t.syncs;
     return ret;
 }
+
+/* ---- all-host-cores variant: independent matrices, one per thread ---- */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    const uint32_t *f, *s;
+    int n, reps;
+    uint32_t golden;
+    int bad;
+} mt_arg;
+
+static void *mt_worker(void *p)
+{
+    mt_arg *a = (mt_arg *)p;
+    uint32_t *r = (uint32_t *)malloc((size_t)a->n * a->n * sizeof(uint32_t));
+    for (int i = 0; i < a->reps; ++i) {
+        uint32_t cnt = 0;
+        uint64_t syncs = 0;
+        a->bad |= orc_cpu_tmr_mm(a->f, a->s, r, a->n, a->golden, &cnt, &syncs) | (cnt != 0);
+    }
+    free(r);
+    return NULL;
+}
+
+/* runs nthreads x reps protected multiplications; returns wall seconds (< 0 on error) */
+double orc_cpu_tmr_mm_threads(const uint32_t *f, const uint32_t *s, int n, uint32_t golden, int nthreads, int reps)
+{
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    mt_arg *args = (mt_arg *)malloc(sizeof(mt_arg) * (size_t)nthreads);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < nthreads; ++t) {
+        args[t] = (mt_arg){f, s, n, reps, golden, 0};
+        pthread_create(&th[t], NULL, mt_worker, &args[t]);
+    }
+    int bad = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        pthread_join(th[t], NULL);
+        bad |= args[t].bad;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(th);
+    free(args);
+    if (bad)
+        return -1.0;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

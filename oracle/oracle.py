@@ -74,6 +74,7 @@ def lib():
         L.orc_mm_xor.restype = C.c_uint32
         L.orc_crc16_plain.restype = C.c_uint16
         L.orc_cpu_tmr_mm.restype = C.c_int
+        L.orc_cpu_tmr_mm_threads.restype = C.c_double
         L.orc_aes_sbox.restype = C.POINTER(C.c_uint8)
         L.orc_aes_rsbox.restype = C.POINTER(C.c_uint8)
         _lib = L
@@ -238,6 +239,14 @@ def cpu_tmr_mm(f, s, xor_golden):
     err = lib().orc_cpu_tmr_mm(_p(f, C.c_uint32), _p(s, C.c_uint32), _p(r, C.c_uint32), C.c_int(n),
                                C.c_uint32(xor_golden), C.byref(cnt), C.byref(syncs))
     return r, int(err), int(cnt.value), int(syncs.value)
+
+
+def cpu_tmr_mm_threads(f, s, xor_golden, nthreads, reps):
+    """nthreads x reps default-mode CPU-TMR multiplications in parallel; returns wall seconds."""
+    f = np.ascontiguousarray(f, dtype=np.uint32)
+    s = np.ascontiguousarray(s, dtype=np.uint32)
+    return float(lib().orc_cpu_tmr_mm_threads(_p(f, C.c_uint32), _p(s, C.c_uint32), C.c_int(f.shape[-1]),
+                                              C.c_uint32(xor_golden), C.c_int(nthreads), C.c_int(reps)))
 
 
 # ---------------------------------------------------------------- the reference itself (oracle/_ref)
