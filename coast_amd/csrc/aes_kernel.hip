@@ -253,8 +253,9 @@ __global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restric
     if (cnt) {
         reinterpret_cast<uint4 *>(states)[item] = make_uint4(s0, s1, s2, s3);
         reinterpret_cast<uint4 *>(keys)[item] = make_uint4(k0, k1, k2, k3);
-        if (NREP == 2 && tl.det) {
-            detItems = 1;
+        if (tl.det) { // unequal copies seen at a sync point of this block (DWC: detected, TMR: corrected)
+            if (NREP == 2)
+                detItems = 1;
             if (detected)
                 detected[item] = 1;
         }
@@ -357,8 +358,9 @@ __global__ __launch_bounds__(256, 5) void aes128_xmr_kernel(uint8_t *__restrict_
     if (cnt) {
         reinterpret_cast<uint4 *>(states)[item] = make_uint4(pack4(s), pack4(s + 4), pack4(s + 8), pack4(s + 12));
         reinterpret_cast<uint4 *>(keys)[item] = make_uint4(pack4(k), pack4(k + 4), pack4(k + 8), pack4(k + 12));
-        if (NREP == 2 && tl.det) {
-            detItems = 1;
+        if (tl.det) { // unequal copies seen at a sync point of this block (DWC: detected, TMR: corrected)
+            if (NREP == 2)
+                detItems = 1;
             if (detected)
                 detected[item] = 1;
         }

@@ -187,8 +187,9 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
             tl.syncs = te.syncs;
             if (cntT[j]) {
                 crcs[itemT[j]] = (uint16_t)voted;
-                if (NREP == 2 && te.det) {
-                    detItems += 1;
+                if (te.det) { // unequal copies at the sync point of this block (DWC: detected, TMR: corrected)
+                    if (NREP == 2)
+                        detItems += 1;
                     if (detected)
                         detected[itemT[j]] = 1;
                 }
@@ -271,8 +272,9 @@ __global__ __launch_bounds__(64) void crc16_general_kernel(const uint8_t *__rest
     uint32_t detItems = 0;
     if (cnt) {
         crcs[item] = (uint16_t)crc;
-        if (NREP == 2 && tl.det) {
-            detItems = 1;
+        if (tl.det) {
+            if (NREP == 2)
+                detItems = 1;
             if (detected)
                 detected[item] = 1;
         }

@@ -104,8 +104,9 @@ __device__ __forceinline__ void mm_epilogue(const uint32_t acc[16], const MmLane
                         dst[jj] = out[ii * 4 + jj];
             }
         }
-        if (NREP == 2 && tl.det) {
-            detItems = (uint32_t)__builtin_popcount(tl.det);
+        if (tl.det) { // per-element flags: unequal copies at a sync point (DWC: detected, TMR: corrected)
+            if (NREP == 2)
+                detItems = (uint32_t)__builtin_popcount(tl.det);
             if (detected) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)

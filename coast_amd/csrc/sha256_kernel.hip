@@ -272,8 +272,9 @@ __global__ __launch_bounds__(256) void sha256_fast_kernel(const uint8_t *__restr
                 for (int b = 0; b < 4; ++b)
                     out[4 * w + b] = (uint8_t)(dg[w] >> (8 * b));
         }
-        if (NREP == 2 && tl.det) {
-            detItems = 1;
+        if (tl.det) { // unequal copies seen at a sync point of this message (DWC: detected, TMR: corrected)
+            if (NREP == 2)
+                detItems = 1;
             if (detected)
                 detected[item] = 1;
         }
@@ -424,8 +425,9 @@ __global__ __launch_bounds__(64) void sha256_general_kernel(const uint8_t *__res
                 for (int b = 0; b < 4; ++b)
                     out[4 * w + b] = (uint8_t)(dg[w] >> (8 * b));
         }
-        if (NREP == 2 && tl.det) {
-            detItems = 1;
+        if (tl.det) { // unequal copies seen at a sync point of this message (DWC: detected, TMR: corrected)
+            if (NREP == 2)
+                detItems = 1;
             if (detected)
                 detected[item] = 1;
         }

@@ -52,7 +52,7 @@ template <int NREP> struct LaneMap {
 struct Tally {
     uint32_t miss = 0;  // voted values whose copies were not all equal      (TMR_ERROR_CNT)
     uint32_t syncs = 0; // sync points executed                               (__SYNC_COUNT)
-    uint32_t det = 0;   // DWC: a compare failed on the current item
+    uint32_t det = 0;   // a sync point of the current item saw unequal copies (DWC: detected, TMR: corrected)
 };
 
 // One sync point on a 32-bit value.
@@ -69,8 +69,10 @@ __device__ __forceinline__ uint32_t xmr_sync(uint32_t v, const LaneMap<NREP> &lm
         const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(lm.base4 + 8, (int)v);
         const bool e01 = (a == b), e02 = (a == c);
         if (count) {
+            const uint32_t m = (e01 && e02) ? 0u : 1u;
             t.syncs += 1;
-            t.miss += (e01 && e02) ? 0u : 1u;
+            t.miss += m;
+            t.det |= m;
         }
         return e01 ? a : c;
     } else if constexpr (NREP == 2) {

@@ -31,7 +31,7 @@ typedef struct {
     unsigned nrep;
     unsigned sync_every;
     orc_stats *st;
-    int detected; /* DWC mismatch seen on the current item */
+    int detected; /* unequal copies seen at a sync point of the current item (DWC: detected, TMR: corrected) */
 } sync_ctx;
 
 /* One sync point on a 32-bit value.  TMR: synchronization.cpp:934-938 (cmp orig,clone1 ; select) and
@@ -44,8 +44,10 @@ static void sync32(sync_ctx *c, uint32_t v[3])
         const int e01 = (v[0] == v[1]);
         const int e02 = (v[0] == v[2]);
         c->st->sync_count += 1;
-        if (!(e01 && e02))
+        if (!(e01 && e02)) {
             c->st->errors_corrected += 1;
+            c->detected = 1; /* per-item flag: this item had a value corrected */
+        }
         const uint32_t voted = e01 ? v[0] : v[2];
         v[0] = v[1] = v[2] = voted;
     } else if (c->nrep == 2) {
@@ -174,7 +176,7 @@ void orc_mm_xmr(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, size_t
                 c.detected = 0;
                 r[item] = mm_item(f + b * nn, s + b * nn, n, i, j, &c, fs + fp, fe - fp);
                 if (c.detected) {
-                    st->dwc_detected += 1;
+                    st->dwc_detected += (cfg->replicas == 2);
                     if (detected)
                         detected[item] = 1;
                 }
@@ -200,7 +202,7 @@ void orc_mm_xmr_items(const uint32_t *f, const uint32_t *s, int n, const uint64_
         c.detected = 0;
         out[q] = mm_item(f + b * nn, s + b * nn, n, i, j, &c, fs + fp, fe - fp);
         if (c.detected) {
-            st->dwc_detected += 1;
+            st->dwc_detected += (cfg->replicas == 2);
             if (detected)
                 detected[q] = 1;
         }
@@ -376,7 +378,7 @@ void orc_sha256_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nms
         c.detected = 0;
         sha_item(msgs + m * stride, len, digests + 32 * m, &c, fs + fp, fe - fp);
         if (c.detected) {
-            st->dwc_detected += 1;
+            st->dwc_detected += (cfg->replicas == 2);
             if (detected)
                 detected[m] = 1;
         }
@@ -604,7 +606,7 @@ void orc_aes128_xmr(uint8_t *states, uint8_t *keys, size_t nblocks, int dir, con
         c.detected = 0;
         aes_item(states + 16 * b, keys + 16 * b, dir ? 1 : 0, &c, fs + fp, fe - fp);
         if (c.detected) {
-            st->dwc_detected += 1;
+            st->dwc_detected += (cfg->replicas == 2);
             if (detected)
                 detected[b] = 1;
         }
@@ -678,7 +680,7 @@ void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint
         c.detected = 0;
         crcs[b] = crc_item(data + (size_t)b * block_len, block_len, &c, fs + fp, fe - fp);
         if (c.detected) {
-            st->dwc_detected += 1;
+            st->dwc_detected += (cfg->replicas == 2);
             if (detected)
                 detected[b] = 1;
         }

@@ -85,7 +85,8 @@ const uint8_t *orc_aes_sbox(void);
 const uint8_t *orc_aes_rsbox(void);
 
 /* ---- replicated (TMR / DWC) semantic model with fault list ---- */
-/* faults need not be sorted; `detected` (may be NULL) gets one byte per item, 1 = DWC mismatch seen. */
+/* faults need not be sorted; `detected` (may be NULL) gets one byte per item: 1 = a sync point of that item saw
+ * unequal copies (DWC: the item would have aborted; TMR: the item had a value corrected). */
 void orc_mm_xmr(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, size_t batch, const orc_cfg *cfg,
                 const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
 void orc_sha256_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nmsgs, uint8_t *digests,
