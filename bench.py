@@ -75,9 +75,15 @@ def cpu_baseline_mm(side, budget_s=12.0):
 
     reps, dt = _time_budget(one, budget_s)
     ureps, du = _time_budget(lambda: orc.mm_plain(f, s), 2.0)  # unprotected arithmetic, for the CPU TMR overhead
-    # all host cores over independent matrices (the reference itself is single-threaded; this is the generous bound)
-    ncpu = os.cpu_count() or 1
-    per_thread = max(1, int(round(4.0 * reps / dt)))  # ~4 s of work per thread
+    # all host cores over independent matrices (the reference itself is single-threaded; this is the generous bound).
+    # Visible CPUs can exceed what the container may use, so calibrate with one matrix per thread and size the timed
+    # run for ~4 s of wall time.
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    w1 = orc.cpu_tmr_mm_threads(f, s, gold, ncpu, 1)
+    per_thread = max(1, min(64, int(4.0 / max(w1, 1e-3))))
     wall = orc.cpu_tmr_mm_threads(f, s, gold, ncpu, per_thread)
     return {
         "value": reps * side * side / dt, "unit": "protected elems/s", "cores": 1, "kind": "port",
