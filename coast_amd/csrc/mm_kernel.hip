@@ -118,16 +118,11 @@ __device__ __forceinline__ void mm_epilogue(const uint32_t acc[16], const MmLane
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, L.lb);
 }
 
-// One MAC = one v_mad_u64_u32 (measured 5.1 cycles/wave-instruction vs 4.5 + 2.1 for v_mul_lo_u32 + half a v_add3_u32,
-// tools/valu_microbench).  Written as asm because hipcc narrows a 64-bit accumulation whose high word is dead back to
-// v_mul_lo_u32 + add.  Pure register VALU: no memory operand, no hazard with its neighbours beyond the vcc clobber.
-__device__ __forceinline__ void mac_u64(unsigned long long &acc, uint32_t a, uint32_t b)
-{
-    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
-}
-
-// One k step of a lane's 4x4 tile as a single asm block: 16 back-to-back v_mad_u64_u32 with no compiler-inserted
-// boundary nops between them.  acc[4*i+j] += a[i] * b[j].
+// One k step of a lane's 4x4 tile as a single asm block: acc[4*i+j] += a[i] * b[j], one v_mad_u64_u32 per MAC
+// (measured 5.1 cycles per wave-instruction vs 4.5 + 2.1 for v_mul_lo_u32 + half a v_add3_u32, tools/valu_microbench).
+// Written as asm because hipcc narrows a 64-bit accumulation whose high word is dead back to v_mul_lo_u32 + add, and as
+// ONE block so that no compiler boundary nops sit between the 16 MACs.  Pure register VALU: no memory operand, no
+// hazard with its neighbours beyond the vcc clobber.
 __device__ __forceinline__ void mac16_u64(unsigned long long (&acc)[16], const uint4 &a, const uint4 &b)
 {
     asm("v_mad_u64_u32 %0, vcc, %16, %20, %0\n\t"
