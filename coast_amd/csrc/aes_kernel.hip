@@ -14,8 +14,10 @@
 //                           little-endian column dwords; SubBytes + ShiftRows + MixColumns of one round are 16 lookups in
 //                           four 1-KiB LDS tables (Te_r[v] = MixColumns column r scaled by S[v]) folded with v_bitop3
 //                           xors -- the same bytes as TI_aes_128.c:142-185 computes one at a time.
+//   aes128_dec_fast_kernel  decryption likewise: InvMixColumns is linear, so the state chain is 16 Td lookups per round
+//                           and InvMix(round key) follows the inverse key schedule through a second table set.
 //   aes128_xmr_kernel       byte-at-a-time exactly as written in the reference, both directions, injector hooks and
-//                           per-round sync points; runs faulted tiles (side stream), decryption, and sync_every != 0.
+//                           per-round sync points; runs faulted tiles (side stream) and sync_every != 0.
 #include "xmr.hpp"
 
 namespace coast {
@@ -28,6 +30,9 @@ __constant__ uint8_t kAesRcon[10] = {0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0
 __device__ uint8_t gAesSbox[256];
 __device__ uint8_t gAesRsbox[256];
 __device__ uint32_t gAesTe[4][256]; // Te_r[v]: bytes (out row 0..3) = MixColumns matrix column r times S[v]
+__device__ uint32_t gAesTd[4][256]; // Td_r[v]:  InvMixColumns matrix column r times rsbox[v]
+__device__ uint32_t gAesTis[4][256]; // Tis_r[v]: InvMixColumns matrix column r times sbox[v] (key-schedule word)
+__device__ uint32_t gAesImcRcon[10]; // InvMixColumns of the column (Rcon[j], 0, 0, 0)
 
 __device__ __forceinline__ uint32_t gf_mul_dev(uint32_t a, uint32_t b)
 {
@@ -66,6 +71,23 @@ __global__ void aes_tables_kernel()
     gAesTe[1][x] = s3 | (s2 << 8) | (s << 16) | (s << 24);
     gAesTe[2][x] = s | (s3 << 8) | (s2 << 16) | (s << 24);
     gAesTe[3][x] = s | (s << 8) | (s3 << 16) | (s2 << 24);
+    __syncthreads(); // gAesRsbox complete (single workgroup)
+    // inverse matrix [14 11 13 9; 9 14 11 13; 13 9 14 11; 11 13 9 14] (the :172-175 pre-step composed with :176-185)
+    const uint32_t w[2] = {(uint32_t)gAesRsbox[x], s};
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t v = w[t];
+        const uint32_t e = gf_mul_dev(v, 14), b = gf_mul_dev(v, 11), d = gf_mul_dev(v, 13), n = gf_mul_dev(v, 9);
+        uint32_t(*T)[256] = t ? gAesTis : gAesTd;
+        T[0][x] = e | (n << 8) | (d << 16) | (b << 24);
+        T[1][x] = b | (e << 8) | (n << 16) | (d << 24);
+        T[2][x] = d | (b << 8) | (e << 16) | (n << 24);
+        T[3][x] = n | (d << 8) | (b << 16) | (e << 24);
+    }
+    if (x < 10) {
+        const uint32_t rc = kAesRcon[x];
+        gAesImcRcon[x] = gf_mul_dev(rc, 14) | (gf_mul_dev(rc, 9) << 8) | (gf_mul_dev(rc, 13) << 16) |
+                         (gf_mul_dev(rc, 11) << 24);
+    }
 }
 
 __device__ __forceinline__ uint32_t xtime(uint32_t v) { return ((v << 1) ^ ((v & 0x80u) ? 0x1bu : 0u)) & 0xffu; } // :88-99
@@ -254,6 +276,148 @@ __global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restric
         reinterpret_cast<uint4 *>(states)[item] = make_uint4(s0, s1, s2, s3);
         reinterpret_cast<uint4 *>(keys)[item] = make_uint4(k0, k1, k2, k3);
         if (tl.det) { // unequal copies seen at a sync point of this block (DWC: detected, TMR: corrected)
+            if (NREP == 2)
+                detItems = 1;
+            if (detected)
+                detected[item] = 1;
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------ fast decryption
+// The reference's decryption round is InvKeySchedule, InvMixColumns (rounds 1..9), InvShiftRows, rsbox ^ key
+// (TI_aes_128.c:132-141, 168-175, 188-212).  InvMixColumns is linear, so InvMix(rsbox[.] ^ key) = Td-lookups ^ InvMix(key):
+// the state chain becomes 16 Td lookups per round, and InvMix(key) follows the (linear) inverse key schedule with one
+// Tis lookup per S-box byte.  The running key itself is still walked back to the cipher key, as the contract requires.
+__device__ __forceinline__ uint32_t aes_xtime4(uint32_t v)
+{
+    return ((v & 0x7f7f7f7fu) << 1) ^ (((v >> 7) & 0x01010101u) * 0x1bu);
+}
+__device__ __forceinline__ uint32_t aes_imc_col(uint32_t x) // InvMixColumns of one packed column (rows in bytes 0..3)
+{
+    const uint32_t t = x ^ __builtin_amdgcn_alignbit(x, x, 16);
+    const uint32_t y = x ^ aes_xtime4(aes_xtime4(t));
+    const uint32_t r8 = __builtin_amdgcn_alignbit(y, y, 8);
+    return aes_xtime4(y ^ r8) ^ aes_xor3(r8, __builtin_amdgcn_alignbit(y, y, 16), __builtin_amdgcn_alignbit(y, y, 24));
+}
+
+template <int NREP>
+__global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
+                                                              uint64_t nblocksData, uint64_t ntiles, Counters ctr,
+                                                              const uint2 *__restrict__ faultRange,
+                                                              uint8_t *__restrict__ detected)
+{
+    __shared__ uint32_t sTd[4][256];
+    __shared__ uint32_t sTis[4][256];
+    __shared__ uint8_t sSb[256];
+    __shared__ uint8_t sRsb[256];
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    const LaneMap<NREP> lm;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sTd[r][tid] = gAesTd[r][tid];
+        sTis[r][tid] = gAesTis[r][tid];
+    }
+    sSb[tid] = gAesSbox[tid];
+    sRsb[tid] = gAesRsbox[tid];
+    if (tid < 4)
+        sCnt[tid] = 0;
+    __syncthreads();
+
+    const uint64_t tile = (uint64_t)blockIdx.x * 4 + (tid >> 6);
+    bool skip = tile >= ntiles;
+    if (!skip && faultRange)
+        skip = faultRange[tile].y != 0u; // aes128_xmr_kernel owns faulted tiles
+    const uint64_t item = tile * IPW + (uint64_t)lm.q;
+    const bool live = !skip && lm.live && item < nblocksData;
+    const bool cnt = live && lm.r == 0;
+    const uint64_t it = live ? item : 0;
+    const uint4 sv = reinterpret_cast<const uint4 *>(states)[it];
+    const uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
+    uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
+
+#define B0(x) ((x) & 0xffu)
+#define B1(x) (((x) >> 8) & 0xffu)
+#define B2(x) (((x) >> 16) & 0xffu)
+#define B3(x) ((x) >> 24)
+#define SUBROT(k) ((uint32_t)sSb[B1(k)] | ((uint32_t)sSb[B2(k)] << 8) | ((uint32_t)sSb[B3(k)] << 16) | ((uint32_t)sSb[B0(k)] << 24))
+    // the last encryption key first (:110-123)
+#pragma unroll
+    for (int rd = 0; rd < 10; ++rd) {
+        k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[rd]);
+        k1 ^= k0;
+        k2 ^= k1;
+        k3 ^= k2;
+    }
+    uint32_t x0 = sv.x ^ k0, x1 = sv.y ^ k1, x2 = sv.z ^ k2, x3 = sv.w ^ k3; // first AddRoundKey (:126-128)
+
+    // round 0: inverse key schedule to round key 9, no InvMixColumns on the state yet
+    k3 ^= k2;
+    k2 ^= k1;
+    k1 ^= k0;
+    k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[9]);
+    uint32_t m0 = aes_imc_col(k0), m1 = aes_imc_col(k1), m2 = aes_imc_col(k2), m3 = aes_imc_col(k3); // InvMix(key 9)
+    {   // InvShiftRows: row r of column j comes from column j-r (:188-207); rsbox ^ key, then next round's InvMixColumns
+        const uint32_t w0 = aes_xor3(sTd[0][B0(x0)], sTd[1][B1(x3)], sTd[2][B2(x2)]) ^ sTd[3][B3(x1)] ^ m0;
+        const uint32_t w1 = aes_xor3(sTd[0][B0(x1)], sTd[1][B1(x0)], sTd[2][B2(x3)]) ^ sTd[3][B3(x2)] ^ m1;
+        const uint32_t w2 = aes_xor3(sTd[0][B0(x2)], sTd[1][B1(x1)], sTd[2][B2(x0)]) ^ sTd[3][B3(x3)] ^ m2;
+        const uint32_t w3 = aes_xor3(sTd[0][B0(x3)], sTd[1][B1(x2)], sTd[2][B2(x1)]) ^ sTd[3][B3(x0)] ^ m3;
+        x0 = w0;
+        x1 = w1;
+        x2 = w2;
+        x3 = w3;
+    }
+#pragma unroll
+    for (int j = 8; j >= 1; --j) { // reference rounds 1..8: key j+1 -> key j, state through Td
+        k3 ^= k2;
+        k2 ^= k1;
+        k1 ^= k0;
+        m3 ^= m2;
+        m2 ^= m1;
+        m1 ^= m0;
+        k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[j]);
+        m0 ^= aes_xor3(sTis[0][B1(k3)], sTis[1][B2(k3)], sTis[2][B3(k3)]) ^ sTis[3][B0(k3)] ^ gAesImcRcon[j];
+        const uint32_t w0 = aes_xor3(sTd[0][B0(x0)], sTd[1][B1(x3)], sTd[2][B2(x2)]) ^ sTd[3][B3(x1)] ^ m0;
+        const uint32_t w1 = aes_xor3(sTd[0][B0(x1)], sTd[1][B1(x0)], sTd[2][B2(x3)]) ^ sTd[3][B3(x2)] ^ m1;
+        const uint32_t w2 = aes_xor3(sTd[0][B0(x2)], sTd[1][B1(x1)], sTd[2][B2(x0)]) ^ sTd[3][B3(x3)] ^ m2;
+        const uint32_t w3 = aes_xor3(sTd[0][B0(x3)], sTd[1][B1(x2)], sTd[2][B2(x1)]) ^ sTd[3][B3(x0)] ^ m3;
+        x0 = w0;
+        x1 = w1;
+        x2 = w2;
+        x3 = w3;
+    }
+    // reference round 9: key 1 -> cipher key, InvShiftRows, rsbox ^ key (x already carries this round's InvMixColumns)
+    k3 ^= k2;
+    k2 ^= k1;
+    k1 ^= k0;
+    k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[0]);
+    uint32_t s0 = ((uint32_t)sRsb[B0(x0)] | ((uint32_t)sRsb[B1(x3)] << 8) | ((uint32_t)sRsb[B2(x2)] << 16) | ((uint32_t)sRsb[B3(x1)] << 24)) ^ k0;
+    uint32_t s1 = ((uint32_t)sRsb[B0(x1)] | ((uint32_t)sRsb[B1(x0)] << 8) | ((uint32_t)sRsb[B2(x3)] << 16) | ((uint32_t)sRsb[B3(x2)] << 24)) ^ k1;
+    uint32_t s2 = ((uint32_t)sRsb[B0(x2)] | ((uint32_t)sRsb[B1(x1)] << 8) | ((uint32_t)sRsb[B2(x0)] << 16) | ((uint32_t)sRsb[B3(x3)] << 24)) ^ k2;
+    uint32_t s3 = ((uint32_t)sRsb[B0(x3)] | ((uint32_t)sRsb[B1(x2)] << 8) | ((uint32_t)sRsb[B2(x1)] << 16) | ((uint32_t)sRsb[B3(x0)] << 24)) ^ k3;
+#undef SUBROT
+#undef B0
+#undef B1
+#undef B2
+#undef B3
+
+    Tally tl;
+    s0 = xmr_sync<NREP>(s0, lm, cnt, tl); // in-place stores of state and key: store-data sync
+    s1 = xmr_sync<NREP>(s1, lm, cnt, tl);
+    s2 = xmr_sync<NREP>(s2, lm, cnt, tl);
+    s3 = xmr_sync<NREP>(s3, lm, cnt, tl);
+    k0 = xmr_sync<NREP>(k0, lm, cnt, tl);
+    k1 = xmr_sync<NREP>(k1, lm, cnt, tl);
+    k2 = xmr_sync<NREP>(k2, lm, cnt, tl);
+    k3 = xmr_sync<NREP>(k3, lm, cnt, tl);
+    uint32_t detItems = 0;
+    if (cnt) {
+        reinterpret_cast<uint4 *>(states)[item] = make_uint4(s0, s1, s2, s3);
+        reinterpret_cast<uint4 *>(keys)[item] = make_uint4(k0, k1, k2, k3);
+        if (tl.det) {
             if (NREP == 2)
                 detItems = 1;
             if (detected)
