@@ -431,3 +431,46 @@ def test_bad_arguments_are_rejected(eng):
     st = torch.zeros(17, dtype=torch.uint8, device="cuda")[1:]  # misaligned aes state array
     cfg = _lib.CoastCfg(2, 0)
     assert L.coast_aes128_batch(eng._h, C.c_void_p(st.data_ptr()), C.c_void_p(st.data_ptr()), 1, 0, C.byref(cfg), None) != 0
+
+
+def test_sha256_4Mi_messages_with_injector(eng, orc):
+    """BASELINE config 4 at full size: 2^22 messages x 64 B, K seeded single-bit flips.  Digests must equal
+    the clean run; errors_corrected / sync_count must equal the oracle's, which is evaluated on the faulted messages only
+    (all other messages contribute 24 clean syncs each)."""
+    import random
+
+    import torch
+
+    import coast_amd
+
+    nm, K = 1 << 22, 4096
+    g = torch.Generator(device="cuda").manual_seed(22)
+    msgs = torch.randint(0, 256, (nm, 64), dtype=torch.uint8, device="cuda", generator=g)
+    clean = eng.sha256_batch(msgs, 64)
+    rnd = random.Random(1)
+    hit = sorted(rnd.sample(range(nm), K))
+    rows = []
+    for m in hit:
+        site = rnd.choice([coast_amd.SITE_SHA_M, coast_amd.SITE_SHA_WV, coast_amd.SITE_SHA_STATE])
+        step = rnd.randrange(0, 3) if site == coast_amd.SITE_SHA_STATE else rnd.randrange(0, 128)
+        rows.append((m, rnd.randrange(3), site, step, rnd.randrange(32), rnd.randrange(8)))
+    eng.reset_stats()
+    eng.inject_faults(coast_amd.make_faults(rows))
+    det = torch.zeros(nm, dtype=torch.uint8, device="cuda")
+    got = eng.sha256_batch(msgs, 64, detected=det)
+    assert torch.equal(got, clean)
+    st = eng.stats()
+    sub = msgs[torch.tensor(hit, device="cuda")].cpu().numpy()
+    sub_rows = [(i,) + r[1:] for i, r in enumerate(rows)]
+    exp, exp_st, exp_det = orc.sha256_xmr(sub, 64, faults=orc.make_faults(sub_rows))
+    assert (exp == got[torch.tensor(hit, device="cuda")].cpu().numpy()).all()
+    assert st["errors_corrected"] == exp_st["errors_corrected"]
+    assert st["sync_count"] == 24 * nm
+    d = det.cpu().numpy()
+    assert int(d.sum()) == int(exp_det.sum()) and (d[hit] == exp_det).all()
+    import hashlib
+
+    sample = msgs[::65537].cpu().numpy()
+    gs = got[::65537].cpu().numpy()
+    for i in range(sample.shape[0]):
+        assert gs[i].tobytes() == hashlib.sha256(sample[i].tobytes()).digest()
