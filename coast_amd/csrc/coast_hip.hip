@@ -19,6 +19,7 @@
 #include "sha256_kernel.hip"
 #include "aes_kernel.hip"
 #include "crc16_kernel.hip"
+#include "vote_kernel.hip"
 
 using namespace coast;
 
@@ -469,6 +470,47 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
 #undef LAUNCH_FAST_K
 #undef LAUNCH_MM
     return after_launch(c, have);
+}
+
+// ------------------------------------------------------------------------------------------------ default mode
+extern "C" int coast_sync_copies(coast_ctx *c, void *const *d_copies, int ncopies, size_t nbytes, void *d_voted,
+                                 int scrub, uint8_t *d_detected)
+{
+    if (!c)
+        return COAST_EINVAL;
+    if (!d_copies || (ncopies != 2 && ncopies != 3) || (nbytes & 3u))
+        return fail(c, COAST_EINVAL, "coast_sync_copies: 2 or 3 copies, byte count a multiple of 4");
+    if (nbytes == 0)
+        return COAST_OK;
+    for (int i = 0; i < ncopies; ++i)
+        if (!d_copies[i] || ((uintptr_t)d_copies[i] & 15u))
+            return fail(c, COAST_EINVAL, "coast_sync_copies: copies must be non-NULL and 16-byte aligned");
+    if (d_voted && ((uintptr_t)d_voted & 15u))
+        return fail(c, COAST_EINVAL, "coast_sync_copies: output must be 16-byte aligned");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t nwords = nbytes / 4;
+    const uint64_t nvec = nwords / 4;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->numCUs * 8, std::max<uint64_t>(1, (nvec + 255) / 256));
+    Counters ctr{c->dSlots};
+    uint32_t *c0 = (uint32_t *)d_copies[0], *c1 = (uint32_t *)d_copies[1];
+    uint32_t *c2 = ncopies == 3 ? (uint32_t *)d_copies[2] : nullptr;
+    if (ncopies == 3)
+        hipLaunchKernelGGL(sync_copies_kernel<3>, dim3(grid), dim3(256), 0, c->stream, c0, c1, c2, nwords,
+                           (uint32_t *)d_voted, scrub, ctr, d_detected);
+    else
+        hipLaunchKernelGGL(sync_copies_kernel<2>, dim3(grid), dim3(256), 0, c->stream, c0, c1, c2, nwords,
+                           (uint32_t *)d_voted, 0, ctr, d_detected);
+    return after_launch(c, 0);
+}
+
+extern "C" int coast_flip_memory(coast_ctx *c, void *d_ptr, size_t byte_offset, unsigned bit)
+{
+    if (!c || !d_ptr || bit > 7)
+        return COAST_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(flip_memory_kernel, dim3(1), dim3(1), 0, c->stream, (uint8_t *)d_ptr + byte_offset, bit);
+    HIP_TRY(c, hipGetLastError());
+    return COAST_OK;
 }
 
 #include "launch_others.inc"

@@ -142,3 +142,23 @@ class Engine:
         self._check(self._lib.coast_crc16_batch(self._h, _ptr(data), block_len, nb, _ptr(out), C.byref(cc),
                                                 _ptr(detected) if detected is not None else None))
         return out
+
+    # -- default mode (memory replicated x3 / x2): vote where the copies re-converge
+    def sync_copies(self, copies, out=None, scrub=True, detected=None):
+        """copies: 3 (TMR) or 2 (DWC) equally shaped contiguous GPU tensors holding the per-copy results of replicas=1
+        launches.  Votes / compares them word by word (32-bit), counts into the engine's counters, optionally repairs
+        the copies in place, and returns the voted tensor."""
+        assert len(copies) in (2, 3)
+        t0 = copies[0]
+        nbytes = t0.numel() * t0.element_size()
+        assert all(t.is_cuda and t.is_contiguous() and t.numel() * t.element_size() == nbytes for t in copies)
+        if out is None:
+            out = torch.empty_like(t0)
+        arr = (C.c_void_p * len(copies))(*[t.data_ptr() for t in copies])
+        self._check(self._lib.coast_sync_copies(self._h, arr, len(copies), nbytes, _ptr(out), int(bool(scrub)),
+                                                _ptr(detected) if detected is not None else None))
+        return out
+
+    def flip_memory(self, tensor, byte_offset, bit):
+        """injectFaultMem analogue: flip one bit of device memory (ordered on the engine's stream)."""
+        self._check(self._lib.coast_flip_memory(self._h, _ptr(tensor), int(byte_offset), int(bit)))

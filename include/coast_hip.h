@@ -126,6 +126,23 @@ int coast_aes128_batch(coast_ctx *ctx, uint8_t *d_states, uint8_t *d_keys, size_
 int coast_crc16_batch(coast_ctx *ctx, const uint8_t *d_data, uint32_t block_len, size_t n_blocks, uint16_t *d_crcs,
                       const coast_cfg *cfg, uint8_t *d_detected);
 
+/* ---- default-mode TMR / DWC: memory replicated as well (docs/source/passes.rst:329,337; cloning.cpp:2417-2462) ----
+ * In COAST's default mode the clones of a region run on their own copies of the data and stores are not voted
+ * (synchronization.cpp:211-215); values are voted where the copies re-converge -- return values, arguments of unprotected
+ * calls, stores to unprotected globals (synchronization.cpp:741-949, verification.cpp:625-682).  Here: run the batch
+ * entry points with replicas = 1 once per memory copy, then call coast_sync_copies on the result arrays.
+ *   ncopies = 3: vote = (a==b)?a:c per 32-bit word, errors_corrected += 1 per word whose copies differ, sync_count += 1
+ *                per word; `scrub` != 0 writes the voted word back into the copies (they re-converge, :527-529).
+ *   ncopies = 2: DWC compare, dwc_detected += 1 per differing word.
+ * d_voted (optional) receives the voted single copy; d_detected (optional) one byte per word.  nbytes % 4 == 0,
+ * all arrays 16-byte aligned.  Memory-resident upsets -- uncorrectable in the -noMemReplication mode of the lane-replicated
+ * kernels -- are corrected here, at 3x the memory traffic. */
+int coast_sync_copies(coast_ctx *ctx, void *const *d_copies, int ncopies, size_t nbytes, void *d_voted, int scrub,
+                      uint8_t *d_detected);
+/* injectFaultMem (simulation/platform/resources/injector.py:209-235): flip bit `bit` (0..7) of one byte of device memory,
+ * ordered on the context's stream */
+int coast_flip_memory(coast_ctx *ctx, void *d_ptr, size_t byte_offset, unsigned bit);
+
 /* ---- single-call host shims with the reference's data contract (host pointers, synchronous) ---- */
 /* matrix_multiply's `side` is a macro in the reference (mm_tmr.c:10), so the glue TU passes it explicitly */
 int coast_matrix_multiply_host(const uint32_t *f, const uint32_t *s, uint32_t *r, int side, const coast_cfg *cfg);

@@ -688,3 +688,39 @@ void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint
     }
     free(fs);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* default mode: vote where three (two) memory copies re-converge                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* The exit vote of COAST's default (memory-replicated) mode over result arrays: docs/source/passes.rst:329,337 --
+ * stores are not voted, values are where they leave the sphere of replication (synchronization.cpp:741-949,
+ * verification.cpp:625-682).  Word-wise (32 bit): TMR vote + count (+ scrub of the copies), DWC compare. */
+void orc_sync_copies(uint32_t *c0, uint32_t *c1, uint32_t *c2, int ncopies, size_t nwords, uint32_t *voted, int scrub,
+                     orc_stats *st, uint8_t *detected)
+{
+    for (size_t w = 0; w < nwords; ++w) {
+        st->sync_count += 1;
+        if (ncopies == 3) {
+            const int e01 = c0[w] == c1[w], e02 = c0[w] == c2[w];
+            const uint32_t v = e01 ? c0[w] : c2[w];
+            if (!(e01 && e02)) {
+                st->errors_corrected += 1;
+                if (detected)
+                    detected[w] = 1;
+                if (scrub)
+                    c0[w] = c1[w] = c2[w] = v;
+            }
+            if (voted)
+                voted[w] = v;
+        } else {
+            if (c0[w] != c1[w]) {
+                st->dwc_detected += 1;
+                if (detected)
+                    detected[w] = 1;
+            }
+            if (voted)
+                voted[w] = c0[w];
+        }
+    }
+}

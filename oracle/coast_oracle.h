@@ -101,6 +101,10 @@ void orc_mm_xmr_items(const uint32_t *f, const uint32_t *s, int n, const uint64_
                       uint32_t *out, const orc_cfg *cfg, const orc_fault *faults, size_t nfaults, orc_stats *st,
                       uint8_t *detected);
 
+/* ---- default (memory-replicated) mode: the exit vote over three (two) result copies, 32-bit words ---- */
+void orc_sync_copies(uint32_t *c0, uint32_t *c1, uint32_t *c2, int ncopies, size_t nwords, uint32_t *voted, int scrub,
+                     orc_stats *st, uint8_t *detected);
+
 /* ---- CPU-TMR baseline: default COAST mode (memory x3, loop-condition votes, -countErrors) ---- */
 /* returns XOR-golden mismatch flag like checkGolden; *cnt gets TMR_ERROR_CNT, *syncs the dynamic vote count */
 int orc_cpu_tmr_mm(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, uint32_t xor_golden, uint32_t *cnt,

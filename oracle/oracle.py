@@ -228,6 +228,20 @@ def crc16_xmr(data, block_len, replicas=3, sync_every=0, faults=None):
     return crcs, st.as_dict(), det
 
 
+def sync_copies(copies, scrub=True):
+    """Default-mode exit vote: copies = 3 (TMR) or 2 (DWC) arrays of 32-bit words.  Returns (voted, copies after
+    scrub, stats, detected per word)."""
+    cs = [np.array(np.ascontiguousarray(c).view(np.uint32).reshape(-1), copy=True) for c in copies]
+    n = cs[0].size
+    voted = np.empty(n, dtype=np.uint32)
+    det = np.zeros(n, dtype=np.uint8)
+    st = Stats()
+    c2 = cs[2] if len(cs) == 3 else cs[0]
+    lib().orc_sync_copies(_p(cs[0], C.c_uint32), _p(cs[1], C.c_uint32), _p(c2, C.c_uint32), C.c_int(len(cs)),
+                          C.c_size_t(n), _p(voted, C.c_uint32), C.c_int(int(scrub)), C.byref(st), _p(det, C.c_uint8))
+    return voted, cs, st.as_dict(), det
+
+
 def cpu_tmr_mm(f, s, xor_golden):
     """Default-mode CPU-TMR restatement (timing baseline).  Returns (r, error_flag, TMR_ERROR_CNT, syncs)."""
     f = np.ascontiguousarray(f, dtype=np.uint32)

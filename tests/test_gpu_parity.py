@@ -474,3 +474,102 @@ def test_sha256_4Mi_messages_with_injector(eng, orc):
     gs = got[::65537].cpu().numpy()
     for i in range(sample.shape[0]):
         assert gs[i].tobytes() == hashlib.sha256(sample[i].tobytes()).digest()
+
+
+# ------------------------------------------------------------------------------------------------ default mode (memory x3)
+@pytest.mark.parametrize("nwords", [1, 3, 4, 5, 1000, 65536 + 7])
+@pytest.mark.parametrize("ncopies,scrub", [(3, True), (3, False), (2, False)])
+def test_default_mode_exit_vote_vs_oracle(eng, orc, nwords, ncopies, scrub):
+    import torch
+
+    rng = np.random.default_rng(nwords * 7 + ncopies + scrub)
+    base = rng.integers(0, 2**32, nwords, dtype=np.uint32)
+    copies = [base.copy() for _ in range(ncopies)]
+    for _ in range(min(nwords, 40)):  # single, double (identical and different) and triple corruptions
+        w = int(rng.integers(0, nwords))
+        for cpy in rng.choice(ncopies, int(rng.integers(1, ncopies + 1)), replace=False):
+            copies[int(cpy)][w] ^= np.uint32(1 << int(rng.integers(0, 32))) if rng.random() < 0.7 else np.uint32(1)
+    exp_v, exp_after, exp_st, exp_det = orc.sync_copies(copies, scrub=scrub)
+    dev = [torch.from_numpy(c.view(np.int32).copy()).cuda() for c in copies]
+    det = torch.zeros(nwords, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    out = eng.sync_copies(dev, scrub=scrub, detected=det)
+    assert (_host(out, np.uint32) == exp_v).all()
+    assert _stats3(eng.stats()) == exp_st
+    assert (det.cpu().numpy() == exp_det).all()
+    for d, e in zip(dev, exp_after):
+        assert (_host(d, np.uint32) == e).all()
+
+
+def test_default_mode_end_to_end_all_kernels(eng, orc):
+    """COAST's default mode (memory x3, stores not voted, docs/source/passes.rst:329,337): three unprotected launches on
+    three HBM copies, upsets in MEMORY (injectFaultMem, injector.py:209-235) and in one copy's registers, exit vote.
+    The voted result equals the fault-free result; the count equals the oracle's for the same corrupted copies."""
+    import torch
+
+    import coast_amd
+
+    rng = np.random.default_rng(2024)
+    one = coast_amd.XmrConfig(coast_amd.UNPROTECTED)
+
+    # ---- mm: flip a bit of f in copy 1 (memory) and an accumulator of copy 2 (register)
+    n, batch = 32, 3
+    f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    fc = [_dev(f) for _ in range(3)]
+    sc = [_dev(s) for _ in range(3)]
+    eng.flip_memory(fc[1], (1 * n * n + 5 * n + 7) * 4 + 2, 3)  # byte 2 of f[1][5][7]
+    f1 = f.copy()
+    f1.reshape(-1)[1 * n * n + 5 * n + 7] ^= np.uint32(1 << (16 + 3))
+    reg_fault = coast_amd.make_faults([(2 * n * n + 9, 0, coast_amd.SITE_MM_ACC, 4, 30)])
+    outs = []
+    eng.reset_stats()
+    for cpy in range(3):
+        if cpy == 2:
+            eng.inject_faults(reg_fault)
+        outs.append(eng.mm_batch(fc[cpy], sc[cpy], cfg=one))
+    voted = eng.sync_copies(outs)
+    clean, _, _ = orc.mm_xmr(f, s, replicas=1)
+    r1, _, _ = orc.mm_xmr(f1, s, replicas=1)
+    r2, _, _ = orc.mm_xmr(f, s, replicas=1, faults=orc.make_faults([(2 * n * n + 9, 0, orc.SITE_MM_ACC, 4, 30)]))
+    exp_v, _, exp_st, _ = orc.sync_copies([clean, r1, r2])
+    assert (_host(voted, np.uint32).reshape(-1) == exp_v).all() and (exp_v == clean.reshape(-1)).all()
+    st = eng.stats()
+    assert st["errors_corrected"] == exp_st["errors_corrected"] == n + 1  # a whole result row + one element
+    assert st["sync_count"] == batch * n * n
+    assert all((_host(o, np.uint32) == clean).all() for o in outs)  # scrubbed: the copies re-converged
+
+    # ---- sha256 / crc16 / aes: a memory upset in one input copy
+    msgs = rng.integers(0, 256, (200, 64), dtype=np.uint8)
+    mc = [torch.from_numpy(msgs.copy()).cuda() for _ in range(3)]
+    eng.flip_memory(mc[0], 17 * 64 + 3, 6)
+    eng.reset_stats()
+    dig = [eng.sha256_batch(m, 64, cfg=one) for m in mc]
+    v = eng.sync_copies(dig)
+    import hashlib
+
+    for i in range(200):
+        assert v[i].cpu().numpy().tobytes() == hashlib.sha256(msgs[i].tobytes()).digest()
+    assert eng.stats()["errors_corrected"] == 8  # the 8 digest words of message 17
+
+    data = rng.integers(0, 256, 512 * 256, dtype=np.uint8)
+    dc = [torch.from_numpy(data.copy()).cuda() for _ in range(3)]
+    eng.flip_memory(dc[2], 300 * 256 + 255, 0)
+    eng.reset_stats()
+    crcs = [eng.crc16_batch(d, 256, cfg=one) for d in dc]
+    v = eng.sync_copies(crcs)
+    exp, _, _ = orc.crc16_xmr(data.reshape(512, 256), 256, replicas=1)
+    assert (_host(v, np.uint16) == exp).all() and eng.stats()["errors_corrected"] == 1
+
+    st_ = rng.integers(0, 256, (64, 16), dtype=np.uint8)
+    key = rng.integers(0, 256, (64, 16), dtype=np.uint8)
+    stc = [torch.from_numpy(st_.copy()).cuda() for _ in range(2)]
+    kc = [torch.from_numpy(key.copy()).cuda() for _ in range(2)]
+    eng.flip_memory(kc[1], 5 * 16 + 9, 4)  # DWC default mode: the mismatch is detected at the exit compare
+    eng.reset_stats()
+    for cpy in range(2):
+        eng.aes128_batch(stc[cpy], kc[cpy], 0, cfg=one)
+    eng.sync_copies(stc, scrub=False)
+    eng.sync_copies(kc, scrub=False)
+    st = eng.stats()
+    assert st["dwc_detected"] >= 4 and st["errors_corrected"] == 0

@@ -167,3 +167,22 @@ def test_cpu_tmr_baseline_matches(orc, golden):
         assert (r == golden["mm"]["r%d" % n]).all() and err == 0 and cnt == 0
         # (n+1)(n^2+n+1) loop-condition votes in matrix_multiply + checkGolden's n^2+1 + return
         assert syncs == (n + 1) * (n * n + n + 1) + n * n + 1 + 1
+
+
+def test_default_mode_exit_vote_semantics(orc):
+    """orc_sync_copies: word-wise (a==b)?a:c with +1 per differing word, scrub re-converges the copies; DWC compares."""
+    a = np.arange(10, dtype=np.uint32)
+    c = [a.copy(), a.copy(), a.copy()]
+    c[1][3] ^= 1 << 7            # single copy hit: corrected
+    c[0][5] ^= 4
+    c[1][5] ^= 4                 # copies 0 and 1 hit identically: the corrupted value wins, counted once
+    c[0][8] ^= 2
+    c[2][8] ^= 16                # 0 != 1 -> copy 2 is taken unconditionally
+    voted, after, st, det = orc.sync_copies(c)
+    exp = a.copy()
+    exp[5] ^= 4
+    exp[8] ^= 16
+    assert (voted == exp).all() and st == {"errors_corrected": 3, "sync_count": 10, "dwc_detected": 0}
+    assert list(np.nonzero(det)[0]) == [3, 5, 8] and all((x == exp).all() for x in after)
+    voted, after, st, det = orc.sync_copies(c[:2])
+    assert st == {"errors_corrected": 0, "sync_count": 10, "dwc_detected": 2} and (voted == c[0]).all()

@@ -78,6 +78,27 @@ def main():
                 mn, av = timeit(lambda: eng.crc16_batch(data[: nb * bl], bl, out=out, cfg=cfg), reps=3, warm=1)
                 res["crc16_1GiB_bl%d_rep%d" % (bl, rep)] = {"ms": mn, "GBs": nb * bl / mn * 1e-6,
                                                             "frac_of_8TBs": nb * bl / mn * 1e-6 / 8000}
+    if want("vote"):
+        # default (memory-replicated) mode: three unprotected mm launches on three copies + the exit vote
+        batch, n = 2048, 256
+        f = [torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device="cuda", generator=g)]
+        s = [torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device="cuda", generator=g)]
+        f += [f[0].clone(), f[0].clone()]
+        s += [s[0].clone(), s[0].clone()]
+        r = [torch.empty_like(f[0]) for _ in range(3)]
+        out = torch.empty_like(f[0])
+        one = coast_amd.XmrConfig(1)
+        mn, av = timeit(lambda: eng.sync_copies(r, out=out))
+        nbytes = r[0].numel() * 4
+        res["exit_vote_3x512MiB"] = {"ms": mn, "GBs_read+write": 4 * nbytes / mn * 1e-6, "frac_of_8TBs": 4 * nbytes / mn * 1e-6 / 8000}
+
+        def default_mode():
+            for c in range(3):
+                eng.mm_batch(f[c], s[c], out=r[c], cfg=one)
+            eng.sync_copies(r, out=out)
+
+        mn, av = timeit(default_mode)
+        res["mm256_default_mode_memx3"] = {"ms": mn, "elems_per_s": batch * n * n / mn * 1e3}
     for k, v in res.items():
         print(k, json.dumps(v))
 
