@@ -419,7 +419,7 @@ def main():
             "sync_count": tot[1], "outputs_match_unprotected": outputs_ok,
             "roofline": roof,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # reported baseline, rank 0 at N=1 only
             out["cpu_baseline"] = wl.cpu()
         print(json.dumps(out))
     if dist:
