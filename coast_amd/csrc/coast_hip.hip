@@ -31,10 +31,8 @@ struct coast_ctx {
     hipStream_t stream = nullptr; // protected kernels
     hipStream_t side = nullptr;   // injector: descriptor upload + indexing
     hipEvent_t evArmed = nullptr;    // side -> main: fault table ready
-    hipEvent_t evConsumed = nullptr; // main -> side: previous table no longer read
     hipEvent_t evMainReady = nullptr; // main -> side: inputs of this launch are complete
     hipEvent_t evSideDone = nullptr;  // side -> main: stepwise (injector) kernel finished
-    bool consumedPending = false;
 
     unsigned long long *dSlots = nullptr;  // [kCounterSlots][kSlotStride]
     unsigned long long *dTotals = nullptr; // internal totals
@@ -42,15 +40,23 @@ struct coast_ctx {
     unsigned long long pendingLaunches = 0;
 
     std::vector<coast_fault> armed; // host copy of the faults waiting for the next launch
-    DevFault *hPinned = nullptr;
-    size_t pinnedCap = 0;
-    DevFault *dList = nullptr;
-    size_t listCap = 0;
-    uint2 *dRange = nullptr;
-    size_t rangeCap = 0;
-    uint32_t *hBlocks = nullptr; // pinned: distinct workgroups that own >= 1 armed fault
-    uint32_t *dBlocks = nullptr;
-    size_t blocksCap = 0;
+    // Fault tables are double-buffered: launch i uploads into buffer i & 1 while launch i-1 may still be reading the
+    // other one, so the injector never waits for the kernel it follows.
+    struct FaultBuf {
+        DevFault *hPinned = nullptr;
+        size_t pinnedCap = 0;
+        DevFault *dList = nullptr;
+        size_t listCap = 0;
+        uint2 *dRange = nullptr;
+        size_t rangeCap = 0;
+        uint32_t *hBlocks = nullptr; // pinned: distinct workgroups / tiles that own >= 1 armed fault
+        uint32_t *dBlocks = nullptr;
+        size_t blocksCap = 0;
+        hipEvent_t evConsumed = nullptr; // main -> side: the kernels reading this buffer have finished
+        bool consumedPending = false;
+    } fb[2];
+    unsigned armCount = 0; // armed launches so far; selects the buffer
+    int curBuf = 0;
 
     uint16_t *dCrcTable = nullptr; // 64 Ki x u16 two-byte-step table of the crc16 stream kernel
     int numCUs = 256;
@@ -126,56 +132,58 @@ int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, 
             blocks.push_back(d.block);
 
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->side)); // pinned staging buffer free again
-    if (dv.size() > c->pinnedCap) {
-        if (c->hPinned)
-            HIP_TRY(c, hipHostFree(c->hPinned));
-        c->pinnedCap = std::max<size_t>(dv.size() * 2, 1024);
-        HIP_TRY(c, hipHostMalloc((void **)&c->hPinned, c->pinnedCap * sizeof(DevFault), hipHostMallocDefault));
+    HIP_TRY(c, hipStreamSynchronize(c->side)); // pinned staging buffers free again (side work ends early in a launch)
+    c->curBuf = (int)(c->armCount++ & 1u);
+    coast_ctx::FaultBuf *b = &c->fb[c->curBuf];
+    if (dv.size() > b->pinnedCap) {
+        if (b->hPinned)
+            HIP_TRY(c, hipHostFree(b->hPinned));
+        b->pinnedCap = std::max<size_t>(dv.size() * 2, 1024);
+        HIP_TRY(c, hipHostMalloc((void **)&b->hPinned, b->pinnedCap * sizeof(DevFault), hipHostMallocDefault));
     }
-    if (blocks.size() > c->blocksCap) {
+    if (blocks.size() > b->blocksCap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->hBlocks)
-            HIP_TRY(c, hipHostFree(c->hBlocks));
-        if (c->dBlocks)
-            HIP_TRY(c, hipFree(c->dBlocks));
-        c->blocksCap = std::max<size_t>(blocks.size() * 2, 1024);
-        HIP_TRY(c, hipHostMalloc((void **)&c->hBlocks, c->blocksCap * sizeof(uint32_t), hipHostMallocDefault));
-        HIP_TRY(c, hipMalloc((void **)&c->dBlocks, c->blocksCap * sizeof(uint32_t)));
+        if (b->hBlocks)
+            HIP_TRY(c, hipHostFree(b->hBlocks));
+        if (b->dBlocks)
+            HIP_TRY(c, hipFree(b->dBlocks));
+        b->blocksCap = std::max<size_t>(blocks.size() * 2, 1024);
+        HIP_TRY(c, hipHostMalloc((void **)&b->hBlocks, b->blocksCap * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc((void **)&b->dBlocks, b->blocksCap * sizeof(uint32_t)));
     }
-    if (c->consumedPending) { // the previous table may still be read by a kernel on the main stream
-        HIP_TRY(c, hipStreamWaitEvent(c->side, c->evConsumed, 0));
-        c->consumedPending = false;
+    if (b->consumedPending) { // the launch before last may still be reading this buffer on the main stream
+        HIP_TRY(c, hipStreamWaitEvent(c->side, b->evConsumed, 0));
+        b->consumedPending = false;
     }
-    if (dv.size() > c->listCap) {
+    if (dv.size() > b->listCap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->dList)
-            HIP_TRY(c, hipFree(c->dList));
-        c->listCap = std::max<size_t>(dv.size() * 2, 1024);
-        HIP_TRY(c, hipMalloc((void **)&c->dList, c->listCap * sizeof(DevFault)));
+        if (b->dList)
+            HIP_TRY(c, hipFree(b->dList));
+        b->listCap = std::max<size_t>(dv.size() * 2, 1024);
+        HIP_TRY(c, hipMalloc((void **)&b->dList, b->listCap * sizeof(DevFault)));
     }
-    if ((size_t)nblocks > c->rangeCap) {
+    if ((size_t)nblocks > b->rangeCap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->dRange)
-            HIP_TRY(c, hipFree(c->dRange));
-        c->rangeCap = std::max<size_t>((size_t)nblocks * 2, 4096);
-        HIP_TRY(c, hipMalloc((void **)&c->dRange, c->rangeCap * sizeof(uint2)));
+        if (b->dRange)
+            HIP_TRY(c, hipFree(b->dRange));
+        b->rangeCap = std::max<size_t>((size_t)nblocks * 2, 4096);
+        HIP_TRY(c, hipMalloc((void **)&b->dRange, b->rangeCap * sizeof(uint2)));
     }
-    memcpy(c->hPinned, dv.data(), dv.size() * sizeof(DevFault));
-    HIP_TRY(c, hipMemcpyAsync(c->dList, c->hPinned, dv.size() * sizeof(DevFault), hipMemcpyHostToDevice, c->side));
-    memcpy(c->hBlocks, blocks.data(), blocks.size() * sizeof(uint32_t));
-    HIP_TRY(c, hipMemcpyAsync(c->dBlocks, c->hBlocks, blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->side));
-    HIP_TRY(c, hipMemsetAsync(c->dRange, 0, (size_t)nblocks * sizeof(uint2), c->side));
+    memcpy(b->hPinned, dv.data(), dv.size() * sizeof(DevFault));
+    HIP_TRY(c, hipMemcpyAsync(b->dList, b->hPinned, dv.size() * sizeof(DevFault), hipMemcpyHostToDevice, c->side));
+    memcpy(b->hBlocks, blocks.data(), blocks.size() * sizeof(uint32_t));
+    HIP_TRY(c, hipMemcpyAsync(b->dBlocks, b->hBlocks, blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->side));
+    HIP_TRY(c, hipMemsetAsync(b->dRange, 0, (size_t)nblocks * sizeof(uint2), c->side));
     const uint32_t k = (uint32_t)dv.size();
-    hipLaunchKernelGGL(fault_range_kernel, dim3((k + 255) / 256), dim3(256), 0, c->side, c->dList, k, c->dRange);
+    hipLaunchKernelGGL(fault_range_kernel, dim3((k + 255) / 256), dim3(256), 0, c->side, b->dList, k, b->dRange);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->evArmed, c->side));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evArmed, 0));
-    ft->list = c->dList;
-    ft->range = c->dRange;
+    ft->list = b->dList;
+    ft->range = b->dRange;
     *have = 1;
     if (dBlockList)
-        *dBlockList = c->dBlocks;
+        *dBlockList = b->dBlocks;
     if (nFaultBlocks)
         *nFaultBlocks = (uint32_t)blocks.size();
     return COAST_OK;
@@ -186,8 +194,9 @@ int after_launch(coast_ctx *c, int haveFaults)
     HIP_TRY(c, hipGetLastError());
     c->pendingLaunches += 1;
     if (haveFaults) {
-        HIP_TRY(c, hipEventRecord(c->evConsumed, c->stream));
-        c->consumedPending = true;
+        coast_ctx::FaultBuf *b = &c->fb[c->curBuf];
+        HIP_TRY(c, hipEventRecord(b->evConsumed, c->stream));
+        b->consumedPending = true;
     }
     return COAST_OK;
 }
@@ -215,7 +224,8 @@ extern "C" int coast_create(coast_ctx **out, int device)
     };
     if (bail(hipSetDevice(device)) || bail(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) ||
         bail(hipEventCreateWithFlags(&c->evArmed, hipEventDisableTiming)) ||
-        bail(hipEventCreateWithFlags(&c->evConsumed, hipEventDisableTiming)) ||
+        bail(hipEventCreateWithFlags(&c->fb[0].evConsumed, hipEventDisableTiming)) ||
+        bail(hipEventCreateWithFlags(&c->fb[1].evConsumed, hipEventDisableTiming)) ||
         bail(hipEventCreateWithFlags(&c->evMainReady, hipEventDisableTiming)) ||
         bail(hipEventCreateWithFlags(&c->evSideDone, hipEventDisableTiming)) ||
         bail(hipMalloc((void **)&c->dSlots, sizeof(unsigned long long) * kCounterSlots * kSlotStride)) ||
@@ -237,22 +247,25 @@ extern "C" void coast_destroy(coast_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->side);
-    if (c->hPinned)
-        (void)hipHostFree(c->hPinned);
-    if (c->dList)
-        (void)hipFree(c->dList);
-    if (c->dRange)
-        (void)hipFree(c->dRange);
-    if (c->hBlocks)
-        (void)hipHostFree(c->hBlocks);
-    if (c->dBlocks)
-        (void)hipFree(c->dBlocks);
+    for (coast_ctx::FaultBuf &b : c->fb) {
+        if (b.hPinned)
+            (void)hipHostFree(b.hPinned);
+        if (b.dList)
+            (void)hipFree(b.dList);
+        if (b.dRange)
+            (void)hipFree(b.dRange);
+        if (b.hBlocks)
+            (void)hipHostFree(b.hBlocks);
+        if (b.dBlocks)
+            (void)hipFree(b.dBlocks);
+        if (b.evConsumed)
+            (void)hipEventDestroy(b.evConsumed);
+    }
     if (c->dCrcTable)
         (void)hipFree(c->dCrcTable);
     (void)hipFree(c->dSlots);
     (void)hipFree(c->dTotals);
     (void)hipEventDestroy(c->evArmed);
-    (void)hipEventDestroy(c->evConsumed);
     (void)hipEventDestroy(c->evMainReady);
     (void)hipEventDestroy(c->evSideDone);
     (void)hipStreamDestroy(c->side);
