@@ -343,14 +343,20 @@ def test_reference_named_host_calls(eng, orc, golden):
 
 
 # ------------------------------------------------------------------------------------------------ drop-in boundary
-@pytest.mark.parametrize("binary,mode,expect", [
-    ("crc16_coast", "TMR", "result: 5ba3"),                 # tests/crc16/crc16.c:40
-    ("aes_coast", "DWC", "Number of errors: 0"),            # tests/aes/aes.c:114 (568 KATs x 3 checks)
-    ("sha256_coast", "TMR", "C:0 E:0 F:0 T:0us"),           # tests/sha256_common/sha256_tmr.c:30
-    ("mm_coast", "TMR", "Error?: 0"),                       # tests/mm_common/mm_tmr.c:40
-    ("matrixMultiply_coast", "TMR", "Number of errors: 0"),  # tests/matrixMultiply/matrixMultiply.c:157, unittest/cfg/full.yml:3
-])
-def test_unmodified_reference_drivers_on_gpu_backend(binary, mode, expect):
+_DRIVERS = {
+    "crc16_coast": "result: 5ba3",                  # tests/crc16/crc16.c:40
+    "aes_coast": "Number of errors: 0",             # tests/aes/aes.c:114 (568 KATs x 3 checks)
+    "sha256_coast": "C:0 E:0 F:0 T:0us",            # tests/sha256_common/sha256_tmr.c:30
+    "mm_coast": "Error?: 0",                        # tests/mm_common/mm_tmr.c:40
+    "matrixMultiply_coast": "Number of errors: 0",  # tests/matrixMultiply/matrixMultiply.c:157, unittest/cfg/full.yml:3
+}
+
+
+# the reference's benchmark x flag matrix (unittest/cfg/full.yml:18-36: "", -DWC, -TMR, -TMR -countErrors x sync-rule
+# variants): every mode must leave the program output unchanged
+@pytest.mark.parametrize("mode,sync_every", [("TMR", 0), ("DWC", 0), ("NONE", 0), ("TMR", 1), ("DWC", 3)])
+@pytest.mark.parametrize("binary", sorted(_DRIVERS))
+def test_unmodified_reference_drivers_on_gpu_backend(binary, mode, sync_every):
     """The reference's own main()s, compiled unchanged from /root/reference in the build container and linked against
     coast_dropin.o + libcoast_hip.so (oracle/Makefile `interpose`), run here on the GPU backend."""
     import os
@@ -360,7 +366,8 @@ def test_unmodified_reference_drivers_on_gpu_backend(binary, mode, expect):
     exe = os.path.join(root, "oracle", "_ref", "bin", binary)
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/bin not built (needs the reference checkout at build time)")
-    env = dict(os.environ, COAST_MODE=mode)
+    expect = _DRIVERS[binary]
+    env = dict(os.environ, COAST_MODE=mode, COAST_SYNC_EVERY=str(sync_every))
     p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, (p.returncode, p.stdout[-500:], p.stderr[-500:])
     assert expect in p.stdout
