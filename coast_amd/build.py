@@ -57,6 +57,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.check_call(cmd)
         subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=gnu11", "-I", os.path.join(HERE, "..", "include"), "-c",
                                dropin_src, "-o", DROPIN_OBJ])
+    demo_src = os.path.join(HERE, "..", "examples", "host_c_demo.c")
+    demo = os.path.join(HERE, "..", "examples", "host_c_demo")
+    if os.path.exists(demo_src) and os.path.exists(DROPIN_OBJ) and (force or _newer(demo, [demo_src, DROPIN_OBJ, LIB])):
+        subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Dside=4", demo_src, os.path.join(CSRC, "mm_glue.c"), DROPIN_OBJ,
+                               "-L", LIBDIR, "-lcoast_hip", "-Wl,-rpath,$ORIGIN/../coast_amd/lib",
+                               "-Wl,-rpath,/opt/rocm/lib", "-o", demo])
     return LIB
 
 

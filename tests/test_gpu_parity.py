@@ -580,3 +580,20 @@ def test_default_mode_end_to_end_all_kernels(eng, orc):
     eng.sync_copies(kc, scrub=False)
     st = eng.stats()
     assert st["dwc_detected"] >= 4 and st["errors_corrected"] == 0
+
+
+@pytest.mark.parametrize("mode", ["TMR", "DWC", "NONE"])
+def test_plain_c_host_program(mode):
+    """examples/host_c_demo.c: a C host program written against the reference's call shapes, linked against
+    coast_dropin.o + libcoast_hip.so by coast_amd/build.py (no reference checkout needed)."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "host_c_demo")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    p = subprocess.run([exe], env=dict(os.environ, COAST_MODE=mode), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.stdout, p.stderr)
+    assert "result: 5ba3" in p.stdout and "C:0 E:0 F:0 T:0us" in p.stdout
+    syncs = {"TMR": 1 + 16 + 8 + 8 + 16, "DWC": 1 + 16 + 8 + 8 + 16, "NONE": 0}[mode]
+    assert "syncs: %d" % syncs in p.stdout
