@@ -597,3 +597,15 @@ def test_plain_c_host_program(mode):
     assert "result: 5ba3" in p.stdout and "C:0 E:0 F:0 T:0us" in p.stdout
     syncs = {"TMR": 1 + 16 + 8 + 8 + 16, "DWC": 1 + 16 + 8 + 8 + 16, "NONE": 0}[mode]
     assert "syncs: %d" % syncs in p.stdout
+
+
+def test_randomized_parity_soak():
+    """tools/fuzz_parity.py for 15 s: random shapes / modes / sync granularities / colliding fault lists vs the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "15", "7"], capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and "fuzz ok" in p.stdout, (p.stdout[-800:], p.stderr[-800:])

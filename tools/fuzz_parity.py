@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""fuzz_parity.py -- randomized GPU-vs-oracle soak: random shapes, modes, sync granularities and fault lists with heavy
+collisions (several faults on one item / replica / step).  Every case must match the oracle bit for bit: outputs,
+errors_corrected, sync_count, dwc_detected and the per-item flags.  Usage: fuzz_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import coast_amd  # noqa: E402
+from oracle import oracle as orc  # noqa: E402  (test infrastructure: this tool is a test)
+
+
+def dev(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        return torch.from_numpy(a.view(np.int32)).cuda()
+    return torch.from_numpy(a).cuda()
+
+
+def faults(rng, k, nitems, nrep, sites, max_step, max_index, hot):
+    rows = []
+    for _ in range(k):
+        item = int(rng.choice(hot)) if hot is not None and rng.random() < 0.5 else int(rng.integers(0, nitems))
+        rows.append((item, int(rng.integers(0, nrep)), int(rng.choice(sites)), int(rng.integers(0, max_step + 1)),
+                     int(rng.integers(0, 32)), int(rng.integers(0, max_index))))
+    return coast_amd.make_faults(rows)
+
+
+def stats3(st):
+    return {k: st[k] for k in ("errors_corrected", "sync_count", "dwc_detected")}
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    eng = coast_amd.Engine(0)
+    t0 = time.time()
+    cases = {"mm": 0, "sha256": 0, "aes": 0, "crc16": 0}
+    while time.time() - t0 < budget:
+        kind = str(rng.choice(list(cases)))
+        rep = int(rng.choice([1, 2, 3]))
+        nrep = rep
+        if kind == "mm":
+            n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 19, 31, 32, 33, 48, 64, 65, 96, 128, 256]))
+            batch = int(rng.integers(1, max(2, 20000 // (n * n)) + 1)) if n < 128 else 1
+            sync_every = int(rng.choice([0, 0, 1, 2, 7, n]))
+            f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+            s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+            nit = batch * n * n
+            hot = rng.integers(0, nit, 3)
+            fl = faults(rng, int(rng.integers(0, 60)) if rep > 1 else 0, nit, nrep, [0, 1, 2], n, 1, hot)
+            exp, est, edet = orc.mm_xmr(f, s, replicas=rep, sync_every=sync_every, faults=fl)
+            det = torch.zeros(nit, dtype=torch.uint8, device="cuda")
+            eng.reset_stats()
+            eng.inject_faults(fl)
+            got = eng.mm_batch(dev(f), dev(s), cfg=coast_amd.XmrConfig(rep, sync_every), detected=det).cpu().numpy().view(np.uint32)
+            ok = (got == exp).all() and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all()
+            desc = "mm n=%d batch=%d rep=%d V=%d k=%d" % (n, batch, rep, sync_every, len(fl))
+        elif kind == "sha256":
+            ln = int(rng.choice([0, 1, 3, 8, 55, 56, 57, 63, 64, 65, 100, 119, 120, 128, 200, 300]))
+            stride = ln + int(rng.choice([0, 0, 1, 3, 4])) if rng.random() < 0.5 else ((ln + 15) // 16) * 16 + 16 * int(rng.integers(0, 2))
+            stride = max(stride, 1)
+            nm = int(rng.integers(1, 400))
+            msgs = rng.integers(0, 256, (nm, stride), dtype=np.uint8)
+            ncomp = ln // 64 + (1 if ln % 64 < 56 else 2)
+            hot = rng.integers(0, nm, 3)
+            rows = []
+            for _ in range(int(rng.integers(0, 80)) if rep > 1 else 0):
+                site = int(rng.choice([8, 9, 10]))
+                step = int(rng.integers(0, ncomp + 1)) if site == 10 else int(rng.integers(0, ncomp * 64))
+                item = int(rng.choice(hot)) if rng.random() < 0.5 else int(rng.integers(0, nm))
+                rows.append((item, int(rng.integers(0, nrep)), site, step, int(rng.integers(0, 32)), int(rng.integers(0, 8))))
+            fl = coast_amd.make_faults(rows)
+            exp, est, edet = orc.sha256_xmr(msgs, ln, replicas=rep, faults=fl)
+            det = torch.zeros(nm, dtype=torch.uint8, device="cuda")
+            eng.reset_stats()
+            eng.inject_faults(fl)
+            got = eng.sha256_batch(torch.from_numpy(msgs).cuda(), ln, cfg=coast_amd.XmrConfig(rep), detected=det).cpu().numpy()
+            ok = (got == exp).all() and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all()
+            desc = "sha256 len=%d stride=%d nm=%d rep=%d k=%d" % (ln, stride, nm, rep, len(fl))
+        elif kind == "aes":
+            n = int(rng.integers(1, 600))
+            d = int(rng.integers(0, 2))
+            sync_every = int(rng.choice([0, 0, 1]))
+            st = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+            key = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+            hot = rng.integers(0, n, 3)
+            fl = faults(rng, int(rng.integers(0, 80)) if rep > 1 else 0, n, nrep, [16, 17], 10, 4, hot)
+            es, ek, est, edet = orc.aes128_xmr(st, key, d, replicas=rep, sync_every=sync_every, faults=fl)
+            ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(key.copy()).cuda()
+            det = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            eng.reset_stats()
+            eng.inject_faults(fl)
+            eng.aes128_batch(ds, dk, d, cfg=coast_amd.XmrConfig(rep, sync_every), detected=det)
+            ok = ((ds.cpu().numpy() == es).all() and (dk.cpu().numpy() == ek).all() and stats3(eng.stats()) == est
+                  and (det.cpu().numpy() == edet).all())
+            desc = "aes n=%d dir=%d rep=%d V=%d k=%d" % (n, d, rep, sync_every, len(fl))
+        else:
+            bl = int(rng.choice([1, 2, 3, 4, 5, 13, 16, 63, 64, 65, 127, 128, 255, 256, 300, 512]))
+            nb = int(rng.integers(1, 500))
+            sync_every = int(rng.choice([0, 0, 0, 1, 5, 64]))
+            data = rng.integers(0, 256, (nb, bl), dtype=np.uint8)
+            hot = rng.integers(0, nb, 3)
+            fl = faults(rng, int(rng.integers(0, 80)) if rep > 1 else 0, nb, nrep, [24, 25], bl, 1, hot)
+            exp, est, edet = orc.crc16_xmr(data, bl, replicas=rep, sync_every=sync_every, faults=fl)
+            det = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+            eng.reset_stats()
+            eng.inject_faults(fl)
+            off = int(rng.integers(0, 4)) if rng.random() < 0.3 else 0   # misaligned base pointer
+            buf = torch.empty(nb * bl + 16, dtype=torch.uint8, device="cuda")
+            buf[off:off + nb * bl].copy_(torch.from_numpy(data.reshape(-1)).cuda())
+            got = eng.crc16_batch(buf[off:off + nb * bl], bl, cfg=coast_amd.XmrConfig(rep, sync_every), detected=det)
+            got = got.cpu().numpy().view(np.uint16)
+            ok = (got == exp).all() and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all()
+            desc = "crc16 bl=%d nb=%d rep=%d V=%d k=%d off=%d" % (bl, nb, rep, sync_every, len(fl), off)
+        cases[kind] += 1
+        if not ok:
+            print("MISMATCH:", desc, "seed", seed)
+            sys.exit(1)
+    print("fuzz ok:", cases, "in %.0f s" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
