@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """fuzz_parity.py -- randomized GPU-vs-oracle soak: random shapes, modes, sync granularities and fault lists with heavy
 collisions (several faults on one item / replica / step).  Every case must match the oracle bit for bit: outputs,
-errors_corrected, sync_count, dwc_detected and the per-item flags.  Usage: fuzz_parity.py [seconds] [seed]"""
+errors_corrected, sync_count, dwc_detected and the per-item flags.  Usage: tests/fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
 import time

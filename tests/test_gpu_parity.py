@@ -600,12 +600,12 @@ def test_plain_c_host_program(mode):
 
 
 def test_randomized_parity_soak():
-    """tools/fuzz_parity.py for 15 s: random shapes / modes / sync granularities / colliding fault lists vs the oracle."""
+    """tests/fuzz_parity.py for 15 s: random shapes / modes / sync granularities / colliding fault lists vs the oracle."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "15", "7"], capture_output=True,
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "15", "7"], capture_output=True,
                        text=True, timeout=600)
     assert p.returncode == 0 and "fuzz ok" in p.stdout, (p.stdout[-800:], p.stderr[-800:])
