@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--workload", default="mm", choices=["mm", "crc16", "sha256", "aes"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU items per step (0 = the BASELINE config's size)")
     ap.add_argument("--side", type=int, default=256)
-    ap.add_argument("--faults", type=int, default=1024, help="single-bit flips injected per GPU per step")
+    ap.add_argument("--faults", type=int, default=4096, help="single-bit flips injected per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -132,7 +132,7 @@ class MM(Workload):
     dtype = "u32"
 
     def __init__(self, a, eng, dev, rank, coast_amd):
-        self.n, self.batch = a.side, a.batch or 2048
+        self.n, self.batch = a.side, a.batch or 16384  # 12.9 GB of f, s, r: ~32 ms kernels (a batch, not one matrix)
         n, batch = self.n, self.batch
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         self.f = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device=dev, generator=g)
