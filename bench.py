@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--workload", default="mm", choices=["mm", "crc16", "sha256", "aes"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU items per step (0 = the BASELINE config's size)")
     ap.add_argument("--side", type=int, default=256)
-    ap.add_argument("--faults", type=int, default=4096, help="single-bit flips injected per GPU per step")
+    ap.add_argument("--faults", type=int, default=-1,
+                    help="single-bit flips injected per GPU per step (default: 4096 for mm, 1024 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -342,6 +343,8 @@ def pmc_traffic(workload, cfg):
 
 def main():
     a = parse()
+    if a.faults < 0:
+        a.faults = 4096 if a.workload == "mm" else 1024
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
