@@ -50,6 +50,7 @@ SYMBOLS = {
     "coast_sha256_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(CoastCfg)]),
     "coast_aes_enc_dec_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint8, C.POINTER(CoastCfg)]),
     "coast_crc16_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(CoastCfg)]),
+    "coast_host_inject_faults": (C.c_int, [C.c_void_p, C.c_size_t]),
     "coast_host_stats": (C.c_int, [C.POINTER(CoastStats), C.c_int]),
 }
 

@@ -15,6 +15,10 @@
  *
  * The protection mode replaces the Makefile's OPT_PASSES: environment COAST_MODE = TMR (default) | DWC | NONE, and
  * COAST_SYNC_EVERY = V for the optional loop-condition sync points.
+ *
+ * Fault injection into the unmodified program (what supervisor.py does through GDB, simulation/platform/
+ * threadFunctions.py:588-600): COAST_INJECT="item:replica:site:step:bit[:index][,...]" arms those single-bit flips for the
+ * COAST_INJECT_CALL-th protected call of the process (default 0, the first one).
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -47,6 +51,49 @@ static coast_cfg dropin_cfg(void)
     return c;
 }
 
+/* arm the environment-described faults right before the chosen protected call */
+static void dropin_maybe_inject(void)
+{
+    static long calls = 0;
+    const char *spec = getenv("COAST_INJECT");
+    const long mine = calls++;
+    if (!spec || !*spec)
+        return;
+    const char *which = getenv("COAST_INJECT_CALL");
+    if (mine != (which ? strtol(which, NULL, 10) : 0))
+        return;
+    coast_fault fl[64];
+    size_t k = 0;
+    const char *p = spec;
+    while (*p && k < 64) {
+        unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+        int nf = 0;
+        char *end;
+        for (;;) {
+            v[nf++] = strtoull(p, &end, 0);
+            p = end;
+            if (*p != ':' || nf == 6)
+                break;
+            ++p;
+        }
+        if (nf >= 5) {
+            fl[k].item = v[0];
+            fl[k].replica = (uint8_t)v[1];
+            fl[k].site = (uint8_t)v[2];
+            fl[k].step = (uint32_t)v[3];
+            fl[k].bit = (uint8_t)v[4];
+            fl[k].index = (uint8_t)v[5];
+            ++k;
+        }
+        while (*p && *p != ',')
+            ++p;
+        if (*p == ',')
+            ++p;
+    }
+    if (k)
+        (void)coast_host_inject_faults(fl, k);
+}
+
 static void dropin_fail(const char *what, int rc)
 {
     fprintf(stderr, "libcoast_dropin: %s failed with code %d (no GPU / no CPU fallback)\n", what, rc);
@@ -68,6 +115,7 @@ static void dropin_account(void)
 unsigned short crc16(const unsigned char *data_p, unsigned char length)
 {
     const coast_cfg cfg = dropin_cfg();
+    dropin_maybe_inject();
     uint16_t crc = 0;
     const int rc = coast_crc16_host(data_p, length, &crc, &cfg);
     if (rc)
@@ -79,6 +127,7 @@ unsigned short crc16(const unsigned char *data_p, unsigned char length)
 void aes_enc_dec(unsigned char *state, unsigned char *key, unsigned char dir)
 {
     const coast_cfg cfg = dropin_cfg();
+    dropin_maybe_inject();
     const int rc = coast_aes_enc_dec_host(state, key, dir, &cfg);
     if (rc)
         dropin_fail("aes_enc_dec", rc);
@@ -89,6 +138,7 @@ void sha256_hash(unsigned char ctx_data[], uint32_t ctx_bitlen[], uint32_t ctx_s
                  uint32_t len, unsigned char hash[])
 {
     const coast_cfg cfg = dropin_cfg();
+    dropin_maybe_inject();
     uint32_t st[8];
     const int rc = coast_sha256_host(data, len, hash, st, &cfg);
     if (rc)
@@ -118,6 +168,7 @@ void sha256_hash(unsigned char ctx_data[], uint32_t ctx_bitlen[], uint32_t ctx_s
 void coast_dropin_matrix_multiply(const void *f, const void *s, void *r, int side)
 {
     const coast_cfg cfg = dropin_cfg();
+    dropin_maybe_inject();
     const int rc = coast_matrix_multiply_host((const uint32_t *)f, (const uint32_t *)s, (uint32_t *)r, side, &cfg);
     if (rc)
         dropin_fail("matrix_multiply", rc);

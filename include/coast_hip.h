@@ -149,6 +149,9 @@ int coast_matrix_multiply_host(const uint32_t *f, const uint32_t *s, uint32_t *r
 int coast_sha256_host(const uint8_t *data, uint32_t len, uint8_t hash[32], uint32_t state_out[8], const coast_cfg *cfg);
 int coast_aes_enc_dec_host(uint8_t *state, uint8_t *key, uint8_t dir, const coast_cfg *cfg);
 int coast_crc16_host(const uint8_t *data, uint32_t length, uint16_t *crc, const coast_cfg *cfg);
+/* arm single-bit flips for the NEXT single-call shim (they run on a library-owned context): lets an external harness
+ * inject into an unmodified driver the way supervisor.py + GDB inject into the running benchmark */
+int coast_host_inject_faults(const coast_fault *faults, size_t k);
 /* counters accumulated by the host shims since the last call (what TMR_ERROR_CNT / __SYNC_COUNT expose) */
 int coast_host_stats(coast_stats *out, int reset);
 

@@ -609,3 +609,33 @@ def test_randomized_parity_soak():
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "15", "7"], capture_output=True,
                        text=True, timeout=600)
     assert p.returncode == 0 and "fuzz ok" in p.stdout, (p.stdout[-800:], p.stderr[-800:])
+
+
+def test_fault_injection_into_unmodified_program():
+    """supervisor.py's job on the drop-in layer: flip one bit inside a protected call of an unmodified C program.
+    Unprotected -> silent data corruption; TMR -> corrected and counted (F:1), output intact; DWC -> the default
+    FAULT_DETECTED_DWC handler aborts the process (synchronization.cpp:1251-1266)."""
+    import os
+    import signal
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "host_c_demo")
+    spec = "0:0:24:5:3"  # item 0, replica 0, crc register before byte 5, bit 3 -- the first protected call is crc16()
+
+    def run(mode):
+        return subprocess.run([exe], env=dict(os.environ, COAST_MODE=mode, COAST_INJECT=spec), capture_output=True,
+                              text=True, timeout=300)
+
+    p = run("NONE")
+    assert p.returncode == 1 and "result: 5ba3" not in p.stdout and "E:1" in p.stdout
+    p = run("TMR")
+    assert p.returncode == 0 and "result: 5ba3" in p.stdout and "C:0 E:0 F:1 T:0us" in p.stdout
+    p = run("DWC")
+    assert p.returncode == -signal.SIGABRT
+    ref = os.path.join(root, "oracle", "_ref", "bin", "crc16_coast")
+    if os.path.exists(ref):  # the reference's own crc16.c main(), unmodified
+        q = subprocess.run([ref], env=dict(os.environ, COAST_MODE="TMR", COAST_INJECT=spec), capture_output=True, text=True)
+        assert q.returncode == 0 and "result: 5ba3" in q.stdout
+        q = subprocess.run([ref], env=dict(os.environ, COAST_MODE="NONE", COAST_INJECT=spec), capture_output=True, text=True)
+        assert "result: 5ba3" not in q.stdout
