@@ -462,9 +462,9 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
                                    d_r, g, 0u, ctr, ft, dBlockList, d_detected);                                \
                 HIP_TRY(c, hipEventRecord(c->evSideDone, c->side));                                             \
             }                                                                                                   \
-            if (n == 256 && g.kt == Mm256<R>::KT && g.rs == Mm256<R>::RS && g.bpm == Mm256<R>::BPM)            \
-                hipLaunchKernelGGL(mm_fast256_kernel<R>, dim3(g.nblocks), block, lds, c->stream, d_f, d_s, d_r,  \
-                                   g, ctr, have ? ft.range : (const uint2 *)nullptr, d_detected);               \
+            if (n == 256 && g.rs == Mm256<R>::RS && g.bpm == Mm256<R>::BPM)                                     \
+                hipLaunchKernelGGL(mm_fast256_kernel<R>, dim3(g.nblocks), block, Mm256<R>::LDS_BYTES, c->stream, \
+                                   d_f, d_s, d_r, g, ctr, have ? ft.range : (const uint2 *)nullptr, d_detected); \
             else if ((n & 3) == 0)                                                                              \
                 LAUNCH_FAST_K(R, true);                                                                         \
             else                                                                                                \
