@@ -16,6 +16,7 @@
 #include "xmr.hpp"
 #include "injector.hip"
 #include "mm_kernel.hip"
+#include "mm_mfma_kernel.hip"
 #include "sha256_kernel.hip"
 #include "aes_kernel.hip"
 #include "crc16_kernel.hip"
@@ -462,7 +463,16 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
                                    d_r, g, 0u, ctr, ft, dBlockList, d_detected);                                \
                 HIP_TRY(c, hipEventRecord(c->evSideDone, c->side));                                             \
             }                                                                                                   \
-            if (n == 256 && g.rs == Mm256<R>::RS && g.bpm == Mm256<R>::BPM)                                     \
+            static const bool mfma = getenv("COAST_MM_ENGINE") && !strcmp(getenv("COAST_MM_ENGINE"), "mfma");   \
+            if (n == 256 && mfma && g.bpm == MmMfma<R>::V_BPM) {                                                \
+                using GM = MmMfma<R>;                                                                           \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma256_kernel<R>,                              \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::LDS_BYTES)); \
+                const uint64_t nbm = (uint64_t)GM::BPM * batch;                                                 \
+                hipLaunchKernelGGL(mm_mfma256_kernel<R>, dim3((uint32_t)nbm), dim3(GM::NTHR), GM::LDS_BYTES,         \
+                                   c->stream, d_f, d_s, d_r, (uint32_t)nbm, ctr,                                \
+                                   have ? ft.range : (const uint2 *)nullptr, d_detected);                       \
+            } else if (n == 256 && g.rs == Mm256<R>::RS && g.bpm == Mm256<R>::BPM)                             \
                 hipLaunchKernelGGL(mm_fast256_kernel<R>, dim3(g.nblocks), block, Mm256<R>::LDS_BYTES, c->stream, \
                                    d_f, d_s, d_r, g, ctr, have ? ft.range : (const uint2 *)nullptr, d_detected); \
             else if ((n & 3) == 0)                                                                              \
