@@ -62,7 +62,8 @@ class CoastLibraryError(RuntimeError):
 
 
 def lib_path() -> str:
-    return _build.LIB
+    # COAST_HIP_LIB: development override (kernel experiments built beside the real library)
+    return os.environ.get("COAST_HIP_LIB") or _build.LIB
 
 
 def load():

@@ -92,6 +92,30 @@ __device__ __forceinline__ uint32_t xmr_sync(uint32_t v, const LaneMap<NREP> &lm
 // just its two neighbours -- lane+1 and lane+2 via whole-wave DPP shifts (wave_shl:1: lane i reads lane i+1) -- instead of
 // three ds_bpermute round trips through the LDS crossbar (24 cycles each, tools/valu_microbench).  Same voter and counter
 // rules as xmr_sync; the returned value is meaningful in replica-0 lanes only.
+// voter of a final sync point on explicit copies: v = this replica, b / c = the next two (replica-0 lanes consume it)
+template <int NREP>
+__device__ __forceinline__ uint32_t xmr_final_vote_vals(uint32_t v, uint32_t b, uint32_t c, bool count, Tally &t)
+{
+    if constexpr (NREP == 1) {
+        return v;
+    } else if constexpr (NREP == 2) {
+        if (count) {
+            t.syncs += 1;
+            t.det |= (v != b) ? 1u : 0u;
+        }
+        return v;
+    } else {
+        const bool e01 = (v == b), e02 = (v == c);
+        if (count) {
+            const uint32_t m = (e01 && e02) ? 0u : 1u;
+            t.syncs += 1;
+            t.miss += m;
+            t.det |= m;
+        }
+        return e01 ? v : c;
+    }
+}
+
 template <int NREP>
 __device__ __forceinline__ uint32_t xmr_final_vote_dpp(uint32_t v, bool count, Tally &t)
 {
@@ -100,23 +124,8 @@ __device__ __forceinline__ uint32_t xmr_final_vote_dpp(uint32_t v, bool count, T
     } else {
         constexpr int kWaveShl1 = 0x130; // DPP_WF_SL1
         const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kWaveShl1, 0xf, 0xf, false);
-        if constexpr (NREP == 2) {
-            if (count) {
-                t.syncs += 1;
-                t.det |= (v != b) ? 1u : 0u;
-            }
-            return v;
-        } else {
-            const uint32_t c = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, kWaveShl1, 0xf, 0xf, false);
-            const bool e01 = (v == b), e02 = (v == c);
-            if (count) {
-                const uint32_t m = (e01 && e02) ? 0u : 1u;
-                t.syncs += 1;
-                t.miss += m;
-                t.det |= m;
-            }
-            return e01 ? v : c;
-        }
+        const uint32_t c = NREP == 3 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, kWaveShl1, 0xf, 0xf, false) : 0u;
+        return xmr_final_vote_vals<NREP>(v, b, c, count, t);
     }
 }
 

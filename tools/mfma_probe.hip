@@ -45,6 +45,41 @@ __global__ __launch_bounds__(256) void rate(int *out, int iters)
     if (s == 0x12345678) out[threadIdx.x] = s;
 }
 
+// (3) do independent VALU instructions issue under a running MFMA?  20 MFMAs over 8 accumulators (the mm kernel's
+//     pattern) + K v_perm_b32 per loop trip, 2 waves per SIMD.
+template <int K> __global__ __launch_bounds__(256, 2) void mix(int *out, int iters)
+{
+    v4i a = {(int)threadIdx.x, 2, 3, 4}, b = {5, 6, (int)threadIdx.x, 8};
+    v16i c[8];
+    for (int t = 0; t < 8; ++t) c[t] = (v16i){0};
+    uint32_t x[8];
+    for (int t = 0; t < 8; ++t) x[t] = threadIdx.x * 2654435761u + t;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int m = 0; m < 20; ++m) {
+            c[m % 8] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c[m % 8], 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < K / 20; ++v) {
+                const int t = (m * (K / 20) + v) % 8;
+                x[t] = __builtin_amdgcn_perm(x[t], x[(t + 3) % 8], 0x05010400u + v);
+            }
+        }
+    }
+    int s = 0;
+    for (int t = 0; t < 8; ++t) { for (int r = 0; r < 16; ++r) s += c[t][r]; s += (int)x[t]; }
+    if (s == 0x12345678) out[threadIdx.x] = s;
+}
+template <int K> static void run_mix(int *dD, int cus)
+{
+    const int iters = 4000, blocks = cus * 2;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(mix<K>, dim3(blocks), dim3(256), 0, 0, dD, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0); hipLaunchKernelGGL(mix<K>, dim3(blocks), dim3(256), 0, 0, dD, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("mix K=%3d VALU per 20 MFMA, 2 waves/SIMD: %.3f ms, %.1f ns per trip per wave-pair (MFMA-only floor = 2*20*32 cycles)\n", K, ms, ms * 1e6 / iters);
+}
+
 int main()
 {
     std::vector<int8_t> A(1024), B(1024);
@@ -71,5 +106,7 @@ int main()
         const double mf = (double)blocks * 4 * iters * 4;
         printf("waves/SIMD %d: %.3f ms, %.1f cycles/MFMA/SIMD @2.4GHz, %.0f TOPS\n", wpb, ms, 2.4e9 * ms * 1e-3 / (mf / (p.multiProcessorCount * 4)), mf * 32768 * 2 / (ms * 1e-3) * 1e-12);
     }
+    run_mix<0>(dD, p.multiProcessorCount); run_mix<40>(dD, p.multiProcessorCount); run_mix<80>(dD, p.multiProcessorCount);
+    run_mix<120>(dD, p.multiProcessorCount); run_mix<160>(dD, p.multiProcessorCount); run_mix<240>(dD, p.multiProcessorCount);
     return bad != 0;
 }

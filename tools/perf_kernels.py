@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import coast_amd  # noqa: E402
 
 
-def timeit(fn, reps=5, warm=2):
+def timeit(fn, reps=int(os.environ.get("PERF_REPS", "5")), warm=int(os.environ.get("PERF_WARM", "2"))):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
