@@ -30,6 +30,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 # issue rate of v_mad_u64_u32 -- the one-instruction 32-bit MAC the kernel is built from -- at 8 waves/SIMD:
 # 5.11 cycles per wave-instruction = 30.78 T lane-MAC/s (tools/valu_microbench, profiles/microbench_r01.txt).
 MAC_PEAK = 30.78e12
+# int8 MFMA: MI355X_MICROARCH.md lists no spec figure, "~2x bf16 rate" (bf16 ~2.5 PFLOP/s dense) and a ubench ceiling of
+# >= 3944 TOPS; tools/mfma_probe reaches 4.2-4.3 POPS with v_mfma_i32_32x32x32_i8 (32 cycles/instruction/SIMD at the
+# ~2.05 GHz the chip sustains under MFMA load).  Peak = 2 x 2.5e15; the measured ceiling is reported next to it.
+I8_MFMA_PEAK = 5.0e15
+I8_MFMA_UBENCH = 4.25e15
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 78.6 T lane-ops/s, full-rate VALU
 
 
@@ -159,24 +164,41 @@ class MM(Workload):
     def config(self, world):
         return {"workload": "matrixMultiply %dx%d uint32 TMR (3-lane replicate + vote), batch %d matrices/GPU, "
                             "%d injected single-bit faults/GPU/step" % (self.n, self.n, self.batch, len(self.faults)),
-                "side": self.n, "batch_per_gpu": self.batch, "replicas": 3,
+                "side": self.n, "batch_per_gpu": self.batch, "replicas": 3, "engine": self.engine(),
                 "parallelism": "dp%d (independent matrices)" % world}
+
+    def engine(self):
+        """which kernel coast_mm_batch dispatches to (coast_hip.hip LAUNCH_MM): side 256 runs on the matrix cores"""
+        return "mfma" if self.n == 256 and os.environ.get("COAST_MM_ENGINE") != "valu" else "valu"
 
     def roofline(self, kern_ms):
         n, batch = self.n, self.batch
-        macs = float(batch) * n ** 3           # algorithmic MACs of one launch (N^3 per matrix)
+        macs = float(batch) * n ** 3           # algorithmic 32-bit MACs of one launch (SURVEY 8d: N^3 per matrix)
         bytes_alg = float(batch) * 12 * n * n  # algorithmic HBM bytes of one launch (read f, s once; write r once)
         t = kern_ms * 1e-3
-        return {
+        hbm = {"hbm_achieved_GBs": bytes_alg / t * 1e-9, "hbm_peak_GBs": HBM_PEAK_GBS,
+               "hbm_frac": bytes_alg / t * 1e-9 / HBM_PEAK_GBS, "algorithmic_bytes": bytes_alg, "kernel_ms": kern_ms}
+        if self.engine() == "mfma":
+            # a wrapping 32-bit MAC = 10 signed-byte limb products (p+q <= 3), per replica: the int8 work the protected
+            # computation needs on the matrix core (lane padding 32/30 and ragged tiles are NOT counted)
+            ops = 2.0 * macs * 10 * 3
+            return dict(hbm, **{
+                "bound": "mfma", "kernel": "mm_mfma_panel_kernel<3>",
+                "achieved": ops / t * 1e-12, "peak": I8_MFMA_PEAK * 1e-12, "unit": "TOP/s (int8)",
+                "frac": ops / t / I8_MFMA_PEAK, "frac_of_ubench_ceiling": ops / t / I8_MFMA_UBENCH,
+                "u32_macs_per_s": macs / t, "int8_ops_per_u32_mac": 2 * 10 * 3,
+                "note": "r = sum_k f*s mod 2^32 as ten int8 GEMMs of signed-byte limbs on v_mfma_i32_32x32x32_i8, x3 replicas in "
+                        "adjacent lane-columns; achieved = 2*N^3*10*3 int8 ops per matrix / kernel time; peak = 2x the bf16 dense "
+                        "peak (MI355X_MICROARCH.md: I8 runs at ~2x bf16 rate; ubench ceilings 3944 there, 4.2-4.3 POPS in "
+                        "tools/mfma_probe at the ~2.05 GHz the chip holds under MFMA load)",
+            })
+        return dict(hbm, **{
             "bound": "valu", "kernel": "mm_fast256_kernel<3>" if n == 256 else "mm_fast_kernel<3>",
             "achieved": macs / t * 1e-12, "peak": MAC_PEAK * 1e-12, "unit": "T int32-MAC/s",
-            "frac": macs / t / MAC_PEAK, "executed_frac": 3.0 * macs / t / MAC_PEAK, "kernel_ms": kern_ms,
-            "hbm_achieved_GBs": bytes_alg / t * 1e-9, "hbm_peak_GBs": HBM_PEAK_GBS,
-            "hbm_frac": bytes_alg / t * 1e-9 / HBM_PEAK_GBS, "algorithmic_bytes": bytes_alg,
-            "note": "32-bit wrapping multiply has no MFMA form; bound = VALU issue of v_mad_u64_u32 (measured 30.78 T "
-                    "lane-MAC/s, profiles/microbench_r01.txt); achieved/frac count ALGORITHMIC MACs (N^3 per matrix), "
-                    "TMR executes 3x of them (executed_frac)",
-        }
+            "frac": macs / t / MAC_PEAK, "executed_frac": 3.0 * macs / t / MAC_PEAK,
+            "note": "VALU engine: bound = issue of v_mad_u64_u32 (measured 30.78 T lane-MAC/s, profiles/microbench_r01.txt); "
+                    "achieved/frac count ALGORITHMIC MACs (N^3 per matrix), TMR executes 3x of them (executed_frac)",
+        })
 
     def cpu(self):
         return cpu_baseline_mm(self.n)
@@ -333,9 +355,9 @@ def pmc_traffic(workload, cfg):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/traffic.json)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        rec = json.load(open(path)).get(workload)
-        if rec and all(cfg.get(k) == v for k, v in rec.get("match", {}).items()):
-            return rec["hbm_bytes_per_launch"], rec.get("source")
+        for key, rec in json.load(open(path)).items():  # records are keyed "<workload>" or "<workload>_<variant>"
+            if key.split("_")[0] == workload and all(cfg.get(k) == v for k, v in rec.get("match", {}).items()):
+                return rec["hbm_bytes_per_launch"], rec.get("source")
     except (OSError, ValueError):
         pass
     return None, None

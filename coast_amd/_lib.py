@@ -62,8 +62,7 @@ class CoastLibraryError(RuntimeError):
 
 
 def lib_path() -> str:
-    # COAST_HIP_LIB: development override (kernel experiments built beside the real library)
-    return os.environ.get("COAST_HIP_LIB") or _build.LIB
+    return _build.LIB
 
 
 def load():

@@ -463,21 +463,15 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
                                    d_r, g, 0u, ctr, ft, dBlockList, d_detected);                                \
                 HIP_TRY(c, hipEventRecord(c->evSideDone, c->side));                                             \
             }                                                                                                   \
-            static const bool mfma = getenv("COAST_MM_ENGINE") && !strcmp(getenv("COAST_MM_ENGINE"), "mfma");   \
+            /* side 256: the int8-MFMA limb kernel; COAST_MM_ENGINE=valu selects the v_mad_u64_u32 kernel instead */   \
+            const char *eng = getenv("COAST_MM_ENGINE");                                                        \
+            const bool mfma = !(eng && !strcmp(eng, "valu"));                                                   \
             if (n == 256 && mfma && g.bpm == MmPanel<R>::V_BPM) {                                               \
                 using GP = MmPanel<R>;                                                                          \
                 HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_panel_kernel<R>,                           \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GP::LDS_BYTES)); \
                 const uint64_t nbm = (uint64_t)GP::BPM * batch;                                                 \
                 hipLaunchKernelGGL(mm_mfma_panel_kernel<R>, dim3((uint32_t)nbm), dim3(GP::NTHR), GP::LDS_BYTES, \
-                                   c->stream, d_f, d_s, d_r, (uint32_t)nbm, ctr,                                \
-                                   have ? ft.range : (const uint2 *)nullptr, d_detected);                       \
-            } else if (n == 256 && mfma && g.bpm == MmMfma<R>::V_BPM) {                                         \
-                using GM = MmMfma<R>;                                                                           \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma256_kernel<R>,                              \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM::LDS_BYTES)); \
-                const uint64_t nbm = (uint64_t)GM::BPM * batch;                                                 \
-                hipLaunchKernelGGL(mm_mfma256_kernel<R>, dim3((uint32_t)nbm), dim3(GM::NTHR), GM::LDS_BYTES,    \
                                    c->stream, d_f, d_s, d_r, (uint32_t)nbm, ctr,                                \
                                    have ? ft.range : (const uint2 *)nullptr, d_detected);                       \
             } else if (n == 256 && g.rs == Mm256<R>::RS && g.bpm == Mm256<R>::BPM)                             \

@@ -152,6 +152,62 @@ def test_mm_256_batch_properties(eng, orc):
     assert (r12.reshape(-1)[items.astype(np.int64)] == exp).all()
 
 
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+def test_mm_256_mfma_and_valu_engines_vs_oracle(eng, orc, replicas, monkeypatch):
+    """Side 256 runs on the int8-MFMA limb kernel by default and on the v_mad_u64_u32 kernel with COAST_MM_ENGINE=valu:
+    both must give the oracle's words, counters and per-item flags, with faults at every site armed."""
+    import coast_amd
+    import torch
+
+    rng = np.random.default_rng(77 + replicas)
+    batch, n = 3, 256
+    f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    fl = _rand_faults(rng, 0 if replicas == 1 else 120, batch * n * n, replicas, [0, 1, 2], n)
+    exp_r, exp_st, exp_det = orc.mm_xmr(f, s, replicas=replicas, faults=fl)
+    clean_r, clean_st, _ = orc.mm_xmr(f, s, replicas=replicas)
+    for engine in ("mfma", "valu"):
+        monkeypatch.setenv("COAST_MM_ENGINE", engine)
+        det = torch.zeros(batch * n * n, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        got = _host(eng.mm_batch(_dev(f), _dev(s), cfg=coast_amd.XmrConfig(replicas), detected=det), np.uint32)
+        assert (got == exp_r).all(), engine
+        assert _stats3(eng.stats()) == exp_st, engine
+        assert (det.cpu().numpy() == exp_det).all(), engine
+        eng.reset_stats()
+        got = _host(eng.mm_batch(_dev(f), _dev(s), cfg=coast_amd.XmrConfig(replicas)), np.uint32)
+        assert (got == clean_r).all() and _stats3(eng.stats()) == clean_st, engine
+
+
+def test_mm_256_limb_edge_values(eng):
+    """The signed-byte limb decomposition behind the MFMA kernel at its carry / sign corners: operands made of
+    0x00, 0x7f, 0x80, 0xff bytes (every digit at -128, -1, 0, 127 and every carry pattern), against numpy mod 2^32."""
+    rng = np.random.default_rng(5)
+    n = 256
+    corner = np.array([0x00, 0x7F, 0x80, 0xFF, 0x01, 0x81], dtype=np.uint32)
+    def pick(shape):
+        b = corner[rng.integers(0, len(corner), shape + (4,))]
+        return (b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16) | (b[..., 3] << 24)).astype(np.uint32)
+    f = np.stack([pick((n, n)), np.full((n, n), 0xFFFFFFFF, np.uint32), np.full((n, n), 0x80000000, np.uint32),
+                  np.full((n, n), 0x7F7F7F7F, np.uint32), np.full((n, n), 0x80808080, np.uint32)])
+    s = np.stack([pick((n, n)), np.full((n, n), 0xFFFFFFFF, np.uint32), np.full((n, n), 0x80000000, np.uint32),
+                  pick((n, n)), np.full((n, n), 0x80808080, np.uint32)])
+    want = np.stack([_mm_mod32(f[b], s[b]) for b in range(f.shape[0])])
+    import coast_amd
+    for replicas in (3, 2, 1):
+        got = _host(eng.mm_batch(_dev(f), _dev(s), cfg=coast_amd.XmrConfig(replicas)), np.uint32)
+        assert (got == want).all(), replicas
+
+
+def _mm_mod32(f, s):
+    """exact (f @ s) mod 2^32 with numpy: split f into 16-bit halves so that uint64 accumulation cannot overflow"""
+    s64 = s.astype(np.uint64)
+    lo = (f & 0xFFFF).astype(np.uint64) @ s64            # < 2^16 * 2^32 * 256 = 2^56
+    hi = (f >> 16).astype(np.uint64) @ s64
+    return ((lo + ((hi & 0xFFFF) << 16)) & 0xFFFFFFFF).astype(np.uint32)
+
+
 # ------------------------------------------------------------------------------------------------ sha256
 @pytest.mark.parametrize("tag", ["10", "4000"])
 def test_sha256_golden(eng, golden, tag):

@@ -21,6 +21,8 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
     -d "$OUT/pmc_sq" -o bench -- $BENCH > /dev/null 2> "$OUT/pmc_sq.err"
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE \
     -d "$OUT/pmc_lds" -o bench -- $BENCH > /dev/null 2> "$OUT/pmc_lds.err"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
+    -d "$OUT/pmc_mfma" -o bench -- $BENCH > /dev/null 2> "$OUT/pmc_mfma.err"
 python $ROOT/tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt" | head -60
 # the raw databases are large: keep only the summaries in the merge-back
