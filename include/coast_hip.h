@@ -104,6 +104,8 @@ int coast_inject_faults(coast_ctx *ctx, const coast_fault *faults, size_t k);
 
 /* matrix_multiply (tests/mm_common/mm_common_tmr.c:3-20; LANL variant tests/matrixMultiply/matrixMultiply.c:95-112):
  * `batch` independent n x n row-major uint32 products, r = (uint32) sum_k f[i][k]*s[k][j].
+ * n == 256 (the benchmark's side) runs on the int8 matrix cores (exact signed-byte limb decomposition of the 32-bit
+ * products); every other side, and n == 256 under COAST_MM_ENGINE=valu, on the VALU kernels.  Same words, counters and flags.
  * d_detected (all batch entry points): optional, one byte per work item, set to 1 where a sync point of that item saw
  * unequal copies -- DWC: the compare that would have called FAULT_DETECTED_DWC(); TMR: a value was out-voted (the per-item
  * view of TMR_ERROR_CNT, what a campaign needs to classify a run as "fault corrected", jsonParser.py:162-186). */
