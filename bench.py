@@ -187,6 +187,8 @@ class MM(Workload):
                 "achieved": ops / t * 1e-12, "peak": I8_MFMA_PEAK * 1e-12, "unit": "TOP/s (int8)",
                 "frac": ops / t / I8_MFMA_PEAK, "frac_of_ubench_ceiling": ops / t / I8_MFMA_UBENCH,
                 "u32_macs_per_s": macs / t, "int8_ops_per_u32_mac": 2 * 10 * 3,
+                # SURVEY 8(d) priced this path against the VALU MAC ceiling (N^3 algorithmic MACs per matrix, x3 executed):
+                "algorithmic_macs_vs_valu_ceiling": macs / t / MAC_PEAK, "executed_macs_vs_valu_ceiling": 3.0 * macs / t / MAC_PEAK,
                 "note": "r = sum_k f*s mod 2^32 as ten int8 GEMMs of signed-byte limbs on v_mfma_i32_32x32x32_i8, x3 replicas in "
                         "adjacent lane-columns; achieved = 2*N^3*10*3 int8 ops per matrix / kernel time; peak = 2x the bf16 dense "
                         "peak (MI355X_MICROARCH.md: I8 runs at ~2x bf16 rate; ubench ceilings 3944 there, 4.2-4.3 POPS in "
