@@ -101,7 +101,8 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
 {
     using G = MmPanel<NREP>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smemP[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: tile columns and slab offsets stay in SGPRs (no waterfall loops)
     const int lc = lane & 31, kh = lane >> 5;
     uint8_t *const wbuf = smemP + G::A_PANEL + wave * G::WAVE_LDS;
 
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
         }
     };
 
+    // (Also tried: reading the next step's B and row-block-0 A fragments behind the last MFMAs of this step -- no gain.)
     // One pipeline step, hand-scheduled as ONE basic block: the loads for step it+2 go out, the 12 fragment reads of step
     // it, then its 20 MFMAs with the conversion of step it+1 slotted between them in ten small stages (sched_barrier pins the
     // order) -- the matrix core and the VALU run side by side instead of taking turns; two waves per SIMD drift into the same
