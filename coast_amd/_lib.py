@@ -15,7 +15,7 @@ assert FAULT_DTYPE.itemsize == 16
 
 
 class CoastCfg(C.Structure):
-    _fields_ = [("replicas", C.c_uint32), ("sync_every", C.c_uint32)]
+    _fields_ = [("replicas", C.c_uint32), ("sync_every", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class CoastStats(C.Structure):

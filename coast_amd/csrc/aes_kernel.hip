@@ -182,10 +182,10 @@ __device__ __forceinline__ void aes_sync(uint32_t s[16], uint32_t k[16], const L
 {
 #pragma unroll
     for (int w = 0; w < 4; ++w)
-        unpack4(xmr_sync<NREP>(pack4(s + 4 * w), lm, cnt, tl), s + 4 * w);
+        unpack4(xmr_store_sync<NREP>(pack4(s + 4 * w), lm, cnt, tl), s + 4 * w);
 #pragma unroll
     for (int w = 0; w < 4; ++w)
-        unpack4(xmr_sync<NREP>(pack4(k + 4 * w), lm, cnt, tl), k + 4 * w);
+        unpack4(xmr_store_sync<NREP>(pack4(k + 4 * w), lm, cnt, tl), k + 4 * w);
 }
 
 // ------------------------------------------------------------------------------------------------ fast encryption
@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256, 5) void aes128_xmr_kernel(uint8_t *__restrict_
     __shared__ __attribute__((aligned(16))) uint8_t sRsb[256];
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
-    const LaneMap<NREP> lm;
+    LaneMap<NREP> lm;
+    lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
     // blockDim.x / 64 tiles per workgroup: 1 when walking the faulted-tile list, 4 when covering a whole batch
     const uint32_t tslot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const bool slotOk = tslot < nslots; // the last workgroup of a whole-batch launch may hang over

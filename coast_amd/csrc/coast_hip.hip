@@ -95,6 +95,8 @@ int check_cfg(coast_ctx *ctx, const coast_cfg *cfg)
         return COAST_EINVAL;
     if (!cfg || cfg->replicas < 1 || cfg->replicas > 3)
         return fail(ctx, COAST_EINVAL, "coast_cfg.replicas must be 1 (none), 2 (DWC) or 3 (TMR)");
+    if (cfg->flags & ~(uint32_t)COAST_F_NO_STORE_DATA_SYNC)
+        return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: unknown bits", cfg->flags);
     return COAST_OK;
 }
 
@@ -426,9 +428,10 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     rc = arm_faults(c, g.nblocks, decode_mm, &h, &ft, &have, &dBlockList, &nFaultBlocks);
     if (rc)
         return rc;
-    Counters ctr{c->dSlots};
+    Counters ctr{c->dSlots, cfg->flags};
     const dim3 block(256);
-    const bool allGeneral = cfg->sync_every != 0; // extra sync points: every workgroup takes the stepwise kernel
+    // extra sync points, or -noStoreDataSync: every workgroup takes the stepwise kernel
+    const bool allGeneral = cfg->sync_every != 0 || cfg->flags != 0;
 #define LAUNCH_FAST(R, V, K)                                                                                    \
     do {                                                                                                        \
         if (lds > 64 * 1024)                                                                                    \
@@ -516,7 +519,7 @@ extern "C" int coast_sync_copies(coast_ctx *c, void *const *d_copies, int ncopie
     const uint64_t nwords = nbytes / 4;
     const uint64_t nvec = nwords / 4;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->numCUs * 8, std::max<uint64_t>(1, (nvec + 255) / 256));
-    Counters ctr{c->dSlots};
+    Counters ctr{c->dSlots, 0u};
     uint32_t *c0 = (uint32_t *)d_copies[0], *c1 = (uint32_t *)d_copies[1];
     uint32_t *c2 = ncopies == 3 ? (uint32_t *)d_copies[2] : nullptr;
     if (ncopies == 3)

@@ -13,8 +13,16 @@
  *   FAULT_DETECTED_DWC()             default handler = abort() (synchronization.cpp:1251-1266); weak, because a program
  *                                    may define its own (tests/TMRregression/unitTests/stackProtect.c:67)
  *
- * The protection mode replaces the Makefile's OPT_PASSES: environment COAST_MODE = TMR (default) | DWC | NONE, and
- * COAST_SYNC_EVERY = V for the optional loop-condition sync points.
+ * The protection mode replaces the Makefile's OPT_PASSES (tests/crc16/Makefile:3, unittest/cfg/full.yml:18-36):
+ *   COAST_OPT_PASSES = the reference's own flag string, e.g. "-TMR -countErrors", "-DWC -noMemReplication -noLoadSync":
+ *       -TMR / -DWC / neither          3 / 2 / 1 replicas
+ *       -noMemReplication              the lane-replicated engine; WITHOUT it (the reference's default) every clone runs on its
+ *                                      own memory copy and the copies are voted at the region exit (COAST_F_HOST_MEMORY_REPLICATED)
+ *       -noStoreDataSync               COAST_F_NO_STORE_DATA_SYNC (only meaningful next to -noMemReplication, as in the reference)
+ *       -countErrors -countSyncs -storeDataSync -noLoadSync -noStoreAddrSync -i -s   accepted; always on / no effect here
+ *                                      (include/coast_hip.h says why)
+ *   or, shorter, COAST_MODE = TMR (default) | DWC | NONE  (lane-replicated engine);
+ *   COAST_SYNC_EVERY = V adds the optional loop-condition sync points.
  *
  * Fault injection into the unmodified program (what supervisor.py does through GDB, simulation/platform/
  * threadFunctions.py:588-600): COAST_INJECT="item:replica:site:step:bit[:index][,...]" arms those single-bit flips for the
@@ -35,11 +43,27 @@ __attribute__((weak, noinline)) void FAULT_DETECTED_DWC(void)
     abort();
 }
 
+static int has_flag(const char *passes, const char *flag)
+{
+    const size_t n = strlen(flag);
+    for (const char *p = strstr(passes, flag); p; p = strstr(p + 1, flag))
+        if ((p == passes || p[-1] == ' ') && (p[n] == '\0' || p[n] == ' '))
+            return 1;
+    return 0;
+}
+
 static coast_cfg dropin_cfg(void)
 {
-    coast_cfg c = {3u, 0u};
+    coast_cfg c = {3u, 0u, 0u};
+    const char *passes = getenv("COAST_OPT_PASSES");
     const char *m = getenv("COAST_MODE");
-    if (m) {
+    if (passes) {
+        c.replicas = has_flag(passes, "-TMR") ? 3u : has_flag(passes, "-DWC") ? 2u : 1u;
+        if (!has_flag(passes, "-noMemReplication"))
+            c.flags |= COAST_F_HOST_MEMORY_REPLICATED;
+        else if (has_flag(passes, "-noStoreDataSync"))
+            c.flags |= COAST_F_NO_STORE_DATA_SYNC;
+    } else if (m) {
         if (!strcmp(m, "DWC") || !strcmp(m, "-DWC"))
             c.replicas = 2u;
         else if (!strcmp(m, "NONE") || !strcmp(m, ""))

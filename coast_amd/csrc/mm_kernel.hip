@@ -82,7 +82,7 @@ __device__ __forceinline__ void mm_epilogue(const uint32_t acc[16], const MmLane
         const bool valid = L.live && (L.i0 + (e >> 2)) < n && (L.j0 + (e & 3)) < n;
         Tally te = tl;
         te.det = 0;
-        out[e] = xmr_sync<NREP>(acc[e], L.lm, valid && L.lm.r == 0, te);
+        out[e] = xmr_store_sync<NREP>(acc[e], L.lm, valid && L.lm.r == 0, te);
         tl.miss = te.miss;
         tl.syncs = te.syncs;
         tl.det |= te.det << e; // per-element DWC flags
@@ -431,7 +431,8 @@ __global__ __launch_bounds__(256) void mm_general_kernel(const uint32_t *__restr
     uint32_t *sCnt = smem + 2 * g.kt * (g.rs + g.npad);
 
     const uint32_t lb = blockList ? blockList[blockIdx.x] : blockIdx.x;
-    const MmLane<NREP> L(g, lb);
+    MmLane<NREP> L(g, lb);
+    L.lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
     const LaneMap<NREP> &lm = L.lm;
     const int tid = threadIdx.x;
     const int n = g.n;

@@ -371,7 +371,8 @@ __global__ __launch_bounds__(64) void sha256_general_kernel(const uint8_t *__res
 {
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
-    const LaneMap<NREP> lm;
+    LaneMap<NREP> lm;
+    lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
     const uint32_t tile = tileList ? tileList[blockIdx.x] : blockIdx.x;
     const int slot = lm.q;
     const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
@@ -404,13 +405,13 @@ __global__ __launch_bounds__(64) void sha256_general_kernel(const uint8_t *__res
         sha_compress_hooked(st, m, c, ft, fr, slot, lm.r, lm.live);
 #pragma unroll
         for (int w = 0; w < 8; ++w)
-            st[w] = xmr_sync<NREP>(st[w], lm, cnt, tl);
+            st[w] = xmr_store_sync<NREP>(st[w], lm, cnt, tl);
     }
     sha_state_hook(st, ncomp, ft, fr, slot, lm.r, lm.live); // step == ncompress: before the digest
     uint32_t dg[8];
 #pragma unroll
     for (int w = 0; w < 8; ++w)
-        dg[w] = bswap32(xmr_sync<NREP>(st[w], lm, cnt, tl));
+        dg[w] = bswap32(xmr_store_sync<NREP>(st[w], lm, cnt, tl));
 
     uint32_t detItems = 0;
     if (cnt) {

@@ -29,7 +29,9 @@ struct FaultTab {
 
 struct Counters {
     unsigned long long *slots; // [kCounterSlots][kSlotStride]
+    uint32_t flags;            // coast_cfg.flags of the launch (kFlagNoStoreDataSync), read by the general kernels
 };
+constexpr uint32_t kFlagNoStoreDataSync = 1u; // == COAST_F_NO_STORE_DATA_SYNC
 
 template <int NREP> struct LaneMap {
     static constexpr int kItemsPerWave = kWave / NREP;
@@ -38,6 +40,7 @@ template <int NREP> struct LaneMap {
     int r;     // replica id
     bool live; // false for the idle lane(s) when 64 % NREP != 0
     int base4; // byte address (lane*4) of replica 0 of this item, for ds_bpermute
+    bool storeSync = true; // false under -noStoreDataSync (general kernels only): xmr_store_sync passes values through
     __device__ __forceinline__ LaneMap()
     {
         lane = threadIdx.x & (kWave - 1);
@@ -92,6 +95,16 @@ __device__ __forceinline__ uint32_t xmr_sync(uint32_t v, const LaneMap<NREP> &lm
 // just its two neighbours -- lane+1 and lane+2 via whole-wave DPP shifts (wave_shl:1: lane i reads lane i+1) -- instead of
 // three ds_bpermute round trips through the LDS crossbar (24 cycles each, tools/valu_microbench).  Same voter and counter
 // rules as xmr_sync; the returned value is meaningful in replica-0 lanes only.
+// Sync point on the DATA of a store (synchronization.cpp:476-561).  -noStoreDataSync (:197-224, :324) drops it: every
+// replica keeps its own value, replica 0's reaches memory, nothing is counted.
+template <int NREP>
+__device__ __forceinline__ uint32_t xmr_store_sync(uint32_t v, const LaneMap<NREP> &lm, bool count, Tally &t)
+{
+    if (!lm.storeSync)
+        return v;
+    return xmr_sync<NREP>(v, lm, count, t);
+}
+
 // voter of a final sync point on explicit copies: v = this replica, b / c = the next two (replica-0 lanes consume it)
 template <int NREP>
 __device__ __forceinline__ uint32_t xmr_final_vote_vals(uint32_t v, uint32_t b, uint32_t c, bool count, Tally &t)

@@ -15,15 +15,17 @@ import torch
 from . import _lib
 
 TMR, DWC, UNPROTECTED = 3, 2, 1
+F_NO_STORE_DATA_SYNC = 1  # coast_cfg.flags: the reference's -noStoreDataSync (include/coast_hip.h)
 
 
 @dataclass(frozen=True)
 class XmrConfig:
     replicas: int = TMR   # 3 = -TMR, 2 = -DWC, 1 = no protection
     sync_every: int = 0   # extra loop-condition sync points every V steps (0 = mandatory sync points only)
+    flags: int = 0        # F_NO_STORE_DATA_SYNC = the reference's -noStoreDataSync
 
     def c(self):
-        return _lib.CoastCfg(self.replicas, self.sync_every)
+        return _lib.CoastCfg(self.replicas, self.sync_every, self.flags)
 
 
 def make_faults(rows):

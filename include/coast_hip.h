@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define COAST_HIP_ABI_VERSION 1
+#define COAST_HIP_ABI_VERSION 2 /* 2: coast_cfg.flags */
 
 enum {
     COAST_OK = 0,
@@ -39,7 +39,28 @@ enum {
 typedef struct coast_cfg {
     uint32_t replicas;
     uint32_t sync_every;
+    uint32_t flags; /* COAST_F_*; 0 = the defaults above */
 } coast_cfg;
+
+/* The reference's remaining replication-rule flags (dataflowProtection.cpp:14-18,39-40; unittest/cfg/full.yml:18-36):
+ *   -noStoreDataSync  COAST_F_NO_STORE_DATA_SYNC: store data is not voted / compared (synchronization.cpp:197-224,324);
+ *                     replica 0's value is stored as it is and nothing is counted for it.  Loop-condition and return-value
+ *                     sync points stay (mm: sync_every votes; crc16: every sync point -- its result is a return value).
+ *                     The reference warns against combining it with -noMemReplication (interface.cpp:250-252): nothing then
+ *                     protects the stored data.  It exists for the overhead studies and the clean-run matrix.
+ *   -noLoadSync, -noStoreAddrSync   no effect here: addresses are built from wave-uniform scalars and lane indices, which are
+ *                     outside the sphere of replication in this design (SURVEY.md section 8a', last table row), so there is no
+ *                     replicated address to vote -- the engine always behaves as if both were given.
+ *   -storeDataSync    the lane-replicated engine always votes store data (the default here); in the memory-replicated mode it
+ *                     is what coast_sync_copies(..., scrub = 1) does at the region exit.
+ *   -i / -s           instruction interleaving vs segmenting: replicas are lanes of one instruction, there is no order. */
+enum {
+    COAST_F_NO_STORE_DATA_SYNC = 1u,
+    /* single-call host shims only (the batch entry points reject it): run the region in the reference's DEFAULT mode,
+     * memory replicated as well -- one unprotected launch per memory copy + the exit vote of coast_sync_copies(scrub).
+     * Without it the shims use the lane-replicated -noMemReplication engine. */
+    COAST_F_HOST_MEMORY_REPLICATED = 0x100u
+};
 
 /* Counters.  errors_corrected is TMR_ERROR_CNT (synchronization.cpp:269-294,1391-1443: +1 per voted value whose
  * copies are not all equal); sync_count is __SYNC_COUNT (:103-121,1415-1425); dwc_detected counts the work items on

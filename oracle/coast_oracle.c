@@ -32,6 +32,7 @@ typedef struct {
     unsigned sync_every;
     orc_stats *st;
     int detected; /* unequal copies seen at a sync point of the current item (DWC: detected, TMR: corrected) */
+    unsigned flags;
 } sync_ctx;
 
 /* One sync point on a 32-bit value.  TMR: synchronization.cpp:934-938 (cmp orig,clone1 ; select) and
@@ -100,6 +101,14 @@ static inline uint32_t flip(uint32_t v, unsigned bit, uint32_t mask)
     return v ^ ((1u << (bit & 31)) & mask);
 }
 
+/* A sync point on the DATA of a store (synchronization.cpp:476-561): dropped by -noStoreDataSync (:197-224, :324) --
+ * every copy keeps its own value and replica 0's is what reaches the single memory copy. */
+static void store_sync32(sync_ctx *c, uint32_t v[3])
+{
+    if (!(c->flags & ORC_F_NO_STORE_DATA_SYNC))
+        sync32(c, v);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* matrix multiply                                                                            */
 /* ------------------------------------------------------------------------------------------ */
@@ -153,7 +162,7 @@ static uint32_t mm_item(const uint32_t *f, const uint32_t *s, int n, int i, int 
     for (size_t q = 0; q < nf; ++q)
         if (fl[q].step == (uint32_t)n && fl[q].site == ORC_SITE_MM_ACC && fl[q].replica < R)
             acc[fl[q].replica] = flip(acc[fl[q].replica], fl[q].bit, 0xffffffffu);
-    sync32(c, acc); /* store-data sync, synchronization.cpp:476-561 */
+    store_sync32(c, acc); /* store-data sync, synchronization.cpp:476-561 */
     return acc[0];
 }
 
@@ -161,7 +170,7 @@ void orc_mm_xmr(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, size_t
                 const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
 {
     orc_fault *fs = sorted_faults(faults, nfaults);
-    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0};
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0, cfg->flags};
     const size_t nn = (size_t)n * n;
     size_t fp = 0;
     for (size_t b = 0; b < batch; ++b)
@@ -190,7 +199,7 @@ void orc_mm_xmr_items(const uint32_t *f, const uint32_t *s, int n, const uint64_
                       uint8_t *detected)
 {
     orc_fault *fs = sorted_faults(faults, nfaults);
-    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0};
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0, cfg->flags};
     const size_t nn = (size_t)n * n;
     for (size_t q = 0; q < nitems; ++q) {
         const uint64_t item = items[q];
@@ -288,7 +297,7 @@ static void sha_sync_state(sync_ctx *c, uint32_t st[3][8])
 {
     for (unsigned w = 0; w < 8; ++w) {
         uint32_t v[3] = {st[0][w], st[1][w], st[2][w]};
-        sync32(c, v);
+        store_sync32(c, v); /* ctx_state[w] / hash[] are memory stores */
         st[0][w] = v[0];
         st[1][w] = v[1];
         st[2][w] = v[2];
@@ -359,7 +368,7 @@ static void sha_item(const uint8_t *data, uint32_t len, uint8_t hash[32], sync_c
 void orc_sha256_plain(const uint8_t *data, uint32_t len, uint8_t hash[32])
 {
     orc_stats st = {0, 0, 0, 0};
-    sync_ctx c = {1, 0, &st, 0};
+    sync_ctx c = {1, 0, &st, 0, 0};
     sha_item(data, len, hash, &c, NULL, 0);
 }
 
@@ -367,7 +376,7 @@ void orc_sha256_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nms
                     const orc_cfg *cfg, const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
 {
     orc_fault *fs = sorted_faults(faults, nfaults);
-    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0};
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0, cfg->flags};
     size_t fp = 0;
     for (size_t m = 0; m < nmsgs; ++m) {
         while (fp < nfaults && fs[fp].item < m)
@@ -545,7 +554,7 @@ static void aes_sync(sync_ctx *c, uint8_t s[3][16], uint8_t k[3][16])
         for (int w = 0; w < 4; ++w) {
             uint8_t(*a)[16] = half ? k : s;
             uint32_t v[3] = {ld32(a[0] + 4 * w), ld32(a[1] + 4 * w), ld32(a[2] + 4 * w)};
-            sync32(c, v);
+            store_sync32(c, v); /* state[i] = ..., key[i] = ... are memory stores */
             for (int r = 0; r < 3; ++r)
                 st32(a[r] + 4 * w, v[r]);
         }
@@ -587,7 +596,7 @@ static void aes_item(uint8_t state[16], uint8_t key[16], int dir, sync_ctx *c, c
 void orc_aes128_plain(uint8_t state[16], uint8_t key[16], uint8_t dir)
 {
     orc_stats st = {0, 0, 0, 0};
-    sync_ctx c = {1, 0, &st, 0};
+    sync_ctx c = {1, 0, &st, 0, 0};
     aes_item(state, key, dir ? 1 : 0, &c, NULL, 0);
 }
 
@@ -595,7 +604,7 @@ void orc_aes128_xmr(uint8_t *states, uint8_t *keys, size_t nblocks, int dir, con
                     const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
 {
     orc_fault *fs = sorted_faults(faults, nfaults);
-    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0};
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0, cfg->flags};
     size_t fp = 0;
     for (size_t b = 0; b < nblocks; ++b) {
         while (fp < nfaults && fs[fp].item < b)
@@ -669,7 +678,7 @@ void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint
                    const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
 {
     orc_fault *fs = sorted_faults(faults, nfaults);
-    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0};
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0, cfg->flags};
     size_t fp = 0;
     for (size_t b = 0; b < nblocks; ++b) {
         while (fp < nfaults && fs[fp].item < b)

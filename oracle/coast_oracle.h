@@ -73,7 +73,10 @@ typedef struct {
 typedef struct {
     uint32_t replicas;   /* 1 = unprotected, 2 = DWC, 3 = TMR */
     uint32_t sync_every; /* 0 = only at the mandatory sync points; V>0 = also every V steps (kernel specific) */
+    uint32_t flags;      /* ORC_F_* */
 } orc_cfg;
+/* -noStoreDataSync (dataflowProtection.cpp:16; synchronization.cpp:197-224,324): the data of stores is not synchronised */
+enum { ORC_F_NO_STORE_DATA_SYNC = 1u };
 
 /* ---- plain (unprotected) restatements of the reference kernels ---- */
 void orc_mm_plain(const uint32_t *f, const uint32_t *s, uint32_t *r, int n);

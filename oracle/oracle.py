@@ -27,7 +27,7 @@ assert FAULT_DTYPE.itemsize == 16
 
 
 class Cfg(C.Structure):
-    _fields_ = [("replicas", C.c_uint32), ("sync_every", C.c_uint32)]
+    _fields_ = [("replicas", C.c_uint32), ("sync_every", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -147,7 +147,7 @@ def crc16_plain(data: bytes) -> int:
 
 
 # ---------------------------------------------------------------- replicated model
-def mm_xmr(f, s, replicas=3, sync_every=0, faults=None):
+def mm_xmr(f, s, replicas=3, sync_every=0, faults=None, flags=0):
     """f, s: (batch, n, n) uint32.  Returns (r, stats dict, detected per item)."""
     f = np.ascontiguousarray(f, dtype=np.uint32)
     s = np.ascontiguousarray(s, dtype=np.uint32)
@@ -158,14 +158,14 @@ def mm_xmr(f, s, replicas=3, sync_every=0, faults=None):
     fl = _faults(faults)
     st = Stats()
     det = np.zeros(batch * n * n, dtype=np.uint8)
-    cfg = Cfg(replicas, sync_every)
+    cfg = Cfg(replicas, sync_every, flags)
     lib().orc_mm_xmr(_p(f, C.c_uint32), _p(s, C.c_uint32), _p(r, C.c_uint32), C.c_int(n), C.c_size_t(batch),
                      C.byref(cfg), fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st),
                      _p(det, C.c_uint8))
     return r, st.as_dict(), det
 
 
-def mm_xmr_items(f, s, items, replicas=3, sync_every=0, faults=None):
+def mm_xmr_items(f, s, items, replicas=3, sync_every=0, faults=None, flags=0):
     f = np.ascontiguousarray(f, dtype=np.uint32)
     s = np.ascontiguousarray(s, dtype=np.uint32)
     n = f.shape[-1]
@@ -174,14 +174,14 @@ def mm_xmr_items(f, s, items, replicas=3, sync_every=0, faults=None):
     fl = _faults(faults)
     st = Stats()
     det = np.zeros(len(items), dtype=np.uint8)
-    cfg = Cfg(replicas, sync_every)
+    cfg = Cfg(replicas, sync_every, flags)
     lib().orc_mm_xmr_items(_p(f, C.c_uint32), _p(s, C.c_uint32), C.c_int(n), _p(items, C.c_uint64),
                            C.c_size_t(len(items)), _p(out, C.c_uint32), C.byref(cfg),
                            fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st), _p(det, C.c_uint8))
     return out, st.as_dict(), det
 
 
-def sha256_xmr(msgs, length, replicas=3, faults=None):
+def sha256_xmr(msgs, length, replicas=3, faults=None, flags=0):
     """msgs: (nmsgs, stride) uint8, each message = first `length` bytes of its row."""
     msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
     nm, stride = msgs.shape
@@ -189,7 +189,7 @@ def sha256_xmr(msgs, length, replicas=3, faults=None):
     fl = _faults(faults)
     st = Stats()
     det = np.zeros(nm, dtype=np.uint8)
-    cfg = Cfg(replicas, 0)
+    cfg = Cfg(replicas, 0, flags)
     pad = np.concatenate([msgs.reshape(-1), np.zeros(8, np.uint8)])  # keep 0-length rows addressable
     lib().orc_sha256_xmr(_p(pad, C.c_uint8), C.c_size_t(stride), C.c_uint32(length), C.c_size_t(nm),
                          _p(dig, C.c_uint8), C.byref(cfg), fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)),
@@ -197,7 +197,7 @@ def sha256_xmr(msgs, length, replicas=3, faults=None):
     return dig, st.as_dict(), det
 
 
-def aes128_xmr(states, keys, direction, replicas=2, sync_every=0, faults=None):
+def aes128_xmr(states, keys, direction, replicas=2, sync_every=0, faults=None, flags=0):
     """states, keys: (n, 16) uint8; returns new (states, keys, stats, detected) -- inputs untouched."""
     s = np.array(states, dtype=np.uint8, copy=True, order="C")
     k = np.array(keys, dtype=np.uint8, copy=True, order="C")
@@ -205,13 +205,13 @@ def aes128_xmr(states, keys, direction, replicas=2, sync_every=0, faults=None):
     fl = _faults(faults)
     st = Stats()
     det = np.zeros(n, dtype=np.uint8)
-    cfg = Cfg(replicas, sync_every)
+    cfg = Cfg(replicas, sync_every, flags)
     lib().orc_aes128_xmr(_p(s, C.c_uint8), _p(k, C.c_uint8), C.c_size_t(n), C.c_int(direction), C.byref(cfg),
                          fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st), _p(det, C.c_uint8))
     return s, k, st.as_dict(), det
 
 
-def crc16_xmr(data, block_len, replicas=3, sync_every=0, faults=None):
+def crc16_xmr(data, block_len, replicas=3, sync_every=0, faults=None, flags=0):
     """data: (nblocks, block_len) uint8."""
     data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, max(block_len, 1))[:, :block_len]
     data = np.ascontiguousarray(data)
@@ -220,7 +220,7 @@ def crc16_xmr(data, block_len, replicas=3, sync_every=0, faults=None):
     fl = _faults(faults)
     st = Stats()
     det = np.zeros(nb, dtype=np.uint8)
-    cfg = Cfg(replicas, sync_every)
+    cfg = Cfg(replicas, sync_every, flags)
     pad = np.concatenate([data.reshape(-1), np.zeros(8, np.uint8)])
     lib().orc_crc16_xmr(_p(pad, C.c_uint8), C.c_uint32(block_len), C.c_size_t(nb), _p(crcs, C.c_uint16),
                         C.byref(cfg), fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st),

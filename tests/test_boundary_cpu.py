@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libcoast_hip.so does not export %s" % n
     assert set(names) == set(_lib.SYMBOLS), "python binding and header disagree"
-    assert lib.coast_abi_version() == 1
+    assert lib.coast_abi_version() == 2  # 2: coast_cfg.flags
 
 
 def test_header_compiles_as_c_and_layouts_match(tmp_path):
@@ -40,7 +40,7 @@ def test_header_compiles_as_c_and_layouts_match(tmp_path):
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     from coast_amd import _lib
 
-    assert sizes == [_lib.FAULT_DTYPE.itemsize, C.sizeof(_lib.CoastCfg), C.sizeof(_lib.CoastStats)] == [16, 8, 32]
+    assert sizes == [_lib.FAULT_DTYPE.itemsize, C.sizeof(_lib.CoastCfg), C.sizeof(_lib.CoastStats)] == [16, 12, 32]
     from oracle import oracle as orc
 
     assert orc.FAULT_DTYPE == _lib.FAULT_DTYPE  # the oracle and the product consume the same fault records

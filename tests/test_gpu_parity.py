@@ -429,6 +429,115 @@ def test_unmodified_reference_drivers_on_gpu_backend(binary, mode, sync_every):
     assert expect in p.stdout
 
 
+# the reference's full flag matrix, verbatim (unittest/cfg/full.yml:18-36), through COAST_OPT_PASSES: flags without
+# -noMemReplication run the memory-replicated default mode (one launch per copy + exit vote), the others the lane engine
+_OPT_PASSES = ["", "-DWC", "-TMR", "-TMR -countErrors", "-DWC -noMemReplication", "-TMR -noMemReplication",
+               "-DWC -noLoadSync", "-TMR -noLoadSync", "-DWC -noStoreDataSync", "-TMR -noStoreDataSync",
+               "-DWC -noStoreAddrSync", "-TMR -noStoreAddrSync", "-DWC -noMemReplication -noLoadSync",
+               "-TMR -noMemReplication -noLoadSync", "-DWC -noMemReplication -noStoreDataSync",
+               "-TMR -noMemReplication -noStoreDataSync", "-DWC -noMemReplication -noStoreAddrSync",
+               "-TMR -noMemReplication -noStoreAddrSync"]
+
+
+@pytest.mark.parametrize("binary", ["matrixMultiply_coast", "crc16_coast", "aes_coast"])  # the three of full.yml:1-14 on this path
+def test_reference_flag_matrix_clean_runs(binary):
+    """unittest/unittest.py runs every benchmark under every OPT_PASSES entry and greps the output: same here."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "bin", binary)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/bin not built (needs the reference checkout at build time)")
+    for passes in _OPT_PASSES:
+        p = subprocess.run([exe], env=dict(os.environ, COAST_OPT_PASSES=passes), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and _DRIVERS[binary] in p.stdout, (passes, p.returncode, p.stdout[-300:], p.stderr[-300:])
+
+
+def test_memory_replicated_shims_correct_injected_faults():
+    """COAST_OPT_PASSES without -noMemReplication = the reference's default mode in the single-call shims: the upset hits
+    one memory copy's launch and is out-voted at the region exit (TMR), or trips the compare (DWC)."""
+    import os
+    import signal
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "host_c_demo")
+    for replica in (0, 1, 2):
+        spec = "0:%d:24:5:3" % replica  # crc register of copy `replica` before byte 5, bit 3, in the first protected call
+        p = subprocess.run([exe], env=dict(os.environ, COAST_OPT_PASSES="-TMR -countErrors", COAST_INJECT=spec),
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "result: 5ba3" in p.stdout and "C:0 E:0 F:1 T:0us" in p.stdout, (replica, p.stdout)
+    p = subprocess.run([exe], env=dict(os.environ, COAST_OPT_PASSES="-DWC", COAST_INJECT="0:1:24:5:3"), capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == -signal.SIGABRT
+    # -noStoreDataSync next to -noMemReplication: crc16's sync points are a return value and loop conditions, so it stays protected
+    p = subprocess.run([exe], env=dict(os.environ, COAST_OPT_PASSES="-TMR -noMemReplication -noStoreDataSync",
+                                       COAST_INJECT="0:0:24:5:3"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "result: 5ba3" in p.stdout
+
+
+@pytest.mark.parametrize("replicas", [3, 2])
+def test_no_store_data_sync_flag_vs_oracle(eng, orc, replicas):
+    """-noStoreDataSync (coast_cfg.flags): store data is neither voted nor counted; replica 0's value reaches memory, so its
+    upsets become silent corruption and the other replicas' upsets vanish -- exactly as the oracle's restatement says."""
+    import torch
+
+    import coast_amd
+
+    F = coast_amd.F_NO_STORE_DATA_SYNC
+    rng = np.random.default_rng(900 + replicas)
+    # mm, with the loop-condition votes (sync_every) that the flag leaves in place
+    for n, batch, sync_every in ((17, 3, 0), (32, 2, 5), (256, 1, 0)):
+        f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+        s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+        fl = _rand_faults(rng, 60, batch * n * n, replicas, [0, 1, 2], n)
+        exp_r, exp_st, exp_det = orc.mm_xmr(f, s, replicas=replicas, sync_every=sync_every, faults=fl, flags=F)
+        det = torch.zeros(batch * n * n, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        got = _host(eng.mm_batch(_dev(f), _dev(s), cfg=coast_amd.XmrConfig(replicas, sync_every, F), detected=det), np.uint32)
+        assert (got == exp_r).all() and _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all()
+        clean, _, _ = orc.mm_xmr(f, s, replicas=replicas)
+        assert sync_every or exp_st["sync_count"] == 0  # no sync point left without the loop votes
+        assert (got != clean).any()                  # replica-0 upsets got through
+    # sha256 and aes: every sync point of the frozen schedule is a store
+    nm, length = 300, 100
+    msgs = rng.integers(0, 256, (nm, 100), dtype=np.uint8)
+    rows = [(int(rng.integers(0, nm)), int(rng.integers(0, replicas)), int(rng.choice([8, 9, 10])), int(rng.integers(0, 2)),
+             int(rng.integers(0, 32)), int(rng.integers(0, 8))) for _ in range(80)]
+    fl = coast_amd.make_faults(rows)
+    exp, exp_st, exp_det = orc.sha256_xmr(msgs, length, replicas=replicas, faults=fl, flags=F)
+    det = torch.zeros(nm, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    got = eng.sha256_batch(torch.from_numpy(msgs).cuda(), length, cfg=coast_amd.XmrConfig(replicas, 0, F), detected=det)
+    assert (got.cpu().numpy() == exp).all() and _stats3(eng.stats()) == _stats3(exp_st)
+    assert exp_st["sync_count"] == 0 and exp_st["errors_corrected"] == 0
+    assert (det.cpu().numpy() == exp_det).all()
+    nb = 400
+    st, key = rng.integers(0, 256, (nb, 16), dtype=np.uint8), rng.integers(0, 256, (nb, 16), dtype=np.uint8)
+    fl = _rand_faults(rng, 90, nb, replicas, [16, 17], 10, max_index=4)
+    for direction in (0, 1):
+        es, ek, exp_st, exp_det = orc.aes128_xmr(st, key, direction, replicas=replicas, faults=fl, flags=F)
+        ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(key.copy()).cuda()
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        eng.aes128_batch(ds, dk, direction, cfg=coast_amd.XmrConfig(replicas, 0, F))
+        assert (ds.cpu().numpy() == es).all() and (dk.cpu().numpy() == ek).all() and _stats3(eng.stats()) == exp_st
+    # crc16: return-value and loop-condition sync points only -- the flag changes nothing
+    data = rng.integers(0, 256, (300, 200), dtype=np.uint8)
+    fl = _rand_faults(rng, 60, 300, replicas, [24, 25], 200)
+    exp, exp_st, _ = orc.crc16_xmr(data, 200, replicas=replicas, faults=fl, flags=F)
+    exp0, exp_st0, _ = orc.crc16_xmr(data, 200, replicas=replicas, faults=fl)
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    got = _host(eng.crc16_batch(torch.from_numpy(data).cuda(), 200, cfg=coast_amd.XmrConfig(replicas, 0, F)), np.uint16)
+    assert (got == exp).all() and (exp == exp0).all() and _stats3(eng.stats()) == _stats3(exp_st) == _stats3(exp_st0)
+    with pytest.raises(Exception):  # unknown flag bits, and the host-shim-only bit, are rejected by the batch entry points
+        eng.crc16_batch(torch.from_numpy(data).cuda(), 200, cfg=coast_amd.XmrConfig(replicas, 0, 0x100))
+
+
 # ------------------------------------------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("n", [512, 1100, 2048])
 def test_mm_large_sides_generic_kernels(eng, orc, n):

@@ -186,3 +186,37 @@ def test_default_mode_exit_vote_semantics(orc):
     assert list(np.nonzero(det)[0]) == [3, 5, 8] and all((x == exp).all() for x in after)
     voted, after, st, det = orc.sync_copies(c[:2])
     assert st == {"errors_corrected": 0, "sync_count": 10, "dwc_detected": 2} and (voted == c[0]).all()
+
+
+def test_no_store_data_sync_semantics(orc):
+    """-noStoreDataSync (synchronization.cpp:197-224, :324): the final store of r[i][j] is not voted -- replica 0's word is
+    stored, upsets in the other replicas vanish, nothing is counted; loop-condition votes (sync_every) are untouched;
+    crc16 has no store sync point at all (its result is a return value)."""
+    import coast_amd
+
+    def t3(st):
+        return (st["errors_corrected"], st["sync_count"], st["dwc_detected"])
+
+    rng = np.random.default_rng(3)
+    n = 9
+    f = rng.integers(0, 2**32, (1, n, n), dtype=np.uint32)
+    s = rng.integers(0, 2**32, (1, n, n), dtype=np.uint32)
+    clean, st0, _ = orc.mm_xmr(f, s)
+    assert t3(st0) == (0, n * n, 0)
+    F = 1
+    r, st, det = orc.mm_xmr(f, s, flags=F)
+    assert (r == clean).all() and t3(st) == (0, 0, 0)
+    hit1 = coast_amd.make_faults([(5, 1, 0, 3, 7)])      # replica 1: invisible
+    r, st, det = orc.mm_xmr(f, s, faults=hit1, flags=F)
+    assert (r == clean).all() and t3(st) == (0, 0, 0) and not det.any()
+    hit0 = coast_amd.make_faults([(5, 0, 0, 3, 7)])      # replica 0: silent data corruption
+    r, st, det = orc.mm_xmr(f, s, faults=hit0, flags=F)
+    assert r.reshape(-1)[5] != clean.reshape(-1)[5] and (np.delete(r.reshape(-1), 5) == np.delete(clean.reshape(-1), 5)).all()
+    assert t3(st) == (0, 0, 0)
+    r, st, det = orc.mm_xmr(f, s, sync_every=2, faults=hit0, flags=F)   # the loop vote after k=3 repairs it
+    assert (r == clean).all() and t3(st)[0] == 1 and t3(st)[1] == n * n * ((n - 1) // 2)
+    data = rng.integers(0, 256, (4, 50), dtype=np.uint8)
+    fl = coast_amd.make_faults([(2, 0, 24, 10, 3)])
+    a = orc.crc16_xmr(data, 50, faults=fl, flags=F)
+    b = orc.crc16_xmr(data, 50, faults=fl)
+    assert (a[0] == b[0]).all() and t3(a[1]) == t3(b[1]) == (1, 4, 0)
