@@ -1,0 +1,161 @@
+// cache_test_kernel.hip -- protected calc_sum of tests/cache_test/cacheTest.c:101-177: a batch of int arrays is summed,
+// every element that is not its own index is counted and rewritten (the benchmark's memory scrub).
+//
+// Work item = one array, walked by a lane group (NREP adjacent lanes, one per replica) exactly as the reference walks it;
+// replicated registers: the running sum, the loaded element, numberOfErrors.  Sync points (frozen schedule, oracle
+// ct_item): the data-dependent branch condition `array[i] != i` of every element -- a terminator sync on an i1
+// (synchronization.cpp:146-155, 741-949): all copies continue on the voted outcome, so the replica lanes cannot diverge;
+// the returned sum (ReturnInst sync); the error count where it is stored (store-data sync).  `array[i] = i` stores the loop
+// index, a scalar outside the sphere of replication.
+//
+// The i1 votes are exact but not one exchange each: 32 conditions travel as one mask, the voter is the per-bit form of
+// select(a == b, a, c) = (a & ~(a^b)) | (c & (a^b)), and TMR_ERROR_CNT grows by popcount((a^b) | (a^c)) -- one per
+// condition whose copies were not all equal, as :1391-1443 counts them.
+//
+// Roofline: HBM.  Algorithmic bytes = 4 n per array read (+ 8 per array written; rewrites only where memory was corrupt).
+// Each lane streams its own array with 16-byte loads, eight in flight per group of 32 elements.
+#include "xmr.hpp"
+
+namespace coast {
+
+enum { SITE_CT_SUM = 32, SITE_CT_VAL = 33, SITE_CT_NERR = 34 };
+
+// vote a mask of up to 32 branch conditions (bit k = condition k of the group, `gmask` = the bits in use)
+template <int NREP>
+__device__ __forceinline__ uint32_t xmr_vote_conditions(uint32_t m, uint32_t gmask, const LaneMap<NREP> &lm, bool count, Tally &t)
+{
+    if constexpr (NREP == 1) {
+        return m;
+    } else {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(lm.base4, (int)m);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(lm.base4 + 4, (int)m);
+        if constexpr (NREP == 2) {
+            if (count) {
+                t.syncs += (uint32_t)__builtin_popcount(gmask);
+                t.det |= ((a ^ b) & gmask) ? 1u : 0u;
+            }
+            return a; // the region goes on with replica 0's outcome (the reference would be in the error handler)
+        } else {
+            const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(lm.base4 + 8, (int)m);
+            const uint32_t ab = a ^ b, bad = (ab | (a ^ c)) & gmask;
+            if (count) {
+                t.syncs += (uint32_t)__builtin_popcount(gmask);
+                t.miss += (uint32_t)__builtin_popcount(bad);
+                t.det |= bad ? 1u : 0u;
+            }
+            return (a & ~ab) | (c & ab);
+        }
+    }
+}
+
+// four waves per workgroup, one tile of IPW arrays per wave
+template <int NREP>
+__global__ __launch_bounds__(256) void cache_test_kernel(uint32_t *__restrict__ arrays, uint32_t n, uint64_t narrays,
+                                                         uint64_t ntiles, int32_t *__restrict__ sums,
+                                                         uint32_t *__restrict__ nerrs, Counters ctr, FaultTab ft,
+                                                         uint8_t *__restrict__ detected)
+{
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    LaneMap<NREP> lm;
+    lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
+    const uint64_t tile = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const bool tileOk = tile < ntiles;
+    const int slot = lm.q;
+    const uint64_t item = tile * IPW + (uint64_t)slot;
+    const bool live = tileOk && lm.live && item < narrays;
+    uint32_t *a = arrays + (live ? item : 0) * (uint64_t)n;
+    const bool vec = ((n & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(arrays) & 15u) == 0u);
+
+    if (threadIdx.x < 4)
+        sCnt[threadIdx.x] = 0;
+    __syncthreads();
+
+    uint2 fr = make_uint2(0u, 0u);
+    if (ft.range && tileOk)
+        fr = ft.range[tile];
+    const bool stepwise = fr.y != 0u; // wave-uniform: an armed fault points into this tile
+    const bool cnt = live && lm.r == 0;
+    Tally tl;
+    uint32_t sum = 0, nerr = 0;
+
+    // injector hook: sum / numberOfErrors before element `step` (step == n: after the loop)
+    auto regHook = [&](uint32_t step) {
+        for (uint32_t q = 0; q < fr.y; ++q) {
+            const DevFault df = ft.list[fr.x + q];
+            if (df.step != step || (int)df.local != slot || (int)df.replica != lm.r || !lm.live)
+                continue;
+            if (df.site == SITE_CT_SUM)
+                sum = flip_bit(sum, df.bit, 0xffffffffu);
+            else if (df.site == SITE_CT_NERR)
+                nerr = flip_bit(nerr, df.bit, 0xffffffffu);
+        }
+    };
+
+    // a tile with an armed fault votes element by element, so that an upset of numberOfErrors lands between the same two
+    // increments as in the reference's instruction order
+    const uint32_t G = stepwise ? 1u : 32u;
+    for (uint32_t base = 0; base < n; base += G) {
+        const uint32_t gcount = (n - base) < G ? (n - base) : G;
+        const uint32_t gmask = gcount == 32u ? 0xffffffffu : ((1u << gcount) - 1u);
+        uint32_t mask = 0;
+        if (!stepwise && vec && gcount == 32u) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = *reinterpret_cast<const uint4 *>(a + base + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i0 = base + 4u * (uint32_t)u;
+                sum += v[u].x + v[u].y + v[u].z + v[u].w;
+                mask |= (v[u].x != i0 ? 1u : 0u) << (4 * u);
+                mask |= (v[u].y != i0 + 1u ? 1u : 0u) << (4 * u + 1);
+                mask |= (v[u].z != i0 + 2u ? 1u : 0u) << (4 * u + 2);
+                mask |= (v[u].w != i0 + 3u ? 1u : 0u) << (4 * u + 3);
+            }
+        } else {
+            for (uint32_t e = 0; e < gcount; ++e) {
+                const uint32_t i = base + e;
+                if (stepwise)
+                    regHook(i);
+                uint32_t v = a[i];
+                if (stepwise) {
+                    for (uint32_t q = 0; q < fr.y; ++q) {
+                        const DevFault df = ft.list[fr.x + q];
+                        if (df.site == SITE_CT_VAL && df.step == i && (int)df.local == slot && (int)df.replica == lm.r &&
+                            lm.live)
+                            v = flip_bit(v, df.bit, 0xffffffffu);
+                    }
+                }
+                sum += v;
+                mask |= (v != i ? 1u : 0u) << e;
+            }
+        }
+        const uint32_t voted = xmr_vote_conditions<NREP>(mask, gmask, lm, cnt, tl) & gmask;
+        nerr += (uint32_t)__builtin_popcount(voted);
+        if (cnt && voted) { // the taken branches: array[i] = i (single memory copy, written once)
+            for (uint32_t m = voted; m; m &= m - 1u) {
+                const uint32_t e = (uint32_t)__builtin_ctz(m);
+                a[base + e] = base + e;
+            }
+        }
+    }
+    if (stepwise)
+        regHook(n);
+    sum = xmr_sync<NREP>(sum, lm, cnt, tl);         // return-value sync
+    nerr = xmr_store_sync<NREP>(nerr, lm, cnt, tl); // stored error count
+    uint32_t detItems = 0;
+    if (cnt) {
+        sums[item] = (int32_t)sum;
+        nerrs[item] = nerr;
+        if (tl.det) {
+            if (NREP == 2)
+                detItems = 1;
+            if (detected)
+                detected[item] = 1;
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+} // namespace coast

@@ -21,6 +21,7 @@
 #include "aes_kernel.hip"
 #include "crc16_kernel.hip"
 #include "vote_kernel.hip"
+#include "cache_test_kernel.hip"
 
 using namespace coast;
 

@@ -6,6 +6,8 @@
  *   unsigned short crc16(const unsigned char*, unsigned char)                     tests/crc16/crc16.c:21
  *   void aes_enc_dec(unsigned char *state, unsigned char *key, unsigned char dir) tests/aes/TI_aes_128.h:42
  *   void sha256_hash(ctx_data, ctx_bitlen, ctx_state, data, len, hash)            tests/sha256_common/sha256_common_tmr.c:101
+ *   int  coast_dropin_calc_sum(array, n)               target of cache_glue.c (calc_sum, tests/cache_test/cacheTest.c:101;
+ *                                                      `data_array_elements` is a macro, :78)
  *   void coast_dropin_matrix_multiply(f, s, r, side)   target of the per-benchmark glue TU (matrix_multiply's `side`
  *                                                      is a macro, tests/mm_common/mm_tmr.c:10, so it is not in its ABI)
  *   TMR_ERROR_CNT, __SYNC_COUNT      the globals the pass emits (synchronization.cpp:269-294, :103-121); weak, because
@@ -197,4 +199,59 @@ void coast_dropin_matrix_multiply(const void *f, const void *s, void *r, int sid
     if (rc)
         dropin_fail("matrix_multiply", rc);
     dropin_account();
+}
+
+/* calc_sum (tests/cache_test/cacheTest.c:101-177).  The sum, the compare of every element with its index and the rewrite
+ * run protected on the GPU; what calc_sum does around them with the program's own globals (error bookkeeping and the
+ * YAML-ish report, robust_printing = 1) is replayed here from the array as it was found, so the program's output stays
+ * byte-identical.  The globals are the benchmark's: weak references, absent in every other program this object links into. */
+extern unsigned long int ind __attribute__((weak));
+extern int local_errors __attribute__((weak));
+extern int sum_errors __attribute__((weak));
+extern int in_block __attribute__((weak));
+extern int golden __attribute__((weak));
+
+int coast_dropin_calc_sum(int *array, int n)
+{
+    const coast_cfg cfg = dropin_cfg();
+    dropin_maybe_inject();
+    int *found = (int *)malloc((size_t)n * sizeof(int));
+    if (!found)
+        dropin_fail("calc_sum", COAST_ENOMEM);
+    memcpy(found, array, (size_t)n * sizeof(int));
+    int32_t sum = 0;
+    uint32_t nerr = 0;
+    const int rc = coast_cache_test_host((int32_t *)array, (uint32_t)n, &sum, &nerr, &cfg);
+    if (rc)
+        dropin_fail("calc_sum", rc);
+    dropin_account();
+    int first_error = 0;
+    if (nerr && &local_errors && &in_block && &ind) {
+        for (int i = 0; i < n; ++i) {
+            if (found[i] == i)
+                continue;
+            if (!first_error) {
+                if (!in_block)
+                    printf(" - i: %lu\r\n", ind);
+                printf("   E: {%i: %i,", i, found[i]);
+                first_error = 1;
+                in_block = 1;
+            } else {
+                printf("%i: %i,", i, found[i]);
+            }
+            local_errors++;
+        }
+        if (first_error)
+            printf("}\r\n");
+    }
+    if (&golden && &local_errors && &sum_errors && &in_block && &ind && sum != golden && local_errors == 0) {
+        sum_errors++;
+        local_errors++;
+        if (!in_block)
+            printf(" - i: %lu\r\n", ind);
+        printf("   S: {%i: %i}\r\n", golden, sum);
+        in_block = 1;
+    }
+    free(found);
+    return sum;
 }

@@ -145,6 +145,18 @@ class Engine:
                                                 _ptr(detected) if detected is not None else None))
         return out
 
+    def cache_test_batch(self, arrays, cfg: XmrConfig = XmrConfig(), detected=None):
+        """arrays: (n_arrays, n) int32 on the GPU, scrubbed IN PLACE (calc_sum, tests/cache_test/cacheTest.c:101-177).
+        Returns (sums int32, error counts as int32 bit patterns)."""
+        assert arrays.is_cuda and arrays.dtype == torch.int32 and arrays.dim() == 2 and arrays.is_contiguous()
+        na, n = arrays.shape
+        sums = torch.empty(na, dtype=torch.int32, device=arrays.device)
+        nerrs = torch.empty(na, dtype=torch.int32, device=arrays.device)
+        cc = cfg.c()
+        self._check(self._lib.coast_cache_test_batch(self._h, _ptr(arrays), n, na, _ptr(sums), _ptr(nerrs), C.byref(cc),
+                                                     _ptr(detected) if detected is not None else None))
+        return sums, nerrs
+
     # -- default mode (memory replicated x3 / x2): vote where the copies re-converge
     def sync_copies(self, copies, out=None, scrub=True, detected=None):
         """copies: 3 (TMR) or 2 (DWC) equally shaped contiguous GPU tensors holding the per-copy results of replicas=1

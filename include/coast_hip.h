@@ -84,13 +84,16 @@ enum {
     COAST_SITE_AES_STATE = 16, /* state dword `index` at the start of main-loop round `step` (10: after the loop) */
     COAST_SITE_AES_KEY = 17,   /* running round-key dword `index`, same timing */
     COAST_SITE_CRC_CRC = 24,   /* crc register before byte `step` (== length: after the loop) */
-    COAST_SITE_CRC_X = 25      /* temporary x of byte `step` after x ^= x>>4 */
+    COAST_SITE_CRC_X = 25,     /* temporary x of byte `step` after x ^= x>>4 */
+    COAST_SITE_CT_SUM = 32,    /* cache_test: running sum before element `step` is added (step == n: after the loop) */
+    COAST_SITE_CT_VAL = 33,    /* the loaded array[step], right after the load */
+    COAST_SITE_CT_NERR = 34    /* numberOfErrors before element `step` (step == n: after the loop) */
 };
 
 /* One single-event upset: new = old XOR (1 << bit) on the 32-bit register holding the value
  * (FaultInjector.flipOneBit, injector.py:202-207).  Only replica-private state can be hit. */
 typedef struct coast_fault {
-    uint64_t item;   /* mm: b*n*n + i*n + j ; sha256: message ; aes: block ; crc16: block */
+    uint64_t item;   /* mm: b*n*n + i*n + j ; sha256: message ; aes: block ; crc16: block ; cache_test: array */
     uint32_t step;
     uint8_t replica; /* 0 .. replicas-1 */
     uint8_t site;    /* COAST_SITE_* */
@@ -149,6 +152,13 @@ int coast_aes128_batch(coast_ctx *ctx, uint8_t *d_states, uint8_t *d_keys, size_
 int coast_crc16_batch(coast_ctx *ctx, const uint8_t *d_data, uint32_t block_len, size_t n_blocks, uint16_t *d_crcs,
                       const coast_cfg *cfg, uint8_t *d_detected);
 
+/* calc_sum (tests/cache_test/cacheTest.c:101-177, the memory-scrub benchmark of unittest/cfg/full.yml:13): n_arrays arrays
+ * of n_elems ints, array a at d_arrays + a*n_elems.  Per array: d_sums[a] = the sum of its elements as found (:108),
+ * d_nerrs[a] = how many were not equal to their index (:110-111); those are rewritten IN PLACE (:134).  Sync points: every
+ * element's branch condition, the returned sum, the stored error count. */
+int coast_cache_test_batch(coast_ctx *ctx, int32_t *d_arrays, uint32_t n_elems, size_t n_arrays, int32_t *d_sums,
+                           uint32_t *d_nerrs, const coast_cfg *cfg, uint8_t *d_detected);
+
 /* ---- default-mode TMR / DWC: memory replicated as well (docs/source/passes.rst:329,337; cloning.cpp:2417-2462) ----
  * In COAST's default mode the clones of a region run on their own copies of the data and stores are not voted
  * (synchronization.cpp:211-215); values are voted where the copies re-converge -- return values, arguments of unprotected
@@ -172,6 +182,8 @@ int coast_matrix_multiply_host(const uint32_t *f, const uint32_t *s, uint32_t *r
 int coast_sha256_host(const uint8_t *data, uint32_t len, uint8_t hash[32], uint32_t state_out[8], const coast_cfg *cfg);
 int coast_aes_enc_dec_host(uint8_t *state, uint8_t *key, uint8_t dir, const coast_cfg *cfg);
 int coast_crc16_host(const uint8_t *data, uint32_t length, uint16_t *crc, const coast_cfg *cfg);
+/* calc_sum's `data_array_elements` is a macro in the reference (cacheTest.c:78), so the glue TU passes it explicitly */
+int coast_cache_test_host(int32_t *array, uint32_t n_elems, int32_t *sum, uint32_t *nerr, const coast_cfg *cfg);
 /* arm single-bit flips for the NEXT single-call shim (they run on a library-owned context): lets an external harness
  * inject into an unmodified driver the way supervisor.py + GDB inject into the running benchmark */
 int coast_host_inject_faults(const coast_fault *faults, size_t k);

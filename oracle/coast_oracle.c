@@ -699,6 +699,93 @@ void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* cache_test                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* calc_sum, tests/cache_test/cacheTest.c:101-177 without its printing: sum += array[i] (:108); an element that is not its
+ * index is counted and rewritten (:110-111, :134-135). */
+void orc_cache_test_plain(int32_t *array, uint32_t n, int32_t *sum, uint32_t *nerr)
+{
+    uint32_t s = 0, e = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        s += (uint32_t)array[i];
+        if (array[i] != (int32_t)i) {
+            ++e;
+            array[i] = (int32_t)i;
+        }
+    }
+    *sum = (int32_t)s;
+    *nerr = e;
+}
+
+/* Protected calc_sum, -noMemReplication rule set.  Replicated registers: sum, the loaded element, numberOfErrors.
+ * Sync points: the data-dependent branch condition `array[i] != i` of every element (terminator sync on the i1,
+ * synchronization.cpp:146-155, 741-949 -- all copies continue on the voted outcome, so the clones cannot take different
+ * paths); the returned sum (ReturnInst sync); the error count where it is stored (store-data sync).  `array[i] = i` stores
+ * the loop index, which is a wave-uniform scalar outside the sphere of replication: nothing to vote.  DWC: a mismatch is
+ * flagged (the reference would not return from the handler) and the region continues on replica 0's condition. */
+static void ct_item(int32_t *a, uint32_t n, int32_t *sum_out, uint32_t *nerr_out, sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    uint32_t sum[3] = {0, 0, 0}, nerr[3] = {0, 0, 0};
+    const unsigned R = c->nrep;
+    for (uint32_t i = 0; i <= n; ++i) {
+        for (size_t q = 0; q < nf; ++q) {
+            if (fl[q].step != i || fl[q].replica >= R)
+                continue;
+            if (fl[q].site == ORC_SITE_CT_SUM)
+                sum[fl[q].replica] = flip(sum[fl[q].replica], fl[q].bit, 0xffffffffu);
+            else if (fl[q].site == ORC_SITE_CT_NERR)
+                nerr[fl[q].replica] = flip(nerr[fl[q].replica], fl[q].bit, 0xffffffffu);
+        }
+        if (i == n)
+            break;
+        uint32_t cond[3] = {0, 0, 0};
+        for (unsigned r = 0; r < R; ++r) {
+            uint32_t v = (uint32_t)a[i]; /* loads repeated from the same address: cloning.cpp:2247-2255 */
+            for (size_t q = 0; q < nf; ++q)
+                if (fl[q].site == ORC_SITE_CT_VAL && fl[q].step == i && fl[q].replica == r)
+                    v = flip(v, fl[q].bit, 0xffffffffu);
+            sum[r] += v;
+            cond[r] = (v != i) ? 1u : 0u;
+        }
+        sync32(c, cond); /* the branch condition */
+        if (cond[0]) {
+            for (unsigned r = 0; r < R; ++r)
+                nerr[r] += 1;
+            a[i] = (int32_t)i;
+        }
+    }
+    sync32(c, sum);        /* return value */
+    store_sync32(c, nerr); /* stored to the caller's error count */
+    *sum_out = (int32_t)sum[0];
+    *nerr_out = nerr[0];
+}
+
+void orc_cache_test_xmr(int32_t *arrays, uint32_t n, size_t narrays, int32_t *sums, uint32_t *nerrs, const orc_cfg *cfg,
+                        const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
+{
+    orc_fault *fs = sorted_faults(faults, nfaults);
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0, cfg->flags};
+    size_t fp = 0;
+    for (size_t b = 0; b < narrays; ++b) {
+        while (fp < nfaults && fs[fp].item < b)
+            ++fp;
+        size_t fe = fp;
+        while (fe < nfaults && fs[fe].item == b)
+            ++fe;
+        c.detected = 0;
+        ct_item(arrays + (size_t)b * n, n, &sums[b], &nerrs[b], &c, fs + fp, fe - fp);
+        if (c.detected) {
+            st->dwc_detected += (cfg->replicas == 2);
+            if (detected)
+                detected[b] = 1;
+        }
+        fp = fe;
+    }
+    free(fs);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* default mode: vote where three (two) memory copies re-converge                             */
 /* ------------------------------------------------------------------------------------------ */
 

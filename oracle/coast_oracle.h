@@ -50,7 +50,11 @@ enum {
     ORC_SITE_AES_KEY = 17,   /* dword `index` (0..3) of the running round key, same timing */
 
     ORC_SITE_CRC_CRC = 24, /* crc register before byte `step` (step == length: after the loop) */
-    ORC_SITE_CRC_X = 25    /* temporary x of byte `step`, after x ^= x>>4 */
+    ORC_SITE_CRC_X = 25,   /* temporary x of byte `step`, after x ^= x>>4 */
+
+    ORC_SITE_CT_SUM = 32,  /* cache_test: running sum before element `step` is added (step == n: after the loop) */
+    ORC_SITE_CT_VAL = 33,  /* the loaded array[step], right after the load */
+    ORC_SITE_CT_NERR = 34  /* numberOfErrors before element `step` (step == n: after the loop) */
 };
 
 /* One single-bit flip.  16 bytes; identical layout to coast_fault in include/coast_hip.h. */
@@ -98,6 +102,12 @@ void orc_aes128_xmr(uint8_t *states, uint8_t *keys, size_t nblocks, int dir, con
                     const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
 void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint16_t *crcs, const orc_cfg *cfg,
                    const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
+
+/* calc_sum (tests/cache_test/cacheTest.c:101-177): n_arrays arrays of n ints, scrubbed in place; per array the sum (taken
+ * BEFORE the fixes, :108) and the number of elements that were != their index (:110-111) */
+void orc_cache_test_plain(int32_t *array, uint32_t n, int32_t *sum, uint32_t *nerr);
+void orc_cache_test_xmr(int32_t *arrays, uint32_t n, size_t narrays, int32_t *sums, uint32_t *nerrs, const orc_cfg *cfg,
+                        const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
 
 /* sparse variants: evaluate only the listed items (used to check huge batches) */
 void orc_mm_xmr_items(const uint32_t *f, const uint32_t *s, int n, const uint64_t *items, size_t nitems,

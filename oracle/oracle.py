@@ -228,6 +228,23 @@ def crc16_xmr(data, block_len, replicas=3, sync_every=0, faults=None, flags=0):
     return crcs, st.as_dict(), det
 
 
+def cache_test_xmr(arrays, replicas=3, faults=None, flags=0):
+    """arrays: (narrays, n) int32; returns (scrubbed arrays, sums, error counts, stats, detected) -- calc_sum of
+    tests/cache_test/cacheTest.c:101-177 under the protection model."""
+    a = np.array(np.ascontiguousarray(arrays, dtype=np.int32), copy=True)
+    na, n = a.shape
+    sums = np.empty(na, dtype=np.int32)
+    nerrs = np.empty(na, dtype=np.uint32)
+    fl = _faults(faults)
+    st = Stats()
+    det = np.zeros(na, dtype=np.uint8)
+    cfg = Cfg(replicas, 0, flags)
+    lib().orc_cache_test_xmr(_p(a, C.c_int32), C.c_uint32(n), C.c_size_t(na), _p(sums, C.c_int32), _p(nerrs, C.c_uint32),
+                             C.byref(cfg), fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st),
+                             _p(det, C.c_uint8))
+    return a, sums, nerrs, st.as_dict(), det
+
+
 def sync_copies(copies, scrub=True):
     """Default-mode exit vote: copies = 3 (TMR) or 2 (DWC) arrays of 32-bit words.  Returns (voted, copies after
     scrub, stats, detected per word)."""

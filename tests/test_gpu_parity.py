@@ -398,6 +398,60 @@ def test_reference_named_host_calls(eng, orc, golden):
     assert st["errors_corrected"] == 0 and st["sync_count"] == 81 + 16 + 16 + 1 and st["launches"] == 5
 
 
+# ------------------------------------------------------------------------------------------------ cache_test
+@pytest.mark.parametrize("n,na", [(600, 333), (37, 100), (64, 65), (1, 5), (2048, 7)])
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+def test_cache_test_faults_vs_oracle(eng, orc, n, na, replicas):
+    """calc_sum: memory upsets (scrubbed and counted by the workload itself) plus register upsets at every site."""
+    import torch
+
+    import coast_amd
+
+    rng = np.random.default_rng(n * 31 + na + replicas)
+    a = np.tile(np.arange(n, dtype=np.int32), (na, 1))
+    hits = rng.integers(0, na * n, max(1, na * n // 50))
+    a.reshape(-1)[hits] = rng.integers(-2**31, 2**31, hits.size, dtype=np.int64).astype(np.int32)
+    fl = _rand_faults(rng, 0 if replicas == 1 else 80, na, replicas, [32, 33, 34], n)
+    exp_a, exp_s, exp_e, exp_st, exp_det = orc.cache_test_xmr(a, replicas=replicas, faults=fl)
+    d = torch.from_numpy(a.copy()).cuda()
+    det = torch.zeros(na, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    sums, nerrs = eng.cache_test_batch(d, cfg=coast_amd.XmrConfig(replicas), detected=det)
+    assert (d.cpu().numpy() == exp_a).all()
+    assert (sums.cpu().numpy() == exp_s).all() and (nerrs.cpu().numpy().view(np.uint32) == exp_e).all()
+    assert _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all()
+    if replicas == 3:  # an array hit in ONE replica only is fully masked: its outputs are those of the fault-free run
+        c_a, c_s, c_e, _, _ = orc.cache_test_xmr(a, replicas=1)
+        hit = {}
+        for f in fl:
+            hit.setdefault(int(f["item"]), set()).add(int(f["replica"]))
+        ok = np.array([len(hit.get(i, ())) <= 1 for i in range(na)])
+        assert (exp_a[ok] == c_a[ok]).all() and (exp_s[ok] == c_s[ok]).all() and (exp_e[ok] == c_e[ok]).all()
+    # second pass over the scrubbed arrays: nothing left to fix, the reference's golden sum n(n-1)/2 everywhere
+    eng.reset_stats()
+    sums, nerrs = eng.cache_test_batch(d, cfg=coast_amd.XmrConfig(replicas))
+    assert (sums.cpu().numpy() == np.int32((n * (n - 1) // 2) & 0x7FFFFFFF)).all() and not nerrs.any()
+
+
+def test_cache_test_scrubs_device_memory_upsets(eng):
+    """The benchmark's purpose: an upset in the (single) memory copy is found by the compare, counted and repaired."""
+    import torch
+
+    import coast_amd
+
+    d = torch.arange(600, dtype=torch.int32, device="cuda").repeat(1000, 1).contiguous()
+    eng.flip_memory(d, (123 * 600 + 77) * 4 + 2, 5)
+    eng.flip_memory(d, (999 * 600 + 599) * 4, 0)
+    eng.reset_stats()
+    sums, nerrs = eng.cache_test_batch(d, cfg=coast_amd.XmrConfig(coast_amd.TMR))
+    e = nerrs.cpu().numpy()
+    assert e.sum() == 2 and e[123] == 1 and e[999] == 1
+    assert (d == torch.arange(600, dtype=torch.int32, device="cuda")).all()
+    assert sums[0].item() == 179700 and sums[123].item() != 179700
+    assert eng.stats()["errors_corrected"] == 0  # all replicas agreed: the memory was wrong, not a register
+
+
 # ------------------------------------------------------------------------------------------------ drop-in boundary
 _DRIVERS = {
     "crc16_coast": "result: 5ba3",                  # tests/crc16/crc16.c:40
@@ -405,6 +459,7 @@ _DRIVERS = {
     "sha256_coast": "C:0 E:0 F:0 T:0us",            # tests/sha256_common/sha256_tmr.c:30
     "mm_coast": "Error?: 0",                        # tests/mm_common/mm_tmr.c:40
     "matrixMultiply_coast": "Number of errors: 0",  # tests/matrixMultiply/matrixMultiply.c:157, unittest/cfg/full.yml:3
+    "cacheTest_coast": "0\n",                       # tests/cache_test/cacheTest.c:213 prints local_errors
 }
 
 
@@ -439,7 +494,7 @@ _OPT_PASSES = ["", "-DWC", "-TMR", "-TMR -countErrors", "-DWC -noMemReplication"
                "-TMR -noMemReplication -noStoreAddrSync"]
 
 
-@pytest.mark.parametrize("binary", ["matrixMultiply_coast", "crc16_coast", "aes_coast"])  # the three of full.yml:1-14 on this path
+@pytest.mark.parametrize("binary", ["matrixMultiply_coast", "crc16_coast", "aes_coast", "cacheTest_coast"])  # full.yml:1-14 on this path
 def test_reference_flag_matrix_clean_runs(binary):
     """unittest/unittest.py runs every benchmark under every OPT_PASSES entry and greps the output: same here."""
     import os

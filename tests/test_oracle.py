@@ -220,3 +220,40 @@ def test_no_store_data_sync_semantics(orc):
     a = orc.crc16_xmr(data, 50, faults=fl, flags=F)
     b = orc.crc16_xmr(data, 50, faults=fl)
     assert (a[0] == b[0]).all() and t3(a[1]) == t3(b[1]) == (1, 4, 0)
+
+
+def test_cache_test_golden_and_protection_model(orc):
+    """calc_sum (tests/cache_test/cacheTest.c:101-177): the reference's own golden (generateGolden, :88: 179700 for 600
+    elements), the scrub, and the sync-point arithmetic of the restated protection."""
+    import coast_amd
+
+    n = 600
+    a = np.tile(np.arange(n, dtype=np.int32), (5, 1))
+    out, sums, nerrs, st, det = orc.cache_test_xmr(a)
+    assert (sums == 179700).all() and (nerrs == 0).all() and (out == a).all()
+    assert st == {"errors_corrected": 0, "sync_count": 5 * (n + 2), "dwc_detected": 0}   # n conditions + sum + count
+    b = a.copy()
+    b[1, 7] = 99          # memory upsets: every replica sees them -> the branch is taken, the element is rewritten
+    b[3, 0] = -5
+    b[3, 599] = 0
+    out, sums, nerrs, st, det = orc.cache_test_xmr(b)
+    assert (out == a).all() and nerrs.tolist() == [0, 1, 0, 2, 0] and st["errors_corrected"] == 0 and not det.any()
+    assert sums.tolist() == [179700, 179700 + 92, 179700, 179700 - 5 - 599, 179700]    # the sum sees the array as found
+    for rep in (2, 1):
+        o2, s2, e2, st2, _ = orc.cache_test_xmr(b, replicas=rep)
+        assert (o2 == out).all() and (s2 == sums).all() and (e2 == nerrs).all()
+        assert st2["sync_count"] == (5 * (n + 2) if rep == 2 else 0)
+    # register upsets in one replica: out-voted, counted once per unequal vote
+    fl = coast_amd.make_faults([(0, 1, 33, 5, 3),      # loaded array[5] of replica 1: its condition AND its sum go wrong -> 2 votes
+                                (2, 0, 32, 100, 9),    # running sum of replica 0 -> the return-value vote
+                                (4, 2, 34, 600, 0)])   # numberOfErrors of replica 2 after the loop -> the stored-count vote
+    out, sums, nerrs, st, det = orc.cache_test_xmr(a, faults=fl)
+    assert (sums == 179700).all() and (nerrs == 0).all() and (out == a).all()
+    assert st["errors_corrected"] == 4 and det.tolist() == [1, 0, 1, 0, 1]
+    # the same upsets unprotected: silent corruption (replica 0 is the only copy)
+    fl0 = coast_amd.make_faults([(0, 0, 33, 5, 3), (2, 0, 32, 100, 9)])
+    out, sums, nerrs, st, det = orc.cache_test_xmr(a, replicas=1, faults=fl0)
+    assert sums[0] != 179700 and nerrs[0] == 1 and sums[2] != 179700
+    # DWC: flagged, never corrected
+    out, sums, nerrs, st, det = orc.cache_test_xmr(a, replicas=2, faults=coast_amd.make_faults([(3, 1, 32, 10, 4)]))
+    assert st["dwc_detected"] == 1 and det.tolist() == [0, 0, 0, 1, 0]
