@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="mm", choices=["mm", "crc16", "sha256", "aes"])
+    ap.add_argument("--workload", default="mm", choices=["mm", "crc16", "sha256", "aes", "cache_test"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU items per step (0 = the BASELINE config's size)")
     ap.add_argument("--side", type=int, default=256)
     ap.add_argument("--faults", type=int, default=-1,
@@ -120,6 +120,11 @@ def cpu_baseline_items(kind, budget_s=10.0):
         reps, dt = _time_budget(lambda: orc.sha256_xmr(msgs, 64, replicas=3), budget_s)
         return {"value": reps * msgs.shape[0] / dt, "unit": "msgs/s", "cores": 1, "kind": "port",
                 "sample": "%d x 32768 messages x 64 B, oracle TMR model, gcc -O3, %.1f s" % (reps, dt)}
+    if kind == "cache_test":
+        arrs = np.tile(np.arange(600, dtype=np.int32), (1 << 13, 1))
+        reps, dt = _time_budget(lambda: orc.cache_test_xmr(arrs, replicas=3), budget_s)
+        return {"value": reps * arrs.size * 4 / dt * 1e-9, "unit": "GB/s", "cores": 1, "kind": "port",
+                "sample": "%d x 8192 arrays x 600 ints, oracle TMR model, gcc -O3, %.1f s" % (reps, dt)}
     st = rng.integers(0, 256, (1 << 15, 16), dtype=np.uint8)
     key = rng.integers(0, 256, (1 << 15, 16), dtype=np.uint8)
     reps, dt = _time_budget(lambda: orc.aes128_xmr(st, key, 0, replicas=2), budget_s)
@@ -350,7 +355,47 @@ class AES(Workload):
         return cpu_baseline_items("aes")
 
 
-WORKLOADS = {"mm": MM, "crc16": CRC16, "sha256": SHA256, "aes": AES}
+class CacheTest(Workload):
+    metric = "protected bytes/sec + corrected-fault count, cache_test (calc_sum) TMR scrub"
+    unit = "GB/s"
+    dtype = "i32"
+
+    def __init__(self, a, eng, dev, rank, coast_amd):
+        self.n = 600                      # data_array_elements, tests/cache_test/cacheTest.c:78
+        self.na = a.batch or (1 << 22)    # 4 Mi arrays x 2400 B = 9.4 GiB per GPU
+        self.arr = torch.arange(self.n, dtype=torch.int32, device=dev).repeat(self.na, 1).contiguous()
+        self.cfg = coast_amd.XmrConfig(coast_amd.TMR)
+        self.eng = eng
+        rng = np.random.default_rng(11 + rank)
+        items = rng.choice(self.na, a.faults, replace=False)
+        self.faults = coast_amd.make_faults([(int(it), int(rng.integers(0, 3)), coast_amd.SITE_CT_SUM,
+                                              int(rng.integers(0, self.n + 1)), int(rng.integers(0, 32))) for it in items])
+        self.units_per_step = self.na * self.n * 4 * 1e-9  # GB
+        self.sums = self.nerrs = None
+
+    def launch(self):
+        self.sums, self.nerrs = self.eng.cache_test_batch(self.arr, cfg=self.cfg)
+
+    def check(self):
+        return bool((self.sums == 179700).all()) and not bool(self.nerrs.any())  # generateGolden, cacheTest.c:88
+
+    def config(self, world):
+        return {"workload": "cache_test calc_sum, %d-int arrays TMR, %.1f GiB/GPU, %d injected single-bit faults/GPU/step"
+                            % (self.n, self.na * self.n * 4 / 2**30, len(self.faults)),
+                "array_elems": self.n, "arrays_per_gpu": self.na, "replicas": 3,
+                "parallelism": "dp%d (independent arrays)" % world}
+
+    def roofline(self, kern_ms):
+        b = float(self.na) * (self.n * 4 + 8)
+        t = kern_ms * 1e-3
+        return {"bound": "hbm", "kernel": "cache_test_kernel<3>", "achieved": b / t * 1e-9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": b / t * 1e-9 / HBM_PEAK_GBS, "kernel_ms": kern_ms, "algorithmic_bytes": b}
+
+    def cpu(self):
+        return cpu_baseline_items("cache_test")
+
+
+WORKLOADS = {"mm": MM, "crc16": CRC16, "sha256": SHA256, "aes": AES, "cache_test": CacheTest}
 
 
 def pmc_traffic(workload, cfg):

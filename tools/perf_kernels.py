@@ -99,6 +99,15 @@ def main():
 
         mn, av = timeit(default_mode)
         res["mm256_default_mode_memx3"] = {"ms": mn, "elems_per_s": batch * n * n / mn * 1e3}
+    if want("cache"):
+        na, n = 1 << 20, 600
+        arr = torch.arange(n, dtype=torch.int32, device="cuda").repeat(na, 1).contiguous()
+        for rep in (3, 2, 1):
+            cfg = coast_amd.XmrConfig(rep)
+            mn, av = timeit(lambda: eng.cache_test_batch(arr, cfg=cfg))
+            res["cache_test_1Mx600_rep%d" % rep] = {"ms": mn, "GBs": na * n * 4 / mn * 1e-6,
+                                                    "frac_of_8TBs": na * n * 4 / mn * 1e-6 / 8000}
+        del arr
     for k, v in res.items():
         print(k, json.dumps(v))
 
