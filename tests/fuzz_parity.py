@@ -40,7 +40,7 @@ def main():
     rng = np.random.default_rng(seed)
     eng = coast_amd.Engine(0)
     t0 = time.time()
-    cases = {"mm": 0, "sha256": 0, "aes": 0, "crc16": 0}
+    cases = {"mm": 0, "sha256": 0, "aes": 0, "crc16": 0, "cache_test": 0}
     while time.time() - t0 < budget:
         kind = str(rng.choice(list(cases)))
         rep = int(rng.choice([1, 2, 3]))
@@ -100,6 +100,26 @@ def main():
             ok = ((ds.cpu().numpy() == es).all() and (dk.cpu().numpy() == ek).all() and stats3(eng.stats()) == est
                   and (det.cpu().numpy() == edet).all())
             desc = "aes n=%d dir=%d rep=%d V=%d k=%d" % (n, d, rep, sync_every, len(fl))
+        elif kind == "cache_test":
+            n = int(rng.choice([1, 2, 3, 4, 5, 31, 32, 33, 36, 64, 100, 128, 600, 601, 1000]))
+            na = int(rng.integers(1, 300))
+            flags = int(rng.choice([0, 0, 1]))
+            a = np.tile(np.arange(n, dtype=np.int32), (na, 1))
+            if rng.random() < 0.7:  # memory upsets for the scrub to find
+                hits = rng.integers(0, na * n, int(rng.integers(1, 20)))
+                a.reshape(-1)[hits] = rng.integers(-2**31, 2**31, hits.size, dtype=np.int64).astype(np.int32)
+            hot = rng.integers(0, na, 3)
+            fl = faults(rng, int(rng.integers(0, 60)) if rep > 1 else 0, na, nrep, [32, 33, 34], n, 1, hot)
+            ea, es, ee, est, edet = orc.cache_test_xmr(a, replicas=rep, faults=fl, flags=flags)
+            d = torch.from_numpy(a.copy()).cuda()
+            det = torch.zeros(na, dtype=torch.uint8, device="cuda")
+            eng.reset_stats()
+            eng.inject_faults(fl)
+            sums, nerrs = eng.cache_test_batch(d, cfg=coast_amd.XmrConfig(rep, 0, flags), detected=det)
+            ok = ((d.cpu().numpy() == ea).all() and (sums.cpu().numpy() == es).all()
+                  and (nerrs.cpu().numpy().view(np.uint32) == ee).all() and stats3(eng.stats()) == est
+                  and (det.cpu().numpy() == edet).all())
+            desc = "cache_test n=%d na=%d rep=%d flags=%d k=%d" % (n, na, rep, flags, len(fl))
         else:
             bl = int(rng.choice([1, 2, 3, 4, 5, 13, 16, 63, 64, 65, 127, 128, 255, 256, 300, 512]))
             nb = int(rng.integers(1, 500))

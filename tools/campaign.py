@@ -30,7 +30,7 @@ MODES = {"TMR": coast_amd.TMR, "DWC": coast_amd.DWC, "NONE": coast_amd.UNPROTECT
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("-b", "--benchmark", default="mm", choices=["mm", "sha256", "aes", "crc16"])
+    ap.add_argument("-b", "--benchmark", default="mm", choices=["mm", "sha256", "aes", "crc16", "cache_test"])
     ap.add_argument("-m", "--mode", default="TMR", choices=list(MODES))
     ap.add_argument("-t", "--runs", type=int, default=5000)
     ap.add_argument("--seed", type=int, default=0)
@@ -86,6 +86,20 @@ def main():
         eng.inject_faults(coast_amd.make_faults(rows))
         eng.aes128_batch(st, key, 0, cfg=cfg, detected=det)
         bad = (st != gs).any(dim=1) | (key != gk).any(dim=1)
+        flagged = det.bool()
+    elif a.benchmark == "cache_test":
+        n = 600  # data_array_elements, cacheTest.c:78
+        arr = torch.arange(n, dtype=torch.int32, device="cuda").repeat(runs, 1).contiguous()
+        gs, ge = eng.cache_test_batch(arr.clone(), cfg=clean)
+        rows = [(run, int(rng.integers(0, nrep)), int(rng.choice([coast_amd.SITE_CT_SUM, coast_amd.SITE_CT_VAL,
+                                                                  coast_amd.SITE_CT_NERR])),
+                 int(rng.integers(0, n + 1)), int(rng.integers(0, 32))) for run in range(runs)]
+        det = torch.zeros(runs, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(coast_amd.make_faults(rows))
+        work = arr.clone()
+        sums, nerrs = eng.cache_test_batch(work, cfg=cfg, detected=det)
+        bad = (sums != gs) | (nerrs != ge) | (work != arr).any(dim=1)
         flagged = det.bool()
     else:
         bl = 255  # the reference's maximum length (unsigned char, crc16.c:21)
