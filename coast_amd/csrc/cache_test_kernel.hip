@@ -64,14 +64,25 @@ template <int NREP>
 __global__ __launch_bounds__(256) void cache_test_kernel(uint32_t *__restrict__ arrays, uint32_t n, uint64_t narrays,
                                                          uint64_t ntiles, int32_t *__restrict__ sums,
                                                          uint32_t *__restrict__ nerrs, Counters ctr, FaultTab ft,
+                                                         const uint32_t *__restrict__ tileList, uint32_t nListed,
                                                          uint8_t *__restrict__ detected)
 {
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
     LaneMap<NREP> lm;
     lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
-    const uint64_t tile = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-    const bool tileOk = tile < ntiles;
+    // main launch (tileList == nullptr): every tile except those an armed fault points into; side launch: exactly those,
+    // element by element with the injector hooks, next to the main one (disjoint arrays)
+    const uint64_t widx = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint64_t tile = tileList ? (widx < nListed ? tileList[widx] : ntiles) : widx;
+    bool tileOk = tile < ntiles;
+    uint2 fr = make_uint2(0u, 0u);
+    if (ft.range && tileOk)
+        fr = ft.range[tile];
+    if (!tileList && fr.y != 0u) { // the side launch owns this tile
+        tileOk = false;
+        fr = make_uint2(0u, 0u);
+    }
     const int slot = lm.q;
     const uint64_t item = tile * IPW + (uint64_t)slot;
     const bool live = tileOk && lm.live && item < narrays;
@@ -82,24 +93,34 @@ __global__ __launch_bounds__(256) void cache_test_kernel(uint32_t *__restrict__ 
         sCnt[threadIdx.x] = 0;
     __syncthreads();
 
-    uint2 fr = make_uint2(0u, 0u);
-    if (ft.range && tileOk)
-        fr = ft.range[tile];
     const bool stepwise = fr.y != 0u; // wave-uniform: an armed fault points into this tile
     const bool cnt = live && lm.r == 0;
     Tally tl;
     uint32_t sum = 0, nerr = 0;
 
-    // injector hook: sum / numberOfErrors before element `step` (step == n: after the loop)
-    auto regHook = [&](uint32_t step) {
-        for (uint32_t q = 0; q < fr.y; ++q) {
-            const DevFault df = ft.list[fr.x + q];
-            if (df.step != step || (int)df.local != slot || (int)df.replica != lm.r || !lm.live)
-                continue;
-            if (df.site == SITE_CT_SUM)
-                sum = flip_bit(sum, df.bit, 0xffffffffu);
-            else if (df.site == SITE_CT_NERR)
-                nerr = flip_bit(nerr, df.bit, 0xffffffffu);
+    // injector hook: the running sum (site SITE_CT_SUM), the loaded element (SITE_CT_VAL) or numberOfErrors (SITE_CT_NERR)
+    // before / at element `step` (step == n: after the loop).  A tile rarely owns more than a few faults: they are read
+    // once into registers instead of being fetched from the table 3 x n times.
+    constexpr uint32_t kLocal = 4;
+    DevFault lf[kLocal];
+    const uint32_t nLocal = fr.y <= kLocal ? fr.y : 0u; // more than that: scan the table
+#pragma unroll
+    for (uint32_t q = 0; q < kLocal; ++q)
+        if (q < nLocal)
+            lf[q] = ft.list[fr.x + q];
+    auto regHook = [&](uint32_t step, uint32_t site, uint32_t &reg) {
+        auto hit = [&](const DevFault &df) {
+            if (df.step == step && df.site == site && (int)df.local == slot && (int)df.replica == lm.r && lm.live)
+                reg = flip_bit(reg, df.bit, 0xffffffffu);
+        };
+        if (nLocal) {
+#pragma unroll
+            for (uint32_t q = 0; q < kLocal; ++q)
+                if (q < nLocal)
+                    hit(lf[q]);
+        } else {
+            for (uint32_t q = 0; q < fr.y; ++q)
+                hit(ft.list[fr.x + q]);
         }
     };
 
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(256) void cache_test_kernel(uint32_t *__restrict__ 
     uint4 *stage = sStage[threadIdx.x >> 6];
     const int cl = lm.lane & 7, ca = lm.lane >> 3; // cooperative fetch: chunk of the group, array within the instruction
     constexpr int ROUNDS = (IPW + 7) / 8;
-    const bool coop = !stepwise && vec; // wave-uniform
+    const bool coop = vec; // wave-uniform
     uint4 pre[ROUNDS];
     auto fetch = [&](uint32_t base) { // 32 elements (fewer in the last group) of every array of the tile
 #pragma unroll
@@ -123,11 +144,8 @@ __global__ __launch_bounds__(256) void cache_test_kernel(uint32_t *__restrict__ 
     if (coop)
         fetch(0);
 
-    // a tile with an armed fault votes element by element, so that an upset of numberOfErrors lands between the same two
-    // increments as in the reference's instruction order
-    const uint32_t G = stepwise ? 1u : 32u;
-    for (uint32_t base = 0; base < n; base += G) {
-        const uint32_t gcount = (n - base) < G ? (n - base) : G;
+    for (uint32_t base = 0; base < n; base += 32u) {
+        const uint32_t gcount = (n - base) < 32u ? (n - base) : 32u;
         const uint32_t gmask = gcount == 32u ? 0xffffffffu : ((1u << gcount) - 1u);
         uint32_t mask = 0;
         if (coop) {
@@ -139,10 +157,13 @@ __global__ __launch_bounds__(256) void cache_test_kernel(uint32_t *__restrict__ 
             wave_lds_fence();
             if (base + 32u < n)
                 fetch(base + 32u); // in flight under the compares
+        }
+        const uint4 *row = stage + (lm.live ? slot : 0) * 9;
+        if (coop && !stepwise) {
             uint4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                v[u] = stage[(lm.live ? slot : 0) * 9 + u]; // chunks past the end of the array were stored as zeros
+                v[u] = row[u]; // chunks past the end of the array were stored as zeros
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t i0 = base + 4u * (uint32_t)u;
@@ -153,26 +174,27 @@ __global__ __launch_bounds__(256) void cache_test_kernel(uint32_t *__restrict__ 
                 mask |= (v[u].w != i0 + 3u ? 1u : 0u) << (4 * u + 3);
             }
             mask &= gmask;
-        } else {
+        } else { // element by element: ragged / misaligned arrays, and tiles with an armed fault (injector hooks)
             for (uint32_t e = 0; e < gcount; ++e) {
                 const uint32_t i = base + e;
                 if (stepwise)
-                    regHook(i);
-                uint32_t v = a[i];
-                if (stepwise) {
-                    for (uint32_t q = 0; q < fr.y; ++q) {
-                        const DevFault df = ft.list[fr.x + q];
-                        if (df.site == SITE_CT_VAL && df.step == i && (int)df.local == slot && (int)df.replica == lm.r &&
-                            lm.live)
-                            v = flip_bit(v, df.bit, 0xffffffffu);
-                    }
-                }
+                    regHook(i, SITE_CT_SUM, sum);
+                uint32_t v = coop ? reinterpret_cast<const uint32_t *>(row)[e] : a[i];
+                if (stepwise)
+                    regHook(i, SITE_CT_VAL, v);
                 sum += v;
                 mask |= (v != i ? 1u : 0u) << e;
             }
         }
         const uint32_t voted = xmr_vote_conditions<NREP>(mask, gmask, lm, cnt, tl) & gmask;
-        nerr += (uint32_t)__builtin_popcount(voted);
+        if (stepwise) { // an upset of numberOfErrors lands between the same two increments as in the reference's order
+            for (uint32_t e = 0; e < gcount; ++e) {
+                regHook(base + e, SITE_CT_NERR, nerr);
+                nerr += (voted >> e) & 1u;
+            }
+        } else {
+            nerr += (uint32_t)__builtin_popcount(voted);
+        }
         if (cnt && voted) { // the taken branches: array[i] = i (single memory copy, written once)
             for (uint32_t m = voted; m; m &= m - 1u) {
                 const uint32_t e = (uint32_t)__builtin_ctz(m);
@@ -180,8 +202,10 @@ __global__ __launch_bounds__(256) void cache_test_kernel(uint32_t *__restrict__ 
             }
         }
     }
-    if (stepwise)
-        regHook(n);
+    if (stepwise) {
+        regHook(n, SITE_CT_SUM, sum);
+        regHook(n, SITE_CT_NERR, nerr);
+    }
     sum = xmr_sync<NREP>(sum, lm, cnt, tl);         // return-value sync
     nerr = xmr_store_sync<NREP>(nerr, lm, cnt, tl); // stored error count
     uint32_t detItems = 0;
