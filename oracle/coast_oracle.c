@@ -699,6 +699,132 @@ void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* CHStone sha                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* tests/chstone/sha/sha.c.  Not FIPS SHA-1: the schedule has no rotate (W[i] = W[i-3]^W[i-8]^W[i-14]^W[i-16], :92-94 --
+ * the original "SHA"), and the 16 input words are assembled LITTLE-endian from the byte stream by the file's own memcpy
+ * (:61-80).  sha_final (:153-172) writes the 0x80 marker with `sha_info_data[count++] = 0x80` where count is a BYTE count
+ * used as a WORD index: only count == 0, i.e. a total length that is a multiple of 64, pads the way the routine means to
+ * (word 0 = 0x80, words 1..13 = 0, word 14 = bit count high, word 15 = bit count low), and that is the only case the
+ * benchmark exercises (2 x 8192 bytes, sha.h:59-60).  Sync points of the protected version: sha_info_digest[i] += ... at
+ * the end of every sha_transform are memory stores (:113-117) -> five store-data votes per transform. */
+static inline uint32_t rotl(uint32_t x, unsigned n) { return (x << n) | (x >> (32 - n)); }
+
+static void chsha_transform(uint32_t dg[3][5], const uint32_t in[16], unsigned nrep, uint32_t cidx, const orc_fault *fl,
+                            size_t nf)
+{
+    for (unsigned r = 0; r < nrep; ++r) {
+        uint32_t W[80], v[5];
+        for (unsigned t = 0; t < 80; ++t) {
+            W[t] = t < 16 ? in[t] : (W[t - 3] ^ W[t - 8] ^ W[t - 14] ^ W[t - 16]);
+            for (size_t q = 0; q < nf; ++q)
+                if (fl[q].site == ORC_SITE_CHSHA_W && fl[q].replica == r && fl[q].step == cidx * 80 + t)
+                    W[t] = flip(W[t], fl[q].bit, 0xffffffffu);
+        }
+        for (unsigned w = 0; w < 5; ++w)
+            v[w] = dg[r][w];
+        for (unsigned t = 0; t < 80; ++t) {
+            for (size_t q = 0; q < nf; ++q)
+                if (fl[q].site == ORC_SITE_CHSHA_WV && fl[q].replica == r && fl[q].step == cidx * 80 + t)
+                    v[fl[q].index % 5] = flip(v[fl[q].index % 5], fl[q].bit, 0xffffffffu);
+            const uint32_t A = v[0], B = v[1], C = v[2], D = v[3], E = v[4];
+            uint32_t f, k;
+            if (t < 20) {
+                f = (B & C) | (~B & D);
+                k = 0x5a827999u;
+            } else if (t < 40) {
+                f = B ^ C ^ D;
+                k = 0x6ed9eba1u;
+            } else if (t < 60) {
+                f = (B & C) | (B & D) | (C & D);
+                k = 0x8f1bbcdcu;
+            } else {
+                f = B ^ C ^ D;
+                k = 0xca62c1d6u;
+            }
+            const uint32_t temp = rotl(A, 5) + f + E + W[t] + k;
+            v[4] = D;
+            v[3] = C;
+            v[2] = rotl(B, 30);
+            v[1] = A;
+            v[0] = temp;
+        }
+        for (unsigned w = 0; w < 5; ++w)
+            dg[r][w] += v[w];
+    }
+}
+
+static void chsha_item(const uint8_t *data, uint32_t len, uint32_t out[5], sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    static const uint32_t IV[5] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u, 0xc3d2e1f0u};
+    uint32_t dg[3][5];
+    const unsigned R = c->nrep;
+    for (unsigned r = 0; r < 3; ++r)
+        for (unsigned w = 0; w < 5; ++w)
+            dg[r][w] = IV[w];
+    const uint32_t nblk = len / 64;
+    for (uint32_t cidx = 0; cidx <= nblk; ++cidx) {
+        uint32_t in[16];
+        if (cidx < nblk) {
+            const uint8_t *p = data + (size_t)cidx * 64;
+            for (unsigned t = 0; t < 16; ++t)
+                in[t] = (uint32_t)p[4 * t] | ((uint32_t)p[4 * t + 1] << 8) | ((uint32_t)p[4 * t + 2] << 16) |
+                        ((uint32_t)p[4 * t + 3] << 24);
+        } else { /* sha_final with count == 0 */
+            memset(in, 0, sizeof in);
+            in[0] = 0x80u;
+            in[14] = len >> 29;
+            in[15] = len << 3;
+        }
+        for (size_t q = 0; q < nf; ++q)
+            if (fl[q].site == ORC_SITE_CHSHA_DIGEST && fl[q].step == cidx && fl[q].replica < R)
+                dg[fl[q].replica][fl[q].index % 5] = flip(dg[fl[q].replica][fl[q].index % 5], fl[q].bit, 0xffffffffu);
+        chsha_transform(dg, in, R, cidx, fl, nf);
+        for (unsigned w = 0; w < 5; ++w) {
+            uint32_t v[3] = {dg[0][w], dg[1][w], dg[2][w]};
+            store_sync32(c, v);
+            dg[0][w] = v[0];
+            dg[1][w] = v[1];
+            dg[2][w] = v[2];
+        }
+    }
+    for (unsigned w = 0; w < 5; ++w)
+        out[w] = dg[0][w];
+}
+
+void orc_chsha_plain(const uint8_t *data, uint32_t len, uint32_t digest[5])
+{
+    orc_stats st = {0, 0, 0, 0};
+    sync_ctx c = {1, 0, &st, 0, 0};
+    chsha_item(data, len, digest, &c, NULL, 0);
+}
+
+void orc_chsha_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nmsgs, uint32_t *digests, const orc_cfg *cfg,
+                   const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
+{
+    orc_fault *fs = sorted_faults(faults, nfaults);
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0, cfg->flags};
+    size_t fp = 0;
+    for (size_t m = 0; m < nmsgs; ++m) {
+        while (fp < nfaults && fs[fp].item < m)
+            ++fp;
+        size_t fe = fp;
+        while (fe < nfaults && fs[fe].item == m)
+            ++fe;
+        c.detected = 0;
+        chsha_item(msgs + m * stride, len, digests + 5 * m, &c, fs + fp, fe - fp);
+        if (c.detected) {
+            st->dwc_detected += (cfg->replicas == 2);
+            if (detected)
+                detected[m] = 1;
+        }
+        fp = fe;
+    }
+    free(fs);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* cache_test                                                                                 */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -54,7 +54,11 @@ enum {
 
     ORC_SITE_CT_SUM = 32,  /* cache_test: running sum before element `step` is added (step == n: after the loop) */
     ORC_SITE_CT_VAL = 33,  /* the loaded array[step], right after the load */
-    ORC_SITE_CT_NERR = 34  /* numberOfErrors before element `step` (step == n: after the loop) */
+    ORC_SITE_CT_NERR = 34, /* numberOfErrors before element `step` (step == n: after the loop) */
+
+    ORC_SITE_CHSHA_W = 40,     /* CHStone sha: schedule word W[step%80] of transform step/80, right after it is produced */
+    ORC_SITE_CHSHA_WV = 41,    /* working variable index 0..4 (A..E) before round step%80 of transform step/80 */
+    ORC_SITE_CHSHA_DIGEST = 42 /* sha_info_digest[index] before transform `step` */
 };
 
 /* One single-bit flip.  16 bytes; identical layout to coast_fault in include/coast_hip.h. */
@@ -108,6 +112,12 @@ void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint
 void orc_cache_test_plain(int32_t *array, uint32_t n, int32_t *sum, uint32_t *nerr);
 void orc_cache_test_xmr(int32_t *arrays, uint32_t n, size_t narrays, int32_t *sums, uint32_t *nerrs, const orc_cfg *cfg,
                         const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
+
+/* CHStone sha (tests/chstone/sha/sha.c; unittest/cfg/full.yml:5): sha_init + sha_update over `len` bytes + sha_final, the
+ * five sha_info_digest words.  len must be a multiple of 64 (what sha_final supports, see the .c file). */
+void orc_chsha_plain(const uint8_t *data, uint32_t len, uint32_t digest[5]);
+void orc_chsha_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nmsgs, uint32_t *digests, const orc_cfg *cfg,
+                   const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
 
 /* sparse variants: evaluate only the listed items (used to check huge batches) */
 void orc_mm_xmr_items(const uint32_t *f, const uint32_t *s, int n, const uint64_t *items, size_t nitems,

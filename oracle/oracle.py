@@ -95,6 +95,23 @@ def ref():
     return _ref
 
 
+def ref_chsha(data):
+    """the reference's CHStone sha (sha_init / sha_update / sha_final) over `data` (len % 64 == 0) -> 5 uint32"""
+    d = (C.c_uint32 * 5)()
+    buf = bytes(data)
+    ref().ref_chsha(buf, C.c_int(len(buf)), d)
+    return np.array(list(d), dtype=np.uint32)
+
+
+def ref_chsha_vectors():
+    """the benchmark's built-in input (2 x 8192 bytes, sha_data.c) and the digest of the reference's own sha_stream()"""
+    R = ref()
+    arr = (C.c_ubyte * (2 * 8192)).in_dll(R, "ref_chsha_indata")
+    d = (C.c_uint32 * 5)()
+    R.ref_chsha_stream(d)
+    return np.frombuffer(bytes(arr), np.uint8).reshape(2, 8192).copy(), np.array(list(d), dtype=np.uint32)
+
+
 def _faults(faults):
     if faults is None:
         return np.zeros(0, dtype=FAULT_DTYPE)
@@ -226,6 +243,23 @@ def crc16_xmr(data, block_len, replicas=3, sync_every=0, faults=None, flags=0):
                         C.byref(cfg), fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st),
                         _p(det, C.c_uint8))
     return crcs, st.as_dict(), det
+
+
+def chsha_xmr(msgs, length, replicas=3, faults=None, flags=0):
+    """CHStone sha (tests/chstone/sha/sha.c): msgs (nmsgs, stride) uint8, `length` a multiple of 64; returns
+    (digests (nmsgs, 5) uint32, stats, detected)."""
+    msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+    nm, stride = msgs.shape
+    assert length % 64 == 0 and length <= stride
+    dig = np.empty((nm, 5), dtype=np.uint32)
+    fl = _faults(faults)
+    st = Stats()
+    det = np.zeros(nm, dtype=np.uint8)
+    cfg = Cfg(replicas, 0, flags)
+    pad = np.concatenate([msgs.reshape(-1), np.zeros(8, np.uint8)])
+    lib().orc_chsha_xmr(_p(pad, C.c_uint8), C.c_size_t(stride), C.c_uint32(length), C.c_size_t(nm), _p(dig, C.c_uint32),
+                        C.byref(cfg), fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st), _p(det, C.c_uint8))
+    return dig, st.as_dict(), det
 
 
 def cache_test_xmr(arrays, replicas=3, faults=None, flags=0):

@@ -22,6 +22,7 @@ def golden():
     g["mm"] = dict(np.load(os.path.join(GOLDEN, "mm_fixtures.npz")))
     g["sha"] = dict(np.load(os.path.join(GOLDEN, "sha_fixtures.npz")))
     g["aes_kat"] = np.load(os.path.join(GOLDEN, "aes_kat.npz"))["kat"]
+    g["chsha"] = dict(np.load(os.path.join(GOLDEN, "chsha_fixtures.npz")))
     return g
 
 

@@ -141,6 +141,22 @@ def main():
     vec.append({"data": b"123456789".hex(), "crc": orc.ref_crc16(b"123456789")})
     out["crc16_vectors"] = vec
 
+    # ---------------- CHStone sha (tests/chstone/sha): the benchmark's own vectors, its expected digest (sha_driver.c:49-50)
+    # and outputs of the reference run here on random inputs
+    indata, stream_digest = orc.ref_chsha_vectors()
+    txt = open(os.path.join(REF, "chstone/sha/sha_driver.c")).read()
+    out_data = [int(v, 16) for v in re.findall(r"0x([0-9a-fA-F]{8})UL", txt)]
+    assert len(out_data) == 5 and stream_digest.tolist() == out_data, "reference sha_stream() != its own outData"
+    assert orc.ref_chsha(indata.tobytes()).tolist() == out_data
+    rng = random.Random(5)
+    chv = {"indata": indata, "outData": np.array(out_data, dtype=np.uint32)}
+    for q, ln in enumerate((0, 64, 128, 192, 1024, 4096)):
+        d = bytes(rng.randrange(256) for _ in range(ln))
+        chv["rand%d" % q] = np.frombuffer(d, np.uint8)
+        chv["rand%d_digest" % q] = orc.ref_chsha(d)
+    np.savez_compressed(os.path.join(HERE, "chsha_fixtures.npz"), **chv)
+    out["chsha_outData"] = out_data
+
     with open(os.path.join(HERE, "golden.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(HERE)))

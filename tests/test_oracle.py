@@ -257,3 +257,40 @@ def test_cache_test_golden_and_protection_model(orc):
     # DWC: flagged, never corrected
     out, sums, nerrs, st, det = orc.cache_test_xmr(a, replicas=2, faults=coast_amd.make_faults([(3, 1, 32, 10, 4)]))
     assert st["dwc_detected"] == 1 and det.tolist() == [0, 0, 0, 1, 0]
+
+
+def test_chstone_sha_golden_and_protection_model(orc, golden):
+    """CHStone sha (tests/chstone/sha): the benchmark's own input and expected digest (sha_driver.c:49-50), outputs of the
+    reference run in the build container on random inputs, and the restated protection (five store-data votes per
+    sha_transform)."""
+    import coast_amd
+
+    ch = golden["chsha"]
+    msg = ch["indata"].reshape(1, -1)                       # sha_stream: 2 x 8192 bytes, one running hash
+    dig, st, det = orc.chsha_xmr(msg, 16384)
+    assert dig[0].tolist() == ch["outData"].tolist() == golden["chsha_outData"]
+    assert st == {"errors_corrected": 0, "sync_count": 5 * 257, "dwc_detected": 0}   # 256 data blocks + the padding block
+    for q in range(6):
+        d = ch["rand%d" % q]
+        m = np.zeros((1, max(d.size, 64)), dtype=np.uint8)
+        m[0, :d.size] = d
+        assert orc.chsha_xmr(m, d.size, replicas=1)[0][0].tolist() == ch["rand%d_digest" % q].tolist()
+    if orc.ref() is not None:                               # build container: against the reference itself, more inputs
+        rng = np.random.default_rng(1)
+        for ln in (64, 320, 2048):
+            d = rng.integers(0, 256, ln, dtype=np.uint8)
+            assert orc.chsha_xmr(d.reshape(1, -1), ln)[0][0].tolist() == orc.ref_chsha(d.tobytes()).tolist()
+    # protection model on a 3-block message
+    rng = np.random.default_rng(2)
+    msgs = rng.integers(0, 256, (4, 192), dtype=np.uint8)
+    clean, st0, _ = orc.chsha_xmr(msgs, 192)
+    assert st0["sync_count"] == 4 * 5 * 4
+    fl = coast_amd.make_faults([(0, 1, 40, 80 + 17, 5),        # W[17] of transform 1, replica 1
+                                (1, 0, 41, 3 * 80 + 79, 31, 4),  # E before the last round of the padding transform, replica 0
+                                (2, 2, 42, 2, 0, 3)])          # sha_info_digest[3] before transform 2, replica 2
+    dig, st, det = orc.chsha_xmr(msgs, 192, faults=fl)
+    assert (dig == clean).all() and det.tolist() == [1, 1, 1, 0] and st["errors_corrected"] >= 3
+    dig1, _, _ = orc.chsha_xmr(msgs, 192, replicas=1, faults=coast_amd.make_faults([(1, 0, 41, 3 * 80 + 79, 31, 4)]))
+    assert (dig1[1] != clean[1]).any() and (dig1[[0, 2, 3]] == clean[[0, 2, 3]]).all()
+    _, st2, det2 = orc.chsha_xmr(msgs, 192, replicas=2, faults=coast_amd.make_faults([(3, 1, 40, 5, 9)]))
+    assert st2["dwc_detected"] == 1 and det2.tolist() == [0, 0, 0, 1]
