@@ -15,3 +15,4 @@ SITE_SHA_M, SITE_SHA_WV, SITE_SHA_STATE = 8, 9, 10
 SITE_AES_STATE, SITE_AES_KEY = 16, 17
 SITE_CRC_CRC, SITE_CRC_X = 24, 25
 SITE_CT_SUM, SITE_CT_VAL, SITE_CT_NERR = 32, 33, 34
+SITE_CHSHA_W, SITE_CHSHA_WV, SITE_CHSHA_DIGEST = 40, 41, 42

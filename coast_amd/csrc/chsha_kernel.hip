@@ -1,0 +1,197 @@
+// chsha_kernel.hip -- protected CHStone sha (tests/chstone/sha/sha.c: sha_init / sha_update / sha_final; the benchmark of
+// unittest/cfg/full.yml:5), a batch of messages.
+//
+// Not FIPS SHA-1: the message schedule has no rotate (W[i] = W[i-3]^W[i-8]^W[i-14]^W[i-16], sha.c:92-94) and the sixteen
+// input words are assembled LITTLE-endian by the file's own memcpy (:61-80) -- on a little-endian GPU that is a plain
+// dword load.  sha_final (:153-172) indexes the word array with a byte count; it pads as intended only when the length is a
+// multiple of 64 (word 0 = 0x80, 14 = bit count high, 15 = bit count low), which is all the benchmark does (2 x 8192
+// bytes) and all this entry point accepts.
+//
+// Work item = one message, walked by a lane group (NREP adjacent lanes); replicated registers: sha_info_digest (5), the
+// working variables A..E, the 16-word schedule window.  Sync points: `sha_info_digest[i] += ...` at the end of every
+// sha_transform are memory stores (:113-117) -> five store-data votes per transform (oracle chsha_item).
+//
+// Arithmetic: 80 rounds fully unrolled, rolling 16-register schedule window, v_bitop3 for f1 (0xCA), f3 (0xE8) and the
+// three-way XORs (0x96), v_alignbit for the rotates: ~9 VALU per round per lane.  VALU-bound like sha256.
+#include "xmr.hpp"
+
+namespace coast {
+
+enum { SITE_CHSHA_W = 40, SITE_CHSHA_WV = 41, SITE_CHSHA_DIGEST = 42 };
+
+__device__ __forceinline__ uint32_t chsha_rotl(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
+
+// the armed faults of one tile, copied into registers once (a tile rarely owns more than a few)
+struct TileFaults {
+    static constexpr uint32_t kLocal = 4;
+    DevFault lf[kLocal];
+    uint32_t nLocal, n;
+    const DevFault *list;
+    __device__ __forceinline__ void load(const FaultTab &ft, uint2 fr)
+    {
+        n = fr.y;
+        list = ft.list + fr.x;
+        nLocal = fr.y <= kLocal ? fr.y : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < kLocal; ++q)
+            if (q < nLocal)
+                lf[q] = list[q];
+    }
+    template <class F> __device__ __forceinline__ void each(F &&f) const
+    {
+        if (nLocal) {
+#pragma unroll
+            for (uint32_t q = 0; q < kLocal; ++q)
+                if (q < nLocal)
+                    f(lf[q]);
+        } else {
+            for (uint32_t q = 0; q < n; ++q)
+                f(list[q]);
+        }
+    }
+};
+
+// sha_transform (sha.c:82-118).  HOOKS: word t of the schedule is produced right before round t and a W hook of step t is
+// applied there, a working-variable hook before round t; rounds never feed the schedule, so every value that depends on a
+// flipped word is computed after the flip exactly as in the reference's "all of W first" order.
+template <bool HOOKS>
+__device__ __forceinline__ void chsha_transform(uint32_t dg[5], uint32_t W[16], uint32_t cidx, const TileFaults &tf, int slot,
+                                                int rep, bool laneLive)
+{
+    uint32_t v[5] = {dg[0], dg[1], dg[2], dg[3], dg[4]};
+#pragma unroll
+    for (int t = 0; t < 80; ++t) {
+        if (t >= 16)
+            W[t & 15] = __builtin_amdgcn_bitop3_b32(W[(t - 3) & 15], W[(t - 8) & 15], W[(t - 14) & 15], 0x96) ^ W[t & 15];
+        if constexpr (HOOKS) {
+            tf.each([&](const DevFault &df) {
+                if ((int)df.local != slot || (int)df.replica != rep || !laneLive || df.step != cidx * 80u + (uint32_t)t)
+                    return;
+                const uint32_t mask = 1u << (df.bit & 31u);
+                if (df.site == SITE_CHSHA_W) {
+                    W[t & 15] ^= mask;
+                } else if (df.site == SITE_CHSHA_WV) {
+#pragma unroll
+                    for (int w = 0; w < 5; ++w)
+                        if (w == (int)(df.index % 5u))
+                            v[w] ^= mask;
+                }
+            });
+        }
+        uint32_t f, k;
+        if (t < 20) {
+            f = __builtin_amdgcn_bitop3_b32(v[1], v[2], v[3], 0xCA); // (B & C) | (~B & D)
+            k = 0x5a827999u;
+        } else if (t < 40) {
+            f = __builtin_amdgcn_bitop3_b32(v[1], v[2], v[3], 0x96); // B ^ C ^ D
+            k = 0x6ed9eba1u;
+        } else if (t < 60) {
+            f = __builtin_amdgcn_bitop3_b32(v[1], v[2], v[3], 0xE8); // majority
+            k = 0x8f1bbcdcu;
+        } else {
+            f = __builtin_amdgcn_bitop3_b32(v[1], v[2], v[3], 0x96);
+            k = 0xca62c1d6u;
+        }
+        const uint32_t temp = chsha_rotl(v[0], 5) + f + v[4] + W[t & 15] + k;
+        v[4] = v[3];
+        v[3] = v[2];
+        v[2] = chsha_rotl(v[1], 30);
+        v[1] = v[0];
+        v[0] = temp;
+    }
+#pragma unroll
+    for (int w = 0; w < 5; ++w)
+        dg[w] += v[w];
+}
+
+// four waves per workgroup, one tile of IPW messages per wave.  Main launch (tileList == nullptr): every tile except those
+// an armed fault points into; side launch: exactly those, with the injector hooks, beside the main one (disjoint messages).
+template <int NREP, bool HOOKS>
+__global__ __launch_bounds__(256) void chsha_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
+                                                    uint64_t nmsgs, uint64_t ntiles, uint32_t *__restrict__ digests,
+                                                    Counters ctr, FaultTab ft, const uint32_t *__restrict__ tileList,
+                                                    uint32_t nListed, uint8_t *__restrict__ detected)
+{
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    LaneMap<NREP> lm;
+    lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
+    const uint64_t widx = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint64_t tile = tileList ? (widx < nListed ? tileList[widx] : ntiles) : widx;
+    bool tileOk = tile < ntiles;
+    uint2 fr = make_uint2(0u, 0u);
+    if (ft.range && tileOk)
+        fr = ft.range[tile];
+    if (!HOOKS && fr.y != 0u) { // the side launch owns this tile
+        tileOk = false;
+        fr = make_uint2(0u, 0u);
+    }
+    TileFaults tf;
+    tf.load(ft, HOOKS ? fr : make_uint2(0u, 0u));
+    const int slot = lm.q;
+    const uint64_t item = tile * IPW + (uint64_t)slot;
+    const bool live = tileOk && lm.live && item < nmsgs;
+    const bool cnt = live && lm.r == 0;
+    const uint8_t *msg = msgs + (live ? item : 0) * stride;
+    const bool aligned = ((stride & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(msgs) & 3u) == 0u);
+
+    if (threadIdx.x < 4)
+        sCnt[threadIdx.x] = 0;
+    __syncthreads();
+
+    uint32_t dg[5] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u, 0xc3d2e1f0u}; // sha_init, :120-128
+    Tally tl;
+    const uint32_t nblk = len >> 6;
+    for (uint32_t c = 0; c <= nblk; ++c) {
+        uint32_t W[16];
+        if (c < nblk) {
+            const uint8_t *p = msg + (size_t)c * 64;
+            if (aligned) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    W[t] = reinterpret_cast<const uint32_t *>(p)[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    W[t] = (uint32_t)p[4 * t] | ((uint32_t)p[4 * t + 1] << 8) | ((uint32_t)p[4 * t + 2] << 16) |
+                           ((uint32_t)p[4 * t + 3] << 24);
+            }
+        } else { // sha_final with count == 0
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                W[t] = 0u;
+            W[0] = 0x80u;
+            W[14] = len >> 29;
+            W[15] = len << 3;
+        }
+        if constexpr (HOOKS) {
+            tf.each([&](const DevFault &df) {
+                if (df.site != SITE_CHSHA_DIGEST || df.step != c || (int)df.local != slot || (int)df.replica != lm.r || !lm.live)
+                    return;
+#pragma unroll
+                for (int w = 0; w < 5; ++w)
+                    if (w == (int)(df.index % 5u))
+                        dg[w] ^= 1u << (df.bit & 31u);
+            });
+        }
+        chsha_transform<HOOKS>(dg, W, c, tf, slot, lm.r, lm.live);
+#pragma unroll
+        for (int w = 0; w < 5; ++w) // sha_info_digest[w] += ... are stores: store-data sync
+            dg[w] = xmr_store_sync<NREP>(dg[w], lm, cnt, tl);
+    }
+    uint32_t detItems = 0;
+    if (cnt) {
+#pragma unroll
+        for (int w = 0; w < 5; ++w)
+            digests[item * 5 + w] = dg[w];
+        if (tl.det) {
+            if (NREP == 2)
+                detItems = 1;
+            if (detected)
+                detected[item] = 1;
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+} // namespace coast

@@ -22,6 +22,7 @@
 #include "crc16_kernel.hip"
 #include "vote_kernel.hip"
 #include "cache_test_kernel.hip"
+#include "chsha_kernel.hip"
 
 using namespace coast;
 

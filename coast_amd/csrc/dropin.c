@@ -8,6 +8,8 @@
  *   void sha256_hash(ctx_data, ctx_bitlen, ctx_state, data, len, hash)            tests/sha256_common/sha256_common_tmr.c:101
  *   int  coast_dropin_calc_sum(array, n)               target of cache_glue.c (calc_sum, tests/cache_test/cacheTest.c:101;
  *                                                      `data_array_elements` is a macro, :78)
+ *   void coast_dropin_sha_stream(indata, in_i, vsize, block_size, digest)   target of chsha_glue.c (CHStone sha_stream,
+ *                                                      tests/chstone/sha/sha.c:174-186; VSIZE / BLOCK_SIZE are macros)
  *   void coast_dropin_matrix_multiply(f, s, r, side)   target of the per-benchmark glue TU (matrix_multiply's `side`
  *                                                      is a macro, tests/mm_common/mm_tmr.c:10, so it is not in its ABI)
  *   TMR_ERROR_CNT, __SYNC_COUNT      the globals the pass emits (synchronization.cpp:269-294, :103-121); weak, because
@@ -254,4 +256,35 @@ int coast_dropin_calc_sum(int *array, int n)
     }
     free(found);
     return sum;
+}
+
+/* sha_stream (tests/chstone/sha/sha.c:174-186): sha_init, one sha_update per input vector, sha_final -- a running hash over
+ * the concatenation of the vectors' first in_i[j] bytes.  Every in_i[j] must be a multiple of 64 (the benchmark's are 8192):
+ * the reference's sha_update keeps no partial block across calls and its sha_final pads only block-aligned totals. */
+void coast_dropin_sha_stream(const unsigned char *indata, const int *in_i, int vsize, int block_size, unsigned int *digest)
+{
+    const coast_cfg cfg = dropin_cfg();
+    size_t total = 0;
+    for (int j = 0; j < vsize; ++j) {
+        if (in_i[j] < 0 || in_i[j] > block_size || (in_i[j] & 63))
+            dropin_fail("sha_stream (vector length not a multiple of 64)", COAST_EINVAL);
+        total += (size_t)in_i[j];
+    }
+    unsigned char *buf = (unsigned char *)malloc(total ? total : 1);
+    if (!buf)
+        dropin_fail("sha_stream", COAST_ENOMEM);
+    size_t off = 0;
+    for (int j = 0; j < vsize; ++j) {
+        memcpy(buf + off, indata + (size_t)j * (size_t)block_size, (size_t)in_i[j]);
+        off += (size_t)in_i[j];
+    }
+    dropin_maybe_inject();
+    uint32_t dg[5];
+    const int rc = coast_chsha_host(buf, (uint32_t)total, dg, &cfg);
+    free(buf);
+    if (rc)
+        dropin_fail("sha_stream", rc);
+    for (int w = 0; w < 5; ++w)
+        digest[w] = dg[w];
+    dropin_account();
 }

@@ -145,6 +145,18 @@ class Engine:
                                                 _ptr(detected) if detected is not None else None))
         return out
 
+    def chsha_batch(self, msgs, length, out=None, cfg: XmrConfig = XmrConfig(), detected=None):
+        """CHStone sha (tests/chstone/sha/sha.c): msgs (n_msgs, stride) uint8 on the GPU, `length` a multiple of 64.
+        Returns (n_msgs, 5) digests as int32 bit patterns."""
+        assert msgs.is_cuda and msgs.dtype == torch.uint8 and msgs.dim() == 2 and msgs.is_contiguous()
+        n, stride = msgs.shape
+        if out is None:
+            out = torch.empty((n, 5), dtype=torch.int32, device=msgs.device)
+        cc = cfg.c()
+        self._check(self._lib.coast_chsha_batch(self._h, _ptr(msgs), stride, length, n, _ptr(out), C.byref(cc),
+                                                _ptr(detected) if detected is not None else None))
+        return out
+
     def cache_test_batch(self, arrays, cfg: XmrConfig = XmrConfig(), detected=None):
         """arrays: (n_arrays, n) int32 on the GPU, scrubbed IN PLACE (calc_sum, tests/cache_test/cacheTest.c:101-177).
         Returns (sums int32, error counts as int32 bit patterns)."""

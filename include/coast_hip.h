@@ -87,7 +87,10 @@ enum {
     COAST_SITE_CRC_X = 25,     /* temporary x of byte `step` after x ^= x>>4 */
     COAST_SITE_CT_SUM = 32,    /* cache_test: running sum before element `step` is added (step == n: after the loop) */
     COAST_SITE_CT_VAL = 33,    /* the loaded array[step], right after the load */
-    COAST_SITE_CT_NERR = 34    /* numberOfErrors before element `step` (step == n: after the loop) */
+    COAST_SITE_CT_NERR = 34,   /* numberOfErrors before element `step` (step == n: after the loop) */
+    COAST_SITE_CHSHA_W = 40,      /* CHStone sha: schedule word W[step%80] of transform step/80, right after it is produced */
+    COAST_SITE_CHSHA_WV = 41,     /* working variable index 0..4 (A..E) before round step%80 of transform step/80 */
+    COAST_SITE_CHSHA_DIGEST = 42  /* sha_info_digest[index] before transform `step` */
 };
 
 /* One single-event upset: new = old XOR (1 << bit) on the 32-bit register holding the value
@@ -159,6 +162,13 @@ int coast_crc16_batch(coast_ctx *ctx, const uint8_t *d_data, uint32_t block_len,
 int coast_cache_test_batch(coast_ctx *ctx, int32_t *d_arrays, uint32_t n_elems, size_t n_arrays, int32_t *d_sums,
                            uint32_t *d_nerrs, const coast_cfg *cfg, uint8_t *d_detected);
 
+/* CHStone sha (tests/chstone/sha/sha.c: sha_init + sha_update + sha_final; unittest/cfg/full.yml:5): n_msgs messages of
+ * `len` bytes (a multiple of 64 -- the only lengths the reference's sha_final pads as intended), message m at
+ * d_msgs + m*stride; d_digests receives the five sha_info_digest words per message.  Not FIPS SHA-1 (no rotate in the
+ * schedule, little-endian input words) -- bit-exact with the reference, its own test vector included. */
+int coast_chsha_batch(coast_ctx *ctx, const uint8_t *d_msgs, size_t stride, uint32_t len, size_t n_msgs,
+                      uint32_t *d_digests, const coast_cfg *cfg, uint8_t *d_detected);
+
 /* ---- default-mode TMR / DWC: memory replicated as well (docs/source/passes.rst:329,337; cloning.cpp:2417-2462) ----
  * In COAST's default mode the clones of a region run on their own copies of the data and stores are not voted
  * (synchronization.cpp:211-215); values are voted where the copies re-converge -- return values, arguments of unprotected
@@ -184,6 +194,7 @@ int coast_aes_enc_dec_host(uint8_t *state, uint8_t *key, uint8_t dir, const coas
 int coast_crc16_host(const uint8_t *data, uint32_t length, uint16_t *crc, const coast_cfg *cfg);
 /* calc_sum's `data_array_elements` is a macro in the reference (cacheTest.c:78), so the glue TU passes it explicitly */
 int coast_cache_test_host(int32_t *array, uint32_t n_elems, int32_t *sum, uint32_t *nerr, const coast_cfg *cfg);
+int coast_chsha_host(const uint8_t *data, uint32_t len, uint32_t digest[5], const coast_cfg *cfg);
 /* arm single-bit flips for the NEXT single-call shim (they run on a library-owned context): lets an external harness
  * inject into an unmodified driver the way supervisor.py + GDB inject into the running benchmark */
 int coast_host_inject_faults(const coast_fault *faults, size_t k);

@@ -40,7 +40,7 @@ def main():
     rng = np.random.default_rng(seed)
     eng = coast_amd.Engine(0)
     t0 = time.time()
-    cases = {"mm": 0, "sha256": 0, "aes": 0, "crc16": 0, "cache_test": 0}
+    cases = {"mm": 0, "sha256": 0, "aes": 0, "crc16": 0, "cache_test": 0, "chsha": 0}
     while time.time() - t0 < budget:
         kind = str(rng.choice(list(cases)))
         rep = int(rng.choice([1, 2, 3]))
@@ -100,6 +100,29 @@ def main():
             ok = ((ds.cpu().numpy() == es).all() and (dk.cpu().numpy() == ek).all() and stats3(eng.stats()) == est
                   and (det.cpu().numpy() == edet).all())
             desc = "aes n=%d dir=%d rep=%d V=%d k=%d" % (n, d, rep, sync_every, len(fl))
+        elif kind == "chsha":
+            ln = 64 * int(rng.choice([0, 1, 2, 3, 5, 8, 16]))
+            stride = ln + int(rng.choice([0, 0, 1, 3, 4, 16]))
+            nm = int(rng.integers(1, 200))
+            flags = int(rng.choice([0, 0, 1]))
+            msgs = rng.integers(0, 256, (nm, max(stride, 1)), dtype=np.uint8)
+            ncomp = ln // 64 + 1
+            hot = rng.integers(0, nm, 3)
+            rows = []
+            for _ in range(int(rng.integers(0, 60)) if rep > 1 else 0):
+                site = int(rng.choice([40, 41, 42]))
+                step = int(rng.integers(0, ncomp)) if site == 42 else int(rng.integers(0, ncomp * 80))
+                item = int(rng.choice(hot)) if rng.random() < 0.5 else int(rng.integers(0, nm))
+                rows.append((item, int(rng.integers(0, nrep)), site, step, int(rng.integers(0, 32)), int(rng.integers(0, 5))))
+            fl = coast_amd.make_faults(rows)
+            exp, est, edet = orc.chsha_xmr(msgs, ln, replicas=rep, faults=fl, flags=flags)
+            det = torch.zeros(nm, dtype=torch.uint8, device="cuda")
+            eng.reset_stats()
+            eng.inject_faults(fl)
+            got = eng.chsha_batch(torch.from_numpy(msgs).cuda(), ln, cfg=coast_amd.XmrConfig(rep, 0, flags), detected=det)
+            ok = ((got.cpu().numpy().view(np.uint32) == exp).all() and stats3(eng.stats()) == est
+                  and (det.cpu().numpy() == edet).all())
+            desc = "chsha len=%d stride=%d nm=%d rep=%d flags=%d k=%d" % (ln, stride, nm, rep, flags, len(fl))
         elif kind == "cache_test":
             n = int(rng.choice([1, 2, 3, 4, 5, 31, 32, 33, 36, 64, 100, 128, 600, 601, 1000]))
             na = int(rng.integers(1, 300))

@@ -398,6 +398,58 @@ def test_reference_named_host_calls(eng, orc, golden):
     assert st["errors_corrected"] == 0 and st["sync_count"] == 81 + 16 + 16 + 1 and st["launches"] == 5
 
 
+# ------------------------------------------------------------------------------------------------ CHStone sha
+def test_chstone_sha_golden(eng, golden):
+    """The benchmark's own vectors and expected digest (tests/chstone/sha/sha_driver.c:49-50), and the reference's outputs
+    on random inputs (generated in the build container, tests/golden/gen_golden.py)."""
+    import torch
+
+    import coast_amd
+
+    ch = golden["chsha"]
+    msg = torch.from_numpy(ch["indata"].reshape(1, -1).copy()).cuda()
+    for replicas in (3, 2, 1):
+        eng.reset_stats()
+        got = _host(eng.chsha_batch(msg, 16384, cfg=coast_amd.XmrConfig(replicas)), np.uint32)
+        assert got[0].tolist() == ch["outData"].tolist()
+        assert eng.stats()["sync_count"] == (5 * 257 if replicas > 1 else 0)
+    for q in range(6):
+        d = ch["rand%d" % q]
+        m = np.zeros((1, max(d.size, 64)), dtype=np.uint8)
+        m[0, :d.size] = d
+        got = _host(eng.chsha_batch(torch.from_numpy(m).cuda(), int(d.size)), np.uint32)
+        assert got[0].tolist() == ch["rand%d_digest" % q].tolist()
+
+
+@pytest.mark.parametrize("length,stride", [(0, 64), (64, 64), (192, 192), (192, 195), (1024, 1040), (16384, 16384)])
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+def test_chstone_sha_faults_vs_oracle(eng, orc, replicas, length, stride):
+    import torch
+
+    import coast_amd
+
+    rng = np.random.default_rng(4242 + length + stride + replicas)
+    nm = 150 if length < 16384 else 40
+    msgs = rng.integers(0, 256, (nm, stride), dtype=np.uint8)
+    ncomp = length // 64 + 1
+    rows = []
+    for _ in range(0 if replicas == 1 else 100):
+        site = int(rng.choice([40, 41, 42]))
+        step = int(rng.integers(0, ncomp)) if site == 42 else int(rng.integers(0, ncomp * 80))
+        rows.append((int(rng.integers(0, nm)), int(rng.integers(0, replicas)), site, step, int(rng.integers(0, 32)),
+                     int(rng.integers(0, 5))))
+    fl = coast_amd.make_faults(rows)
+    exp, exp_st, exp_det = orc.chsha_xmr(msgs, length, replicas=replicas, faults=fl)
+    det = torch.zeros(nm, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    got = _host(eng.chsha_batch(torch.from_numpy(msgs).cuda(), length, cfg=coast_amd.XmrConfig(replicas), detected=det), np.uint32)
+    assert (got == exp).all()
+    assert _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all()
+    with pytest.raises(Exception):  # sha_final pads only block-aligned totals
+        eng.chsha_batch(torch.from_numpy(msgs).cuda(), 63 if stride >= 63 else 1)
+
+
 # ------------------------------------------------------------------------------------------------ cache_test
 @pytest.mark.parametrize("n,na", [(600, 333), (37, 100), (64, 65), (1, 5), (2048, 7)])
 @pytest.mark.parametrize("replicas", [3, 2, 1])
@@ -460,6 +512,7 @@ _DRIVERS = {
     "mm_coast": "Error?: 0",                        # tests/mm_common/mm_tmr.c:40
     "matrixMultiply_coast": "Number of errors: 0",  # tests/matrixMultiply/matrixMultiply.c:157, unittest/cfg/full.yml:3
     "cacheTest_coast": "0\n",                       # tests/cache_test/cacheTest.c:213 prints local_errors
+    "chstone_sha_coast": "RESULT: PASS",            # tests/chstone/sha/sha_driver.c:63, unittest/cfg/full.yml:5-6
 }
 
 
@@ -494,7 +547,8 @@ _OPT_PASSES = ["", "-DWC", "-TMR", "-TMR -countErrors", "-DWC -noMemReplication"
                "-TMR -noMemReplication -noStoreAddrSync"]
 
 
-@pytest.mark.parametrize("binary", ["matrixMultiply_coast", "crc16_coast", "aes_coast", "cacheTest_coast"])  # full.yml:1-14 on this path
+@pytest.mark.parametrize("binary", ["matrixMultiply_coast", "crc16_coast", "aes_coast", "cacheTest_coast",
+                                    "chstone_sha_coast"])  # full.yml:1-14 on this path
 def test_reference_flag_matrix_clean_runs(binary):
     """unittest/unittest.py runs every benchmark under every OPT_PASSES entry and greps the output: same here."""
     import os

@@ -99,6 +99,14 @@ def main():
 
         mn, av = timeit(default_mode)
         res["mm256_default_mode_memx3"] = {"ms": mn, "elems_per_s": batch * n * n / mn * 1e3}
+    if want("chsha"):
+        nm, ln = 1 << 17, 16384  # 2 GiB of messages of the benchmark's size (2 x 8192 bytes)
+        msgs = torch.randint(0, 256, (nm, ln), dtype=torch.uint8, device="cuda", generator=g)
+        for rep in (3, 2, 1):
+            cfg = coast_amd.XmrConfig(rep)
+            mn, av = timeit(lambda: eng.chsha_batch(msgs, ln, cfg=cfg))
+            res["chsha_128Kx16KiB_rep%d" % rep] = {"ms": mn, "GBs": nm * ln / mn * 1e-6, "msgs_per_s": nm / mn * 1e3}
+        del msgs
     if want("cache"):
         na, n = 1 << 20, 600
         arr = torch.arange(n, dtype=torch.int32, device="cuda").repeat(na, 1).contiguous()
