@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="mm", choices=["mm", "crc16", "sha256", "aes", "cache_test"])
+    ap.add_argument("--workload", default="mm", choices=["mm", "crc16", "sha256", "aes", "cache_test", "chsha"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU items per step (0 = the BASELINE config's size)")
     ap.add_argument("--side", type=int, default=256)
     ap.add_argument("--faults", type=int, default=-1,
@@ -120,6 +120,11 @@ def cpu_baseline_items(kind, budget_s=10.0):
         reps, dt = _time_budget(lambda: orc.sha256_xmr(msgs, 64, replicas=3), budget_s)
         return {"value": reps * msgs.shape[0] / dt, "unit": "msgs/s", "cores": 1, "kind": "port",
                 "sample": "%d x 32768 messages x 64 B, oracle TMR model, gcc -O3, %.1f s" % (reps, dt)}
+    if kind == "chsha":
+        msgs = rng.integers(0, 256, (1 << 9, 16384), dtype=np.uint8)
+        reps, dt = _time_budget(lambda: orc.chsha_xmr(msgs, 16384, replicas=3), budget_s)
+        return {"value": reps * msgs.size / dt * 1e-9, "unit": "GB/s", "cores": 1, "kind": "port",
+                "sample": "%d x 512 messages x 16 KiB, oracle TMR model, gcc -O3, %.1f s" % (reps, dt)}
     if kind == "cache_test":
         arrs = np.tile(np.arange(600, dtype=np.int32), (1 << 13, 1))
         reps, dt = _time_budget(lambda: orc.cache_test_xmr(arrs, replicas=3), budget_s)
@@ -395,7 +400,55 @@ class CacheTest(Workload):
         return cpu_baseline_items("cache_test")
 
 
-WORKLOADS = {"mm": MM, "crc16": CRC16, "sha256": SHA256, "aes": AES, "cache_test": CacheTest}
+class ChSha(Workload):
+    metric = "protected bytes/sec + corrected-fault count, CHStone sha TMR"
+    unit = "GB/s"
+    dtype = "u32"
+
+    def __init__(self, a, eng, dev, rank, coast_amd):
+        self.len = 16384                  # the benchmark's message: 2 x 8192 bytes, tests/chstone/sha/sha.h:59-60
+        self.nm = a.batch or (1 << 18)    # 256 Ki messages = 4 GiB per GPU
+        g = torch.Generator(device=dev).manual_seed(21 + rank)
+        self.msgs = torch.randint(0, 256, (self.nm, self.len), dtype=torch.uint8, device=dev, generator=g)
+        self.out = torch.empty((self.nm, 5), dtype=torch.int32, device=dev)
+        self.cfg = coast_amd.XmrConfig(coast_amd.TMR)
+        self.eng, self.ca = eng, coast_amd
+        rng = np.random.default_rng(5 + rank)
+        items = rng.choice(self.nm, a.faults, replace=False)
+        self.faults = coast_amd.make_faults([(int(it), int(rng.integers(0, 3)), coast_amd.SITE_CHSHA_WV,
+                                              int(rng.integers(0, 257 * 80)), int(rng.integers(0, 32)), int(rng.integers(0, 5)))
+                                             for it in items])
+        self.units_per_step = self.nm * self.len * 1e-9  # GB
+
+    def launch(self):
+        self.eng.chsha_batch(self.msgs, self.len, out=self.out, cfg=self.cfg)
+
+    def check(self):
+        ref = self.eng.chsha_batch(self.msgs[:1024], self.len, cfg=self.ca.XmrConfig(self.ca.UNPROTECTED))
+        return bool(torch.equal(ref, self.out[:1024]))
+
+    def config(self, world):
+        return {"workload": "CHStone sha, %d-byte messages TMR, %.1f GiB/GPU, %d injected single-bit faults/GPU/step"
+                            % (self.len, self.nm * self.len / 2**30, len(self.faults)),
+                "msg_len": self.len, "msgs_per_gpu": self.nm, "replicas": 3,
+                "parallelism": "dp%d (independent messages)" % world}
+
+    def roofline(self, kern_ms):
+        # per 64-byte block and lane: 80 rounds x (2 v_bitop3 + 1 v_xor + 2 v_alignbit + 2 v_add3) at their measured issue
+        # costs (2.44 / 2.7 / 4.2 / 4.2 cycles per wave-instruction, profiles/microbench_r01.txt) = 1952 cycles per wave
+        # for 21 messages x 64 bytes (TMR): 0.69 B/cycle/SIMD
+        b = float(self.nm) * self.len
+        t = kern_ms * 1e-3
+        ceiling = 21 * 64 / 1952.0 * 1024 * 2.1e9
+        return {"bound": "valu", "kernel": "chsha_kernel<3,false>", "achieved": b / t * 1e-9, "peak": ceiling * 1e-9,
+                "unit": "GB/s (instruction-mix ceiling of the 80-round transform at 2.1 GHz)", "frac": b / t / ceiling,
+                "kernel_ms": kern_ms, "algorithmic_bytes": b, "hbm_frac": b / t * 1e-9 / HBM_PEAK_GBS}
+
+    def cpu(self):
+        return cpu_baseline_items("chsha")
+
+
+WORKLOADS = {"mm": MM, "crc16": CRC16, "sha256": SHA256, "aes": AES, "cache_test": CacheTest, "chsha": ChSha}
 
 
 def pmc_traffic(workload, cfg):

@@ -30,7 +30,7 @@ MODES = {"TMR": coast_amd.TMR, "DWC": coast_amd.DWC, "NONE": coast_amd.UNPROTECT
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("-b", "--benchmark", default="mm", choices=["mm", "sha256", "aes", "crc16", "cache_test"])
+    ap.add_argument("-b", "--benchmark", default="mm", choices=["mm", "sha256", "aes", "crc16", "cache_test", "chsha"])
     ap.add_argument("-m", "--mode", default="TMR", choices=list(MODES))
     ap.add_argument("-t", "--runs", type=int, default=5000)
     ap.add_argument("--seed", type=int, default=0)
@@ -86,6 +86,21 @@ def main():
         eng.inject_faults(coast_amd.make_faults(rows))
         eng.aes128_batch(st, key, 0, cfg=cfg, detected=det)
         bad = (st != gs).any(dim=1) | (key != gk).any(dim=1)
+        flagged = det.bool()
+    elif a.benchmark == "chsha":
+        ln = 192  # three data blocks + the padding block per run
+        msgs = torch.randint(0, 256, (runs, ln), dtype=torch.uint8, device="cuda", generator=g)
+        gold = eng.chsha_batch(msgs, ln, cfg=clean)
+        rows = []
+        for run in range(runs):
+            site = int(rng.choice([coast_amd.SITE_CHSHA_W, coast_amd.SITE_CHSHA_WV, coast_amd.SITE_CHSHA_DIGEST]))
+            step = int(rng.integers(0, 4)) if site == coast_amd.SITE_CHSHA_DIGEST else int(rng.integers(0, 4 * 80))
+            rows.append((run, int(rng.integers(0, nrep)), site, step, int(rng.integers(0, 32)), int(rng.integers(0, 5))))
+        det = torch.zeros(runs, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(coast_amd.make_faults(rows))
+        out = eng.chsha_batch(msgs, ln, cfg=cfg, detected=det)
+        bad = (out != gold).any(dim=1)
         flagged = det.bool()
     elif a.benchmark == "cache_test":
         n = 600  # data_array_elements, cacheTest.c:78
