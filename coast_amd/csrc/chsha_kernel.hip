@@ -174,7 +174,18 @@ __global__ __launch_bounds__(256) void chsha_kernel(const uint8_t *__restrict__ 
                         dg[w] ^= 1u << (df.bit & 31u);
             });
         }
-        chsha_transform<HOOKS>(dg, W, c, tf, slot, lm.r, lm.live);
+        // only a transform that an armed fault points into pays for the hooks (wave-uniform: the table is the tile's)
+        bool hooked = false;
+        if constexpr (HOOKS) {
+            tf.each([&](const DevFault &df) {
+                if ((df.site == SITE_CHSHA_W || df.site == SITE_CHSHA_WV) && df.step / 80u == c)
+                    hooked = true;
+            });
+        }
+        if (HOOKS && hooked)
+            chsha_transform<true>(dg, W, c, tf, slot, lm.r, lm.live);
+        else
+            chsha_transform<false>(dg, W, c, tf, slot, lm.r, lm.live);
 #pragma unroll
         for (int w = 0; w < 5; ++w) // sha_info_digest[w] += ... are stores: store-data sync
             dg[w] = xmr_store_sync<NREP>(dg[w], lm, cnt, tl);
