@@ -10,6 +10,8 @@
  *                                                      `data_array_elements` is a macro, :78)
  *   void coast_dropin_sha_stream(indata, in_i, vsize, block_size, digest)   target of chsha_glue.c (CHStone sha_stream,
  *                                                      tests/chstone/sha/sha.c:174-186; VSIZE / BLOCK_SIZE are macros)
+ *   int  coast_dropin_chstone_aes(statemt, key, type, dir)   target of chaes_glue.c (CHStone encrypt / decrypt,
+ *                                                      tests/chstone/aes/aes_enc.c:67, aes_dec.c:66)
  *   void coast_dropin_matrix_multiply(f, s, r, side)   target of the per-benchmark glue TU (matrix_multiply's `side`
  *                                                      is a macro, tests/mm_common/mm_tmr.c:10, so it is not in its ABI)
  *   TMR_ERROR_CNT, __SYNC_COUNT      the globals the pass emits (synchronization.cpp:269-294, :103-121); weak, because
@@ -287,4 +289,29 @@ void coast_dropin_sha_stream(const unsigned char *indata, const int *in_i, int v
     for (int w = 0; w < 5; ++w)
         digest[w] = dg[w];
     dropin_account();
+}
+
+/* CHStone aes: encrypt / decrypt (tests/chstone/aes/aes_enc.c:67-134, aes_dec.c:66-140) keep the block and the key as one
+ * byte per int.  The benchmark runs type 128128 only (aes.c:93-94: AES-128, 128-bit block); that is FIPS-197 AES-128, the
+ * same function as aes_enc_dec, so the block goes through the protected AES engine (the key buffer it consumes is a copy:
+ * CHStone expands the key into `word` and leaves `key` alone).  Returns the state in the caller's int array; the glue prints
+ * and checks it the way the two functions do.  Other Rijndael sizes of the `type` switch are not served. */
+int coast_dropin_chstone_aes(int *statemt, const int *key, int type, int dir)
+{
+    if (type != 128128)
+        dropin_fail("CHStone aes (only type 128128 = AES-128 is served)", COAST_EINVAL);
+    coast_cfg cfg = dropin_cfg();
+    unsigned char st[16], k[16];
+    for (int i = 0; i < 16; ++i) {
+        st[i] = (unsigned char)statemt[i];
+        k[i] = (unsigned char)key[i];
+    }
+    dropin_maybe_inject();
+    const int rc = coast_aes_enc_dec_host(st, k, (uint8_t)(dir != 0), &cfg);
+    if (rc)
+        dropin_fail("CHStone aes", rc);
+    for (int i = 0; i < 16; ++i)
+        statemt[i] = st[i];
+    dropin_account();
+    return 0;
 }

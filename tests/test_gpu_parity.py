@@ -513,6 +513,9 @@ _DRIVERS = {
     "matrixMultiply_coast": "Number of errors: 0",  # tests/matrixMultiply/matrixMultiply.c:157, unittest/cfg/full.yml:3
     "cacheTest_coast": "0\n",                       # tests/cache_test/cacheTest.c:213 prints local_errors
     "chstone_sha_coast": "RESULT: PASS",            # tests/chstone/sha/sha_driver.c:63, unittest/cfg/full.yml:5-6
+    # tests/chstone/aes: the whole stdout of the reference binary, byte for byte (captured from the gcc build of the sources)
+    "chstone_aes_coast": "encrypted message \t3925841d02dc09fbdc118597196a0b32\ndecrypto message\t"
+                         "3243f6a8885a308d313198a2e0370734RESULT: PASS\n",
 }
 
 
@@ -548,7 +551,7 @@ _OPT_PASSES = ["", "-DWC", "-TMR", "-TMR -countErrors", "-DWC -noMemReplication"
 
 
 @pytest.mark.parametrize("binary", ["matrixMultiply_coast", "crc16_coast", "aes_coast", "cacheTest_coast",
-                                    "chstone_sha_coast"])  # full.yml:1-14 on this path
+                                    "chstone_sha_coast", "chstone_aes_coast"])  # full.yml:1-14 on this path
 def test_reference_flag_matrix_clean_runs(binary):
     """unittest/unittest.py runs every benchmark under every OPT_PASSES entry and greps the output: same here."""
     import os
