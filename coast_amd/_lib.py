@@ -20,7 +20,15 @@ class CoastCfg(C.Structure):
 
 class CoastStats(C.Structure):
     _fields_ = [("errors_corrected", C.c_uint64), ("sync_count", C.c_uint64), ("dwc_detected", C.c_uint64),
-                ("launches", C.c_uint64)]
+                ("launches", C.c_uint64), ("kernel_ms", C.c_double), ("hbm_bytes", C.c_double)]
+
+
+class CoastLaunchInfo(C.Structure):
+    _fields_ = [("engine", C.c_uint32), ("reserved", C.c_uint32), ("general_blocks", C.c_uint64),
+                ("fast_blocks", C.c_uint64), ("armed_faults", C.c_uint64), ("algorithmic_bytes", C.c_double)]
+
+
+ENGINE_NAMES = {0: "none", 1: "valu", 2: "matrix_core", 3: "stepwise", 4: "vote"}
 
 
 # every symbol include/coast_hip.h declares (tests check the library exports all of them)
@@ -34,6 +42,9 @@ SYMBOLS = {
     "coast_reduce_counters": (C.c_int, [C.c_void_p]),
     "coast_read_stats": (C.c_int, [C.c_void_p, C.POINTER(CoastStats)]),
     "coast_reset_stats": (C.c_int, [C.c_void_p]),
+    "coast_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "coast_last_launch_info": (C.c_int, [C.c_void_p, C.POINTER(CoastLaunchInfo)]),
+    "coast_source_hash": (C.c_char_p, []),
     "coast_inject_faults": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "coast_mm_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t,
                                  C.POINTER(CoastCfg), C.c_void_p]),
@@ -77,14 +88,15 @@ def load():
     if _lib is not None:
         return _lib
     path = lib_path()
-    if not os.path.exists(path):
-        # a fresh checkout: compile the HIP library in-tree (still the native path -- there is nothing to fall back to)
-        try:
-            _build.build()
-        except Exception as e:  # no hipcc, compile error ...
-            raise CoastLibraryError(
-                "%s is missing and could not be built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`. "
-                "coast_amd has no CPU fallback." % (path, e)) from e
+    # A fresh checkout or edited sources: (re)compile the HIP library in-tree -- still the native path, there is nothing
+    # to fall back to.  build() is a no-op when the library was built from exactly these sources (content hash, not
+    # mtimes: the prebuilt .so travels to the GPU box with the snapshot).
+    try:
+        _build.build()
+    except Exception as e:  # no hipcc, compile error ...
+        raise CoastLibraryError(
+            "%s is missing or stale and could not be built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "coast_amd has no CPU fallback." % (path, e)) from e
     try:
         L = C.CDLL(path)
     except OSError as e:
@@ -96,5 +108,9 @@ def load():
             raise CoastLibraryError("%s does not export %s" % (path, name)) from e
         fn.restype = res
         fn.argtypes = args
+    want = _build.source_hash()
+    got = L.coast_source_hash().decode()
+    if got != want:
+        raise CoastLibraryError("%s was built from other sources (library %s, tree %s): rebuild it" % (path, got, want))
     _lib = L
     return L

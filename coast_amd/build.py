@@ -4,6 +4,7 @@ hipcc cross-compiles without a GPU, so this is also the driver's "does it build"
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -31,6 +32,26 @@ def _newer(target: str, sources) -> bool:
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def source_hash() -> str:
+    """Content hash of everything libcoast_hip.so / libcoast_dropin.so are compiled from.  It is compiled into the library
+    (coast_source_hash()), so a stale binary is detected wherever the tree travels."""
+    h = hashlib.sha256()
+    for path in sources():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _stamp_ok(want: str) -> bool:
+    """the hash is a string constant inside the library: no side file to lose"""
+    try:
+        with open(LIB, "rb") as fh:
+            return want.encode() in fh.read()
+    except OSError:
+        return False
+
+
 def sources():
     out = [os.path.join(HERE, "..", "include", "coast_hip.h")]
     for f in sorted(os.listdir(CSRC)):
@@ -41,15 +62,16 @@ def sources():
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = sources()
-    if force or _newer(LIB, srcs):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB,
-               os.path.join(CSRC, "coast_hip.hip")]
+    want = source_hash()
+    stale = force or not os.path.exists(LIB) or not _stamp_ok(want)
+    if stale:
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
+               '-DCOAST_SOURCE_HASH="%s"' % want, "-o", LIB, os.path.join(CSRC, "coast_hip.hip")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     dropin_src = os.path.join(CSRC, "dropin.c")
-    if os.path.exists(dropin_src) and (force or _newer(DROPIN, [dropin_src, LIB])):
+    if os.path.exists(dropin_src) and (stale or not os.path.exists(DROPIN) or not os.path.exists(DROPIN_OBJ)):
         cmd = ["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-I", os.path.join(HERE, "..", "include"), "-o", DROPIN,
                dropin_src, "-L", LIBDIR, "-lcoast_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:

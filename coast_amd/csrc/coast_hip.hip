@@ -57,12 +57,26 @@ struct coast_ctx {
         size_t blocksCap = 0;
         hipEvent_t evConsumed = nullptr; // main -> side: the kernels reading this buffer have finished
         bool consumedPending = false;
+        hipEvent_t evUploaded = nullptr; // side: the H2D copies out of hPinned / hBlocks have finished
+        bool uploadPending = false;
     } fb[2];
     unsigned armCount = 0; // armed launches so far; selects the buffer
     int curBuf = 0;
 
     uint16_t *dCrcTable = nullptr; // 64 Ki x u16 two-byte-step table of the crc16 stream kernel
     int numCUs = 256;
+
+    coast_launch_info last = {};   // what the most recent protected launch dispatched to
+    double hbmBytes = 0.0;         // algorithmic HBM bytes of the launches since the last reset
+    // Optional kernel timing (coast_set_profiling): a pair of timing events around every protected launch on the
+    // context's stream, folded into kernelMs whenever the stream is known to be idle.
+    bool profiling = false;
+    struct EvPair {
+        hipEvent_t a, b;
+    };
+    std::vector<EvPair> evPending, evFree;
+    double kernelMs = 0.0;
+    bool evOpen = false;
 
     std::string err;
 };
@@ -108,8 +122,8 @@ typedef bool (*decode_fn)(const coast_fault &, const void *geom, DevFault &);
 
 // Upload the armed faults for a launch of `nblocks` workgroups.  Runs entirely on the side stream; the main stream
 // waits on evArmed.  Returns haveFaults (0/1) through *have.
-int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, FaultTab *ft, int *have,
-               const uint32_t **dBlockList = nullptr, uint32_t *nFaultBlocks = nullptr)
+int arm_faults_impl(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, FaultTab *ft, int *have,
+                    const uint32_t **dBlockList, uint32_t *nFaultBlocks, bool fullKeyOrder)
 {
     *have = 0;
     if (dBlockList)
@@ -120,26 +134,54 @@ int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, 
     ft->range = nullptr;
     if (c->armed.empty())
         return COAST_OK;
+    // The armed list is consumed by exactly one launch -- but only once its table is safely enqueued: if anything below
+    // fails, the faults stay armed for the caller's retry.
+    struct Restore {
+        coast_ctx *c;
+        std::vector<coast_fault> taken;
+        bool commit = false;
+        ~Restore()
+        {
+            if (!commit)
+                c->armed.insert(c->armed.begin(), taken.begin(), taken.end());
+        }
+    } guard{c, {}};
+    guard.taken.swap(c->armed);
     std::vector<DevFault> dv;
-    dv.reserve(c->armed.size());
-    for (const coast_fault &f : c->armed) {
+    dv.reserve(guard.taken.size());
+    for (const coast_fault &f : guard.taken) {
         DevFault d;
         if (dec(f, geom, d))
             dv.push_back(d);
     }
-    c->armed.clear(); // consumed by exactly one launch
-    if (dv.empty())
+    if (dv.empty()) {
+        guard.commit = true; // nothing in the list addresses this launch: dropped, as the oracle ignores them
         return COAST_OK;
-    std::stable_sort(dv.begin(), dv.end(), [](const DevFault &a, const DevFault &b) { return a.block < b.block; });
+    }
+    if (fullKeyOrder) // consumers that walk a workgroup's faults element by element, in program order of the upsets
+        std::stable_sort(dv.begin(), dv.end(), [](const DevFault &a, const DevFault &b) {
+            if (a.block != b.block)
+                return a.block < b.block;
+            if (a.local != b.local)
+                return a.local < b.local;
+            if (a.step != b.step)
+                return a.step < b.step;
+            return a.site < b.site;
+        });
+    else
+        std::stable_sort(dv.begin(), dv.end(), [](const DevFault &a, const DevFault &b) { return a.block < b.block; });
     std::vector<uint32_t> blocks;
     for (const DevFault &d : dv)
         if (blocks.empty() || blocks.back() != d.block)
             blocks.push_back(d.block);
 
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->side)); // pinned staging buffers free again (side work ends early in a launch)
-    c->curBuf = (int)(c->armCount++ & 1u);
-    coast_ctx::FaultBuf *b = &c->fb[c->curBuf];
+    const int nextBuf = (int)(c->armCount & 1u);
+    coast_ctx::FaultBuf *b = &c->fb[nextBuf];
+    if (b->uploadPending) { // this buffer's pinned staging area was last read by the upload two armed launches ago
+        HIP_TRY(c, hipEventSynchronize(b->evUploaded));
+        b->uploadPending = false;
+    }
     if (dv.size() > b->pinnedCap) {
         if (b->hPinned)
             HIP_TRY(c, hipHostFree(b->hPinned));
@@ -178,12 +220,18 @@ int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, 
     HIP_TRY(c, hipMemcpyAsync(b->dList, b->hPinned, dv.size() * sizeof(DevFault), hipMemcpyHostToDevice, c->side));
     memcpy(b->hBlocks, blocks.data(), blocks.size() * sizeof(uint32_t));
     HIP_TRY(c, hipMemcpyAsync(b->dBlocks, b->hBlocks, blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->side));
+    HIP_TRY(c, hipEventRecord(b->evUploaded, c->side));
+    b->uploadPending = true;
     HIP_TRY(c, hipMemsetAsync(b->dRange, 0, (size_t)nblocks * sizeof(uint2), c->side));
     const uint32_t k = (uint32_t)dv.size();
     hipLaunchKernelGGL(fault_range_kernel, dim3((k + 255) / 256), dim3(256), 0, c->side, b->dList, k, b->dRange);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->evArmed, c->side));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evArmed, 0));
+    c->curBuf = nextBuf;
+    c->armCount += 1;
+    guard.commit = true;
+    c->last.armed_faults = dv.size();
     ft->list = b->dList;
     ft->range = b->dRange;
     *have = 1;
@@ -194,10 +242,83 @@ int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, 
     return COAST_OK;
 }
 
-int after_launch(coast_ctx *c, int haveFaults)
+// Kernel timing (coast_set_profiling): fold every finished event pair into kernelMs.  `wait`: the stream is known to be idle
+// (or the pool is full), so block on the stragglers.
+int profile_fold(coast_ctx *c, bool wait)
+{
+    size_t keep = 0;
+    for (size_t i = 0; i < c->evPending.size(); ++i) {
+        coast_ctx::EvPair e = c->evPending[i];
+        if (wait)
+            HIP_TRY(c, hipEventSynchronize(e.b));
+        float ms = 0.f;
+        const hipError_t q = hipEventElapsedTime(&ms, e.a, e.b);
+        if (q == hipSuccess) {
+            c->kernelMs += (double)ms;
+            c->evFree.push_back(e);
+        } else if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            c->evPending[keep++] = e;
+        } else {
+            return fail(c, COAST_EHIP, "hipEventElapsedTime failed: %s", hipGetErrorString(q));
+        }
+    }
+    c->evPending.resize(keep);
+    return COAST_OK;
+}
+
+int profile_begin(coast_ctx *c)
+{
+    c->evOpen = false;
+    if (!c->profiling)
+        return COAST_OK;
+    if (c->evPending.size() >= 1024) {
+        int rc = profile_fold(c, true);
+        if (rc)
+            return rc;
+    }
+    coast_ctx::EvPair e;
+    if (!c->evFree.empty()) {
+        e = c->evFree.back();
+        c->evFree.pop_back();
+    } else {
+        HIP_TRY(c, hipEventCreate(&e.a));
+        HIP_TRY(c, hipEventCreate(&e.b));
+    }
+    HIP_TRY(c, hipEventRecord(e.a, c->stream));
+    c->evPending.push_back(e);
+    c->evOpen = true;
+    return COAST_OK;
+}
+
+// Every protected launch starts here: reset the launch record, upload the armed faults on the side stream (the main stream
+// waits for the table), open the timing bracket behind that wait.
+int arm_faults(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *geom, FaultTab *ft, int *have,
+               const uint32_t **dBlockList = nullptr, uint32_t *nFaultBlocks = nullptr, bool fullKeyOrder = false)
+{
+    c->last = coast_launch_info{};
+    int rc = arm_faults_impl(c, nblocks, dec, geom, ft, have, dBlockList, nFaultBlocks, fullKeyOrder);
+    if (rc)
+        return rc;
+    return profile_begin(c);
+}
+
+// ... and ends here.  engine / generalBlocks / fastBlocks: what was dispatched (coast_last_launch_info); algBytes: the
+// algorithmic HBM bytes of the launch (DESIGN.md section 4 gives the per-unit figures), accumulated into coast_stats.
+int after_launch(coast_ctx *c, int haveFaults, uint32_t engine = COAST_ENGINE_NONE, uint64_t generalBlocks = 0,
+                 uint64_t fastBlocks = 0, double algBytes = 0.0)
 {
     HIP_TRY(c, hipGetLastError());
     c->pendingLaunches += 1;
+    if (c->evOpen) {
+        HIP_TRY(c, hipEventRecord(c->evPending.back().b, c->stream));
+        c->evOpen = false;
+    }
+    c->last.engine = engine;
+    c->last.general_blocks = generalBlocks;
+    c->last.fast_blocks = fastBlocks;
+    c->last.algorithmic_bytes = algBytes;
+    c->hbmBytes += algBytes;
     if (haveFaults) {
         coast_ctx::FaultBuf *b = &c->fb[c->curBuf];
         HIP_TRY(c, hipEventRecord(b->evConsumed, c->stream));
@@ -210,6 +331,11 @@ int after_launch(coast_ctx *c, int haveFaults)
 
 // ------------------------------------------------------------------------------------------------ context
 extern "C" int coast_abi_version(void) { return COAST_HIP_ABI_VERSION; }
+
+#ifndef COAST_SOURCE_HASH
+#define COAST_SOURCE_HASH "unknown"
+#endif
+extern "C" const char *coast_source_hash(void) { return COAST_SOURCE_HASH; }
 
 extern "C" int coast_create(coast_ctx **out, int device)
 {
@@ -231,6 +357,8 @@ extern "C" int coast_create(coast_ctx **out, int device)
         bail(hipEventCreateWithFlags(&c->evArmed, hipEventDisableTiming)) ||
         bail(hipEventCreateWithFlags(&c->fb[0].evConsumed, hipEventDisableTiming)) ||
         bail(hipEventCreateWithFlags(&c->fb[1].evConsumed, hipEventDisableTiming)) ||
+        bail(hipEventCreateWithFlags(&c->fb[0].evUploaded, hipEventDisableTiming)) ||
+        bail(hipEventCreateWithFlags(&c->fb[1].evUploaded, hipEventDisableTiming)) ||
         bail(hipEventCreateWithFlags(&c->evMainReady, hipEventDisableTiming)) ||
         bail(hipEventCreateWithFlags(&c->evSideDone, hipEventDisableTiming)) ||
         bail(hipMalloc((void **)&c->dSlots, sizeof(unsigned long long) * kCounterSlots * kSlotStride)) ||
@@ -265,7 +393,14 @@ extern "C" void coast_destroy(coast_ctx *c)
             (void)hipFree(b.dBlocks);
         if (b.evConsumed)
             (void)hipEventDestroy(b.evConsumed);
+        if (b.evUploaded)
+            (void)hipEventDestroy(b.evUploaded);
     }
+    for (auto *v : {&c->evPending, &c->evFree})
+        for (coast_ctx::EvPair &e : *v) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
     if (c->dCrcTable)
         (void)hipFree(c->dCrcTable);
     (void)hipFree(c->dSlots);
@@ -321,6 +456,27 @@ extern "C" int coast_read_stats(coast_ctx *c, coast_stats *out)
     out->sync_count = h[1];
     out->dwc_detected = h[2];
     out->launches = h[3];
+    rc = profile_fold(c, true); // the stream is idle: every bracket has closed
+    if (rc)
+        return rc;
+    out->kernel_ms = c->kernelMs;
+    out->hbm_bytes = c->hbmBytes;
+    return COAST_OK;
+}
+
+extern "C" int coast_set_profiling(coast_ctx *c, int enable)
+{
+    if (!c)
+        return COAST_EINVAL;
+    c->profiling = enable != 0;
+    return COAST_OK;
+}
+
+extern "C" int coast_last_launch_info(const coast_ctx *c, coast_launch_info *out)
+{
+    if (!c || !out)
+        return COAST_EINVAL;
+    *out = c->last;
     return COAST_OK;
 }
 
@@ -332,6 +488,12 @@ extern "C" int coast_reset_stats(coast_ctx *c)
     HIP_TRY(c, hipMemsetAsync(c->dSlots, 0, sizeof(unsigned long long) * kCounterSlots * kSlotStride, c->stream));
     HIP_TRY(c, hipMemsetAsync(totals_of(c), 0, sizeof(unsigned long long) * 4, c->stream));
     c->pendingLaunches = 0;
+    // timing brackets still in flight belong to the period being discarded
+    for (coast_ctx::EvPair &e : c->evPending)
+        c->evFree.push_back(e);
+    c->evPending.clear();
+    c->kernelMs = 0.0;
+    c->hbmBytes = 0.0;
     return COAST_OK;
 }
 
@@ -375,6 +537,27 @@ bool decode_mm(const coast_fault &f, const void *gp, DevFault &d)
     return true;
 }
 
+// side 256 on the matrix cores: workgroup = 64 rows of one matrix, element = (row in the panel, column)
+bool decode_mm_mfma(const coast_fault &f, const void *gp, DevFault &d)
+{
+    const MmHostGeom &h = *(const MmHostGeom *)gp;
+    const uint64_t nn = (uint64_t)h.g.n * h.g.n;
+    if (f.item >= nn * h.batch || f.replica >= h.replicas)
+        return false;
+    if (f.site > COAST_SITE_MM_OPB || f.step > (uint32_t)h.g.n)
+        return false;
+    const uint64_t mat = f.item / nn, e = f.item % nn;
+    const uint32_t i = (uint32_t)(e / h.g.n), j = (uint32_t)(e % h.g.n);
+    d.block = (uint32_t)(mat * (uint64_t)(h.g.n / 64) + i / 64u);
+    d.local = ((i % 64u) << 8) | j;
+    d.step = f.step;
+    d.replica = f.replica;
+    d.site = f.site;
+    d.bit = f.bit;
+    d.index = f.index;
+    return true;
+}
+
 } // namespace
 
 extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t *d_s, uint32_t *d_r, int n,
@@ -387,6 +570,9 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
         return COAST_OK; // an empty batch is a no-op (armed faults stay armed for the next real launch)
     if (!d_f || !d_s || !d_r || n < 1 || n > 4096)
         return fail(c, COAST_EINVAL, "coast_mm_batch: bad pointers or side %d (1..4096)", n);
+    if ((((uintptr_t)d_f | (uintptr_t)d_s | (uintptr_t)d_r) & ((n & 3) == 0 ? 15u : 3u)) != 0)
+        return fail(c, COAST_EINVAL, "coast_mm_batch: f, s, r must be %d-byte aligned for side %d (16-byte vector accesses "
+                                     "when the side is a multiple of 4)", (n & 3) == 0 ? 16 : 4, n);
     HIP_TRY(c, hipSetDevice(c->device));
 
     MmHostGeom h;
@@ -423,17 +609,27 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
         return fail(c, COAST_EINVAL, "coast_mm_batch: %llu workgroups exceed the grid limit", (unsigned long long)nb);
     g.nblocks = (uint32_t)nb;
 
+    // extra sync points, or -noStoreDataSync: every workgroup takes the stepwise kernel
+    const bool allGeneral = cfg->sync_every != 0 || cfg->flags != 0;
+    // side 256: the int8-MFMA limb kernel, injector hooks included; COAST_MM_ENGINE=valu selects the v_mad_u64_u32 kernels
+    const char *eng = getenv("COAST_MM_ENGINE");
+    const bool mfma = n == 256 && !allGeneral && !(eng && !strcmp(eng, "valu"));
+    const uint64_t nbm = (uint64_t)(n / 64) * batch; // workgroups of the panel kernel: 64 rows of one matrix each
+
     FaultTab ft;
     int have = 0;
     const uint32_t *dBlockList = nullptr;
     uint32_t nFaultBlocks = 0;
-    rc = arm_faults(c, g.nblocks, decode_mm, &h, &ft, &have, &dBlockList, &nFaultBlocks);
+    if (mfma)
+        rc = arm_faults(c, (uint32_t)nbm, decode_mm_mfma, &h, &ft, &have, nullptr, nullptr, true);
+    else
+        rc = arm_faults(c, g.nblocks, decode_mm, &h, &ft, &have, &dBlockList, &nFaultBlocks);
     if (rc)
         return rc;
     Counters ctr{c->dSlots, cfg->flags};
     const dim3 block(256);
-    // extra sync points, or -noStoreDataSync: every workgroup takes the stepwise kernel
-    const bool allGeneral = cfg->sync_every != 0 || cfg->flags != 0;
+    uint32_t engine = COAST_ENGINE_VALU;
+    uint64_t generalBlocks = 0, fastBlocks = g.nblocks;
 #define LAUNCH_FAST(R, V, K)                                                                                    \
     do {                                                                                                        \
         if (lds > 64 * 1024)                                                                                    \
@@ -453,12 +649,29 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     } while (0)
 #define LAUNCH_MM(R)                                                                                            \
     do {                                                                                                        \
+        if (mfma) { /* armed upsets are applied and out-voted inside the panel kernel: no VALU workgroup runs */ \
+            using GP = MmPanel<R>;                                                                              \
+            static_assert(GP::BPM == 256 / 64, "panel geometry");                                               \
+            HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_panel_kernel<R>,                               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)GP::LDS_BYTES));    \
+            FaultTab ftm = ft;                                                                                  \
+            if (!have)                                                                                          \
+                ftm.list = nullptr, ftm.range = nullptr;                                                        \
+            hipLaunchKernelGGL(mm_mfma_panel_kernel<R>, dim3((uint32_t)nbm), dim3(GP::NTHR), GP::LDS_BYTES,     \
+                               c->stream, d_f, d_s, d_r, (uint32_t)nbm, ctr, ftm, d_detected);                  \
+            engine = COAST_ENGINE_MATRIX_CORE;                                                                  \
+            fastBlocks = nbm;                                                                                   \
+            break;                                                                                              \
+        }                                                                                                       \
         if (lds > 64 * 1024)                                                                                    \
             HIP_TRY(c, hipFuncSetAttribute((const void *)mm_general_kernel<R>,                                  \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
         if (allGeneral) {                                                                                       \
             hipLaunchKernelGGL(mm_general_kernel<R>, dim3(g.nblocks), block, lds, c->stream, d_f, d_s, d_r, g,  \
                                cfg->sync_every, ctr, ft, (const uint32_t *)nullptr, d_detected);                \
+            engine = COAST_ENGINE_STEPWISE;                                                                     \
+            generalBlocks = g.nblocks;                                                                          \
+            fastBlocks = 0;                                                                                     \
         } else {                                                                                                \
             const bool sideGeneral = have && nFaultBlocks;                                                      \
             if (sideGeneral) { /* faulted workgroups: stepwise kernel on the side stream, beside the fast one */ \
@@ -467,19 +680,10 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
                 hipLaunchKernelGGL(mm_general_kernel<R>, dim3(nFaultBlocks), block, lds, c->side, d_f, d_s,     \
                                    d_r, g, 0u, ctr, ft, dBlockList, d_detected);                                \
                 HIP_TRY(c, hipEventRecord(c->evSideDone, c->side));                                             \
+                generalBlocks = nFaultBlocks;                                                                   \
+                fastBlocks = g.nblocks - nFaultBlocks;                                                          \
             }                                                                                                   \
-            /* side 256: the int8-MFMA limb kernel; COAST_MM_ENGINE=valu selects the v_mad_u64_u32 kernel instead */   \
-            const char *eng = getenv("COAST_MM_ENGINE");                                                        \
-            const bool mfma = !(eng && !strcmp(eng, "valu"));                                                   \
-            if (n == 256 && mfma && g.bpm == MmPanel<R>::V_BPM) {                                               \
-                using GP = MmPanel<R>;                                                                          \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_panel_kernel<R>,                           \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GP::LDS_BYTES)); \
-                const uint64_t nbm = (uint64_t)GP::BPM * batch;                                                 \
-                hipLaunchKernelGGL(mm_mfma_panel_kernel<R>, dim3((uint32_t)nbm), dim3(GP::NTHR), GP::LDS_BYTES, \
-                                   c->stream, d_f, d_s, d_r, (uint32_t)nbm, ctr,                                \
-                                   have ? ft.range : (const uint2 *)nullptr, d_detected);                       \
-            } else if (n == 256 && g.rs == Mm256<R>::RS && g.bpm == Mm256<R>::BPM)                             \
+            if (n == 256 && g.rs == Mm256<R>::RS && g.bpm == Mm256<R>::BPM)                                    \
                 hipLaunchKernelGGL(mm_fast256_kernel<R>, dim3(g.nblocks), block, Mm256<R>::LDS_BYTES, c->stream, \
                                    d_f, d_s, d_r, g, ctr, have ? ft.range : (const uint2 *)nullptr, d_detected); \
             else if ((n & 3) == 0)                                                                              \
@@ -499,7 +703,7 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
 #undef LAUNCH_FAST
 #undef LAUNCH_FAST_K
 #undef LAUNCH_MM
-    return after_launch(c, have);
+    return after_launch(c, have, engine, generalBlocks, fastBlocks, 12.0 * (double)n * (double)n * (double)batch);
 }
 
 // ------------------------------------------------------------------------------------------------ default mode
@@ -522,6 +726,12 @@ extern "C" int coast_sync_copies(coast_ctx *c, void *const *d_copies, int ncopie
     const uint64_t nvec = nwords / 4;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->numCUs * 8, std::max<uint64_t>(1, (nvec + 255) / 256));
     Counters ctr{c->dSlots, 0u};
+    c->last = coast_launch_info{};
+    {
+        int prc = profile_begin(c);
+        if (prc)
+            return prc;
+    }
     uint32_t *c0 = (uint32_t *)d_copies[0], *c1 = (uint32_t *)d_copies[1];
     uint32_t *c2 = ncopies == 3 ? (uint32_t *)d_copies[2] : nullptr;
     if (ncopies == 3)
@@ -530,7 +740,8 @@ extern "C" int coast_sync_copies(coast_ctx *c, void *const *d_copies, int ncopie
     else
         hipLaunchKernelGGL(sync_copies_kernel<2>, dim3(grid), dim3(256), 0, c->stream, c0, c1, c2, nwords,
                            (uint32_t *)d_voted, 0, ctr, d_detected);
-    return after_launch(c, 0);
+    return after_launch(c, 0, COAST_ENGINE_VOTE, 0, grid,
+                        (double)nbytes * (ncopies + (d_voted ? 1 : 0) + (scrub && ncopies == 3 ? ncopies : 0)));
 }
 
 extern "C" int coast_flip_memory(coast_ctx *c, void *d_ptr, size_t byte_offset, unsigned bit)

@@ -14,9 +14,19 @@
 // feeds all replicas"), so the NREP copies of r[i][j] come out of the matrix core in NREP adjacent lanes, each from its
 // own B registers and its own accumulators, and the voter is the same cross-lane exchange as everywhere else.  The A
 // operand (rows of f) is shared by all output columns of the instruction -- it is common-mode, like the LDS copy it was
-// read from (memory is outside the sphere of replication in this mode).  Armed faults keep their exact semantics: the
-// VALU mm_general_kernel recomputes every workgroup-sized tile range that owns a fault, and this kernel neither stores nor
-// counts those elements.
+// read from (memory is outside the sphere of replication in this mode).
+//
+// Injector hooks (mm_patch_faults below).  The reference's fault model is a single-bit flip of a 32-bit register of ONE
+// replica at a step of the k loop: the `unsigned long sum` accumulator (mm_common_tmr.c:13) or one of the two loaded
+// operands.  The matrix core holds that accumulator as four int32 limb sums of 32-deep slabs, so there is no register to
+// flip at "k = 37"; but everything after the flip is linear mod 2^32, so the upset has an exact consequence on the
+// replica's recombined word and THAT is what the hook applies, in the replica's own lane, before the voter looks at it:
+//     ACC, step k < n :  v += (p ^ m) - p,  p = sum_{k'<k} f[i][k'] s[k'][j]  (+ the replica's earlier deltas)
+//     ACC, step n     :  v ^= m                                  (the register itself: the loop is over)
+//     OPA / OPB, step k: v += (a ^ ma)(b ^ mb) - (a ^ ma')(b ^ mb')   (masks of this step before / after this fault)
+// The prefix p is recomputed by the wave on the VALU from the single memory copy (<= 4 MACs per lane).  From there on the
+// kernel is on its own: `bad` sees the disagreeing lanes, the select voter out-votes (or, for a double hit, does not), the
+// counters and per-item flags follow -- the VALU engine is not involved (coast_last_launch_info reports general_blocks 0).
 //
 // Tiling (MmPanel below).  A workgroup owns 64 rows of ONE matrix for ALL its columns: the rows' byte planes
 // (64 x 256 x 4 planes = 64 KB) are converted once -- 2 VALU ops per element + a 4x4 byte transpose with v_perm_b32 -- and stay
@@ -31,9 +41,8 @@
 //
 // Voter.  The common case costs 2 VALU per element: bad |= v ^ shl1(v) (DPP: the next lane's copy), and once per tile
 // bad |= shl1(bad) (OR distributes over the lane shift).  For replica 0, bad == 0 <=> all copies of all its elements agree,
-// and then the vote IS v.  Only when some lane of the wave saw a difference -- or an armed fault's VALU workgroup overlaps
-// the tile -- is the full compare-and-select voter (xmr_final_vote_vals, with its counters) run over the tile: same
-// result, same counts.
+// and then the vote IS v.  Only when some lane of the wave saw a difference is the full compare-and-select voter
+// (xmr_final_vote_vals, with its counters and per-item flags) run over the tile: same result, same counts.
 #include <type_traits>
 
 #include "xmr.hpp"
@@ -97,7 +106,7 @@ __device__ __forceinline__ void wave_lds_sync()
 template <int NREP>
 __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void mm_mfma_panel_kernel(
     const uint32_t *__restrict__ F, const uint32_t *__restrict__ S, uint32_t *__restrict__ R, uint32_t nblocks, Counters ctr,
-    const uint2 *__restrict__ faultRange, uint8_t *__restrict__ detected)
+    FaultTab ft, uint8_t *__restrict__ detected)
 {
     using G = MmPanel<NREP>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smemP[];
@@ -136,16 +145,13 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
         }
     }
 
-    // Armed faults: does any VALU workgroup range that overlaps this workgroup's 64 rows own one?  (wave-uniform; the
-    // fine per-tile test below runs only then)
-    bool blockArmed = false;
-    if (faultRange) {
-        const uint32_t rb64 = (uint32_t)row0 / 64u;
-        const uint32_t vbLo = (rb64 * 1024u) / (uint32_t)G::V_TPB, vbHi = (rb64 * 1024u + 1023u) / (uint32_t)G::V_TPB;
-        uint32_t any = 0;
-        for (uint32_t vb = vbLo + (uint32_t)lane; vb <= vbHi; vb += 64u)
-            any |= faultRange[mat * (uint32_t)G::V_BPM + vb].y;
-        blockArmed = __ballot(any != 0u) != 0ull;
+    // Armed faults of this workgroup's 64 x 256 elements: {first, count} in the table the injector sorted by
+    // (workgroup, element, step, site).  Wave-uniform; almost always count == 0.
+    uint32_t fFirst = 0, fCount = 0;
+    if (ft.range) {
+        const uint2 rg = ft.range[lb];
+        fFirst = __builtin_amdgcn_readfirstlane(rg.x);
+        fCount = __builtin_amdgcn_readfirstlane(rg.y);
     }
 
     // ---- this wave's work: column tiles wave, wave + NW, ... ; one pipeline step = one k slab of one tile
@@ -231,19 +237,88 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
                     bad |= v ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
             }
         }
-        if (NREP == 3) // OR distributes over the lane shift: one more exchange covers (replica 1 ^ replica 2) of every element
-            bad |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bad, 0x130, 0xf, 0xf, false);
-        uint32_t skip = 0;
-        if (blockArmed) { // rare: which of this lane's 8 row groups (4 rows each) lie in a VALU workgroup range with a fault
-            const int colc = col < G::N ? col : G::N - 1;
+        if (fCount != 0u) { // rare (wave-uniform): armed upsets somewhere in this workgroup's rows -- any in this tile?
+            bool hit = false;
+            uint32_t curKey = 0xffffffffu, curStep = 0xffffffffu;
+            uint32_t dsum[3] = {0u, 0u, 0u}, am[3] = {0u, 0u, 0u}, bm[3] = {0u, 0u, 0u};
+#pragma unroll 1
+            for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
+                const DevFault *fp = ft.list + q;
+                const uint32_t local = __builtin_amdgcn_readfirstlane(fp->local);
+                const int frow = (int)(local >> 8), fcol = (int)(local & 255u);
+                if (fcol < col0 || fcol >= col0 + G::CPW)
+                    continue;
+                const uint32_t fstep = __builtin_amdgcn_readfirstlane(fp->step);
+                const uint32_t packed = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(&fp->replica));
+                const uint32_t frep = packed & 0xffu, fsite = (packed >> 8) & 0xffu, m = 1u << ((packed >> 16) & 31u);
+                if (local != curKey) { // a new element: its replicas start from clean running deltas
+                    curKey = local;
+                    curStep = 0xffffffffu;
+                    dsum[0] = dsum[1] = dsum[2] = 0u;
+                }
+                if (fstep != curStep) { // operand masks belong to one MAC
+                    curStep = fstep;
+                    am[0] = am[1] = am[2] = bm[0] = bm[1] = bm[2] = 0u;
+                }
+                const uint32_t *fr = f + frow * G::N, *sc = s + fcol;
+                const uint32_t dprev = frep == 0u ? dsum[0] : frep == 1u ? dsum[1] : dsum[2];
+                uint32_t delta = 0u;
+                bool flipFinal = false;
+                if (fsite == (uint32_t)SITE_MM_ACC) {
+                    if (fstep >= (uint32_t)G::N) {
+                        flipFinal = true; // the loop is over: the register is the recombined word itself
+                    } else {
+                        uint32_t part = 0u; // this replica's accumulator before the MAC of k == step
+                        for (uint32_t k = (uint32_t)lane; k < fstep; k += 64u)
+                            part += fr[k] * sc[k * G::N];
+                        const uint32_t pfx = __builtin_amdgcn_readfirstlane(wave_sum(part)) + dprev;
+                        delta = (pfx ^ m) - pfx;
+                    }
+                } else if (fstep < (uint32_t)G::N) {
+                    const uint32_t a = __builtin_amdgcn_readfirstlane(fr[fstep]), bq = __builtin_amdgcn_readfirstlane(sc[fstep * G::N]);
+                    const uint32_t ma = frep == 0u ? am[0] : frep == 1u ? am[1] : am[2];
+                    const uint32_t mb = frep == 0u ? bm[0] : frep == 1u ? bm[1] : bm[2];
+                    const uint32_t ma2 = fsite == (uint32_t)SITE_MM_OPA ? ma ^ m : ma, mb2 = fsite == (uint32_t)SITE_MM_OPB ? mb ^ m : mb;
+                    delta = (a ^ ma2) * (bq ^ mb2) - (a ^ ma) * (bq ^ mb);
 #pragma unroll
-            for (int q4 = 0; q4 < 8; ++q4) {
-                const int row = row0 + (q4 >> 2) * 32 + 8 * (q4 & 3) + 4 * kh;
-                const uint32_t vb = mat * (uint32_t)G::V_BPM + (uint32_t)(((row >> 2) * 64 + (colc >> 2)) / G::V_TPB);
-                skip |= (faultRange[vb].y != 0u ? 1u : 0u) << q4;
+                    for (int rr = 0; rr < 3; ++rr)
+                        if (frep == (uint32_t)rr) {
+                            am[rr] = ma2;
+                            bm[rr] = mb2;
+                        }
+                } else {
+                    continue; // an operand of a MAC that never runs
+                }
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+                    if (frep == (uint32_t)rr)
+                        dsum[rr] += delta;
+                // the replica's lane and register: tile row -> (rb, e, kh) as in elemRow
+                const int tl32 = frow & 31;
+                const int tIdx = (frow >> 5) * 16 + (tl32 & 3) + 4 * (tl32 >> 3);
+                const bool mineLane = lane == ((tl32 >> 2) & 1) * 32 + (fcol - col0) * NREP + (int)frep;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t v = (uint32_t)acc[rb][0][e];
+                        const uint32_t nv = flipFinal ? v ^ m : v + delta;
+                        acc[rb][0][e] = (int)((mineLane && tIdx == rb * 16 + e) ? nv : v);
+                    }
+                hit = true;
+            }
+            if (hit && NREP > 1) { // the voter's quick look, again, on the upset registers
+                bad = 0;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        bad |= (uint32_t)acc[rb][0][e] ^ (uint32_t)__builtin_amdgcn_update_dpp(0, acc[rb][0][e], 0x130, 0xf, 0xf, false);
             }
         }
-        const bool slow = __ballot(writer && (skip != 0u || bad != 0u)) != 0ull; // wave-uniform
+        if (NREP == 3) // OR distributes over the lane shift: one more exchange covers (replica 1 ^ replica 2) of every element
+            bad |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bad, 0x130, 0xf, 0xf, false);
+        const bool slow = __ballot(writer && bad != 0u) != 0ull; // wave-uniform
         uint32_t *stage = reinterpret_cast<uint32_t *>(wbuf); // both slab buffers are idle: slab 7 was just consumed
         if (!slow) {
             wave_lds_sync();
@@ -273,9 +348,9 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
             }
             wave_lds_sync();
         } else {
-            // An upset was caught in this tile, or a VALU workgroup that owns an armed fault overlaps it (its elements belong
-            // to mm_general_kernel).  Rare, so compact rather than fast: eight elements of every lane at a time go through
-            // the wave's LDS, the full voter reads its two neighbours from there, element-wise stores.
+            // The copies of some element of this tile disagree: an upset was caught.  Rare, so compact rather than fast: eight
+            // elements of every lane at a time go through the wave's LDS, the full compare-and-select voter with its counters
+            // reads its two neighbours from there, element-wise stores.
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 const int rb = ch >> 1, eb = (ch & 1) * 8;
@@ -289,7 +364,7 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
                     const int e = eb + j, orow = elemRow(rb, e);
                     const uint32_t v = stage[j * 64 + lane], b = stage[j * 64 + ((lane + 1) & 63)],
                                    c = stage[j * 64 + ((lane + 2) & 63)];
-                    const bool mine = writer && !((skip >> (rb * 4 + (e >> 2))) & 1u);
+                    const bool mine = writer;
                     Tally te = tl;
                     te.det = 0;
                     const uint32_t voted = xmr_final_vote_vals<NREP>(v, b, c, mine, te);

@@ -96,10 +96,23 @@ class Engine:
         st = _lib.CoastStats()
         self._check(self._lib.coast_read_stats(self._h, C.byref(st)))
         return {"errors_corrected": int(st.errors_corrected), "sync_count": int(st.sync_count),
-                "dwc_detected": int(st.dwc_detected), "launches": int(st.launches)}
+                "dwc_detected": int(st.dwc_detected), "launches": int(st.launches),
+                "kernel_ms": float(st.kernel_ms), "hbm_bytes": float(st.hbm_bytes)}
 
     def reset_stats(self):
         self._check(self._lib.coast_reset_stats(self._h))
+
+    def set_profiling(self, on: bool = True):
+        """HIP timing events around every protected launch on the engine's stream -> stats()['kernel_ms']."""
+        self._check(self._lib.coast_set_profiling(self._h, int(bool(on))))
+
+    def last_launch(self) -> dict:
+        """What the most recent protected launch dispatched to (coast_last_launch_info)."""
+        li = _lib.CoastLaunchInfo()
+        self._check(self._lib.coast_last_launch_info(self._h, C.byref(li)))
+        return {"engine": _lib.ENGINE_NAMES.get(int(li.engine), str(li.engine)), "general_blocks": int(li.general_blocks),
+                "fast_blocks": int(li.fast_blocks), "armed_faults": int(li.armed_faults),
+                "algorithmic_bytes": float(li.algorithmic_bytes)}
 
     # -- protected regions
     def mm_batch(self, f, s, out=None, cfg: XmrConfig = XmrConfig(), detected=None):

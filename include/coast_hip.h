@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define COAST_HIP_ABI_VERSION 2 /* 2: coast_cfg.flags */
+#define COAST_HIP_ABI_VERSION 3 /* 2: coast_cfg.flags; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info, new flags/sites */
 
 enum {
     COAST_OK = 0,
@@ -70,7 +70,29 @@ typedef struct coast_stats {
     uint64_t sync_count;
     uint64_t dwc_detected;
     uint64_t launches;
+    double kernel_ms; /* GPU time of the protected launches since the last reset, measured with HIP events on the context's
+                       * stream around every launch; 0 unless coast_set_profiling(ctx, 1) */
+    double hbm_bytes; /* ALGORITHMIC HBM bytes of those launches (each input byte read once, each output byte written
+                       * once; per-unit figures in DESIGN.md section 4) -- hbm_bytes / kernel_ms is the roofline numerator */
 } coast_stats;
+
+/* What the most recent protected launch on a context dispatched to (a debugging / test aid: e.g. that a faulted side-256
+ * matrix_multiply was voted on the matrix cores and not handed to the stepwise VALU kernel). */
+enum {
+    COAST_ENGINE_NONE = 0,
+    COAST_ENGINE_VALU = 1,        /* lean lane-replicated kernel (+ the stepwise kernel beside it for `general_blocks`) */
+    COAST_ENGINE_MATRIX_CORE = 2, /* mm side 256: int8-MFMA limb kernel, injector hooks inside */
+    COAST_ENGINE_STEPWISE = 3,    /* every workgroup in the stepwise kernel (sync_every != 0, flags, unaligned rows ...) */
+    COAST_ENGINE_VOTE = 4         /* coast_sync_copies */
+};
+typedef struct coast_launch_info {
+    uint32_t engine;         /* COAST_ENGINE_* */
+    uint32_t reserved;
+    uint64_t general_blocks; /* workgroups / tiles run by the stepwise (hooked) kernel */
+    uint64_t fast_blocks;    /* workgroups / tiles run by the lean kernel */
+    uint64_t armed_faults;   /* single-bit flips the launch consumed */
+    double algorithmic_bytes;
+} coast_launch_info;
 
 /* Fault sites, replacing the QEMU/GDB injector's "random register" targets
  * (simulation/platform/resources/injector.py:163-167,237-260). */
@@ -111,6 +133,8 @@ int coast_create(coast_ctx **out, int device);
 void coast_destroy(coast_ctx *ctx);
 const char *coast_last_error(const coast_ctx *ctx);
 int coast_abi_version(void);
+/* content hash of the sources the library was compiled from (coast_amd/build.py compares it with the tree's) */
+const char *coast_source_hash(void);
 /* protected kernels run on `hip_stream` (a hipStream_t; NULL = the null stream) */
 int coast_set_stream(coast_ctx *ctx, void *hip_stream);
 /* Optional: totals are accumulated into the caller's device buffer of 4 x uint64
@@ -121,6 +145,9 @@ int coast_bind_counters(coast_ctx *ctx, uint64_t *d_totals);
 int coast_reduce_counters(coast_ctx *ctx);
 int coast_read_stats(coast_ctx *ctx, coast_stats *out); /* synchronises the stream */
 int coast_reset_stats(coast_ctx *ctx);
+/* bracket every protected launch with HIP timing events on the context's stream -> coast_stats.kernel_ms */
+int coast_set_profiling(coast_ctx *ctx, int enable);
+int coast_last_launch_info(const coast_ctx *ctx, coast_launch_info *out);
 
 /* ---- on-device fault injector (replaces simulation/platform/supervisor.py + injector.py) ----
  * Arms `k` single-bit flips for the NEXT protected launch on this context.  The descriptor table is written on
@@ -132,7 +159,9 @@ int coast_inject_faults(coast_ctx *ctx, const coast_fault *faults, size_t k);
 /* matrix_multiply (tests/mm_common/mm_common_tmr.c:3-20; LANL variant tests/matrixMultiply/matrixMultiply.c:95-112):
  * `batch` independent n x n row-major uint32 products, r = (uint32) sum_k f[i][k]*s[k][j].
  * n == 256 (the benchmark's side) runs on the int8 matrix cores (exact signed-byte limb decomposition of the 32-bit
- * products); every other side, and n == 256 under COAST_MM_ENGINE=valu, on the VALU kernels.  Same words, counters and flags.
+ * products; armed upsets are applied to the replica's lane and out-voted inside that kernel); every other side, and
+ * n == 256 under COAST_MM_ENGINE=valu, on the VALU kernels.  Same words, counters and flags.  f, s, r: 16-byte aligned
+ * when n is a multiple of 4.
  * d_detected (all batch entry points): optional, one byte per work item, set to 1 where a sync point of that item saw
  * unequal copies -- DWC: the compare that would have called FAULT_DETECTED_DWC(); TMR: a value was out-voted (the per-item
  * view of TMR_ERROR_CNT, what a campaign needs to classify a run as "fault corrected", jsonParser.py:162-186). */

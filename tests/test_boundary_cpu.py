@@ -28,19 +28,20 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libcoast_hip.so does not export %s" % n
     assert set(names) == set(_lib.SYMBOLS), "python binding and header disagree"
-    assert lib.coast_abi_version() == 2  # 2: coast_cfg.flags
+    assert lib.coast_abi_version() == 3  # 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info
 
 
 def test_header_compiles_as_c_and_layouts_match(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "coast_hip.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu\\n",'
-                   'sizeof(coast_fault),sizeof(coast_cfg),sizeof(coast_stats));return 0;}\n')
+    src.write_text('#include "coast_hip.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu %zu\\n",'
+                   'sizeof(coast_fault),sizeof(coast_cfg),sizeof(coast_stats),sizeof(coast_launch_info));return 0;}\n')
     exe = tmp_path / "t"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     from coast_amd import _lib
 
-    assert sizes == [_lib.FAULT_DTYPE.itemsize, C.sizeof(_lib.CoastCfg), C.sizeof(_lib.CoastStats)] == [16, 12, 32]
+    assert sizes == [_lib.FAULT_DTYPE.itemsize, C.sizeof(_lib.CoastCfg), C.sizeof(_lib.CoastStats),
+                     C.sizeof(_lib.CoastLaunchInfo)] == [16, 12, 48, 40]
     from oracle import oracle as orc
 
     assert orc.FAULT_DTYPE == _lib.FAULT_DTYPE  # the oracle and the product consume the same fault records

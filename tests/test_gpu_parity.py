@@ -180,6 +180,87 @@ def test_mm_256_mfma_and_valu_engines_vs_oracle(eng, orc, replicas, monkeypatch)
         assert (got == clean_r).all() and _stats3(eng.stats()) == clean_st, engine
 
 
+def _mm256_case(eng, orc, f, s, fl, replicas):
+    """one faulted launch on the matrix-core engine vs the oracle: words, counters, per-item flags -- and the proof that the
+    matrix-core kernel did the voting itself (no workgroup went to the stepwise VALU kernel)"""
+    import coast_amd
+    import torch
+
+    batch, n = f.shape[0], 256
+    exp_r, exp_st, exp_det = orc.mm_xmr(f, s, replicas=replicas, faults=fl)
+    det = torch.zeros(batch * n * n, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    got = _host(eng.mm_batch(_dev(f), _dev(s), cfg=coast_amd.XmrConfig(replicas), detected=det), np.uint32)
+    li = eng.last_launch()
+    assert li["engine"] == "matrix_core" and li["general_blocks"] == 0 and li["armed_faults"] == len(fl), li
+    assert (got == exp_r).all()
+    assert _stats3(eng.stats()) == exp_st
+    assert (det.cpu().numpy() == exp_det).all()
+    return got, exp_st
+
+
+def test_mm_256_mfma_voter_on_real_disagreement(eng, orc, monkeypatch):
+    """The headline kernel's own voter (mm_mfma_kernel.hip tileEnd): upsets applied to one / two / three replica lanes of
+    the matrix-core output, select semantics (a==b ? a : c, synchronization.cpp:934-938), +1 per voted value whose copies
+    differ (:1391-1443), DWC flags, every site and step class, collisions on one element -- all vs the oracle."""
+    import coast_amd
+
+    monkeypatch.setenv("COAST_MM_ENGINE", "mfma")
+    rng = np.random.default_rng(4242)
+    n = 256
+    f = rng.integers(0, 2**32, (2, n, n), dtype=np.uint32)
+    s = rng.integers(0, 2**32, (2, n, n), dtype=np.uint32)
+    clean, _, _ = orc.mm_xmr(f, s, replicas=3)
+    it = lambda b, i, j: b * n * n + i * n + j
+    ACC, OPA, OPB = 0, 1, 2
+    cases = {
+        "single replica, after the loop":        [(it(0, 3, 5), 1, ACC, n, 7)],
+        "single replica 0 (the writer's own copy)": [(it(0, 3, 5), 0, ACC, n, 31)],
+        "single replica 2":                       [(it(1, 255, 255), 2, ACC, n, 0)],
+        "mid-loop accumulator, k not a slab edge": [(it(0, 64, 9), 1, ACC, 37, 13)],
+        "accumulator at k = 0 (flip of zero)":    [(it(0, 65, 10), 2, ACC, 0, 30)],
+        "operand a":                              [(it(1, 100, 200), 0, OPA, 255, 19)],
+        "operand b":                              [(it(1, 31, 250), 1, OPB, 0, 4)],
+        "operands of a MAC that never runs":      [(it(0, 1, 1), 0, OPA, n, 3), (it(0, 1, 2), 1, OPB, n, 3)],
+        "two replicas hit identically: the wrong value wins the vote": [(it(0, 7, 7), 0, ACC, n, 9), (it(0, 7, 7), 1, ACC, n, 9)],
+        "replicas 0 and 2 differ from 1: c is taken unconditionally": [(it(0, 8, 30), 0, ACC, n, 3), (it(0, 8, 30), 2, ACC, n, 12)],
+        "all three replicas hit differently":     [(it(1, 9, 29), 0, ACC, n, 3), (it(1, 9, 29), 1, ACC, n, 4), (it(1, 9, 29), 2, ACC, n, 5)],
+        "two upsets of one replica, in step order": [(it(0, 200, 100), 1, ACC, 200, 5), (it(0, 200, 100), 1, ACC, 17, 5)],
+        "same MAC: a and b of one replica":       [(it(0, 63, 255), 2, OPA, 77, 1), (it(0, 63, 255), 2, OPB, 77, 30)],
+        "same operand twice: the flips cancel":   [(it(0, 63, 0), 0, OPA, 5, 8), (it(0, 63, 0), 0, OPA, 5, 8)],
+        "accumulator + operand at one step":      [(it(1, 128, 128), 1, OPB, 99, 2), (it(1, 128, 128), 1, ACC, 99, 31)],
+        "neighbouring elements of one tile row":  [(it(0, 40, 10), 2, ACC, n, 1), (it(0, 40, 11), 0, ACC, n, 1), (it(0, 40, 9), 1, ACC, 3, 1)],
+        "ragged last column tile":                [(it(1, 0, 250), 1, ACC, n, 2), (it(1, 63, 255), 0, ACC, 128, 2)],
+        "every row block of a matrix":            [(it(1, r, (r * 7) % n), r % 3, ACC, (r * 5) % (n + 1), r % 32) for r in range(0, n, 13)],
+    }
+    for name, rows in cases.items():
+        fl = coast_amd.make_faults(rows)
+        got, st = _mm256_case(eng, orc, f, s, fl, 3)
+        if name.startswith(("single", "mid-loop", "operand a", "operand b", "neighbouring", "ragged", "every row")):
+            assert (got == clean).all(), name  # every single-replica upset is out-voted
+        if name.startswith("two replicas hit identically"):
+            assert got.reshape(-1)[it(0, 7, 7)] == clean.reshape(-1)[it(0, 7, 7)] ^ (1 << 9), name
+            assert st["errors_corrected"] == 1, name  # a == b (both wrong), c differs: counted once, not corrected
+    # DWC: a compare, no correction -- the item is flagged, replica 0's (possibly wrong) value is stored
+    for rows in ([(it(0, 5, 5), 1, ACC, n, 3)], [(it(0, 5, 6), 0, ACC, 50, 3)], [(it(1, 70, 250), 0, OPA, 3, 3), (it(1, 70, 251), 1, OPB, 3, 3)]):
+        _mm256_case(eng, orc, f, s, coast_amd.make_faults(rows), 2)
+
+
+@pytest.mark.parametrize("replicas", [3, 2])
+def test_mm_256_mfma_dense_random_faults(eng, orc, replicas, monkeypatch):
+    """2000 random upsets over 3 matrices (about one per four tiles, collisions included), every site, matrix-core engine."""
+    monkeypatch.setenv("COAST_MM_ENGINE", "mfma")
+    rng = np.random.default_rng(900 + replicas)
+    batch, n = 3, 256
+    f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    fl = _rand_faults(rng, 2000, batch * n * n, replicas, [0, 1, 2], n)
+    # force collisions: several upsets on the same element / replica / step
+    extra = _rand_faults(rng, 200, 64, replicas, [0, 1, 2], 8)
+    _mm256_case(eng, orc, f, s, np.concatenate([fl, extra]), replicas)
+
+
 def test_mm_256_limb_edge_values(eng):
     """The signed-byte limb decomposition behind the MFMA kernel at its carry / sign corners: operands made of
     0x00, 0x7f, 0x80, 0xff bytes (every digit at -128, -1, 0, 127 and every carry pattern), against numpy mod 2^32."""
