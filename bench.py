@@ -7,14 +7,22 @@ arm the on-device injector with a seeded fault list, run the protected kernel on
 blocks, fold the fault counters and all-reduce them across GPUs (RCCL; the only collective of the path).  Blocks shard
 across ranks with no data exchange, so scaling is weak (per-GPU batch fixed).
 
-Default workload = mm (the metric BASELINE.json quotes).  `--workload crc16|sha256|aes` runs the other BASELINE configs
-through the same harness (development / north-star targets; the driver only runs the default).
+`python bench.py --gpus N` starts the N ranks ITSELF (one process per GPU under torch.distributed.run, backend nccl = RCCL)
+when it was not already launched by torchrun; under torchrun it checks that WORLD_SIZE == N.
 
-Prints ONE JSON line (rank 0).  The oracle is used only for the cpu_baseline leg.
+Default workload = mm (the metric BASELINE.json quotes).  After the headline measurement the default run also times
+short legs of the other BASELINE configs and reports them under "extra" (each with its own roofline / cpu_baseline):
+at N = 1 crc16 (256- and 255-byte blocks), sha256 4 Mi + injector, aes 1 Mi DWC and config 1 (mm 32x32 CPU-TMR); at
+N > 1 the crc16 stream (8 GiB per GPU: N = 8 is the 64 GiB config).  `--workload X` runs one of them as the headline
+instead (development); `--no-extra` skips the legs.
+
+Prints ONE JSON line (rank 0).  The oracle is used only for the cpu_baseline legs.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,10 +32,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+CLK = 2.4e9            # MI355X_MICROARCH.md: max clock 2400 MHz
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # Integer-MAC issue ceiling of the chip.  MI355X_MICROARCH.md gives the full-rate VALU figure (256 CU x 4 SIMD x 32 lanes
 # x 2.4 GHz = 78.6 T lane-ops/s = 157.3 TFLOP/s / 2) but no integer-multiply rates, so the MAC peak is the measured
-# issue rate of v_mad_u64_u32 -- the one-instruction 32-bit MAC the kernel is built from -- at 8 waves/SIMD:
+# issue rate of v_mad_u64_u32 -- the one-instruction 32-bit MAC the VALU kernel is built from -- at 8 waves/SIMD:
 # 5.11 cycles per wave-instruction = 30.78 T lane-MAC/s (tools/valu_microbench, profiles/microbench_r01.txt).
 MAC_PEAK = 30.78e12
 # int8 MFMA: MI355X_MICROARCH.md lists no spec figure, "~2x bf16 rate" (bf16 ~2.5 PFLOP/s dense) and a ubench ceiling of
@@ -35,7 +44,13 @@ MAC_PEAK = 30.78e12
 # ~2.05 GHz the chip sustains under MFMA load).  Peak = 2 x 2.5e15; the measured ceiling is reported next to it.
 I8_MFMA_PEAK = 5.0e15
 I8_MFMA_UBENCH = 4.25e15
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 78.6 T lane-ops/s, full-rate VALU
+N_SIMD = 256 * 4
+# measured issue cost, cycles per wave-instruction at 8 waves/SIMD (profiles/microbench_r01.txt; v_bitop3 from the same probe,
+# DESIGN.md section 4.2)
+CYC = {"v_alignbit": 4.15, "v_bitop3": 2.44, "v_add3": 4.35, "v_add": 2.75, "v_lshr": 2.75}
+# LDS: one ds_read_b32 / ds_read_u8 wave-instruction occupies the CU's LDS for >= 2 cycles (two 32-lane groups, one cycle
+# each when conflict-free: MI355X_MICROARCH.md section LDS) -> 32 lane-lookups per clock per CU
+LDS_LOOKUP_PEAK = 256 * 32 * CLK
 
 
 def parse():
@@ -46,9 +61,11 @@ def parse():
     ap.add_argument("--workload", default="mm", choices=["mm", "crc16", "sha256", "aes", "cache_test", "chsha"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU items per step (0 = the BASELINE config's size)")
     ap.add_argument("--side", type=int, default=256)
+    ap.add_argument("--block-len", type=int, default=256, help="crc16 block length in bytes (the reference's maximum is 255)")
     ap.add_argument("--faults", type=int, default=-1,
                     help="single-bit flips injected per GPU per step (default: 4096 for mm, 1024 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline workload only")
     return ap.parse_args()
 
 
@@ -64,9 +81,21 @@ def _time_budget(fn, budget_s):
     return reps, time.perf_counter() - t0
 
 
-def cpu_baseline_mm(side, budget_s=12.0):
-    """Default-mode CPU-TMR restatement of matrix_multiply (oracle/cpu_tmr_baseline.c), single thread -- the
-    reference is single-threaded by construction.  Bounded sample: as many side x side matrices as fit the budget."""
+def _ncpu():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline_mm(side, budget_s=8.0, threads_wall_s=3.0):
+    """matrix_multiply on the host cores, the two CPU restatements side by side (the real `opt-7 -TMR` binary cannot be
+    built here):
+      * default-mode TMR (oracle/cpu_tmr_baseline.c: memory x3, loop-condition votes, -countErrors) -- what COAST emits by
+        default and what the published 2.9x / 4.5x overheads describe; 1 core and all cores;
+      * the -noMemReplication model (oracle/coast_oracle.c: one memory copy, one vote per stored element) -- the rule set
+        the GPU engine instantiates, so this is the like-for-like line next to the GPU number.
+    Bounded sample: as many side x side matrices as fit the budget."""
     from oracle import oracle as orc
 
     orc.build()
@@ -80,16 +109,13 @@ def cpu_baseline_mm(side, budget_s=12.0):
         assert err == 0 and cnt == 0
 
     reps, dt = _time_budget(one, budget_s)
-    ureps, du = _time_budget(lambda: orc.mm_plain(f, s), 2.0)  # unprotected arithmetic, for the CPU TMR overhead
+    ureps, du = _time_budget(lambda: orc.mm_plain(f, s), min(2.0, budget_s))  # unprotected arithmetic: the CPU TMR overhead
+    nreps, dn = _time_budget(lambda: orc.mm_xmr(f[None], s[None], replicas=3), min(4.0, budget_s))
     # all host cores over independent matrices (the reference itself is single-threaded; this is the generous bound).
-    # Visible CPUs can exceed what the container may use, so calibrate with one matrix per thread and size the timed
-    # run for ~4 s of wall time.
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
+    # Visible CPUs can exceed what the container may use, so calibrate with one matrix per thread first.
+    ncpu = _ncpu()
     w1 = orc.cpu_tmr_mm_threads(f, s, gold, ncpu, 1)
-    per_thread = max(1, min(64, int(4.0 / max(w1, 1e-3))))
+    per_thread = max(1, min(4096, int(threads_wall_s / max(w1, 1e-4))))
     wall = orc.cpu_tmr_mm_threads(f, s, gold, ncpu, per_thread)
     return {
         "value": reps * side * side / dt, "unit": "protected elems/s", "cores": 1, "kind": "port",
@@ -97,6 +123,9 @@ def cpu_baseline_mm(side, budget_s=12.0):
                   "(memory x3, loop-condition votes, -countErrors), gcc -O3, %.1f s" % (reps, side, side, dt),
         "unprotected_elems_per_s": ureps * side * side / du,
         "tmr_overhead_x": (dt / reps) / (du / ureps),
+        "nomemreplication_model": {"value": nreps * side * side / dn, "unit": "protected elems/s", "cores": 1,
+                                   "sample": "%d x %dx%d, oracle -noMemReplication TMR model (one memory copy, one vote per "
+                                             "stored element: the GPU engine's rule set), gcc -O3, %.1f s" % (nreps, side, side, dn)},
         "host_cpus": ncpu,
         "all_cores": {"value": ncpu * per_thread * side * side / wall if wall > 0 else None, "cores": ncpu,
                       "unit": "protected elems/s",
@@ -104,17 +133,18 @@ def cpu_baseline_mm(side, budget_s=12.0):
     }
 
 
-def cpu_baseline_items(kind, budget_s=10.0):
+def cpu_baseline_items(kind, budget_s=6.0, block_len=256):
     """The oracle's replicated model (-noMemReplication schedule, the one the GPU instantiates) timed on one core."""
     from oracle import oracle as orc
 
     orc.build()
     rng = np.random.default_rng(0)
     if kind == "crc16":
-        data = rng.integers(0, 256, (1 << 14, 256), dtype=np.uint8)
-        reps, dt = _time_budget(lambda: orc.crc16_xmr(data, 256, replicas=3), budget_s)
+        data = rng.integers(0, 256, (1 << 14, block_len), dtype=np.uint8)
+        reps, dt = _time_budget(lambda: orc.crc16_xmr(data, block_len, replicas=3), budget_s)
         return {"value": reps * data.size / dt * 1e-9, "unit": "GB/s", "cores": 1, "kind": "port",
-                "sample": "%d x 4 MiB (16384 blocks x 256 B), oracle TMR model, gcc -O3, %.1f s" % (reps, dt)}
+                "sample": "%d x %.1f MiB (16384 blocks x %d B), oracle TMR model, gcc -O3, %.1f s"
+                          % (reps, data.size / 2**20, block_len, dt)}
     if kind == "sha256":
         msgs = rng.integers(0, 256, (1 << 15, 64), dtype=np.uint8)
         reps, dt = _time_budget(lambda: orc.sha256_xmr(msgs, 64, replicas=3), budget_s)
@@ -137,18 +167,72 @@ def cpu_baseline_items(kind, budget_s=10.0):
             "sample": "%d x 32768 blocks encrypt, oracle DWC model, gcc -O3, %.1f s" % (reps, dt)}
 
 
+def config1_cpu_tmr_mm32(eng, coast_amd):
+    """BASELINE.json configs[0]: tests/matrixMultiply 32x32, TMR on the host CPU (no GPU in the measurement).  The reference
+    LLVM pass cannot run here, so this is its default-mode restatement (1 core and all cores) plus the -noMemReplication
+    model; TMR_ERROR_CNT is reported under a seeded list of K single-bit register upsets (one per run, the reference
+    campaign's regime: threadFunctions.py:588-600).  The same list goes through the GPU engine once, as a cross-check of
+    the count (not timed)."""
+    import random
+
+    from oracle import oracle as orc
+
+    orc.build()
+    n, K = 32, 1024
+    random.seed(0)  # the reference generator's algorithm (tests/mm_common/mm_generator.py:42-51), seed 0, size 32:
+    f = np.array([[random.randint(0, 2**32 - 1) for _ in range(n)] for _ in range(n)], dtype=np.uint32)
+    s = np.array([[random.randint(0, 2**32 - 1) for _ in range(n)] for _ in range(n)], dtype=np.uint32)
+    gold = orc.mm_xor(orc.mm_plain(f, s))
+    assert gold == 1605501056
+    out = cpu_baseline_mm(n, budget_s=3.0, threads_wall_s=2.0)
+    rng = np.random.default_rng(32)
+    rows = [(int(b * n * n + rng.integers(0, n * n)), int(rng.integers(0, 3)), int(rng.integers(0, 3)),
+             int(rng.integers(0, n + 1)), int(rng.integers(0, 32))) for b in range(K)]
+    fl = coast_amd.make_faults(rows)  # run b = matrix b of a batch of K identical matrices, one upset each
+    fb, sb = np.repeat(f[None], K, 0), np.repeat(s[None], K, 0)
+    t0 = time.perf_counter()
+    r, st, det = orc.mm_xmr(fb, sb, replicas=3, faults=fl)
+    dt = time.perf_counter() - t0
+    runs_wrong = int(sum(int(np.bitwise_xor.reduce(r[b].reshape(-1))) != gold for b in range(K)))
+    dm = orc.cpu_tmr_mm_campaign(f, s, gold, fl)  # default-mode restatement, one run per upset
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    g = eng.mm_batch(torch.from_numpy(fb.view(np.int32)).cuda(), torch.from_numpy(sb.view(np.int32)).cuda())
+    gst = eng.stats()
+    out.update({
+        "workload": "matrixMultiply 32x32 uint32 (mm_generator.py seed 0, xor_golden 1605501056), TMR on the host CPU",
+        "seeded_fault_list": {
+            "runs": K, "faults_per_run": 1,
+            "TMR_ERROR_CNT_nomemreplication_model": int(st["errors_corrected"]),
+            "runs_with_wrong_golden": runs_wrong, "model_wall_s": dt,
+            "default_mode": dm,
+            "gpu_engine_same_list": {"TMR_ERROR_CNT": int(gst["errors_corrected"]), "sync_count": int(gst["sync_count"]),
+                                     "outputs_equal_model": bool((g.cpu().numpy().view(np.uint32) == r).all())},
+        },
+    })
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 class Workload:
     """setup() allocates device-resident synthetic inputs; launch() enqueues one protected pass."""
+    kernels_per_step = 1
+
+    def free(self):
+        for k in list(self.__dict__):
+            if isinstance(self.__dict__[k], torch.Tensor):
+                del self.__dict__[k]
+        torch.cuda.empty_cache()
 
 
 class MM(Workload):
+    name = "mm"
     metric = "protected elems/sec + corrected-fault count, matrixMultiply TMR"
     unit = "protected elems/s"
     dtype = "u32"
 
     def __init__(self, a, eng, dev, rank, coast_amd):
-        self.n, self.batch = a.side, a.batch or 16384  # 12.9 GB of f, s, r: ~32 ms kernels (SURVEY 8d-2: a batch, not one matrix)
+        self.n, self.batch = a.side, a.batch or 16384  # 12.9 GB of f, s, r: ~9 ms kernels (SURVEY 8d-2: a batch, not one matrix)
         n, batch = self.n, self.batch
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         self.f = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device=dev, generator=g)
@@ -217,12 +301,13 @@ class MM(Workload):
 
 
 class CRC16(Workload):
+    name = "crc16"
     metric = "protected bytes/sec + corrected-fault count, crc16 TMR stream"
     unit = "GB/s"
     dtype = "u16"
 
     def __init__(self, a, eng, dev, rank, coast_amd):
-        self.bl = 256
+        self.bl = a.block_len
         self.nb = a.batch or (1 << 25)  # 2^25 blocks x 256 B = 8 GiB per GPU (64 GiB over 8 GPUs)
         g = torch.Generator(device=dev).manual_seed(16 + rank)
         self.data = torch.empty(self.nb * self.bl, dtype=torch.uint8, device=dev)
@@ -257,17 +342,24 @@ class CRC16(Workload):
     def roofline(self, kern_ms):
         b = float(self.nb) * (self.bl + 2)
         t = kern_ms * 1e-3
-        return {"bound": "hbm", "kernel": "crc16_stream_kernel<3,2,true>", "achieved": b / t * 1e-9, "peak": HBM_PEAK_GBS,
+        return {"bound": "hbm", "kernel": "crc16_stream_kernel<3>", "achieved": b / t * 1e-9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": b / t * 1e-9 / HBM_PEAK_GBS, "kernel_ms": kern_ms, "algorithmic_bytes": b}
 
     def cpu(self):
-        return cpu_baseline_items("crc16")
+        return cpu_baseline_items("crc16", block_len=self.bl)
 
 
 class SHA256(Workload):
+    name = "sha256"
     metric = "protected msgs/sec + corrected-fault count, sha256 TMR"
     unit = "msgs/s"
     dtype = "u32"
+    # VALU instructions of one 64-byte message per replica lane (FIPS 180-4, as sha256_fast_kernel issues them; tools/instr_mix.py
+    # counts the same numbers in the compiled kernel): data block = 64 rounds + 48 schedule words, padding block = 64
+    # rounds on precomputed K+W.  round: 6 v_alignbit (the rotates of Sigma0/Sigma1) + 4 v_bitop3 (two xor3, ch, maj) + 3
+    # v_add3 + 1 v_add; schedule word: 4 v_alignbit + 2 v_lshr + 2 v_bitop3 + 2 v_add; 2 x 8 state adds.
+    MIX = {"v_alignbit": 2 * 64 * 6 + 48 * 4, "v_bitop3": 2 * 64 * 4 + 48 * 2, "v_add3": 2 * 64 * 3,
+           "v_add": 2 * 64 + 48 * 2 + 16, "v_lshr": 48 * 2}
 
     def __init__(self, a, eng, dev, rank, coast_amd):
         self.nm = a.batch or (1 << 22)
@@ -302,12 +394,13 @@ class SHA256(Workload):
                 "parallelism": "dp%d (independent messages)" % world}
 
     def roofline(self, kern_ms):
-        ops = float(self.nm) * (1400 + 900)  # ~1400 VALU ops for the data block (64 rounds + 48 schedule words), ~900 for the
-        # data-free padding block (rounds only)
+        # VALU issue bound.  A TMR wave carries 21 messages; its instruction stream costs sum(count x measured issue cycles).
+        cyc = sum(self.MIX[k] * CYC[k] for k in self.MIX)
+        ceiling = N_SIMD * CLK / cyc * 21
         t = kern_ms * 1e-3
-        return {"bound": "valu", "kernel": "sha256_fast_kernel<3,true>", "achieved": ops / t * 1e-12,
-                "peak": VALU_LANE_OPS * 1e-12, "unit": "T lane-ops/s (algorithmic)", "frac": ops / t / VALU_LANE_OPS,
-                "executed_frac": 3 * ops / t / VALU_LANE_OPS, "kernel_ms": kern_ms,
+        return {"bound": "valu", "kernel": "sha256_fast_kernel<3,true>", "achieved": self.nm / t * 1e-9,
+                "peak": ceiling * 1e-9, "unit": "G msgs/s (instruction-mix issue ceiling at 2.4 GHz)", "frac": self.nm / t / ceiling,
+                "cycles_per_wave_of_21_msgs": cyc, "instruction_mix": self.MIX, "issue_cycles": CYC, "kernel_ms": kern_ms,
                 "hbm_achieved_GBs": self.nm * 96 / t * 1e-9, "algorithmic_bytes": float(self.nm) * 96}
 
     def cpu(self):
@@ -315,9 +408,14 @@ class SHA256(Workload):
 
 
 class AES(Workload):
+    name = "aes"
     metric = "protected blocks/sec + detected-fault count, aes-128 ECB DWC"
     unit = "blocks/s"
     dtype = "u8"
+    kernels_per_step = 1
+    # LDS lookups of one block per replica lane (tools/instr_mix.py on the compiled kernels): encryption 147 ds_read_b32 (four
+    # T-tables x 4 columns x 9 rounds + last round) + 56 ds_read_u8 (S-box: key schedule, last round); decryption 179 + 84
+    LOOKUPS = {0: 147 + 56, 1: 179 + 84}
 
     def __init__(self, a, eng, dev, rank, coast_amd):
         self.n = a.batch or (1 << 20)
@@ -326,7 +424,7 @@ class AES(Workload):
         self.key = torch.randint(0, 256, (self.n, 16), dtype=torch.uint8, device=dev, generator=g)
         self.st, self.k = self.pt.clone(), self.key.clone()
         self.cfg = coast_amd.XmrConfig(coast_amd.DWC)
-        self.eng = eng
+        self.eng, self.ca = eng, coast_amd
         rng = np.random.default_rng(3 + rank)
         items = rng.choice(self.n, a.faults, replace=False)
         self.faults = coast_amd.make_faults([(int(it), int(rng.integers(0, 2)), coast_amd.SITE_AES_STATE,
@@ -342,7 +440,19 @@ class AES(Workload):
         self.dir ^= 1
 
     def check(self):
-        return True
+        """clean sample: DWC result == unprotected result, decrypt(encrypt(x)) == x, and the in-place key contract
+        (encrypt leaves the last round key, decrypt walks it back to the cipher key; TI_aes_128.c:107-231)"""
+        ca = self.ca
+        m = min(self.n, 4096)
+        pt, key = self.pt[:m].clone(), self.key[:m].clone()
+        s1, k1 = pt.clone(), key.clone()
+        self.eng.aes128_batch(s1, k1, 0, cfg=ca.XmrConfig(ca.DWC))
+        s2, k2 = pt.clone(), key.clone()
+        self.eng.aes128_batch(s2, k2, 0, cfg=ca.XmrConfig(ca.UNPROTECTED))
+        ok = torch.equal(s1, s2) and torch.equal(k1, k2) and not torch.equal(s1, pt)
+        k3 = key.clone()
+        self.eng.aes128_batch(s1, k3, 1, cfg=ca.XmrConfig(ca.DWC))
+        return bool(ok and torch.equal(s1, pt) and torch.equal(k3, key))
 
     def config(self, world):
         return {"workload": "aes-128 ECB %d blocks, per-block keys, DWC 2-way compare, alternating enc/dec "
@@ -351,16 +461,21 @@ class AES(Workload):
 
     def roofline(self, kern_ms):
         t = kern_ms * 1e-3
-        b = float(self.n) * 64
-        return {"bound": "valu", "kernel": "aes128_enc_fast_kernel<2> (enc) / aes128_xmr_kernel<2> (dec)", "achieved": b / t * 1e-9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s (VALU/LDS-lookup bound; HBM shown for scale)", "frac": b / t * 1e-9 / HBM_PEAK_GBS,
-                "kernel_ms": kern_ms, "algorithmic_bytes": b}
+        look = 0.5 * (self.LOOKUPS[0] + self.LOOKUPS[1]) * 2  # per block: mean of the enc / dec steps, x 2 replica lanes
+        return {"bound": "lds", "kernel": "aes128_enc_fast_kernel<2> / aes128_dec_fast_kernel<2> (alternating)",
+                "achieved": self.n * look / t * 1e-12, "peak": LDS_LOOKUP_PEAK * 1e-12,
+                "unit": "T lane-lookups/s (LDS: 32 conflict-free 4-byte lookups per clock per CU at 2.4 GHz)",
+                "frac": self.n * look / t / LDS_LOOKUP_PEAK, "lookups_per_block_lane": self.LOOKUPS, "kernel_ms": kern_ms,
+                "hbm_achieved_GBs": self.n * 64 / t * 1e-9, "algorithmic_bytes": float(self.n) * 64,
+                "note": "random table indices: replicas broadcast, distinct blocks conflict on banks, so the conflict-free "
+                        "peak is an upper bound no table kernel reaches; 1 Mi blocks are a 60-80 us launch"}
 
     def cpu(self):
         return cpu_baseline_items("aes")
 
 
 class CacheTest(Workload):
+    name = "cache_test"
     metric = "protected bytes/sec + corrected-fault count, cache_test (calc_sum) TMR scrub"
     unit = "GB/s"
     dtype = "i32"
@@ -401,6 +516,7 @@ class CacheTest(Workload):
 
 
 class ChSha(Workload):
+    name = "chsha"
     metric = "protected bytes/sec + corrected-fault count, CHStone sha TMR"
     unit = "GB/s"
     dtype = "u32"
@@ -456,28 +572,137 @@ def pmc_traffic(workload, cfg):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         for key, rec in json.load(open(path)).items():  # records are keyed "<workload>" or "<workload>_<variant>"
-            if key.split("_")[0] == workload and all(cfg.get(k) == v for k, v in rec.get("match", {}).items()):
+            if (key == workload or key.startswith(workload + "_")) and all(cfg.get(k) == v for k, v in rec.get("match", {}).items()):
                 return rec["hbm_bytes_per_launch"], rec.get("source")
     except (OSError, ValueError):
         pass
     return None, None
 
 
+# ------------------------------------------------------------------------------------------------ one timed run
+def timed_run(wl, eng, dist, dev, steps, warmup, world):
+    """W untimed + K timed steps of one workload, barrier + synchronize on both sides, MAX over ranks.  Kernel time comes
+    from HIP events the C ABI records around every protected launch on the launch stream (coast_stats.kernel_ms)."""
+    from coast_amd.dist import allreduce_counters
+
+    def step():
+        if len(wl.faults):
+            eng.inject_faults(wl.faults)
+        wl.launch()
+        eng.reduce_counters()
+        return allreduce_counters(eng, dist)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.reset_stats()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tot = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    tot = [int(x) for x in tot.cpu().tolist()]
+    st = eng.stats()
+    kern_ms = st["kernel_ms"] / max(steps, 1)
+    return {"dt": dt, "totals": tot, "kernel_ms": kern_ms, "launch_info": eng.last_launch(),
+            "hbm_bytes_per_step": st["hbm_bytes"] / max(steps, 1)}
+
+
+def result_fields(wl, run, a, world, steps, warmup, with_cpu):
+    cfg = wl.config(world)
+    roof = wl.roofline(run["kernel_ms"])
+    traffic, src = pmc_traffic(wl.name, cfg)
+    roof["traffic"] = traffic
+    if src:
+        roof["traffic_source"] = src
+    tot = run["totals"]
+    out = {
+        "metric": wl.metric, "value": float(world) * wl.units_per_step * steps / run["dt"], "unit": wl.unit,
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": run["dt"] / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
+        "config": cfg,
+        "corrected_faults": tot[0], "dwc_detected": tot[2], "injected_faults": len(wl.faults) * steps * world,
+        "sync_count": tot[1], "outputs_match_unprotected": wl.check(),
+        "voted_by": run["launch_info"]["engine"], "stepwise_blocks_last_launch": run["launch_info"]["general_blocks"],
+        "roofline": roof,
+    }
+    if with_cpu:
+        out["cpu_baseline"] = wl.cpu()
+    return out
+
+
+def extra_legs(a, eng, dist, dev, rank, world, coast_amd):
+    """Short legs of the other BASELINE configs (same harness, same contract, fewer steps)."""
+    import copy
+
+    legs = {}
+    plan = [("crc16_256B", CRC16, {"block_len": 256}, 5, 2)]
+    if world == 1:
+        plan += [("crc16_255B", CRC16, {"block_len": 255}, 5, 2), ("sha256", SHA256, {}, 10, 3), ("aes", AES, {}, 20, 4)]
+    for name, cls, over, steps, warm in plan:
+        b = copy.copy(a)
+        b.batch, b.faults = 0, 1024
+        for k, v in over.items():
+            setattr(b, k, v)
+        wl = cls(b, eng, dev, rank, coast_amd)
+        run = timed_run(wl, eng, dist, dev, steps, warm, world)
+        if rank == 0:
+            legs[name] = result_fields(wl, run, b, world, steps, warm, with_cpu=(world == 1 and not a.no_cpu_baseline))
+        wl.free()
+    if world == 1 and rank == 0 and not a.no_cpu_baseline:
+        legs["config1_mm32_cpu_tmr"] = config1_cpu_tmr_mm32(eng, coast_amd)
+    return legs
+
+
+def spawn(a):
+    """--gpus N without a torchrun environment: start the N ranks here (one process per GPU, 127.0.0.1 rendezvous)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
     if a.faults < 0:
         a.faults = 4096 if a.workload == "mm" else 1024
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("COAST_BENCH_ECHO_RANK"):
+        sys.stderr.write("bench.py: rank %d/%d (local %d)\n" % (rank, world, local))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or let bench.py spawn the ranks)"
+                 % (a.gpus, world, a.gpus))
     dist = None
-    ndev = max(torch.cuda.device_count(), 1)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no GPU visible (the engine has no CPU path)")
+    backend = os.environ.get("COAST_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo only for 1-GPU dry runs of N > 1
     if world > 1:
         import torch.distributed as dist
 
+        if backend == "nccl" and ndev < world:
+            sys.exit("bench.py: --gpus %d needs %d GPUs, %d visible (RCCL wants one GPU per rank; COAST_BENCH_BACKEND=gloo "
+                     "dry-runs the rank logic on fewer)" % (world, world, ndev))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local % ndev)  # one process per GPU; the modulo only matters for single-GPU dry runs
-        backend = os.environ.get("COAST_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo for 1-GPU dry runs
+        torch.cuda.set_device(local % ndev)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
         else:
@@ -487,66 +712,24 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     import coast_amd
-    from coast_amd.dist import allreduce_counters
 
     eng = coast_amd.Engine(dev.index)
+    eng.set_profiling(True)
     wl = WORKLOADS[a.workload](a, eng, dev, rank, coast_amd)
-
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
-
-    def step(i=None):
-        if len(wl.faults):
-            eng.inject_faults(wl.faults)
-        if i is not None:
-            ev0[i].record()
-        wl.launch()
-        if i is not None:
-            ev1[i].record()
-        eng.reduce_counters()
-        return allreduce_counters(eng, dist)
-
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    eng.reset_stats()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        tot = step(i)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    tot = [int(x) for x in tot.cpu().tolist()]
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)]))
-    outputs_ok = wl.check()  # untimed: voted output equals the unprotected / independent result
-
+    run = timed_run(wl, eng, dist, dev, a.steps, a.warmup, world)
+    out = None
     if rank == 0:
-        cfg = wl.config(world)
-        roof = wl.roofline(kern_ms)
-        traffic, src = pmc_traffic(a.workload, cfg)
-        roof["traffic"] = traffic
-        if src:
-            roof["traffic_source"] = src
-        out = {
-            "metric": wl.metric, "value": float(world) * wl.units_per_step * a.steps / dt, "unit": wl.unit,
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
-            "config": cfg,
-            "corrected_faults": tot[0], "dwc_detected": tot[2], "injected_faults": len(wl.faults) * a.steps * world,
-            "sync_count": tot[1], "outputs_match_unprotected": outputs_ok,
-            "roofline": roof,
-        }
-        if not a.no_cpu_baseline and world == 1:  # reported baseline, rank 0 at N=1 only
-            out["cpu_baseline"] = wl.cpu()
+        out = result_fields(wl, run, a, world, a.steps, a.warmup, with_cpu=(world == 1 and not a.no_cpu_baseline))
+        out["collective"] = ("%s all_reduce(SUM) of 4 x int64 fault counters per step, %d ranks" % (backend, world)) if world > 1 \
+            else "none (1 rank)"
+    if a.workload == "mm" and not a.no_extra:
+        wl.free()
+        legs = extra_legs(a, eng, dist, dev, rank, world, coast_amd)
+        if rank == 0:
+            out["extra"] = legs
+    if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

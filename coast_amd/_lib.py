@@ -40,6 +40,7 @@ SYMBOLS = {
     "coast_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "coast_bind_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "coast_reduce_counters": (C.c_int, [C.c_void_p]),
+    "coast_allreduce_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "coast_read_stats": (C.c_int, [C.c_void_p, C.POINTER(CoastStats)]),
     "coast_reset_stats": (C.c_int, [C.c_void_p]),
     "coast_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

@@ -85,6 +85,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Dside=4", demo_src, os.path.join(CSRC, "mm_glue.c"), DROPIN_OBJ,
                                "-L", LIBDIR, "-lcoast_hip", "-Wl,-rpath,$ORIGIN/../coast_amd/lib",
                                "-Wl,-rpath,/opt/rocm/lib", "-o", demo])
+    mg_src = os.path.join(HERE, "..", "examples", "multi_gpu_c_demo.c")
+    mg = os.path.join(HERE, "..", "examples", "multi_gpu_c_demo")
+    if os.path.exists(mg_src) and (force or stale or _newer(mg, [mg_src, LIB])):
+        subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                               "-I", os.path.join(HERE, "..", "include"), mg_src, "-L", LIBDIR, "-lcoast_hip",
+                               "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-Wl,-rpath,$ORIGIN/../coast_amd/lib",
+                               "-Wl,-rpath,/opt/rocm/lib", "-o", mg])
     return LIB
 
 

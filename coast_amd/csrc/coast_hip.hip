@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -439,6 +441,39 @@ extern "C" int coast_reduce_counters(coast_ctx *c)
                        c->pendingLaunches);
     HIP_TRY(c, hipGetLastError());
     c->pendingLaunches = 0;
+    return COAST_OK;
+}
+
+// The one collective of the path, for C hosts (one process per GPU, or one process driving several contexts): fold this
+// context's counter slots, then ncclAllReduce(SUM) the four uint64 totals IN PLACE on the context's stream.  RCCL is
+// resolved at first use (dlopen) so that single-GPU hosts carry no dependency on it.
+extern "C" int coast_allreduce_counters(coast_ctx *c, void *rccl_comm)
+{
+    if (!c || !rccl_comm)
+        return COAST_EINVAL;
+    typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    static allreduce_fn fn = nullptr;
+    static std::mutex mu;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!fn) {
+            void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h)
+                h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h)
+                return fail(c, COAST_EHIP, "coast_allreduce_counters: cannot load librccl.so (%s)", dlerror());
+            fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+            if (!fn)
+                return fail(c, COAST_EHIP, "coast_allreduce_counters: librccl.so has no ncclAllReduce");
+        }
+    }
+    int rc = coast_reduce_counters(c);
+    if (rc)
+        return rc;
+    enum { kNcclUint64 = 5, kNcclSum = 0 }; // rccl.h: ncclDataType_t / ncclRedOp_t
+    const int nr = fn(totals_of(c), totals_of(c), 4, kNcclUint64, kNcclSum, rccl_comm, c->stream);
+    if (nr != 0)
+        return fail(c, COAST_EHIP, "ncclAllReduce failed with %d", nr);
     return COAST_OK;
 }
 

@@ -20,7 +20,12 @@ def allreduce_counters(engine, dist=None, group=None) -> torch.Tensor:
     """Global {errors_corrected, sync_count, dwc_detected, launches}.  Local totals stay untouched (cumulative)."""
     tot = engine.counters.clone()
     if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+        if tot.is_cuda and dist.get_backend(group) == "gloo":  # dry runs of the rank logic without RCCL: stage through the host
+            host = tot.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            tot = host.to(tot.device)
+        else:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     return tot
 
 

@@ -143,6 +143,12 @@ int coast_set_stream(coast_ctx *ctx, void *hip_stream);
 int coast_bind_counters(coast_ctx *ctx, uint64_t *d_totals);
 /* fold the per-workgroup counter slots into the totals (async; coast_read_stats does it implicitly) */
 int coast_reduce_counters(coast_ctx *ctx);
+/* Multi-GPU, C hosts: coast_reduce_counters + ncclAllReduce(SUM, 4 x uint64, in place) of the totals over `rccl_comm` (an
+ * ncclComm_t the host created for this context's device: one rank per GPU), on the context's stream.  Afterwards every
+ * rank's totals -- the bound buffer, or what coast_read_stats returns -- are the job-wide {errors_corrected, sync_count,
+ * dwc_detected, launches}: the single global TMR_ERROR_CNT of synchronization.cpp:1428-1431, across GPUs.  Call it once per
+ * batch and reset afterwards (the totals are now global sums).  librccl.so is loaded at first use. */
+int coast_allreduce_counters(coast_ctx *ctx, void *rccl_comm);
 int coast_read_stats(coast_ctx *ctx, coast_stats *out); /* synchronises the stream */
 int coast_reset_stats(coast_ctx *ctx);
 /* bracket every protected launch with HIP timing events on the context's stream -> coast_stats.kernel_ms */

@@ -133,6 +133,8 @@ void orc_sync_copies(uint32_t *c0, uint32_t *c1, uint32_t *c2, int ncopies, size
 int orc_cpu_tmr_mm(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, uint32_t xor_golden, uint32_t *cnt,
                    uint64_t *syncs);
 /* the same on nthreads host threads, reps independent matrices each; returns wall seconds (< 0 on a wrong result) */
+uint64_t orc_cpu_tmr_mm_campaign(const uint32_t *f, const uint32_t *s, int n, uint32_t xor_golden, const orc_fault *faults,
+                                 size_t nfaults, size_t nruns, uint64_t *n_error, uint64_t *n_corrected, uint64_t *n_success);
 double orc_cpu_tmr_mm_threads(const uint32_t *f, const uint32_t *s, int n, uint32_t golden, int nthreads, int reps);
 
 #ifdef __cplusplus

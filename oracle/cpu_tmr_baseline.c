@@ -37,8 +37,13 @@ static inline int vote_cond(int a, int b, int c, tmr_counters *t)
     return (a == b) ? a : c;
 }
 
-int orc_cpu_tmr_mm(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, uint32_t xor_golden, uint32_t *cnt,
-                   uint64_t *syncs)
+/* One protected run.  with_faults is a compile-time constant at both call sites (the timed path carries no fault checks).
+ * A register upset (item = output element e, replica, site ACC / OPA / OPB, step k, bit) hits ONE clone's register -- its
+ * `sum`, or the operand it just loaded -- exactly as in coast_oracle.c:mm_item; in this mode the clone's wrong sum is stored
+ * into ITS copy of `results_matrix` unvoted (synchronization.cpp:211-215) and surfaces in checkGolden's return vote. */
+static inline __attribute__((always_inline)) int tmr_mm_run(const uint32_t *f, const uint32_t *s, uint32_t *r, int n,
+                                                            uint32_t xor_golden, uint32_t *cnt, uint64_t *syncs,
+                                                            const int with_faults, const orc_fault *fl, size_t nf)
 {
     const size_t nn = (size_t)n * n;
     uint32_t *mem = (uint32_t *)malloc(9 * nn * sizeof(uint32_t));
@@ -61,12 +66,40 @@ int orc_cpu_tmr_mm(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, uin
             unsigned long sum0 = 0, sum1 = 0, sum2 = 0;
             int k0 = 0, k1 = 0, k2 = 0;
             while (vote_cond(k0 < n, k1 < n, k2 < n, &t)) {
-                sum0 += (uint32_t)(f0[(size_t)i0 * n + k0] * s0[(size_t)k0 * n + j0]);
-                sum1 += (uint32_t)(f1[(size_t)i1 * n + k1] * s1[(size_t)k1 * n + j1]);
-                sum2 += (uint32_t)(f2[(size_t)i2 * n + k2] * s2[(size_t)k2 * n + j2]);
+                uint32_t a0 = f0[(size_t)i0 * n + k0], b0 = s0[(size_t)k0 * n + j0];
+                uint32_t a1 = f1[(size_t)i1 * n + k1], b1 = s1[(size_t)k1 * n + j1];
+                uint32_t a2 = f2[(size_t)i2 * n + k2], b2 = s2[(size_t)k2 * n + j2];
+                if (with_faults) {
+                    const uint64_t e = (uint64_t)i0 * n + j0;
+                    for (size_t q = 0; q < nf; ++q) {
+                        if (fl[q].item != e || fl[q].step != (uint32_t)k0)
+                            continue;
+                        const uint32_t m = 1u << (fl[q].bit & 31);
+                        unsigned long *sm = fl[q].replica == 0 ? &sum0 : fl[q].replica == 1 ? &sum1 : &sum2;
+                        uint32_t *pa = fl[q].replica == 0 ? &a0 : fl[q].replica == 1 ? &a1 : &a2;
+                        uint32_t *pb = fl[q].replica == 0 ? &b0 : fl[q].replica == 1 ? &b1 : &b2;
+                        if (fl[q].site == ORC_SITE_MM_ACC)
+                            *sm ^= m;
+                        else if (fl[q].site == ORC_SITE_MM_OPA)
+                            *pa ^= m;
+                        else if (fl[q].site == ORC_SITE_MM_OPB)
+                            *pb ^= m;
+                    }
+                }
+                sum0 += (uint32_t)(a0 * b0);
+                sum1 += (uint32_t)(a1 * b1);
+                sum2 += (uint32_t)(a2 * b2);
                 ++k0;
                 ++k1;
                 ++k2;
+            }
+            if (with_faults) {
+                const uint64_t e = (uint64_t)i0 * n + j0;
+                for (size_t q = 0; q < nf; ++q)
+                    if (fl[q].item == e && fl[q].step == (uint32_t)n && fl[q].site == ORC_SITE_MM_ACC) {
+                        unsigned long *sm = fl[q].replica == 0 ? &sum0 : fl[q].replica == 1 ? &sum1 : &sum2;
+                        *sm ^= 1u << (fl[q].bit & 31);
+                    }
             }
             r0[(size_t)i0 * n + j0] = (uint32_t)sum0;
             r1[(size_t)i1 * n + j1] = (uint32_t)sum1;
@@ -96,6 +129,53 @@ int orc_cpu_tmr_mm(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, uin
     if (syncs)
         *syncs = t.syncs;
     return ret;
+}
+
+int orc_cpu_tmr_mm(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, uint32_t xor_golden, uint32_t *cnt,
+                   uint64_t *syncs)
+{
+    return tmr_mm_run(f, s, r, n, xor_golden, cnt, syncs, 0, NULL, 0);
+}
+
+/* Campaign on the default-mode restatement: `nruns` runs of the same n x n product, run b carrying the upsets whose item lies
+ * in [b*n*n, (b+1)*n*n) (one per run = the reference campaign's regime, threadFunctions.py:588-600).  Outcome classes as
+ * jsonParser.py:162-186: E (checkGolden's voted return) != 0 -> error; else TMR_ERROR_CNT > 0 -> fault corrected; else
+ * success.  Returns the summed TMR_ERROR_CNT. */
+uint64_t orc_cpu_tmr_mm_campaign(const uint32_t *f, const uint32_t *s, int n, uint32_t xor_golden, const orc_fault *faults,
+                                 size_t nfaults, size_t nruns, uint64_t *n_error, uint64_t *n_corrected, uint64_t *n_success)
+{
+    const uint64_t nn = (uint64_t)n * n;
+    uint32_t *r = (uint32_t *)malloc(nn * sizeof(uint32_t));
+    orc_fault *mine = (orc_fault *)malloc((nfaults ? nfaults : 1) * sizeof(orc_fault));
+    uint64_t total = 0, ne = 0, nc = 0, ns = 0;
+    for (size_t b = 0; b < nruns; ++b) {
+        size_t k = 0;
+        for (size_t q = 0; q < nfaults; ++q)
+            if (faults[q].item / nn == b && faults[q].replica < 3) {
+                mine[k] = faults[q];
+                mine[k].item = faults[q].item % nn;
+                ++k;
+            }
+        uint32_t cnt = 0;
+        uint64_t syncs = 0;
+        const int err = tmr_mm_run(f, s, r, n, xor_golden, &cnt, &syncs, 1, mine, k);
+        total += cnt;
+        if (err)
+            ++ne;
+        else if (cnt)
+            ++nc;
+        else
+            ++ns;
+    }
+    free(mine);
+    free(r);
+    if (n_error)
+        *n_error = ne;
+    if (n_corrected)
+        *n_corrected = nc;
+    if (n_success)
+        *n_success = ns;
+    return total;
 }
 
 /* ---- all-host-cores variant: independent matrices, one per thread ---- */

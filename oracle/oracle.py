@@ -75,6 +75,7 @@ def lib():
         L.orc_crc16_plain.restype = C.c_uint16
         L.orc_cpu_tmr_mm.restype = C.c_int
         L.orc_cpu_tmr_mm_threads.restype = C.c_double
+        L.orc_cpu_tmr_mm_campaign.restype = C.c_uint64
         L.orc_aes_sbox.restype = C.POINTER(C.c_uint8)
         L.orc_aes_rsbox.restype = C.POINTER(C.c_uint8)
         _lib = L
@@ -304,6 +305,22 @@ def cpu_tmr_mm(f, s, xor_golden):
     err = lib().orc_cpu_tmr_mm(_p(f, C.c_uint32), _p(s, C.c_uint32), _p(r, C.c_uint32), C.c_int(n),
                                C.c_uint32(xor_golden), C.byref(cnt), C.byref(syncs))
     return r, int(err), int(cnt.value), int(syncs.value)
+
+
+def cpu_tmr_mm_campaign(f, s, xor_golden, faults):
+    """Default-mode CPU-TMR restatement under a seeded fault list: run b of the campaign carries the upsets whose item lies in
+    matrix b of a virtual batch (one n x n product per run).  Returns the summed TMR_ERROR_CNT and the outcome classes."""
+    f = np.ascontiguousarray(f, dtype=np.uint32)
+    s = np.ascontiguousarray(s, dtype=np.uint32)
+    n = f.shape[-1]
+    fl = _faults(faults)
+    nruns = int(fl["item"].max() // (n * n)) + 1 if len(fl) else 0
+    ne, nc, ns = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    tot = lib().orc_cpu_tmr_mm_campaign(_p(f, C.c_uint32), _p(s, C.c_uint32), C.c_int(n), C.c_uint32(xor_golden),
+                                        fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.c_size_t(nruns),
+                                        C.byref(ne), C.byref(nc), C.byref(ns))
+    return {"runs": nruns, "TMR_ERROR_CNT": int(tot), "error": int(ne.value), "fault_corrected": int(nc.value),
+            "success": int(ns.value)}
 
 
 def cpu_tmr_mm_threads(f, s, xor_golden, nthreads, reps):

@@ -1,4 +1,6 @@
-"""Multi-GPU path on CPU: world_size-2 gloo run of the sharding + counter all-reduce that bench.py uses with RCCL."""
+"""Multi-GPU path on CPU: world_size-2 gloo run of the sharding + counter all-reduce that bench.py uses with RCCL, and the
+rank-spawning of `bench.py --gpus N`.  The real-Engine variant (coast_bind_counters tensors, two ranks) needs a GPU and lives
+in tests/test_gpu_parity.py::test_bench_two_ranks_*."""
 import os
 import sys
 
@@ -10,7 +12,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class _FakeEngine:  # stands in for coast_amd.Engine: only the counters tensor matters to the collective
+class _FakeEngine:  # stands in for coast_amd.Engine (no device here): only the counters tensor matters to the collective
     def __init__(self, vals):
         self.counters = torch.tensor(vals, dtype=torch.int64)
 
@@ -65,3 +67,31 @@ def test_single_process_is_identity():
 
     eng = _FakeEngine([1, 2, 3, 4])
     assert allreduce_counters(eng, None).tolist() == [1, 2, 3, 4]
+
+
+def test_bench_gpus_n_spawns_n_ranks():
+    """`python bench.py --gpus 2` must start two ranks itself (it used to run one and print n_gpus 1).  Without
+    a GPU every rank stops at the same loud error -- two of them, each with its own RANK, prove the spawn."""
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["COAST_BENCH_ECHO_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by the gpu-marked two-rank tests")
+    assert p.returncode != 0
+    err = p.stderr + p.stdout
+    assert "rank 0/2" in err and "rank 1/2" in err, err[-2000:]
+    assert err.count("no GPU visible") >= 2, err[-2000:]
+
+
+def test_bench_rejects_mismatched_world():
+    import subprocess
+
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)

@@ -613,7 +613,8 @@ def test_unmodified_reference_drivers_on_gpu_backend(binary, mode, sync_every):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "oracle", "_ref", "bin", binary)
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/bin not built (needs the reference checkout at build time)")
+        pytest.fail("oracle/_ref/bin/%s is missing: the drivers are built from the reference checkout in the build container "
+                    "(__graft_entry__.build() -> make -C oracle ref) and must travel to the GPU box with the snapshot" % binary)
     expect = _DRIVERS[binary]
     env = dict(os.environ, COAST_MODE=mode, COAST_SYNC_EVERY=str(sync_every))
     p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
@@ -641,7 +642,8 @@ def test_reference_flag_matrix_clean_runs(binary):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "oracle", "_ref", "bin", binary)
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/bin not built (needs the reference checkout at build time)")
+        pytest.fail("oracle/_ref/bin/%s is missing: the drivers are built from the reference checkout in the build container "
+                    "(__graft_entry__.build() -> make -C oracle ref) and must travel to the GPU box with the snapshot" % binary)
     for passes in _OPT_PASSES:
         p = subprocess.run([exe], env=dict(os.environ, COAST_OPT_PASSES=passes), capture_output=True, text=True, timeout=300)
         assert p.returncode == 0 and _DRIVERS[binary] in p.stdout, (passes, p.returncode, p.stdout[-300:], p.stderr[-300:])
@@ -997,3 +999,102 @@ def test_fault_injection_into_unmodified_program():
         assert q.returncode == 0 and "result: 5ba3" in q.stdout
         q = subprocess.run([ref], env=dict(os.environ, COAST_MODE="NONE", COAST_INJECT=spec), capture_output=True, text=True)
         assert "result: 5ba3" not in q.stdout
+
+
+# ------------------------------------------------------------------------------------------------ multi-GPU path, kernel timing
+def _run_bench(args, env_extra=None, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, env=env,
+                       timeout=timeout)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1500:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_real_engines_counters_all_reduced():
+    """`bench.py --gpus 2` starts two ranks itself; each owns a real Engine whose totals live in the tensor bound through
+    coast_bind_counters, and the per-step all-reduce sums them.  One GPU here, so the ranks share it and the collective runs
+    over gloo (COAST_BENCH_BACKEND=gloo); on the driver's 8-GPU node the same code path runs over RCCL."""
+    args = ["--steps", "3", "--warmup", "1", "--batch", "64", "--faults", "50", "--no-extra", "--no-cpu-baseline"]
+    one = _run_bench(["--gpus", "1"] + args)
+    two = _run_bench(["--gpus", "2"] + args, {"COAST_BENCH_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["corrected_faults"] == 50 * 3 and two["corrected_faults"] == 2 * 50 * 3      # summed over both ranks
+    assert two["sync_count"] == 2 * one["sync_count"] == 2 * 3 * 64 * 256 * 256
+    assert two["injected_faults"] == 2 * one["injected_faults"]
+    assert two["outputs_match_unprotected"] and two["voted_by"] == "matrix_core" and two["stepwise_blocks_last_launch"] == 0
+    assert "gloo" in two["collective"] and "2 ranks" in two["collective"]
+
+
+def test_bench_two_ranks_crc16_stream_sharded():
+    """the 8-GPU config's shape at two ranks: every rank streams its own shard, counters all-reduced"""
+    two = _run_bench(["--gpus", "2", "--workload", "crc16", "--block-len", "255", "--batch", "65536", "--steps", "2", "--warmup", "1",
+                      "--faults", "64", "--no-cpu-baseline"], {"COAST_BENCH_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and two["corrected_faults"] == 2 * 2 * 64 and two["sync_count"] == 2 * 2 * 65536
+    assert two["outputs_match_unprotected"]
+
+
+def test_multi_gpu_c_host_rccl_allreduce():
+    """examples/multi_gpu_c_demo.c: plain C host, one coast_ctx per visible GPU, coast_allreduce_counters over RCCL
+    (ncclCommInitAll).  With one GPU the communicator has one rank; the call path (fold -> ncclAllReduce on the context's
+    stream -> read) is the one the 8-GPU node runs."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "multi_gpu_c_demo")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-800:], p.stderr[-800:])
+    assert "E:0" in p.stdout and "TMR_ERROR_CNT(global) = " in p.stdout
+
+
+def test_profiling_stats_kernel_ms_and_hbm_bytes(eng):
+    """coast_stats.kernel_ms / .hbm_bytes: HIP events around each protected launch on the launch stream, and the
+    algorithmic bytes of the launches; coast_last_launch_info names the engine."""
+    import coast_amd
+    import torch
+
+    n, batch = 256, 64
+    f = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device="cuda")
+    s = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device="cuda")
+    eng.set_profiling(True)
+    try:
+        eng.reset_stats()
+        for _ in range(3):
+            eng.mm_batch(f, s)
+        st = eng.stats()
+        assert st["launches"] == 3 and st["hbm_bytes"] == 3 * 12.0 * n * n * batch
+        assert 0.01 < st["kernel_ms"] < 50.0
+        assert eng.last_launch()["engine"] == "matrix_core" and eng.last_launch()["fast_blocks"] == 4 * batch
+        data = torch.randint(0, 256, (4096 * 255,), dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.crc16_batch(data, 255)
+        st = eng.stats()
+        assert st["hbm_bytes"] == 4096 * 257.0 and st["kernel_ms"] > 0 and eng.last_launch()["engine"] == "valu"
+    finally:
+        eng.set_profiling(False)
+    eng.reset_stats()
+    eng.mm_batch(f, s)
+    assert eng.stats()["kernel_ms"] == 0.0  # off: no events recorded
+
+
+def test_mm_rejects_misaligned_vector_operands(eng):
+    import torch
+
+    buf = torch.zeros(3 * 16 * 16 + 8, dtype=torch.int32, device="cuda")
+    f = buf[1:1 + 256].view(1, 16, 16)  # 4-byte aligned only; side 16 takes the 16-byte vector path
+    good = buf[4:4 + 256].view(1, 16, 16)
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        eng._check(eng._lib.coast_mm_batch(eng._h, f.data_ptr(), good.data_ptr(), good.data_ptr(), 16, 1,
+                                            __import__("ctypes").byref(__import__("coast_amd").XmrConfig().c()), None))
