@@ -88,6 +88,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    override = os.environ.get("COAST_LIB_OVERRIDE")  # development: A/B a differently built library in one GPU session
+    if override:
+        L = C.CDLL(override)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+        return L
     path = lib_path()
     # A fresh checkout or edited sources: (re)compile the HIP library in-tree -- still the native path, there is nothing
     # to fall back to.  build() is a no-op when the library was built from exactly these sources (content hash, not

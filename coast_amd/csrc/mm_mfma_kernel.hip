@@ -36,8 +36,13 @@
 // same private buffer.  No barrier and no cross-wave dependency inside the main loop.  (A first version re-converted 128 rows
 // of f per column block -- 13x for TMR -- and met at a barrier every slab: the matrix core was busy 30 % of the time.)
 // Two workgroups of four waves per CU for TMR / DWC (2 x 75.5 / 80 KB of LDS), one of eight for the unprotected mode.
-// LDS rows are 32 bytes (one k slab of one plane) with the two 16-byte halves swapped on rows whose bit 3 is set:
-// 16 consecutive lanes of a ds_read_b128 then cover all 64 banks, without padding.
+// LDS layouts, both conflict-free for reads and writes without padding (MI355X_MICROARCH.md section LDS: a ds_read_b128 is
+// served in four groups of 16 lanes {0-3,12-15,20-27} ..., a ds_write_b32 in two groups of 32):
+//   f panel   plane[p][row][256 B]: the row's sixteen 16-byte slots (slot = 2 * slab + half) sit at slot ^ (row & 15).  A
+//             fragment read (lane = row, fixed slot) hits 16 different slots in every lane group; a conversion store (one row, 32
+//             consecutive k-quads per group) writes 32 consecutive words of a permuted row.
+//   s slabs   plane[q][column][32 B], the two halves swapped on columns whose bit 3 is set; a conversion lane owns a column
+//             pair and every other pair stores its columns in the opposite order, which spreads a store group over all banks.
 //
 // Voter.  The common case costs 2 VALU per element: bad |= v ^ shl1(v) (DPP: the next lane's copy), and once per tile
 // bad |= shl1(bad) (OR distributes over the lane shift).  For replica 0, bad == 0 <=> all copies of all its elements agree,
@@ -46,6 +51,14 @@
 #include <type_traits>
 
 #include "xmr.hpp"
+
+#ifndef COAST_MM_KNOCK
+// development: timing knock-outs, results wrong (1 no s loads, 2 no s conversion, 16 no vote / staging / stores, 32 no f
+// panel).  What they showed (profiles/r02_mm_knockouts.txt): the parts ADD UP -- MFMAs + fragment reads 5.68 ms, s staging
+// +1.28, epilogue +1.07, f panel +0.24..0.47 = the 8.27 ms of the whole kernel -- i.e. the chip runs at its power limit and
+// every instruction is paid in clock, overlapped or not.
+#define COAST_MM_KNOCK 0
+#endif
 
 namespace coast {
 
@@ -78,21 +91,23 @@ template <int NREP> struct MmPanel {
     static constexpr int BM = 64;                     // rows per workgroup
     static constexpr int BPM = N / BM;                // workgroups per matrix
     static constexpr int NCT = (N + CPW - 1) / CPW;   // column tiles per matrix (26 / 16 / 8), tile t -> wave t % NW
-    static constexpr int PLANE_A = NSLAB * BM * 32;   // bytes per f byte-plane: [slab][row][32]
+    static constexpr int PLANE_A = BM * N;            // bytes per f byte-plane: [row][256], 16-byte slots swizzled by the row
     static constexpr int A_PANEL = 4 * PLANE_A;       // 64 KB
     static constexpr int A_PER_THR = (BM * 8 * NSLAB) / NTHR; // uint4 of the panel per thread (16 / 8)
     static constexpr int PLANE_B = CPW * 32;          // bytes per s byte-plane of one slab of one wave: [column][32]
     static constexpr int B_BUF = 4 * PLANE_B;
     static constexpr int WAVE_LDS = 2 * B_BUF;        // double buffer == the wave's 64 x CPW output tile
-    static constexpr size_t LDS_BYTES = (size_t)A_PANEL + NW * WAVE_LDS;
+    // TMR leaves two of the 32 lane-columns idle: their B operand is read from an all-zero block (one 16-byte slot per plane,
+    // at the planes' stride), so the idle columns of the multiplier array see constant zeros instead of a copy of column 0 --
+    // the kernel runs at the chip's power limit and every toggling MAC is time
+    static constexpr int ZERO_PAD = LPW < 32 ? 3 * PLANE_B + 16 : 0;
+    static constexpr size_t LDS_BYTES = (size_t)A_PANEL + NW * WAVE_LDS + ZERO_PAD;
     static constexpr int CPAIR = CPW / 2;             // column pairs per tile: a staging lane owns 2 columns x 4 k
     static constexpr int KQPR = CPAIR > 8 ? 4 : 8;    // k-quads (tile rows x 4) one staging round of a wave covers
     static constexpr int B_ROUNDS = 8 / KQPR;         // staging rounds per slab (CPAIR * KQPR <= 64 lanes each)
     static constexpr int NSETS = 2;                   // register sets of raw s words = prefetch distance in steps (4: no gain)
     static constexpr int VW = (CPW % 4 == 0) ? 4 : 2; // words per output store
     static constexpr int SEGW = CPW / VW;             // stores per tile row
-    static constexpr int V_TPB = 4 * (kWave / NREP);  // geometry of the VALU kernels, for the faulted-workgroup test
-    static constexpr int V_BPM = (64 * 64 + V_TPB - 1) / V_TPB;
     static_assert(BM * CPW * 4 == WAVE_LDS, "output tile == slab double buffer");
 };
 
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
     uint32_t *r = R + mat * nn + (size_t)row0 * G::N;
 
     // ---- the f panel: 64 rows x 64 k-quads, converted to byte planes once (all loads in flight before the first convert)
-    {
+    if (!(COAST_MM_KNOCK & 32)) {
         uint4 pa[G::A_PER_THR];
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u) {
@@ -134,11 +149,12 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u) {
             const int i = tid + G::NTHR * u;
-            const int row = i >> 6, kq = i & 63, slab = kq >> 3, k8 = kq & 7;
+            const int row = i >> 6, kq = i & 63; // 16-byte slot kq >> 2 = 2 * slab + half, word kq & 3 inside it
             const uint32_t y[4] = {mm_digits(pa[u].x), mm_digits(pa[u].y), mm_digits(pa[u].z), mm_digits(pa[u].w)};
             uint32_t w[4];
             mm_transpose4(y, w);
-            const int dst = slab * (G::BM * 32) + row * 32 + (((k8 >> 2) ^ ((row >> 3) & 1)) * 16) + (k8 & 3) * 4;
+            // a wave stores one row's 64 k-quads: 32 lanes -> 32 consecutive words of (slot ^ row) order = 32 distinct banks
+            const int dst = row * G::N + (((kq >> 2) ^ (row & 15)) * 16) + (kq & 3) * 4;
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 *reinterpret_cast<uint32_t *>(smemP + p * G::PLANE_A + dst) = w[p];
@@ -163,20 +179,33 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
 
     // s: one conversion item = four consecutive k of one column -> one word in each of the four planes; a staging lane owns
     // the two columns of a pair.  Lane -> (pair l % CPAIR, k-quad l / CPAIR + KQPR*round): one dwordx2 load instruction
-    // fetches KQPR full tile rows (CPW contiguous words each).  Buffer loads: per-lane voffset fixed for the whole kernel, the
-    // step's slab / tile column in the scalar offset, the four k rows in the immediate; reads past the matrix return 0 (columns
-    // past the edge and steps past the end are never consumed).  Lanes beyond CPAIR*KQPR mirror a live lane's item: same data,
-    // same destination, no branch.
+    // fetches KQPR full tile rows (CPW contiguous words each) -- single-dword loads of the same bytes cost 12 % of the whole
+    // kernel (measured: the vector-memory path is what the step waits for).  Buffer loads: per-lane voffset fixed for the whole
+    // kernel, the step's slab / tile column in the scalar offset, the four k rows in the immediate; reads past the matrix
+    // return 0 (columns past the edge and steps past the end are never consumed).  Lanes beyond CPAIR*KQPR mirror a live lane's
+    // item: same data, same destination, no branch.
+    // Store banks: a column's plane row is 32 bytes, so columns c and c + 4 share banks and the pairs of a store instruction
+    // (columns 0, 2, 4, 6, 8 ...) would pile three lanes on each bank.  Pairs whose index has bit 1 set therefore handle their
+    // two columns in the opposite order: one instruction then writes columns 0, 2, 5, 7, 8 -- all four bank classes -- and
+    // the only lanes that still share a bank are two-way, which a ds_write_b32 absorbs (MI355X_MICROARCH.md section LDS).
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t rsS =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(s), 0, (int)(nn * 4), 0x00020000);
-    int voffB[G::B_ROUNDS], dstB[G::B_ROUNDS];
-#pragma unroll
-    for (int u = 0; u < G::B_ROUNDS; ++u) {
+    int voffB[G::B_ROUNDS], dstB[G::B_ROUNDS][2];
+    bool swapB;
+    {
         const int l = lane < G::CPAIR * G::KQPR ? lane : lane - G::CPAIR * G::KQPR;
-        const int c = 2 * (l % G::CPAIR), kq = u * G::KQPR + l / G::CPAIR;
-        voffB[u] = ((4 * kq) * G::N + c) * 4;
-        dstB[u] = c * 32 + (((kq >> 2) ^ ((c >> 3) & 1)) * 16) + (kq & 3) * 4; // column c + 1: 32 bytes further, same swizzle
+        swapB = (((l % G::CPAIR) >> 1) & 1) != 0;
+#pragma unroll
+        for (int u = 0; u < G::B_ROUNDS; ++u) {
+            const int c = 2 * (l % G::CPAIR), kq = u * G::KQPR + l / G::CPAIR;
+            voffB[u] = ((4 * kq) * G::N + c) * 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { // the column this lane converts h-th
+                const int ch = c + (h ^ (swapB ? 1 : 0));
+                dstB[u][h] = ch * 32 + (((kq >> 2) ^ ((ch >> 3) & 1)) * 16) + (kq & 3) * 4;
+            }
+        }
     }
     auto gloadB = [&](int it, u32x2_t (&pb)[G::B_ROUNDS][4]) __attribute__((always_inline)) {
         const int soff = ((it & 7) * G::KS * G::N + tileCol0(it)) * 4;
@@ -186,26 +215,36 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
             for (int kk = 0; kk < 4; ++kk)
                 pb[u][kk] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[u] + kk * G::N * 4, soff, 0);
     };
+    auto rawWord = [&](const u32x2_t &v, int h) __attribute__((always_inline)) { // word of the column handled h-th
+        return h == 0 ? (swapB ? v[1] : v[0]) : (swapB ? v[0] : v[1]);
+    };
     auto lstoreB = [&](int it, const u32x2_t (&pb)[G::B_ROUNDS][4]) __attribute__((always_inline)) {
         uint8_t *dstBuf = wbuf + (it & 1) * G::B_BUF;
 #pragma unroll
         for (int u = 0; u < G::B_ROUNDS; ++u) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint32_t y[4] = {mm_digits(pb[u][0][h]), mm_digits(pb[u][1][h]), mm_digits(pb[u][2][h]), mm_digits(pb[u][3][h])};
+                const uint32_t y[4] = {mm_digits(rawWord(pb[u][0], h)), mm_digits(rawWord(pb[u][1], h)),
+                                       mm_digits(rawWord(pb[u][2], h)), mm_digits(rawWord(pb[u][3], h))};
                 uint32_t w[4];
                 mm_transpose4(y, w);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<uint32_t *>(dstBuf + q * G::PLANE_B + dstB[u] + 32 * h) = w[q];
+                    *reinterpret_cast<uint32_t *>(dstBuf + q * G::PLANE_B + dstB[u][h]) = w[q];
             }
         }
     };
 
     // this lane's operand row / column inside the wave tile
     const int tq = lc < G::LPW ? lc / NREP : 0; // idle lane-columns re-read the tile's first column
-    const int aOff = lc * 32 + ((kh ^ ((lc >> 3) & 1)) * 16);
+    const int aOff = lc * G::N + ((kh ^ (lc & 15)) * 16); // slab's slot: XOR with 32 * slab (bits 5..7 of the same field)
     const int bOff = tq * 32 + ((kh ^ ((tq >> 3) & 1)) * 16);
+    const uint8_t *pBpar[2]; // this lane's B fragment address in slab buffer 0 / 1; idle lane-columns: the zero block
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        pBpar[par] = (lc < G::LPW) ? wbuf + par * G::B_BUF + bOff : smemP + G::A_PANEL + G::NW * G::WAVE_LDS;
+    if (G::ZERO_PAD && tid < G::ZERO_PAD / 4)
+        reinterpret_cast<uint32_t *>(smemP + G::A_PANEL + G::NW * G::WAVE_LDS)[tid] = 0u;
     const int rrep = lc % NREP;
     const bool live = lc < G::LPW;
 
@@ -396,8 +435,8 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
         constexpr bool FIRST = decltype(firstTag)::value;
         const int soffLoad = (((it + G::NSETS) & 7) * G::KS * G::N + tileCol0(it + G::NSETS)) * 4;
         const int slab = it & 7;
-        const uint8_t *pA = smemP + slab * (G::BM * 32) + aOff;
-        const uint8_t *pB = wbuf + (it & 1) * G::B_BUF + bOff;
+        const uint8_t *pA = smemP + (aOff ^ (slab * 32));
+        const uint8_t *pB = (it & 1) ? pBpar[1] : pBpar[0]; // `it` is wave-uniform: a scalar select
         v4i_t a[2][4], b[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -407,22 +446,22 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
             a[0][p] = *reinterpret_cast<const v4i_t *>(pA + p * G::PLANE_A);
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            a[1][p] = *reinterpret_cast<const v4i_t *>(pA + p * G::PLANE_A + 32 * 32);
+            a[1][p] = *reinterpret_cast<const v4i_t *>(pA + p * G::PLANE_A + 32 * G::N);
         __builtin_amdgcn_sched_barrier(0);
 
         uint8_t *dstBuf = wbuf + ((it + 1) & 1) * G::B_BUF;
         uint32_t y[4], t[4], w[4];
-        // conversion of (round u, column h of the pair) in five stages
+        // conversion of (round u, the column the lane handles h-th) in five stages
         auto convStage = [&](int k) __attribute__((always_inline)) {
             const int u = k / 10, h = (k / 5) % 2, sub = k % 5;
             if (u >= G::B_ROUNDS)
                 return;
             if (sub == 0) {
-                y[0] = mm_digits(pbConv[u][0][h]);
-                y[1] = mm_digits(pbConv[u][1][h]);
+                y[0] = mm_digits(rawWord(pbConv[u][0], h));
+                y[1] = mm_digits(rawWord(pbConv[u][1], h));
             } else if (sub == 1) {
-                y[2] = mm_digits(pbConv[u][2][h]);
-                y[3] = mm_digits(pbConv[u][3][h]);
+                y[2] = mm_digits(rawWord(pbConv[u][2], h));
+                y[3] = mm_digits(rawWord(pbConv[u][3], h));
             } else if (sub == 2) {
                 t[0] = __builtin_amdgcn_perm(y[1], y[0], 0x05010400u);
                 t[1] = __builtin_amdgcn_perm(y[1], y[0], 0x07030602u);
@@ -436,7 +475,7 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<uint32_t *>(dstBuf + q * G::PLANE_B + dstB[u] + 32 * h) = w[q];
+                    *reinterpret_cast<uint32_t *>(dstBuf + q * G::PLANE_B + dstB[u][h]) = w[q];
             }
         };
         constexpr int NSTAGE = 10 * G::B_ROUNDS;
@@ -447,17 +486,21 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
 #pragma unroll
-                for (int q = 0; q + p < 4; ++q) {
+                for (int qq = 0; qq + p < 4; ++qq) {
+                    // limb sums in the order t = 3 2 1 0 | 3 2 1 | 3 2 | 3: consecutive MFMAs never share an accumulator
+                    // (measured: no difference to 0 1 2 3 | 1 2 3 | ..., the partner wave fills the dependency gap anyway)
+                    const int q = 3 - p - qq;
                     acc[rb][p + q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rb][p], b[q],
                                                                            (FIRST && p == 0) ? zero : acc[rb][p + q], 0, 0, 0);
                     // behind the MFMAs: the 4 * B_ROUNDS loads for step it + NSETS (spread, so that the address unit never holds
                     // the wave up) and the NSTAGE (10 / 20) conversion stages of step it + 1
                     constexpr int LSTRIDE = 4 * G::B_ROUNDS <= 10 ? 2 : 1;
-                    if (m % LSTRIDE == 0 && m / LSTRIDE < 4 * G::B_ROUNDS) {
+                    if (!(COAST_MM_KNOCK & 1) && m % LSTRIDE == 0 && m / LSTRIDE < 4 * G::B_ROUNDS) {
                         const int u = (m / LSTRIDE) / 4, kk = (m / LSTRIDE) % 4;
                         pbLoad[u][kk] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[u] + kk * G::N * 4, soffLoad, 0);
                     }
-                    if (NSTAGE <= 10) {
+                    if (COAST_MM_KNOCK & 2) {
+                    } else if (NSTAGE <= 10) {
                         if (m & 1)
                             convStage(m >> 1);
                     } else {
@@ -484,7 +527,19 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
         if (((it + G::NSETS - 1) & 7) == 7) { // ... and only the last one can close it
             // the tile's epilogue stages through both slab buffers: the next step was converted into one of them a moment
             // ago, so redo that (cheap, the registers still hold it) once the tile is out
-            tileEnd(it + G::NSETS - 1);
+            if (COAST_MM_KNOCK & 16) { // keep the MFMAs alive, drop the vote / staging / stores
+                int sum = 0;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            sum += acc[rb][t][e];
+                if (sum == 0x12345678)
+                    r[lane] = (uint32_t)sum;
+            } else
+                tileEnd(it + G::NSETS - 1);
             lstoreB(it + G::NSETS, pbs[0]);
             wave_lds_sync();
         }

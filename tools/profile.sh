@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
+BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra $*"
 echo "$BENCH" > "$OUT/command.txt"
 # 1) un-profiled reference line
 $BENCH > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
