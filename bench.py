@@ -310,7 +310,8 @@ class CRC16(Workload):
         self.bl = a.block_len
         self.nb = a.batch or (1 << 25)  # 2^25 blocks x 256 B = 8 GiB per GPU (64 GiB over 8 GPUs)
         g = torch.Generator(device=dev).manual_seed(16 + rank)
-        self.data = torch.empty(self.nb * self.bl, dtype=torch.uint8, device=dev)
+        off = int(os.environ.get("COAST_BENCH_CRC_OFFSET", "0"))  # development: start the stream `off` bytes into the allocation
+        self.data = torch.empty(self.nb * self.bl + off, dtype=torch.uint8, device=dev)[off:]
         step = 1 << 28
         for off in range(0, self.data.numel(), step):  # generated on-device, shard by shard
             self.data[off:off + step].copy_(torch.randint(0, 256, (min(step, self.data.numel() - off),),

@@ -19,9 +19,12 @@
 //                         replica-private, the three replica lanes look up the same address (LDS broadcast).
 //                         Each lane streams its own block 64 bytes (4 x dwordx4) at a time, next batch in flight under
 //                         the current one; the replicas of a block issue the same addresses (one fetch).  Blocks that
-//                         are not 16-byte aligned (the reference's own maximum, 255 bytes) use byte-aligned wide loads;
-//                         a tail shorter than 64 bytes goes dword / byte-pair / last-byte (the odd byte is one
-//                         byte-serial step).
+//                         are not 16-byte aligned (the reference's own maximum is 255 bytes) start anywhere: the lane
+//                         loads the DWORD-aligned 16-byte chunks that cover its block (byte-misaligned wide loads take
+//                         the memory pipeline's split path: 1.4 TB/s) and the byte order swap that every dword needs
+//                         anyway becomes a funnel v_perm_b32 over two neighbouring dwords with a per-lane selector --
+//                         alignment costs no instruction.  The tail (block_len % 4 bytes) comes out of the same
+//                         registers: one more pair lookup and / or one byte-serial step.
 //   crc16_general_kernel  byte-serial, exactly as written in crc16.c, with the injector hooks and the optional
 //                         per-V-bytes votes; one wave per tile; runs the tiles that own an armed fault (side stream) or
 //                         every tile when the stream path does not apply.
@@ -51,19 +54,10 @@ __global__ void crc16_table_kernel(uint16_t *__restrict__ t16)
 constexpr int kCrcStreamThreads = 1024;
 constexpr int kCrcTableBytes = 65536 * 2;
 
-struct __attribute__((packed, aligned(1))) CrcU4 { // byte-aligned 16-byte load (global memory is in unaligned mode)
-    uint32_t x, y, z, w;
-};
-struct __attribute__((packed, aligned(1))) CrcU1 {
-    uint32_t x;
-};
-template <bool ALIGNED> __device__ __forceinline__ uint4 crc_load16(const uint8_t *p)
-{
-    if (ALIGNED)
-        return *reinterpret_cast<const uint4 *>(p);
-    const CrcU4 v = *reinterpret_cast<const CrcU4 *>(p);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
+// big-endian dword (b0<<24)|(b1<<16)|(b2<<8)|b3 of the four bytes that start `sh` bytes into the little-endian dword pair
+// {hi, lo}: v_perm_b32 picks byte k of the result from byte sel[k] of the pair (0..3 = lo, 4..7 = hi).  sh = 0 is bswap(lo).
+__device__ __forceinline__ uint32_t crc_perm_sel(uint32_t sh) { return 0x00010203u + 0x01010101u * sh; }
+__device__ __forceinline__ uint32_t crc_be32(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
 template <int NREP, int NT, bool ALIGNED>
 __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
@@ -93,16 +87,39 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
     const uint64_t wave0 = (uint64_t)blockIdx.x * (kCrcStreamThreads / kWave) + (tid >> 6);
     Tally tl;
     uint32_t detItems = 0;
-    const uint32_t nbatch = blockLen >> 6; // 64-byte batches per block
-    const uint32_t rem = blockLen & 63u;   // tail bytes
+    // A block is walked as nd full dwords, then tb tail bytes.  Rows that do not start on a 16-byte boundary are read as the
+    // DWORD-aligned 16-byte chunks that cover them and realigned by the byte swap every dword needs anyway: row dword i =
+    // bytes s .. s+3 of stream dwords i, i + 1 (s = start & 3 per lane) = one funnel v_perm_b32 with a per-lane selector.
+    // Measured on the 8 GiB stream of 255-byte blocks (profiles/r02_crc16_unaligned.txt): byte-aligned 16-byte loads + byte
+    // tail 6.09 ms; this version 3.10 ms; 16-byte-aligned chunks + two more v_cndmask per dword for the lane's dword offset
+    // 3.30 ms (a dword-aligned 16-byte load costs the memory pipeline about as much as the two selects cost the VALU).
+    // Chunks are loaded only while they hold a needed dword, so a row over-reads < 20 bytes -- into the following blocks;
+    // the host keeps the last tile(s) of an unaligned stream away from this kernel.
+    const uint32_t nd = blockLen >> 2, tb = blockLen & 3u;
+    const uint32_t nbFull = nd >> 4, R = nd & 15u;             // 64-byte batches of full dwords, dwords left after them
+    const uint32_t nChunks = (nd + (tb ? 1u : 0u) + 1u + 3u) >> 2; // row dword i sits in stream dwords i, i + 1
 
     for (uint64_t tileBase = wave0 * NT; tileBase < ntiles; tileBase += wavesTotal * NT) {
         // NT independent tiles per wave: NT dependent lookup chains in flight per lane
         const uint8_t *p[NT];
         bool liveT[NT], cntT[NT];
         uint64_t itemT[NT];
-        uint32_t crc[NT];
-        uint4 cur[NT][4], nxt[NT][4];
+        uint32_t crc[NT], sel[NT];
+        uint32_t cur[NT][16], nxt[NT][16]; // one 64-byte batch of the block's dword stream, and the batch after it
+#define CRC_LOAD_CHUNK(dst, j, bt, v)                                                                        \
+    do {                                                                                                     \
+        const uint4 q__ = *reinterpret_cast<const uint4 *>(p[j] + (size_t)(bt) * 64 + 16 * (v));             \
+        dst[j][4 * (v)] = q__.x, dst[j][4 * (v) + 1] = q__.y, dst[j][4 * (v) + 2] = q__.z, dst[j][4 * (v) + 3] = q__.w; \
+    } while (0)
+#define CRC_LOAD_BATCH_GUARDED(dst, bt) /* only the chunks that hold a needed dword (wave-uniform tests; clamping the */ \
+    /* chunk index instead made the compiler narrow the vector loads to dwords: 2.5x slower)                           */ \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) if (4u * (bt) + (uint32_t)v < nChunks)                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) CRC_LOAD_CHUNK(dst, j, bt, v)
+#define CRC_LOAD_BATCH(dst, bt)                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) _Pragma("unroll") for (int v = 0; v < 4; ++v) CRC_LOAD_CHUNK(dst, j, bt, v)
+        // big-endian dword b0 b1 b2 b3 at row dword i of the current batch (the funnel's upper dword: stream dword i + 1)
+#define CRC_NEXT(j, i, out) out = crc_be32((i) < 15 ? cur[j][((i) + 1) & 15] : nxt[j][0], cur[j][i], sel[j])
+#define CRC_WINDOW_INIT(j) (void)0
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const uint64_t tile = tileBase + j;
@@ -112,72 +129,144 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
             itemT[j] = tile * IPW + (uint64_t)lm.q;
             liveT[j] = !skip && lm.live && itemT[j] < nblocksData;
             cntT[j] = liveT[j] && lm.r == 0;
-            p[j] = data + (liveT[j] ? itemT[j] : 0) * (uint64_t)blockLen;
+            const uint8_t *row = data + (liveT[j] ? itemT[j] : 0) * (uint64_t)blockLen;
+            const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(row) & 3u);
+            p[j] = row - sh;
+            sel[j] = crc_perm_sel(sh);
             crc[j] = 0xFFFFu;
-            if (nbatch) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    cur[j][v] = crc_load16<ALIGNED>(p[j] + 16 * v);
-            }
         }
-        for (uint32_t b = 0; b < nbatch; ++b) {
-            const bool more = (b + 1) < nbatch;
-            if (more) {
+        if constexpr (ALIGNED) { // rows are whole 16-byte chunks: exact loads, the byte swap is a plain v_perm
+            const uint32_t nbatch = blockLen >> 6, rem = blockLen & 63u;
+            uint4 c4[NT][4], n4[NT][4];
+            if (nbatch) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
-                        nxt[j][v] = crc_load16<ALIGNED>(p[j] + (size_t)(b + 1) * 64 + 16 * v);
+                        c4[j][v] = *reinterpret_cast<const uint4 *>(p[j] + 16 * v);
+            }
+            for (uint32_t b = 0; b < nbatch; ++b) {
+                const bool more = (b + 1) < nbatch;
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            n4[j][v] = *reinterpret_cast<const uint4 *>(p[j] + (size_t)(b + 1) * 64 + 16 * v);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        uint32_t e[NT];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const uint32_t d = (c == 0) ? c4[j][v].x : (c == 1) ? c4[j][v].y : (c == 2) ? c4[j][v].z : c4[j][v].w;
+                            e[j] = __builtin_bswap32(d); // (b0<<24)|(b1<<16)|(b2<<8)|b3
+                        }
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            crc[j] = T[crc[j] ^ (e[j] >> 16)];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            crc[j] = T[crc[j] ^ (e[j] & 0xffffu)];
+                    }
+                }
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            c4[j][v] = n4[j][v];
+                }
+            }
+            for (uint32_t t = 0; t < rem; t += 4u) { // a block of 16, 32 or 48 bytes past the last batch
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const uint32_t e = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(p[j] + (size_t)nbatch * 64 + t));
+                    crc[j] = T[crc[j] ^ (e >> 16)];
+                    crc[j] = T[crc[j] ^ (e & 0xffffu)];
+                }
+            }
+        } else {
+        if (nbFull) {
+            CRC_LOAD_BATCH(cur, 0u);
+        } else {
+            CRC_LOAD_BATCH_GUARDED(cur, 0u);
+        }
+        for (uint32_t b = 0; b < nbFull; ++b) {
+            if (b + 1u < nbFull) { // the batch after this one: full ...
+                CRC_LOAD_BATCH(nxt, b + 1u);
+            } else { // ... or partial, or just the dword a funnel reaches into
+                CRC_LOAD_BATCH_GUARDED(nxt, b + 1u);
+            }
+            if (b == 0u) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    CRC_WINDOW_INIT(j);
             }
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int i = 0; i < 16; ++i) {
+                uint32_t e[NT];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int j = 0; j < NT; ++j)
+                    CRC_NEXT(j, i, e[j]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    crc[j] = T[crc[j] ^ (e[j] >> 16)];
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    crc[j] = T[crc[j] ^ (e[j] & 0xffffu)];
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    cur[j][i] = nxt[j][i];
+        }
+        if (R | tb) { // what is left of the block: R < 16 full dwords, then tb < 4 bytes -- all of it already in `cur`
+            if (4u * (nbFull + 1u) < nChunks) { // R == 15 with a tail: its funnel reaches one dword further
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    nxt[j][0] = *reinterpret_cast<const uint32_t *>(p[j] + (size_t)(nbFull + 1u) * 64);
+            }
+            if (nbFull == 0u) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    CRC_WINDOW_INIT(j);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if ((uint32_t)i < R) {
                     uint32_t e[NT];
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const uint32_t d = (c == 0) ? cur[j][v].x : (c == 1) ? cur[j][v].y : (c == 2) ? cur[j][v].z : cur[j][v].w;
-                        e[j] = __builtin_bswap32(d); // (b0<<24)|(b1<<16)|(b2<<8)|b3
-                    }
+                    for (int j = 0; j < NT; ++j)
+                        CRC_NEXT(j, i, e[j]);
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         crc[j] = T[crc[j] ^ (e[j] >> 16)];
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         crc[j] = T[crc[j] ^ (e[j] & 0xffffu)];
+                } else if ((uint32_t)i == R && tb) { // b0 [b1 [b2]]: a pair lookup for two bytes, a byte-serial step for the odd one
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        uint32_t e;
+                        CRC_NEXT(j, i, e);
+                        if (tb >= 2u)
+                            crc[j] = T[crc[j] ^ (e >> 16)];
+                        if (tb & 1u)
+                            crc[j] = crc16_byte(crc[j], tb == 1u ? e >> 24 : (e >> 8) & 0xffu);
+                    }
                 }
             }
-            if (more) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        cur[j][v] = nxt[j][v];
-            }
         }
-        if (rem) { // tail shorter than one batch: dwords, then a byte pair, then the odd byte (one byte-serial step)
-            const size_t tb = (size_t)nbatch * 64;
-            uint32_t t = 0;
-            for (; t + 4u <= rem; t += 4u) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const uint32_t e = __builtin_bswap32(reinterpret_cast<const CrcU1 *>(p[j] + tb + t)->x);
-                    crc[j] = T[crc[j] ^ (e >> 16)];
-                    crc[j] = T[crc[j] ^ (e & 0xffffu)];
-                }
-            }
-            if (t + 2u <= rem) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    crc[j] = T[crc[j] ^ (((uint32_t)p[j][tb + t] << 8) | (uint32_t)p[j][tb + t + 1])];
-                t += 2u;
-            }
-            if (t < rem) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    crc[j] = crc16_byte(crc[j], p[j][tb + t]);
-            }
         }
+#undef CRC_NEXT
+#undef CRC_WINDOW_INIT
+#undef CRC_LOAD_BATCH
+#undef CRC_LOAD_BATCH_GUARDED
+#undef CRC_LOAD_CHUNK
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             Tally te = tl;
@@ -205,12 +294,15 @@ __global__ __launch_bounds__(64) void crc16_general_kernel(const uint8_t *__rest
                                                            uint64_t nblocksData, uint16_t *__restrict__ crcs,
                                                            uint32_t syncEvery, Counters ctr, FaultTab ft,
                                                            const uint32_t *__restrict__ tileList,
-                                                           uint8_t *__restrict__ detected)
+                                                           uint8_t *__restrict__ detected, uint32_t tileBase = 0u,
+                                                           uint32_t unlessFaulted = 0u)
 {
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
     const LaneMap<NREP> lm;
-    const uint32_t tile = tileList ? tileList[blockIdx.x] : blockIdx.x;
+    const uint32_t tile = tileList ? tileList[blockIdx.x] : tileBase + blockIdx.x;
+    if (unlessFaulted && ft.range && ft.range[tile].y != 0u)
+        return; // the launch over the armed-fault tiles has this one
     const int slot = lm.q;
     const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
     const bool live = lm.live && item < nblocksData;

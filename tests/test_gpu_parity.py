@@ -440,6 +440,60 @@ def test_crc16_faults_vs_oracle(eng, orc, block_len, replicas, sync_every):
     assert (det.cpu().numpy() == exp_det).all()
 
 
+@pytest.mark.parametrize("block_len", [2, 3, 4, 5, 7, 15, 17, 63, 65, 67, 127, 191, 192, 252, 253, 254, 255, 257, 319, 1000])
+def test_crc16_stream_every_alignment_and_tail(eng, orc, block_len):
+    """The dword-aligned funnel loads of the stream kernel: every row misalignment (the batch starts 0..3 bytes into a
+    dword, rows follow at block_len strides), every tail length, blocks shorter than a chunk and longer than 255 bytes, with
+    the last tile on its own path and nothing read past the end of the allocation (the data tensor ends with the last block).
+    TMR with upsets in the first and the last tile, DWC and unprotected clean."""
+    import torch
+
+    import coast_amd
+
+    rng = np.random.default_rng(9000 + block_len)
+    nb = 21 * 40 + 5
+    for off in (0, 1, 2, 3):
+        raw = rng.integers(0, 256, off + nb * block_len, dtype=np.uint8)
+        dev = torch.from_numpy(raw).cuda()[off:]          # the view starts `off` bytes into the allocation
+        data = raw[off:].reshape(nb, block_len)
+        fl = coast_amd.make_faults([(0, 1, 24, min(1, block_len), 3), (nb - 1, 0, 24, block_len, 9), (nb - 2, 2, 25, 0, 1),
+                                    (400, 2, 24, block_len // 2, 15)])
+        exp, exp_st, exp_det = orc.crc16_xmr(data, block_len, replicas=3, faults=fl)
+        det = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        got = _host(eng.crc16_batch(dev, block_len, detected=det), np.uint16)
+        assert (got == exp).all(), off
+        assert _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all(), off
+        if off in (0, 3):
+            for replicas in (2, 1):
+                exp, exp_st, _ = orc.crc16_xmr(data, block_len, replicas=replicas)
+                eng.reset_stats()
+                got = _host(eng.crc16_batch(dev, block_len, cfg=coast_amd.XmrConfig(replicas)), np.uint16)
+                assert (got == exp).all() and _stats3(eng.stats()) == exp_st, (off, replicas)
+
+
+def test_crc16_255_byte_stream_prefix(eng, orc):
+    """the reference's own maximum block (unsigned char length, crc16.c:21): 16 MiB stream, 1 MiB prefix vs the oracle,
+    linearity over the whole stream"""
+    import torch
+
+    g = torch.Generator(device="cuda").manual_seed(255)
+    nb, bl = 1 << 16, 255
+    a = torch.randint(0, 256, (nb * bl,), dtype=torch.uint8, device="cuda", generator=g)
+    b = torch.randint(0, 256, (nb * bl,), dtype=torch.uint8, device="cuda", generator=g)
+    ca = _host(eng.crc16_batch(a, bl), np.uint16)
+    cb = _host(eng.crc16_batch(b, bl), np.uint16)
+    cx = _host(eng.crc16_batch(a ^ b, bl), np.uint16)
+    assert ((cx ^ ca ^ cb) == orc.crc16_plain(bytes(bl))).all()
+    pre = a[: 4096 * bl].cpu().numpy().reshape(-1, bl)
+    exp, _, _ = orc.crc16_xmr(pre, bl)
+    assert (ca[:4096] == exp).all()
+    last = a[-64 * bl:].cpu().numpy().reshape(-1, bl)  # the tail of the stream, last tile included
+    exp, _, _ = orc.crc16_xmr(last, bl)
+    assert (ca[-64:] == exp).all()
+
+
 def test_crc16_stream_prefix_and_linearity(eng, orc):
     """Stream config: parity on a 1 MiB prefix vs the oracle; CRC linearity crc(a^b) ^ crc(a) ^ crc(b) == crc(0)."""
     import torch
