@@ -167,7 +167,7 @@ def cpu_baseline_items(kind, budget_s=6.0, block_len=256):
             "sample": "%d x 32768 blocks encrypt, oracle DWC model, gcc -O3, %.1f s" % (reps, dt)}
 
 
-def config1_cpu_tmr_mm32(eng, coast_amd):
+def cpu_baseline_config1_mm32(eng, coast_amd):
     """BASELINE.json configs[0]: tests/matrixMultiply 32x32, TMR on the host CPU (no GPU in the measurement).  The reference
     LLVM pass cannot run here, so this is its default-mode restatement (1 core and all cores) plus the -noMemReplication
     model; TMR_ERROR_CNT is reported under a seeded list of K single-bit register upsets (one per run, the reference
@@ -356,11 +356,12 @@ class SHA256(Workload):
     unit = "msgs/s"
     dtype = "u32"
     # VALU instructions of one 64-byte message per replica lane (FIPS 180-4, as sha256_fast_kernel issues them; tools/instr_mix.py
-    # counts the same numbers in the compiled kernel): data block = 64 rounds + 48 schedule words, padding block = 64
-    # rounds on precomputed K+W.  round: 6 v_alignbit (the rotates of Sigma0/Sigma1) + 4 v_bitop3 (two xor3, ch, maj) + 3
-    # v_add3 + 1 v_add; schedule word: 4 v_alignbit + 2 v_lshr + 2 v_bitop3 + 2 v_add; 2 x 8 state adds.
-    MIX = {"v_alignbit": 2 * 64 * 6 + 48 * 4, "v_bitop3": 2 * 64 * 4 + 48 * 2, "v_add3": 2 * 64 * 3,
-           "v_add": 2 * 64 + 48 * 2 + 16, "v_lshr": 48 * 2}
+    # counts the same numbers in the compiled kernel): two compressions (the data block and the padding block, whose schedule
+    # is expanded per replica lane like any other -- it sits inside the triplicated sha256_transform), each 64 rounds + 48
+    # schedule words.  round: 6 v_alignbit (the rotates of Sigma0/Sigma1) + 4 v_bitop3 (two xor3, ch, maj) + 3 v_add3 + 1 v_add;
+    # schedule word: 4 v_alignbit + 2 v_lshr + 2 v_bitop3 + 2 v_add; 2 x 8 state adds.
+    MIX = {"v_alignbit": 2 * (64 * 6 + 48 * 4), "v_bitop3": 2 * (64 * 4 + 48 * 2), "v_add3": 2 * 64 * 3,
+           "v_add": 2 * (64 + 48 * 2) + 16, "v_lshr": 2 * 48 * 2}
 
     def __init__(self, a, eng, dev, rank, coast_amd):
         self.nm = a.batch or (1 << 22)
@@ -660,7 +661,7 @@ def extra_legs(a, eng, dist, dev, rank, world, coast_amd):
             legs[name] = result_fields(wl, run, b, world, steps, warm, with_cpu=(world == 1 and not a.no_cpu_baseline))
         wl.free()
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
-        legs["config1_mm32_cpu_tmr"] = config1_cpu_tmr_mm32(eng, coast_amd)
+        legs["config1_mm32_cpu_tmr"] = cpu_baseline_config1_mm32(eng, coast_amd)
     return legs
 
 

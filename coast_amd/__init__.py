@@ -5,14 +5,15 @@ the thin host-side mirror of the reference's interface for that path: the protec
 names (matrix_multiply, sha256_hash, aes_enc_dec, crc16), the batch engine, the fault injector and the multi-GPU
 counter reduction.  Nothing here computes on the CPU.
 """
-from .engine import DWC, F_NO_STORE_DATA_SYNC, TMR, UNPROTECTED, Engine, XmrConfig, make_faults  # noqa: F401
+from .engine import (DWC, F_ADDR_SYNC, F_BRANCH_SYNC, F_NO_LOAD_SYNC, F_NO_STORE_ADDR_SYNC,  # noqa: F401
+                     F_NO_STORE_DATA_SYNC, TMR, UNPROTECTED, Engine, XmrConfig, make_faults)
 from .hostapi import (FaultDetectedDWC, aes_enc_dec, crc16, host_stats, matrix_multiply,  # noqa: F401
                       sha256_hash)
 from ._lib import FAULT_DTYPE, CoastLibraryError  # noqa: F401
 
 SITE_MM_ACC, SITE_MM_OPA, SITE_MM_OPB = 0, 1, 2
-SITE_SHA_M, SITE_SHA_WV, SITE_SHA_STATE = 8, 9, 10
+SITE_SHA_M, SITE_SHA_WV, SITE_SHA_STATE, SITE_SHA_DATALEN, SITE_SHA_I = 8, 9, 10, 11, 12
 SITE_AES_STATE, SITE_AES_KEY = 16, 17
-SITE_CRC_CRC, SITE_CRC_X = 24, 25
+SITE_CRC_CRC, SITE_CRC_X, SITE_CRC_LEN = 24, 25, 26
 SITE_CT_SUM, SITE_CT_VAL, SITE_CT_NERR = 32, 33, 34
 SITE_CHSHA_W, SITE_CHSHA_WV, SITE_CHSHA_DIGEST = 40, 41, 42

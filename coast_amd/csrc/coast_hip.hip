@@ -107,14 +107,21 @@ int fail(coast_ctx *ctx, int code, const char *fmt, ...)
 
 unsigned long long *totals_of(coast_ctx *c) { return c->dBound ? c->dBound : c->dTotals; }
 
-int check_cfg(coast_ctx *ctx, const coast_cfg *cfg)
+// `indexedOk`: this kernel implements the index-in-the-sphere-of-replication flags (sha256, crc16)
+int check_cfg(coast_ctx *ctx, const coast_cfg *cfg, bool indexedOk = false)
 {
     if (!ctx)
         return COAST_EINVAL;
     if (!cfg || cfg->replicas < 1 || cfg->replicas > 3)
         return fail(ctx, COAST_EINVAL, "coast_cfg.replicas must be 1 (none), 2 (DWC) or 3 (TMR)");
-    if (cfg->flags & ~(uint32_t)COAST_F_NO_STORE_DATA_SYNC)
+    const uint32_t indexed = COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC | COAST_F_NO_LOAD_SYNC | COAST_F_NO_STORE_ADDR_SYNC;
+    if (cfg->flags & ~((uint32_t)COAST_F_NO_STORE_DATA_SYNC | indexed))
         return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: unknown bits", cfg->flags);
+    if ((cfg->flags & indexed) && !indexedOk)
+        return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC are implemented for sha256 "
+                                       "and crc16 (the kernels whose reference source walks a data-dependent counter)", cfg->flags);
+    if ((cfg->flags & (COAST_F_NO_LOAD_SYNC | COAST_F_NO_STORE_ADDR_SYNC)) && !(cfg->flags & COAST_F_ADDR_SYNC))
+        return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: -noLoadSync / -noStoreAddrSync qualify COAST_F_ADDR_SYNC", cfg->flags);
     return COAST_OK;
 }
 

@@ -32,7 +32,7 @@
 
 namespace coast {
 
-enum { SITE_CRC_CRC = 24, SITE_CRC_X = 25 };
+enum { SITE_CRC_CRC = 24, SITE_CRC_X = 25, SITE_CRC_LEN = 26 };
 
 __device__ __forceinline__ uint32_t crc16_byte(uint32_t crc, uint32_t byte)
 {
@@ -321,7 +321,45 @@ __global__ __launch_bounds__(64) void crc16_general_kernel(const uint8_t *__rest
     Tally tl;
     uint32_t crc = 0xFFFFu;
 
-    if (!stepwise) {
+    if (ctr.flags & kFlagBranchSync) {
+        // `while (length--)` as written (crc16.c:25): `length` is a replica-private unsigned char and its loop condition is
+        // voted at every evaluation (terminator sync on an i1, synchronization.cpp:146-155).  `*data_p++` has a constant GEP
+        // offset: no address vote in this function.  Mirrors oracle/coast_oracle.c:crc_item_branch (watchdog, bounded reads).
+        uint32_t ln = blockLen & 0xffu;
+        const uint32_t cap = 4u * blockLen + 256u;
+        for (uint32_t it = 0;; ++it) {
+            uint32_t xm = 0u, cm = 0u;
+            for (uint32_t q = 0; q < fr.y; ++q) {
+                const DevFault df = ft.list[fr.x + q];
+                if (df.step != it || (int)df.local != slot || (int)df.replica != lm.r || !lm.live)
+                    continue;
+                if (df.site == SITE_CRC_LEN)
+                    ln ^= (1u << (df.bit & 31u)) & 0xffu;
+                else if (df.site == SITE_CRC_CRC && it < blockLen)
+                    cm ^= (1u << (df.bit & 31u)) & 0xffffu;
+                else if (df.site == SITE_CRC_X && it < blockLen)
+                    xm ^= (1u << (df.bit & 31u)) & 0xffu;
+            }
+            const uint32_t go = xmr_steer<NREP>(ln != 0u ? 1u : 0u, lm, true, cnt, tl);
+            ln = (ln - 1u) & 0xffu; // length--: on both exits
+            if (!go || it >= cap)
+                break;
+            const uint32_t byte = (live && it < blockLen) ? (uint32_t)p[it] : 0u;
+            crc ^= cm;
+            uint32_t x = ((crc >> 8) ^ byte) & 0xffu;
+            x ^= x >> 4;
+            x ^= xm;
+            crc = ((crc << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xffffu;
+            if (syncEvery && ((it + 1u) % syncEvery) == 0u && (it + 1u) < blockLen)
+                crc = xmr_sync<NREP>(crc, lm, cnt, tl);
+        }
+        for (uint32_t q = 0; q < fr.y; ++q) {
+            const DevFault df = ft.list[fr.x + q];
+            if (df.step == blockLen && df.site == SITE_CRC_CRC && (int)df.local == slot && (int)df.replica == lm.r &&
+                lm.live)
+                crc = flip_bit(crc, df.bit, 0xffffu);
+        }
+    } else if (!stepwise) {
         uint32_t t = 0;
         if (aligned) {
             for (; t + 4u <= blockLen; t += 4u) {

@@ -25,8 +25,10 @@
  *       -noMemReplication              the lane-replicated engine; WITHOUT it (the reference's default) every clone runs on its
  *                                      own memory copy and the copies are voted at the region exit (COAST_F_HOST_MEMORY_REPLICATED)
  *       -noStoreDataSync               COAST_F_NO_STORE_DATA_SYNC (only meaningful next to -noMemReplication, as in the reference)
- *       -countErrors -countSyncs -storeDataSync -noLoadSync -noStoreAddrSync -i -s   accepted; always on / no effect here
- *                                      (include/coast_hip.h says why)
+ *       -countErrors -countSyncs -storeDataSync -i -s   accepted; always on / no effect here (include/coast_hip.h says why)
+ *       -noLoadSync -noStoreAddrSync   accepted; real knobs for crc16 / sha256_hash once COAST_COUNTERS_IN_SOR=1 puts their loop
+ *                                      counters inside the sphere of replication (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC, the
+ *                                      reference's -noMemReplication rule set for them); otherwise no replicated address exists
  *   or, shorter, COAST_MODE = TMR (default) | DWC | NONE  (lane-replicated engine);
  *   COAST_SYNC_EVERY = V adds the optional loop-condition sync points.
  *
@@ -78,6 +80,22 @@ static coast_cfg dropin_cfg(void)
     const char *v = getenv("COAST_SYNC_EVERY");
     if (v)
         c.sync_every = (uint32_t)strtoul(v, NULL, 10);
+    return c;
+}
+
+/* crc16 / sha256_hash: the kernels whose loop counters can be put inside the sphere of replication */
+static coast_cfg dropin_cfg_counters(void)
+{
+    coast_cfg c = dropin_cfg();
+    const char *in = getenv("COAST_COUNTERS_IN_SOR");
+    if (in && *in && *in != '0' && !(c.flags & COAST_F_HOST_MEMORY_REPLICATED) && c.replicas > 1u) {
+        const char *passes = getenv("COAST_OPT_PASSES");
+        c.flags |= COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC;
+        if (passes && has_flag(passes, "-noLoadSync"))
+            c.flags |= COAST_F_NO_LOAD_SYNC;
+        if (passes && has_flag(passes, "-noStoreAddrSync"))
+            c.flags |= COAST_F_NO_STORE_ADDR_SYNC;
+    }
     return c;
 }
 
@@ -144,7 +162,7 @@ static void dropin_account(void)
 
 unsigned short crc16(const unsigned char *data_p, unsigned char length)
 {
-    const coast_cfg cfg = dropin_cfg();
+    const coast_cfg cfg = dropin_cfg_counters();
     dropin_maybe_inject();
     uint16_t crc = 0;
     const int rc = coast_crc16_host(data_p, length, &crc, &cfg);
@@ -167,7 +185,7 @@ void aes_enc_dec(unsigned char *state, unsigned char *key, unsigned char dir)
 void sha256_hash(unsigned char ctx_data[], uint32_t ctx_bitlen[], uint32_t ctx_state[], unsigned char data[],
                  uint32_t len, unsigned char hash[])
 {
-    const coast_cfg cfg = dropin_cfg();
+    const coast_cfg cfg = dropin_cfg_counters();
     dropin_maybe_inject();
     uint32_t st[8];
     const int rc = coast_sha256_host(data, len, hash, st, &cfg);

@@ -111,13 +111,6 @@ template <int NREP> struct MmPanel {
     static_assert(BM * CPW * 4 == WAVE_LDS, "output tile == slab double buffer");
 };
 
-__device__ __forceinline__ void wave_lds_sync()
-{ // LDS operations of one wave execute in issue order; this only pins the compiler's order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <int NREP>
 __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void mm_mfma_panel_kernel(
     const uint32_t *__restrict__ F, const uint32_t *__restrict__ S, uint32_t *__restrict__ R, uint32_t nblocks, Counters ctr,

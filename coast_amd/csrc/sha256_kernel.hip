@@ -19,7 +19,7 @@
 
 namespace coast {
 
-enum { SITE_SHA_M = 8, SITE_SHA_WV = 9, SITE_SHA_STATE = 10 };
+enum { SITE_SHA_M = 8, SITE_SHA_WV = 9, SITE_SHA_STATE = 10, SITE_SHA_DATALEN = 11, SITE_SHA_I = 12 };
 
 __constant__ uint32_t kShaK[64] = { // FIPS 180-4 section 4.2.2; sha256_common_tmr.c:8-19
     0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u,
@@ -138,62 +138,13 @@ __device__ __forceinline__ void sha_compress_unrolled(uint32_t st[8], uint32_t m
     st[7] += h;
 }
 
-// The padding block of a message whose length is a multiple of 64 holds no data: its 16 words (0x80000000, 0 ..., the
-// bit length) and therefore its whole 64-word schedule depend on `len` alone -- a launch-uniform value like a loop bound,
-// outside the sphere of replication.  The host expands that schedule once and passes kw[t] = K[t] + W[t]; the replicated
-// part (the 64 rounds on the replica-private state) is unchanged.  Same digest bit for bit.
-struct ShaTail {
-    uint32_t kw[64];
-    uint32_t enabled;
-};
-
-__device__ __forceinline__ void sha_compress_const(uint32_t st[8], const ShaTail &tail)
-{
-    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
-#define SHA_CSTEP(A, B, C, D, E, F, G, H, T)                                                                     \
-    do {                                                                                                        \
-        const uint32_t ep1_ = xor3(rotr32(E, 6), rotr32(E, 11), rotr32(E, 25));                                 \
-        const uint32_t t1_ = (H + ep1_ + sha_ch(E, F, G)) + tail.kw[(T)];                                       \
-        const uint32_t ep0_ = xor3(rotr32(A, 2), rotr32(A, 13), rotr32(A, 22));                                 \
-        D += t1_;                                                                                               \
-        H = t1_ + ep0_ + sha_maj(A, B, C);                                                                      \
-    } while (0)
-#define SHA_CSTEP8(T)                                                                                            \
-    SHA_CSTEP(a, b, c, d, e, f, g, h, (T) + 0);                                                                 \
-    SHA_CSTEP(h, a, b, c, d, e, f, g, (T) + 1);                                                                 \
-    SHA_CSTEP(g, h, a, b, c, d, e, f, (T) + 2);                                                                 \
-    SHA_CSTEP(f, g, h, a, b, c, d, e, (T) + 3);                                                                 \
-    SHA_CSTEP(e, f, g, h, a, b, c, d, (T) + 4);                                                                 \
-    SHA_CSTEP(d, e, f, g, h, a, b, c, (T) + 5);                                                                 \
-    SHA_CSTEP(c, d, e, f, g, h, a, b, (T) + 6);                                                                 \
-    SHA_CSTEP(b, c, d, e, f, g, h, a, (T) + 7)
-    SHA_CSTEP8(0);
-    SHA_CSTEP8(8);
-    SHA_CSTEP8(16);
-    SHA_CSTEP8(24);
-    SHA_CSTEP8(32);
-    SHA_CSTEP8(40);
-    SHA_CSTEP8(48);
-    SHA_CSTEP8(56);
-#undef SHA_CSTEP8
-#undef SHA_CSTEP
-    st[0] += a;
-    st[1] += b;
-    st[2] += c;
-    st[3] += d;
-    st[4] += e;
-    st[5] += f;
-    st[6] += g;
-    st[7] += h;
-}
-
 // one wave per tile; requires 4-byte aligned message rows (stride % 4 == 0, base % 4 == 0); VEC16: rows 16-byte aligned
 template <int NREP, bool VEC16>
 __global__ __launch_bounds__(256) void sha256_fast_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
                                                           uint64_t nmsgs, uint8_t *__restrict__ digests,
                                                           uint64_t ntiles, Counters ctr,
                                                           const uint2 *__restrict__ faultRange,
-                                                          uint8_t *__restrict__ detected, ShaTail tail)
+                                                          uint8_t *__restrict__ detected)
 {
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
@@ -219,13 +170,6 @@ __global__ __launch_bounds__(256) void sha256_fast_kernel(const uint8_t *__restr
 
     for (uint32_t c = 0; c < ncomp; ++c) {
         uint32_t m[16];
-        if (tail.enabled && c == nfull) { // data-free padding block (len % 64 == 0): host-expanded schedule
-            sha_compress_const(st, tail);
-#pragma unroll
-            for (int w = 0; w < 8; ++w)
-                st[w] = xmr_sync<NREP>(st[w], lm, cnt, tl);
-            continue;
-        }
         if (c < nfull) { // a whole data block
             if (VEC16) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(msg + (size_t)c * 64);
@@ -243,7 +187,10 @@ __global__ __launch_bounds__(256) void sha256_fast_kernel(const uint8_t *__restr
                 for (int t = 0; t < 16; ++t)
                     m[t] = bswap32(src[t]);
             }
-        } else { // tail / padding blocks (:129-164)
+        } else { // tail / padding blocks (:129-164).  A message of k * 64 bytes ends with a block that holds no data: its 16
+                 // words and 48 schedule words depend on `len` alone, yet they are computed here, per replica lane, like
+                 // every other block -- in the reference that expansion sits inside the triplicated sha256_transform (:49-63),
+                 // so it belongs inside the sphere of replication (round 1 expanded it once on the host).
             const bool last = (c + 1u == ncomp);
 #pragma unroll
             for (int t = 0; t < 16; ++t)
@@ -361,6 +308,96 @@ __device__ __forceinline__ void sha_state_hook(uint32_t st[8], uint32_t step, co
     }
 }
 
+// sha256_hash with its byte loop as written (sha256_common_tmr.c:119-127), for COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC: the loop
+// counter `i` and `ctx_datalen` are replica-private registers of the lane; ctx_data[64] is memory -- one copy per message, in
+// LDS, written by the original store (replica 0's lane) at the voted or at its own offset; ctx_bitlen likewise.  Mirrors
+// oracle/coast_oracle.c:sha_item_indexed statement by statement (bounded wild accesses, watchdog).  The replicas of a message
+// always take the same (voted, or replica 0's) direction, so they stay convergent; different messages may diverge.
+template <int NREP>
+__device__ void sha_item_indexed(const uint8_t *msg, uint32_t len, uint32_t st[8], const LaneMap<NREP> &lm, bool laneLive,
+                                 bool cnt, Tally &tl, const FaultTab &ft, uint2 fr, int slot, uint32_t flags, uint8_t *buf)
+{
+    const bool bs = (flags & kFlagBranchSync) != 0u, as = (flags & kFlagAddrSync) != 0u;
+    const bool ls = as && !(flags & kFlagNoLoadSync), ss = as && !(flags & kFlagNoStoreAddrSync);
+    const bool writer = laneLive && lm.r == 0; // the single memory copy is written by the original instruction
+    uint32_t ir = 0u, dl = 0u, cidx = 0u, bl0 = 0u, bl1 = 0u;
+    const uint32_t cap = 4u * len + 256u;
+    uint32_t *buf32 = reinterpret_cast<uint32_t *>(buf);
+    if (writer) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            buf32[t] = 0u;
+    }
+    auto transform = [&]() __attribute__((always_inline)) {
+        uint32_t m[16];
+        wave_lds_sync(); // ctx_data was written by replica 0's lane: the other replicas' loads must not overtake its stores
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            m[t] = bswap32(buf32[t]);
+        wave_lds_sync(); // ... and its next stores must not overtake these loads
+        sha_state_hook(st, cidx, ft, fr, slot, lm.r, lm.live);
+        sha_compress_hooked(st, m, cidx, ft, fr, slot, lm.r, lm.live);
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+            st[w] = xmr_store_sync<NREP>(st[w], lm, cnt, tl);
+        ++cidx;
+    };
+    for (uint32_t it = 0;; ++it) {
+        for (uint32_t q = 0; q < fr.y; ++q) {
+            const DevFault df = ft.list[fr.x + q];
+            if (df.step != it || (int)df.local != slot || (int)df.replica != lm.r || !lm.live)
+                continue;
+            if (df.site == SITE_SHA_I)
+                ir ^= 1u << (df.bit & 31u);
+            else if (df.site == SITE_SHA_DATALEN)
+                dl ^= 1u << (df.bit & 31u);
+        }
+        if (!xmr_steer<NREP>(ir < len ? 1u : 0u, lm, bs, cnt, tl) || it >= cap) // for (i = 0; i < len; ++i)        :119
+            break;
+        const uint32_t li = xmr_steer<NREP>(ir, lm, ls, cnt, tl);                // data[i]                          :120
+        const uint32_t byte = li < len ? (uint32_t)msg[li] : 0u;
+        const uint32_t si = xmr_steer<NREP>(dl, lm, ss, cnt, tl);                // ctx_data[ctx_datalen] = ...      :120
+        if (writer && si < 64u)
+            buf[si] = (uint8_t)byte;
+        dl += 1u;                                                                // ctx_datalen++                    :121
+        if (xmr_steer<NREP>(dl == 64u ? 1u : 0u, lm, bs, cnt, tl)) {             // if (ctx_datalen == 64)           :122
+            transform();
+            bl1 += (bl0 > 0xffffffffu - 512u) ? 1u : 0u;
+            bl0 += 512u;
+            dl = 0u;                                                             // ctx_datalen = 0                  :125
+        }
+        ir += 1u;
+    }
+    const bool shortPad = xmr_steer<NREP>(dl < 56u ? 1u : 0u, lm, bs, cnt, tl) != 0u; // if (ctx_datalen < 56)      :132
+    const uint32_t pi = xmr_steer<NREP>(dl, lm, ss, cnt, tl);                    // ctx_data[i++] = 0x80, i = ctx_datalen
+    if (writer) {
+        if (pi < 64u)
+            buf[pi] = 0x80u;
+        for (uint32_t k = pi + 1u; k < (shortPad ? 56u : 64u); ++k)              // the zero fill: a memset after -O3
+            buf[k] = 0u;
+    }
+    if (!shortPad) {
+        transform();
+        if (writer) {
+#pragma unroll
+            for (int t = 0; t < 14; ++t)
+                buf32[t] = 0u;
+        }
+    }
+    // DBL_INT_ADD(ctx_bitlen[0], ctx_bitlen[1], ctx_datalen * 8): a replicated value stored into the single ctx_bitlen   :150
+    uint32_t add = xmr_store_sync<NREP>(dl * 8u, lm, cnt, tl);
+    if (NREP != 3 || !lm.storeSync)
+        add = xmr_rep0<NREP>(add, lm);
+    bl1 += (bl0 > 0xffffffffu - add) ? 1u : 0u;
+    bl0 += add;
+    if (writer) {
+        buf32[14] = bswap32(bl1);
+        buf32[15] = bswap32(bl0);
+    }
+    transform();
+    sha_state_hook(st, cidx, ft, fr, slot, lm.r, lm.live); // step == ncompress: before the digest
+}
+
 // one wave (64-thread workgroup) per tile
 template <int NREP>
 __global__ __launch_bounds__(64) void sha256_general_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
@@ -371,6 +408,7 @@ __global__ __launch_bounds__(64) void sha256_general_kernel(const uint8_t *__res
 {
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    __shared__ __attribute__((aligned(16))) uint8_t sCtxData[IPW + 1][64]; // indexed mode: ctx_data of every message of the tile
     LaneMap<NREP> lm;
     lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
     const uint32_t tile = tileList ? tileList[blockIdx.x] : blockIdx.x;
@@ -395,19 +433,23 @@ __global__ __launch_bounds__(64) void sha256_general_kernel(const uint8_t *__res
     const uint32_t rem = len & 63u;
     const uint32_t ncomp = (len >> 6) + (rem < 56u ? 1u : 2u);
 
-    for (uint32_t c = 0; c < ncomp; ++c) {
-        uint32_t m[16];
-        const bool last = (c + 1u == ncomp);
+    if (ctr.flags & kFlagIndexed) {
+        sha_item_indexed<NREP>(msg, live ? len : 0u, st, lm, live, cnt, tl, ft, fr, slot, ctr.flags, sCtxData[slot]);
+    } else {
+        for (uint32_t c = 0; c < ncomp; ++c) {
+            uint32_t m[16];
+            const bool last = (c + 1u == ncomp);
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-            m[t] = sha_word(msg, len, c, t, aligned, last);
-        sha_state_hook(st, c, ft, fr, slot, lm.r, lm.live); // ctx_state hook before compression c
-        sha_compress_hooked(st, m, c, ft, fr, slot, lm.r, lm.live);
+            for (int t = 0; t < 16; ++t)
+                m[t] = sha_word(msg, len, c, t, aligned, last);
+            sha_state_hook(st, c, ft, fr, slot, lm.r, lm.live); // ctx_state hook before compression c
+            sha_compress_hooked(st, m, c, ft, fr, slot, lm.r, lm.live);
 #pragma unroll
-        for (int w = 0; w < 8; ++w)
-            st[w] = xmr_store_sync<NREP>(st[w], lm, cnt, tl);
+            for (int w = 0; w < 8; ++w)
+                st[w] = xmr_store_sync<NREP>(st[w], lm, cnt, tl);
+        }
+        sha_state_hook(st, ncomp, ft, fr, slot, lm.r, lm.live); // step == ncompress: before the digest
     }
-    sha_state_hook(st, ncomp, ft, fr, slot, lm.r, lm.live); // step == ncompress: before the digest
     uint32_t dg[8];
 #pragma unroll
     for (int w = 0; w < 8; ++w)

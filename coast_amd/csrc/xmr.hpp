@@ -32,6 +32,11 @@ struct Counters {
     uint32_t flags;            // coast_cfg.flags of the launch (kFlagNoStoreDataSync), read by the general kernels
 };
 constexpr uint32_t kFlagNoStoreDataSync = 1u; // == COAST_F_NO_STORE_DATA_SYNC
+constexpr uint32_t kFlagBranchSync = 2u;      // == COAST_F_BRANCH_SYNC: loop / byte counters are replica-private, their branch conditions voted
+constexpr uint32_t kFlagAddrSync = 4u;        // == COAST_F_ADDR_SYNC: GEP offsets built from them are voted ...
+constexpr uint32_t kFlagNoLoadSync = 8u;      // == COAST_F_NO_LOAD_SYNC: ... except load addresses
+constexpr uint32_t kFlagNoStoreAddrSync = 16u; // == COAST_F_NO_STORE_ADDR_SYNC: ... except store addresses
+constexpr uint32_t kFlagIndexed = kFlagBranchSync | kFlagAddrSync;
 
 template <int NREP> struct LaneMap {
     static constexpr int kItemsPerWave = kWave / NREP;
@@ -105,6 +110,29 @@ __device__ __forceinline__ uint32_t xmr_store_sync(uint32_t v, const LaneMap<NRE
     return xmr_sync<NREP>(v, lm, count, t);
 }
 
+// replica 0's copy of a value: what the ORIGINAL instruction consumes when a use is not a sync point
+template <int NREP> __device__ __forceinline__ uint32_t xmr_rep0(uint32_t v, const LaneMap<NREP> &lm)
+{
+    if constexpr (NREP == 1)
+        return v;
+    else
+        return (uint32_t)__builtin_amdgcn_ds_bpermute(lm.base4, (int)v);
+}
+
+// A sync point that STEERS: a branch condition (syncTerminator, synchronization.cpp:741-949) or a GEP offset (syncGEP,
+// :413-474).  Synchronised, TMR: every copy continues with the voted value.  DWC: the copies are compared (a mismatch flags
+// the item) and the original instruction's operand -- replica 0's -- is used; not synchronised: replica 0's as well.
+template <int NREP>
+__device__ __forceinline__ uint32_t xmr_steer(uint32_t v, const LaneMap<NREP> &lm, bool synced, bool count, Tally &t)
+{
+    if (synced) {
+        const uint32_t voted = xmr_sync<NREP>(v, lm, count, t);
+        if (NREP == 3)
+            return voted;
+    }
+    return xmr_rep0<NREP>(v, lm);
+}
+
 // voter of a final sync point on explicit copies: v = this replica, b / c = the next two (replica-0 lanes consume it)
 template <int NREP>
 __device__ __forceinline__ uint32_t xmr_final_vote_vals(uint32_t v, uint32_t b, uint32_t c, bool count, Tally &t)
@@ -140,6 +168,16 @@ __device__ __forceinline__ uint32_t xmr_final_vote_dpp(uint32_t v, bool count, T
         const uint32_t c = NREP == 3 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, kWaveShl1, 0xf, 0xf, false) : 0u;
         return xmr_final_vote_vals<NREP>(v, b, c, count, t);
     }
+}
+
+// Lanes of one wave that hand data to each other through LDS: the hardware executes a wave's LDS operations in issue order,
+// but the compiler treats lanes as independent threads and may forward / reorder a lane's own stores and loads (e.g. lay out
+// the readers' side of a branch before the writer's).  This pins the order at the hand-over point.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)

@@ -16,6 +16,7 @@ from . import _lib
 
 TMR, DWC, UNPROTECTED = 3, 2, 1
 F_NO_STORE_DATA_SYNC = 1  # coast_cfg.flags: the reference's -noStoreDataSync (include/coast_hip.h)
+F_BRANCH_SYNC, F_ADDR_SYNC, F_NO_LOAD_SYNC, F_NO_STORE_ADDR_SYNC = 2, 4, 8, 16  # counters inside the SoR (sha256, crc16)
 
 
 @dataclass(frozen=True)

@@ -48,14 +48,34 @@ typedef struct coast_cfg {
  *                     sync points stay (mm: sync_every votes; crc16: every sync point -- its result is a return value).
  *                     The reference warns against combining it with -noMemReplication (interface.cpp:250-252): nothing then
  *                     protects the stored data.  It exists for the overhead studies and the clean-run matrix.
- *   -noLoadSync, -noStoreAddrSync   no effect here: addresses are built from wave-uniform scalars and lane indices, which are
- *                     outside the sphere of replication in this design (SURVEY.md section 8a', last table row), so there is no
- *                     replicated address to vote -- the engine always behaves as if both were given.
+ *   -noLoadSync, -noStoreAddrSync   by default addresses are built from wave-uniform scalars and lane indices, which are
+ *                     outside the sphere of replication in this design (SURVEY.md section 8a', last table row): no replicated
+ *                     address exists and the engine behaves as if both were given.  COAST_F_ADDR_SYNC (below) puts the
+ *                     counters of sha256 / crc16 inside the SoR; there the two flags are real knobs.
  *   -storeDataSync    the lane-replicated engine always votes store data (the default here); in the memory-replicated mode it
  *                     is what coast_sync_copies(..., scrub = 1) does at the region exit.
  *   -i / -s           instruction interleaving vs segmenting: replicas are lanes of one instruction, there is no order. */
 enum {
     COAST_F_NO_STORE_DATA_SYNC = 1u,
+    /* Loop / byte counters INSIDE the sphere of replication (sha256, crc16 -- the kernels whose reference source walks a
+     * data-dependent counter; the launch runs the stepwise kernel).  By default such counters are wave-uniform scalars outside
+     * the SoR (see -noLoadSync above); with these flags they are replica-private lane registers with their own fault sites,
+     * and the reference's rules for them apply:
+     *   COAST_F_BRANCH_SYNC         every evaluation of a branch condition on them is a sync point (synchronization.cpp:146-155,
+     *                               741-949): sha256 `i < len`, `ctx_datalen == 64` per byte and `ctx_datalen < 56`
+     *                               (sha256_common_tmr.c:119,122,132); crc16 `length--` per byte (crc16.c:25).  Not set, the
+     *                               branch follows the original instruction's operand = replica 0's copy.
+     *   COAST_F_ADDR_SYNC           GEP offsets built from them are sync points (:226-235, 333-372, 413-474), the reference's
+     *                               default under -noMemReplication: sha256 data[i] (a load address) and ctx_data[ctx_datalen]
+     *                               (a store address), sha256_common_tmr.c:120.  crc16's `*data_p++` has a constant offset:
+     *                               nothing to vote.  Not set, the access uses replica 0's offset.
+     *   COAST_F_NO_LOAD_SYNC        -noLoadSync: with ADDR_SYNC, load addresses are not voted (:341-352)
+     *   COAST_F_NO_STORE_ADDR_SYNC  -noStoreAddrSync: with ADDR_SYNC, store addresses are not voted (:354-367)
+     * The reference's `-TMR -noMemReplication` is BRANCH_SYNC | ADDR_SYNC. */
+    COAST_F_BRANCH_SYNC = 2u,
+    COAST_F_ADDR_SYNC = 4u,
+    COAST_F_NO_LOAD_SYNC = 8u,
+    COAST_F_NO_STORE_ADDR_SYNC = 16u,
     /* single-call host shims only (the batch entry points reject it): run the region in the reference's DEFAULT mode,
      * memory replicated as well -- one unprotected launch per memory copy + the exit vote of coast_sync_copies(scrub).
      * Without it the shims use the lane-replicated -noMemReplication engine. */
@@ -103,10 +123,13 @@ enum {
     COAST_SITE_SHA_M = 8,  /* schedule word m[step%64] of compression step/64, right after it is produced */
     COAST_SITE_SHA_WV = 9, /* working variable index 0..7 (a..h) before round step%64 of compression step/64 */
     COAST_SITE_SHA_STATE = 10, /* ctx_state[index] before compression `step` (== ncompress: before the digest) */
+    COAST_SITE_SHA_DATALEN = 11, /* COAST_F_BRANCH_SYNC / ADDR_SYNC: ctx_datalen before the loop condition of byte-loop iteration `step` */
+    COAST_SITE_SHA_I = 12,       /* the byte loop's counter i, same timing */
     COAST_SITE_AES_STATE = 16, /* state dword `index` at the start of main-loop round `step` (10: after the loop) */
     COAST_SITE_AES_KEY = 17,   /* running round-key dword `index`, same timing */
     COAST_SITE_CRC_CRC = 24,   /* crc register before byte `step` (== length: after the loop) */
     COAST_SITE_CRC_X = 25,     /* temporary x of byte `step` after x ^= x>>4 */
+    COAST_SITE_CRC_LEN = 26,   /* COAST_F_BRANCH_SYNC: the `length` register (8 bits live) before the loop condition of iteration `step` */
     COAST_SITE_CT_SUM = 32,    /* cache_test: running sum before element `step` is added (step == n: after the loop) */
     COAST_SITE_CT_VAL = 33,    /* the loaded array[step], right after the load */
     COAST_SITE_CT_NERR = 34,   /* numberOfErrors before element `step` (step == n: after the loop) */

@@ -365,6 +365,112 @@ static void sha_item(const uint8_t *data, uint32_t len, uint8_t hash[32], sync_c
             hash[4 * w + b] = (uint8_t)(st[0][w] >> (24 - 8 * b));
 }
 
+/* A sync point on a GEP offset (syncGEP, synchronization.cpp:413-474): the voted value replaces the offset operand of the
+ * GEP in all copies (:456-458) -- the index REGISTERS keep their own values (the next `++` works on them).  Returns the
+ * offset the single memory access uses: the voted one, or replica 0's (the original instruction's operand) when this class
+ * of address is not synchronised. */
+static uint32_t gep_offset(sync_ctx *c, const uint32_t idx[3], int synced)
+{
+    uint32_t v[3] = {idx[0], idx[1], idx[2]};
+    if (synced)
+        sync32(c, v);
+    return v[0];
+}
+
+/* A sync point on a conditional branch (syncTerminator, :741-949): the i1 condition of every copy is voted and all copies
+ * take the voted direction; not synchronised, the branch is the original instruction's. */
+static int branch_cond(sync_ctx *c, uint32_t c0, uint32_t c1, uint32_t c2, int synced)
+{
+    uint32_t v[3] = {c0, c1, c2};
+    if (synced)
+        sync32(c, v);
+    return (int)v[0];
+}
+
+/* sha256_hash with its byte loop as written (:119-127), for ORC_F_BRANCH_SYNC / ORC_F_ADDR_SYNC: the loop counter `i` and
+ * `ctx_datalen` are replica-private registers; ctx_data[64] and ctx_bitlen[] are memory (single copy, -noMemReplication).
+ * Shape after -O3 (tests/hifive1/sha256.tmr/Makefile:4 runs it before -TMR): the byte loop and its two branches survive,
+ * the padding loops are memsets (library calls, not replicated: functions.config:12) and the output loop is unrolled.
+ * Accesses outside the message / outside ctx_data[64] are bounded here (a wild index reads 0 / stores nothing) and a loop that
+ * a corrupted counter keeps alive is cut by a watchdog after 4 * len + 256 iterations -- on the reference those are wild
+ * accesses and a supervisor timeout (jsonParser.py:162-186). */
+static void sha_item_indexed(const uint8_t *data, uint32_t len, uint8_t hash[32], sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    uint32_t st[3][8], ir[3] = {0, 0, 0}, dl[3] = {0, 0, 0};
+    uint8_t buf[64];
+    uint32_t bitlen[2] = {0, 0};
+    uint32_t cidx = 0, it = 0;
+    const unsigned R = c->nrep;
+    const int bs = (c->flags & ORC_F_BRANCH_SYNC) != 0, as = (c->flags & ORC_F_ADDR_SYNC) != 0;
+    const int ls = as && !(c->flags & ORC_F_NO_LOAD_SYNC), ss = as && !(c->flags & ORC_F_NO_STORE_ADDR_SYNC);
+    const uint64_t cap = 4ull * len + 256ull;
+    memset(buf, 0, sizeof buf);
+    for (unsigned r = 0; r < 3; ++r)
+        for (unsigned w = 0; w < 8; ++w)
+            st[r][w] = SHA_IV[w];
+    for (;; ++it) {
+        for (size_t q = 0; q < nf; ++q)
+            if (fl[q].step == it && fl[q].replica < R) {
+                if (fl[q].site == ORC_SITE_SHA_I)
+                    ir[fl[q].replica] = flip(ir[fl[q].replica], fl[q].bit, 0xffffffffu);
+                else if (fl[q].site == ORC_SITE_SHA_DATALEN)
+                    dl[fl[q].replica] = flip(dl[fl[q].replica], fl[q].bit, 0xffffffffu);
+            }
+        if (!branch_cond(c, ir[0] < len, ir[R > 1 ? 1 : 0] < len, ir[R > 2 ? 2 : 0] < len, bs) || it >= cap)
+            break;                                            /* for (i = 0; i < len; ++i)                    :119 */
+        const uint32_t li = gep_offset(c, ir, ls);            /* data[i]                                       :120 */
+        const uint8_t byte = li < len ? data[li] : 0;
+        const uint32_t si = gep_offset(c, dl, ss);            /* ctx_data[ctx_datalen] = ...                   :120 */
+        if (si < 64)
+            buf[si] = byte;
+        for (unsigned r = 0; r < 3; ++r)
+            dl[r] += 1;                                       /* ctx_datalen++                                 :121 */
+        if (branch_cond(c, dl[0] == 64, dl[R > 1 ? 1 : 0] == 64, dl[R > 2 ? 2 : 0] == 64, bs)) { /*           :122 */
+            sha_state_faults(st, R, cidx, fl, nf);
+            sha_compress(st, buf, R, cidx, fl, nf);
+            sha_sync_state(c, st);
+            ++cidx;
+            if (bitlen[0] > 0xffffffffu - 512u)
+                ++bitlen[1];
+            bitlen[0] += 512u;
+            dl[0] = dl[1] = dl[2] = 0;                        /* ctx_datalen = 0                               :125 */
+        }
+        for (unsigned r = 0; r < 3; ++r)
+            ir[r] += 1;
+    }
+    const int shortPad = branch_cond(c, dl[0] < 56, dl[R > 1 ? 1 : 0] < 56, dl[R > 2 ? 2 : 0] < 56, bs); /*     :132 */
+    const uint32_t pi = gep_offset(c, dl, ss);                /* ctx_data[i++] = 0x80 with i = ctx_datalen  :133,137 */
+    if (pi < 64)
+        buf[pi] = 0x80;
+    for (uint32_t k = pi + 1; k < (shortPad ? 56u : 64u); ++k) /* while (i < 56 / 64) ctx_data[i++] = 0: a memset */
+        buf[k] = 0;
+    if (!shortPad) {
+        sha_state_faults(st, R, cidx, fl, nf);
+        sha_compress(st, buf, R, cidx, fl, nf);
+        sha_sync_state(c, st);
+        ++cidx;
+        memset(buf, 0, 56);
+    }
+    uint32_t add[3] = {dl[0] * 8u, dl[1] * 8u, dl[2] * 8u};   /* DBL_INT_ADD(..., ctx_datalen * 8): a store of a    */
+    store_sync32(c, add);                                     /* replicated value into ctx_bitlen[0]            :150 */
+    if (bitlen[0] > 0xffffffffu - add[0])
+        ++bitlen[1];
+    bitlen[0] += add[0];
+    for (unsigned b = 0; b < 4; ++b) {
+        buf[63 - b] = (uint8_t)(bitlen[0] >> (8 * b));
+        buf[59 - b] = (uint8_t)(bitlen[1] >> (8 * b));
+    }
+    sha_state_faults(st, R, cidx, fl, nf);
+    sha_compress(st, buf, R, cidx, fl, nf);
+    sha_sync_state(c, st);
+    ++cidx;
+    sha_state_faults(st, R, cidx, fl, nf);
+    sha_sync_state(c, st);
+    for (unsigned w = 0; w < 8; ++w)
+        for (unsigned b = 0; b < 4; ++b)
+            hash[4 * w + b] = (uint8_t)(st[0][w] >> (24 - 8 * b));
+}
+
 void orc_sha256_plain(const uint8_t *data, uint32_t len, uint8_t hash[32])
 {
     orc_stats st = {0, 0, 0, 0};
@@ -385,7 +491,10 @@ void orc_sha256_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nms
         while (fe < nfaults && fs[fe].item == m)
             ++fe;
         c.detected = 0;
-        sha_item(msgs + m * stride, len, digests + 32 * m, &c, fs + fp, fe - fp);
+        if (cfg->flags & ORC_F_INDEXED)
+            sha_item_indexed(msgs + m * stride, len, digests + 32 * m, &c, fs + fp, fe - fp);
+        else
+            sha_item(msgs + m * stride, len, digests + 32 * m, &c, fs + fp, fe - fp);
         if (c.detected) {
             st->dwc_detected += (cfg->replicas == 2);
             if (detected)
@@ -647,10 +756,55 @@ uint16_t orc_crc16_plain(const uint8_t *data, uint32_t length)
     return crc;
 }
 
+/* crc16 with `while (length--)` as written (crc16.c:25), for ORC_F_BRANCH_SYNC: `length` is a replica-private unsigned char,
+ * its loop condition is voted at every evaluation (a terminator sync on an i1, synchronization.cpp:146-155); `*data_p++` has a
+ * constant GEP offset, so there is no address vote in this function (syncGEP returns early, :428-431) and ORC_F_ADDR_SYNC
+ * changes nothing.  A corrupted counter that keeps the loop alive is cut after 4 * len + 256 iterations; bytes past the
+ * block read as 0. */
+static uint16_t crc_item_branch(const uint8_t *data, uint32_t len, sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    uint32_t crc[3] = {0xFFFF, 0xFFFF, 0xFFFF}, ln[3] = {len & 0xffu, len & 0xffu, len & 0xffu};
+    const unsigned R = c->nrep;
+    const int bs = (c->flags & ORC_F_BRANCH_SYNC) != 0;
+    const uint64_t cap = 4ull * len + 256ull;
+    for (uint32_t it = 0;; ++it) {
+        for (size_t q = 0; q < nf; ++q)
+            if (fl[q].site == ORC_SITE_CRC_LEN && fl[q].step == it && fl[q].replica < R)
+                ln[fl[q].replica] = flip(ln[fl[q].replica], fl[q].bit, 0xffu);
+        const int go = branch_cond(c, ln[0] != 0, ln[R > 1 ? 1 : 0] != 0, ln[R > 2 ? 2 : 0] != 0, bs);
+        for (unsigned r = 0; r < 3; ++r)
+            ln[r] = (ln[r] - 1u) & 0xffu; /* length-- : the decrement happens on both exits */
+        if (!go || it >= cap)
+            break;
+        const uint8_t byte = it < len ? data[it] : 0;
+        for (unsigned r = 0; r < R; ++r) {
+            for (size_t q = 0; q < nf; ++q)
+                if (fl[q].site == ORC_SITE_CRC_CRC && fl[q].step == it && it < len && fl[q].replica == r)
+                    crc[r] = flip(crc[r], fl[q].bit, 0xffffu);
+            uint8_t x = (uint8_t)((crc[r] >> 8) ^ byte);
+            x ^= (uint8_t)(x >> 4);
+            for (size_t q = 0; q < nf; ++q)
+                if (fl[q].site == ORC_SITE_CRC_X && fl[q].step == it && it < len && fl[q].replica == r)
+                    x = (uint8_t)flip(x, fl[q].bit, 0xffu);
+            crc[r] = (uint16_t)((uint16_t)(crc[r] << 8) ^ (uint16_t)((uint16_t)x << 12) ^
+                                (uint16_t)((uint16_t)x << 5) ^ (uint16_t)x);
+        }
+        if (c->sync_every && ((it + 1) % c->sync_every) == 0 && (it + 1) < len)
+            sync32(c, crc);
+    }
+    for (size_t q = 0; q < nf; ++q)
+        if (fl[q].site == ORC_SITE_CRC_CRC && fl[q].step == len && fl[q].replica < R)
+            crc[fl[q].replica] = flip(crc[fl[q].replica], fl[q].bit, 0xffffu);
+    sync32(c, crc);
+    return (uint16_t)crc[0];
+}
+
 static uint16_t crc_item(const uint8_t *data, uint32_t len, sync_ctx *c, const orc_fault *fl, size_t nf)
 {
     uint32_t crc[3] = {0xFFFF, 0xFFFF, 0xFFFF};
     const unsigned R = c->nrep;
+    if (c->flags & ORC_F_BRANCH_SYNC)
+        return crc_item_branch(data, len, c, fl, nf);
     for (uint32_t t = 0; t < len; ++t) {
         for (unsigned r = 0; r < R; ++r) {
             for (size_t q = 0; q < nf; ++q)

@@ -45,12 +45,15 @@ enum {
     ORC_SITE_SHA_M = 8,    /* schedule word m[step%64] of compression step/64, right after it is produced */
     ORC_SITE_SHA_WV = 9,   /* working variable a..h (index 0..7) before round step%64 of compression step/64 */
     ORC_SITE_SHA_STATE = 10, /* ctx_state[index] before compression `step` (step == ncompress: before the digest) */
+    ORC_SITE_SHA_DATALEN = 11, /* indexed mode: ctx_datalen before the loop condition of iteration `step` is evaluated */
+    ORC_SITE_SHA_I = 12,       /* indexed mode: the byte loop's counter i, same timing */
 
     ORC_SITE_AES_STATE = 16, /* dword `index` (0..3) of the state at the start of main-loop round `step` (10: after loop) */
     ORC_SITE_AES_KEY = 17,   /* dword `index` (0..3) of the running round key, same timing */
 
     ORC_SITE_CRC_CRC = 24, /* crc register before byte `step` (step == length: after the loop) */
     ORC_SITE_CRC_X = 25,   /* temporary x of byte `step`, after x ^= x>>4 */
+    ORC_SITE_CRC_LEN = 26, /* ORC_F_BRANCH_SYNC mode: the `length` register (8 bits live) before the loop condition of iteration `step` */
 
     ORC_SITE_CT_SUM = 32,  /* cache_test: running sum before element `step` is added (step == n: after the loop) */
     ORC_SITE_CT_VAL = 33,  /* the loaded array[step], right after the load */
@@ -84,7 +87,15 @@ typedef struct {
     uint32_t flags;      /* ORC_F_* */
 } orc_cfg;
 /* -noStoreDataSync (dataflowProtection.cpp:16; synchronization.cpp:197-224,324): the data of stores is not synchronised */
-enum { ORC_F_NO_STORE_DATA_SYNC = 1u };
+enum {
+    ORC_F_NO_STORE_DATA_SYNC = 1u,
+    /* loop / byte counters INSIDE the sphere of replication (default: outside, SURVEY 8a' last table row): */
+    ORC_F_BRANCH_SYNC = 2u,        /* their branch conditions are voted (synchronization.cpp:146-155, 741-949) */
+    ORC_F_ADDR_SYNC = 4u,          /* GEP offsets built from them are voted (:226-235, 333-372, 413-474) ... */
+    ORC_F_NO_LOAD_SYNC = 8u,       /* ... except load addresses (-noLoadSync, :341-352) */
+    ORC_F_NO_STORE_ADDR_SYNC = 16u /* ... except store addresses (-noStoreAddrSync, :354-367) */
+};
+#define ORC_F_INDEXED (ORC_F_BRANCH_SYNC | ORC_F_ADDR_SYNC)
 
 /* ---- plain (unprotected) restatements of the reference kernels ---- */
 void orc_mm_plain(const uint32_t *f, const uint32_t *s, uint32_t *r, int n);

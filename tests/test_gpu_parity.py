@@ -1152,3 +1152,142 @@ def test_mm_rejects_misaligned_vector_operands(eng):
     with pytest.raises(RuntimeError, match="16-byte aligned"):
         eng._check(eng._lib.coast_mm_batch(eng._h, f.data_ptr(), good.data_ptr(), good.data_ptr(), 16, 1,
                                             __import__("ctypes").byref(__import__("coast_amd").XmrConfig().c()), None))
+
+
+# ------------------------------------------------------------------------------------------------ counters inside the SoR
+@pytest.mark.parametrize("length", [0, 1, 10, 55, 56, 63, 64, 65, 119, 120, 128, 200])
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+def test_sha256_indexed_flags_vs_oracle(eng, orc, length, replicas):
+    """COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC (+ -noLoadSync / -noStoreAddrSync): the byte loop of sha256_hash with `i` and
+    `ctx_datalen` as replica-private registers (sha256_common_tmr.c:119-132).  Clean runs: the digest is unchanged and
+    sync_count follows the schedule (one vote per evaluated condition / per voted GEP offset); upsets of the two counters, of the
+    state and of the schedule words: digest, TMR_ERROR_CNT, __SYNC_COUNT and the per-message flags equal the oracle's --
+    including the runs where an unvoted address lets the upset through (silent data corruption)."""
+    import torch
+
+    import coast_amd as ca
+
+    rng = np.random.default_rng(31 * length + replicas)
+    nm = 45
+    msgs = rng.integers(0, 256, (nm, max(length, 4)), dtype=np.uint8)
+    B, A, NL, NS = ca.F_BRANCH_SYNC, ca.F_ADDR_SYNC, ca.F_NO_LOAD_SYNC, ca.F_NO_STORE_ADDR_SYNC
+    for flags in (B | A, B, A, A | NL, A | NS, B | A | NL | NS, B | A | ca.F_NO_STORE_DATA_SYNC):
+        exp, exp_st, _ = orc.sha256_xmr(msgs, length, replicas=replicas, flags=flags)
+        eng.reset_stats()
+        got = _host(eng.sha256_batch(_dev(msgs), length, cfg=ca.XmrConfig(replicas, 0, flags)), np.uint8)
+        assert (got == exp).all() and _stats3(eng.stats()) == exp_st, flags
+        assert all(hashlib.sha256(msgs[i, :length].tobytes()).digest() == got[i].tobytes() for i in range(nm))
+        assert eng.last_launch()["engine"] == "stepwise"
+        if replicas == 1:
+            continue
+        rows = []
+        for _ in range(60):
+            site = int(rng.choice([8, 9, 10, 11, 12, 11, 12]))
+            step = int(rng.integers(0, length + 2)) if site >= 11 else (int(rng.integers(0, 4)) if site == 10 else int(rng.integers(0, 192)))
+            bit = int(rng.integers(0, 8)) if site >= 11 else int(rng.integers(0, 32))  # low bits: the loop stays near its bounds
+            rows.append((int(rng.integers(0, nm)), int(rng.integers(0, replicas)), site, step, bit, int(rng.integers(0, 8))))
+        rows.append((3, 0, 12, min(2, length), 31))  # replica 0's loop counter, top bit: exits at once unless the branch is voted
+        rows.append((5, 1, 11, min(1, length), 6))   # ctx_datalen +/- 64
+        fl = ca.make_faults(rows)
+        exp, exp_st, exp_det = orc.sha256_xmr(msgs, length, replicas=replicas, flags=flags, faults=fl)
+        det = torch.zeros(nm, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        got = _host(eng.sha256_batch(_dev(msgs), length, cfg=ca.XmrConfig(replicas, 0, flags), detected=det), np.uint8)
+        assert (got == exp).all(), flags
+        assert _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all(), flags
+
+
+def test_sha256_address_votes_are_what_stops_a_replica0_index_upset(eng, orc):
+    """the reason -noMemReplication votes addresses (passes.rst:331): replica 0's ctx_datalen feeds the one store.  With the
+    vote the upset is corrected and counted; with -noStoreAddrSync the byte lands in the wrong slot and the digest is wrong,
+    silently (TMR_ERROR_CNT only sees the branch conditions)."""
+    import coast_amd as ca
+
+    msg = np.arange(200, dtype=np.uint8)[None]
+    good = hashlib.sha256(msg[0].tobytes()).digest()
+    fl = ca.make_faults([(0, 0, ca.SITE_SHA_DATALEN, 70, 2)])
+    out = {}
+    for name, flags in (("voted", ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC),
+                        ("noStoreAddrSync", ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC | ca.F_NO_STORE_ADDR_SYNC)):
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        got = _host(eng.sha256_batch(_dev(msg), 200, cfg=ca.XmrConfig(3, 0, flags)), np.uint8)
+        out[name] = (got[0].tobytes() == good, eng.stats()["errors_corrected"])
+        exp, exp_st, _ = orc.sha256_xmr(msg, 200, flags=flags, faults=fl)
+        assert (got == exp).all() and eng.stats()["errors_corrected"] == exp_st["errors_corrected"]
+    assert out["voted"][0] and out["voted"][1] > 0
+    assert not out["noStoreAddrSync"][0]
+
+
+@pytest.mark.parametrize("block_len", [1, 13, 64, 200, 255])
+@pytest.mark.parametrize("replicas,sync_every", [(3, 0), (3, 7), (2, 0), (1, 0)])
+def test_crc16_branch_sync_vs_oracle(eng, orc, block_len, replicas, sync_every):
+    """COAST_F_BRANCH_SYNC on crc16: `while (length--)` (crc16.c:25) voted at every evaluation, `length` a replica-private
+    unsigned char with its own fault site; ADDR_SYNC is accepted and changes nothing (`*data_p++` has a constant offset)."""
+    import torch
+
+    import coast_amd as ca
+
+    rng = np.random.default_rng(block_len * 5 + replicas + sync_every)
+    nb = 300
+    data = rng.integers(0, 256, (nb, block_len), dtype=np.uint8)
+    for flags in (ca.F_BRANCH_SYNC, ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC):
+        exp, exp_st, _ = orc.crc16_xmr(data, block_len, replicas=replicas, sync_every=sync_every, flags=flags)
+        eng.reset_stats()
+        got = _host(eng.crc16_batch(torch.from_numpy(data).cuda(), block_len, cfg=ca.XmrConfig(replicas, sync_every, flags)), np.uint16)
+        assert (got == exp).all() and _stats3(eng.stats()) == exp_st
+        if replicas > 1:
+            assert exp_st["sync_count"] >= nb * (block_len + 2)
+    if replicas == 1:
+        return
+    fl = _rand_faults(rng, 120, nb, replicas, [24, 25, 26, 26], block_len + 1)
+    exp, exp_st, exp_det = orc.crc16_xmr(data, block_len, replicas=replicas, sync_every=sync_every, flags=ca.F_BRANCH_SYNC, faults=fl)
+    det = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    got = _host(eng.crc16_batch(torch.from_numpy(data).cuda(), block_len, cfg=ca.XmrConfig(replicas, sync_every, ca.F_BRANCH_SYNC),
+                                detected=det), np.uint16)
+    assert (got == exp).all()
+    assert _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all()
+
+
+def test_indexed_flags_are_rejected_where_not_implemented(eng):
+    import torch
+
+    import coast_amd as ca
+
+    f = torch.zeros((1, 16, 16), dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="sha256 and crc16"):
+        eng.mm_batch(f, f, cfg=ca.XmrConfig(3, 0, ca.F_BRANCH_SYNC))
+    with pytest.raises(RuntimeError, match="qualify COAST_F_ADDR_SYNC"):
+        eng.sha256_batch(torch.zeros((1, 64), dtype=torch.uint8, device="cuda"), 64, cfg=ca.XmrConfig(3, 0, ca.F_NO_LOAD_SYNC))
+    with pytest.raises(RuntimeError, match="block_len <= 255"):
+        eng.crc16_batch(torch.zeros(512, dtype=torch.uint8, device="cuda"), 256, cfg=ca.XmrConfig(3, 0, ca.F_BRANCH_SYNC))
+
+
+def test_dropin_counters_in_sor_env():
+    """COAST_COUNTERS_IN_SOR=1: the unmodified C program's crc16() / sha256_hash() run with their loop counters replicated and
+    the reference's -noMemReplication votes on them; -noLoadSync / -noStoreAddrSync of COAST_OPT_PASSES then change __SYNC_COUNT."""
+    import os
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "host_c_demo")
+
+    def syncs(passes, sor):
+        env = dict(os.environ, COAST_OPT_PASSES=passes)
+        if sor:
+            env["COAST_COUNTERS_IN_SOR"] = "1"
+        p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "result: 5ba3" in p.stdout and "E:0" in p.stdout, (p.stdout, p.stderr)
+        return int(re.search(r"syncs: (\d+)", p.stdout).group(1))
+
+    base = syncs("-TMR -noMemReplication", False)
+    full = syncs("-TMR -noMemReplication", True)
+    nl = syncs("-TMR -noMemReplication -noLoadSync", True)
+    ns = syncs("-TMR -noMemReplication -noStoreAddrSync", True)
+    # crc16("Automated TMR", 13): + 14 loop conditions; sha256_hash("abc", 3): + (3+1) + 3 + 3 + 3 + 1 + 1 + 1
+    assert full == base + 14 + 16
+    assert nl == full - 3 and ns == full - 4
