@@ -1291,3 +1291,58 @@ def test_dropin_counters_in_sor_env():
     # crc16("Automated TMR", 13): + 14 loop conditions; sha256_hash("abc", 3): + (3+1) + 3 + 3 + 3 + 1 + 1 + 1
     assert full == base + 14 + 16
     assert nl == full - 3 and ns == full - 4
+
+
+# ------------------------------------------------------------------------------------------------ campaign front-end
+def _campaign(argv, eng):
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("coast_campaign", os.path.join(root, "tools", "campaign.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a = mod.parse(argv)
+    records, summary = mod.run_campaign(a, eng)
+    return mod, a, records, summary
+
+
+def test_campaign_registers_mm256_on_the_matrix_core_engine(eng, tmp_path, monkeypatch):
+    """tools/campaign.py, register section (supervisor.py -s registers): 300 runs = 300 side-256 products, one upset each,
+    voted by the matrix-core kernel itself.  TMR: no run ends in an error; unprotected: the same upsets corrupt outputs."""
+    monkeypatch.setenv("COAST_MM_ENGINE", "mfma")
+    mod, a, rec, s = _campaign(["-b", "mm", "-m", "TMR", "-t", "300", "--side", "256", "-l", str(tmp_path)], eng)
+    assert s["engine"] == "matrix_core" and s["stepwise_blocks"] == 0
+    assert s["errors"] == 0 and s["faults"] > 250 and s["success"] + s["faults"] == 300
+    assert s["TMR_ERROR_CNT"] == s["faults"]  # one voted value per effective upset
+    prefix = mod.write_logs(a, rec, s)
+    log = open(prefix + ".log").read()
+    js = __import__("json").load(open(prefix + ".json"))
+    assert len(js["runs"]) == 300 and js["summary"]["faults"] == s["faults"]
+    assert "C:0 E:0 F:1 T:" in log and "Total runs: 300" in log and "Faults:" in log
+    _, _, _, n = _campaign(["-b", "mm", "-m", "NONE", "-t", "300", "--side", "256", "-n"], eng)
+    assert n["errors"] > 250 and n["faults"] == 0
+    _, _, _, d = _campaign(["-b", "mm", "-m", "DWC", "-t", "300", "--side", "256", "-n"], eng)
+    assert d["errors"] == 0 and d["aborts"] == d["timeouts"] > 250
+
+
+@pytest.mark.parametrize("bench", ["crc16", "sha256", "aes", "mm"])
+def test_campaign_memory_section_both_memory_modes(eng, bench):
+    """supervisor.py -s <memory section>: the upset hits the run's memory image (coast_flip_memory = injectFaultMem).
+    -noMemReplication has one copy: every replica reads the corrupted word and TMR cannot see it (the reference's 86.3 %
+    coverage ~ unmitigated 85.4 %); COAST's default mode keeps three copies and out-votes it at the region exit (98.8 %)."""
+    args = ["-b", bench, "-t", "400", "-s", "memory", "-n", "--seed", "3"]
+    _, _, _, none = _campaign(args + ["-m", "NONE"], eng)
+    _, _, _, lane = _campaign(args + ["-m", "TMR", "--mem-mode", "nomemrep"], eng)
+    _, _, _, deflt = _campaign(args + ["-m", "TMR", "--mem-mode", "default"], eng)
+    _, _, _, dwc = _campaign(args + ["-m", "DWC", "--mem-mode", "default"], eng)
+    assert lane["errors"] == none["errors"] > 300 and lane["faults"] == 0          # same seed, same flips, same damage
+    assert deflt["errors"] == 0 and deflt["faults"] == none["errors"]              # every effective flip out-voted and counted
+    assert dwc["errors"] == 0 and dwc["aborts"] == none["errors"]                  # ... or detected
+
+
+@pytest.mark.parametrize("bench", ["sha256", "aes", "crc16", "chsha", "cache_test"])
+def test_campaign_registers_other_benchmarks(eng, bench):
+    _, _, _, t = _campaign(["-b", bench, "-m", "TMR", "-t", "500", "-n"], eng)
+    _, _, _, d = _campaign(["-b", bench, "-m", "DWC", "-t", "500", "-n"], eng)
+    assert t["errors"] == 0 and d["errors"] == 0 and t["faults"] == d["aborts"] > 0

@@ -1,150 +1,313 @@
 #!/usr/bin/env python3
-"""campaign.py -- fault-injection campaign on the on-device injector.
+"""campaign.py -- fault-injection campaign front-end on the MI355X engine.
 
-Replaces the QEMU/GDB flow of simulation/platform/supervisor.py (one run = boot, pick a uniformly random time and
-target, flip one bit of a 32-bit word -- injector.py:202-207, threadFunctions.py:508-520 -- read `C: E: F: T:`) and the
-summary of jsonParser.py:148-203.  Here one RUN = one protected work item (a matrix product element's matrix, a
-message, an AES block, a CRC block) that receives exactly one single-bit flip at a uniformly random
-(replica, site, step, bit); thousands of runs execute as one batch launch.  Classification per run, as
-jsonParser.py:162-186 does it:
-    error     output differs from the golden (fault-free) output          (E > 0: silent data corruption)
-    fault     output correct and a vote saw unequal copies                (F > 0: corrected)
-    detected  DWC compare failed (the run would have called FAULT_DETECTED_DWC() and aborted)
-    success   output correct, nothing noticed (the flip hit dead state)
+Replaces the QEMU/GDB flow of simulation/platform/supervisor.py: there one run = boot the benchmark, stop it at a uniformly
+random time, flip one bit of a 32-bit word in a random register or in a chosen memory section (resources/injector.py:202-260,
+threadFunctions.py:508-520), let it finish and read `C: E: F: T:` from the UART; the campaign is logged per run
+(supervisor.py:420-437: <board>_<benchmark>_<timestamp>.log / .json) and summarised by jsonParser.py:148-203.  Here one RUN =
+one protected work item (one matrix product, one message, one AES block, one CRC block ...) that receives exactly one
+single-bit upset; thousands of runs execute as ONE batch launch, and the same artefacts come out: a per-run .json, the UART
+lines in a .log, and the jsonParser summary table.
 
-    python tools/campaign.py -b mm -m TMR -t 5000          # cf. docs/images/msp430/fault_injection_results2.png
+    -s registers   a replica-private register (the on-device injector: uniformly random replica / site / step / bit)
+    -s memory      a random bit of a random 32-bit word of the run's input memory (coast_flip_memory = injectFaultMem)
+    --mem-mode nomemrep   the lane-replicated engine: `-TMR -noMemReplication` -- one memory copy, so a memory upset reaches
+                          every replica (reference: 86.3 % coverage ~ unmitigated, docs/images/msp430/fault_injection_results.png)
+    --mem-mode default    COAST's default mode: one unprotected launch per memory copy + the exit vote (coast_sync_copies);
+                          the upset sits in one copy and is out-voted (reference: 98.8 %)
+
+Classification per run, exactly jsonParser.summarizeRuns (:162-186): errors > 0 -> error; else faults > 0 -> fault (counted
+with the successes in "Successes"); a DWC compare failure is FAULT_DETECTED_DWC() -> abort(), which the reference's
+supervisor sees as abort + timeout.
+
+    python tools/campaign.py -b mm -m TMR -t 5000 --side 256            # register upsets, matrix-core engine
+    python tools/campaign.py -b crc16 -m TMR -t 5000 -s memory --mem-mode default
 """
 import argparse
+import datetime
 import json
 import os
 import sys
+import time
 
 import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import coast_amd  # noqa: E402
+import coast_amd as ca  # noqa: E402
 
-MODES = {"TMR": coast_amd.TMR, "DWC": coast_amd.DWC, "NONE": coast_amd.UNPROTECTED}
+MODES = {"TMR": ca.TMR, "DWC": ca.DWC, "NONE": ca.UNPROTECTED}
+
+
+# ------------------------------------------------------------------------------------------------ benchmarks
+class Bench:
+    """inputs(): fresh device tensors of `runs` work items; run(): one protected launch -> (runs, k) output tensor;
+    memory(): the input tensors that make up a run's memory image; reg_fault(): one random register upset of run r."""
+
+
+class MM(Bench):
+    def __init__(self, a, eng, g):
+        self.n, self.eng = a.side, eng
+
+    def inputs(self, runs, g):
+        n = self.n
+        return [torch.randint(-2**31, 2**31, (runs, n, n), dtype=torch.int32, device="cuda", generator=g) for _ in range(2)]
+
+    def run(self, inp, cfg, det=None):
+        d = None if det is None else torch.zeros(inp[0].numel(), dtype=torch.uint8, device="cuda")
+        out = self.eng.mm_batch(inp[0], inp[1], cfg=cfg, detected=d)
+        if det is not None:
+            det |= d.reshape(inp[0].shape[0], -1).any(dim=1).to(torch.uint8)
+        return out.reshape(inp[0].shape[0], -1)
+
+    def reg_fault(self, r, nrep, rng):
+        n = self.n
+        return (r * n * n + int(rng.integers(0, n * n)), int(rng.integers(0, nrep)), int(rng.integers(0, 3)),
+                int(rng.integers(0, n + 1)), int(rng.integers(0, 32)))
+
+
+class SHA256(Bench):
+    def __init__(self, a, eng, g):
+        self.eng, self.len = eng, 64
+
+    def inputs(self, runs, g):
+        return [torch.randint(0, 256, (runs, self.len), dtype=torch.uint8, device="cuda", generator=g)]
+
+    def run(self, inp, cfg, det=None):
+        return self.eng.sha256_batch(inp[0], self.len, cfg=cfg, detected=det)
+
+    def reg_fault(self, r, nrep, rng):
+        site = int(rng.choice([ca.SITE_SHA_M, ca.SITE_SHA_WV, ca.SITE_SHA_STATE]))
+        step = int(rng.integers(0, 3)) if site == ca.SITE_SHA_STATE else int(rng.integers(0, 128))
+        return (r, int(rng.integers(0, nrep)), site, step, int(rng.integers(0, 32)), int(rng.integers(0, 8)))
+
+
+class AES(Bench):
+    def __init__(self, a, eng, g):
+        self.eng = eng
+
+    def inputs(self, runs, g):
+        return [torch.randint(0, 256, (runs, 16), dtype=torch.uint8, device="cuda", generator=g) for _ in range(2)]
+
+    def run(self, inp, cfg, det=None):
+        st, key = inp[0].clone(), inp[1].clone()  # aes_enc_dec works in place on state AND key (TI_aes_128.c:107-231)
+        self.eng.aes128_batch(st, key, 0, cfg=cfg, detected=det)
+        return torch.cat([st, key], dim=1)
+
+    def reg_fault(self, r, nrep, rng):
+        return (r, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_AES_STATE, ca.SITE_AES_KEY])),
+                int(rng.integers(0, 11)), int(rng.integers(0, 32)), int(rng.integers(0, 4)))
+
+
+class CRC16(Bench):
+    def __init__(self, a, eng, g):
+        self.eng, self.bl = eng, 255  # the reference's maximum length (unsigned char, crc16.c:21) ... rows padded to 256
+
+    def inputs(self, runs, g):
+        return [torch.randint(0, 256, (runs, 256), dtype=torch.uint8, device="cuda", generator=g)]
+
+    def run(self, inp, cfg, det=None):
+        data = inp[0][:, : self.bl].contiguous().reshape(-1)
+        return self.eng.crc16_batch(data, self.bl, cfg=cfg, detected=det).reshape(-1, 1)
+
+    def reg_fault(self, r, nrep, rng):
+        return (r, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_CRC_CRC, ca.SITE_CRC_X])),
+                int(rng.integers(0, self.bl + 1)), int(rng.integers(0, 32)))
+
+
+class ChSha(Bench):
+    def __init__(self, a, eng, g):
+        self.eng, self.len = eng, 192
+
+    def inputs(self, runs, g):
+        return [torch.randint(0, 256, (runs, self.len), dtype=torch.uint8, device="cuda", generator=g)]
+
+    def run(self, inp, cfg, det=None):
+        return self.eng.chsha_batch(inp[0], self.len, cfg=cfg, detected=det)
+
+    def reg_fault(self, r, nrep, rng):
+        site = int(rng.choice([ca.SITE_CHSHA_W, ca.SITE_CHSHA_WV, ca.SITE_CHSHA_DIGEST]))
+        step = int(rng.integers(0, 4)) if site == ca.SITE_CHSHA_DIGEST else int(rng.integers(0, 4 * 80))
+        return (r, int(rng.integers(0, nrep)), site, step, int(rng.integers(0, 32)), int(rng.integers(0, 5)))
+
+
+class CacheTest(Bench):
+    def __init__(self, a, eng, g):
+        self.eng, self.n = eng, 600  # data_array_elements, cacheTest.c:78
+
+    def inputs(self, runs, g):
+        return [torch.arange(self.n, dtype=torch.int32, device="cuda").repeat(runs, 1).contiguous()]
+
+    def run(self, inp, cfg, det=None):
+        work = inp[0].clone()  # calc_sum scrubs the array in place
+        sums, nerrs = self.eng.cache_test_batch(work, cfg=cfg, detected=det)
+        return torch.cat([sums.reshape(-1, 1), nerrs.reshape(-1, 1), work], dim=1)
+
+    def reg_fault(self, r, nrep, rng):
+        return (r, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_CT_SUM, ca.SITE_CT_VAL, ca.SITE_CT_NERR])),
+                int(rng.integers(0, self.n + 1)), int(rng.integers(0, 32)))
+
+
+BENCHES = {"mm": MM, "sha256": SHA256, "aes": AES, "crc16": CRC16, "chsha": ChSha, "cache_test": CacheTest}
+
+
+# ------------------------------------------------------------------------------------------------ one campaign
+def flip_memory(eng, inp, r, rng):
+    """injectFaultMem (injector.py:209-235) on run r's memory image: a uniformly random 32-bit word, a uniformly random bit"""
+    sizes = [t[r].numel() * t.element_size() for t in inp]
+    words = [s // 4 for s in sizes]
+    w = int(rng.integers(0, sum(words)))
+    k = 0
+    while w >= words[k]:
+        w -= words[k]
+        k += 1
+    bit = int(rng.integers(0, 32))
+    byte_off = r * sizes[k] + 4 * w + bit // 8
+    eng.flip_memory(inp[k], byte_off, bit % 8)
+    return {"tensor": k, "word": w, "bit": bit}
+
+
+def run_campaign(a, eng=None):
+    rng = np.random.default_rng(a.seed)
+    eng = eng or ca.Engine(0)
+    g = torch.Generator(device="cuda").manual_seed(a.seed)
+    rep = MODES[a.mode]
+    nrep = max(rep, 1)
+    runs = a.runs
+    bench = BENCHES[a.benchmark](a, eng, g)
+    inp = bench.inputs(runs, g)
+    clean = ca.XmrConfig(ca.UNPROTECTED)
+    gold = bench.run(inp, clean).clone()
+    det = torch.zeros(runs, dtype=torch.uint8, device="cuda")
+    targets = []
+    t0 = time.perf_counter()
+    eng.reset_stats()
+    if a.section == "registers":
+        rows = [bench.reg_fault(r, nrep, rng) for r in range(runs)]
+        for r, row in enumerate(rows):
+            targets.append({"replica": row[1], "site": row[2], "step": row[3], "bit": row[4]})
+        eng.inject_faults(ca.make_faults(rows))
+        out = bench.run(inp, ca.XmrConfig(rep), det)
+        engine = eng.last_launch()
+    elif a.mem_mode == "nomemrep" or rep == ca.UNPROTECTED:
+        for r in range(runs):  # the single memory copy is hit: every replica loads the same corrupted word
+            targets.append(flip_memory(eng, inp, r, rng))
+        out = bench.run(inp, ca.XmrConfig(rep), det)
+        engine = eng.last_launch()
+    else:
+        # default mode (docs/source/passes.rst:329,337): memory replicated, the clones run on their own copies, the values that
+        # leave the region are voted.  The upset sits in ONE copy.
+        copies = [[t.clone() for t in inp] for _ in range(nrep)]
+        for r in range(runs):
+            k = int(rng.integers(0, nrep))
+            tgt = flip_memory(eng, copies[k], r, rng)
+            tgt["copy"] = k
+            targets.append(tgt)
+        outs = [bench.run(c, clean) for c in copies]
+        width = outs[0].shape[1] * outs[0].element_size()
+        w4 = (width + 3) // 4 * 4  # the exit vote works on 32-bit words: every run's row is padded to whole words
+        rows8 = [torch.nn.functional.pad(o.contiguous().view(torch.uint8).reshape(runs, width), (0, w4 - width)).contiguous()
+                 for o in outs]
+        wd = torch.zeros(runs * w4 // 4, dtype=torch.uint8, device="cuda")
+        voted = eng.sync_copies(rows8, scrub=True, detected=wd)
+        det |= wd.reshape(runs, -1).any(dim=1).to(torch.uint8)
+        out = voted[:, :width].contiguous().view(gold.dtype).reshape(runs, -1)
+        engine = eng.last_launch()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    st = eng.stats()
+    bad = (out.reshape(runs, -1) != gold.reshape(runs, -1)).any(dim=1).cpu().numpy()
+    flagged = det.bool().cpu().numpy()
+
+    records, counts = [], {"success": 0, "errors": 0, "faults": 0, "timeouts": 0, "invalids": 0, "aborts": 0}
+    us = wall * 1e6 / runs
+    for r in range(runs):
+        if rep == ca.DWC and flagged[r]:  # FAULT_DETECTED_DWC() -> abort(): the supervisor logs an abort and a timeout
+            cls, e, f = "abort", 0, 0
+            counts["timeouts"] += 1
+            counts["aborts"] += 1
+        elif bad[r]:
+            cls, e, f = "error", 1, int(flagged[r])
+            counts["errors"] += 1
+        elif flagged[r]:
+            cls, e, f = "fault", 0, 1
+            counts["faults"] += 1
+        else:
+            cls, e, f = "success", 0, 0
+            counts["success"] += 1
+        records.append({"run": r, "section": a.section, "target": targets[r],
+                        "result": {"core": 0, "errors": e, "faults": f, "runtime_us": us}, "class": cls})
+    name = "%s_%s_%s_%s" % (a.benchmark, a.mode, a.section, a.mem_mode if a.section == "memory" else "injector")
+    summary = {
+        "name": name, "benchmark": a.benchmark, "mode": a.mode, "section": a.section,
+        "mem_mode": a.mem_mode if a.section == "memory" else None, "runs": runs,
+        "success": counts["success"], "errors": counts["errors"], "faults": counts["faults"],
+        "timeouts": counts["timeouts"], "invalids": counts["invalids"], "aborts": counts["aborts"],
+        "coverage_pct": 100.0 * (runs - counts["errors"]) / runs,
+        "TMR_ERROR_CNT": st["errors_corrected"], "__SYNC_COUNT": st["sync_count"], "dwc_detected": st["dwc_detected"],
+        "engine": engine["engine"], "stepwise_blocks": engine["general_blocks"], "wall_s": wall,
+        "seconds_per_injection": wall / runs,
+        "fault_model": "one single-bit flip of a 32-bit word per run (FaultInjector.flipOneBit, injector.py:202-207)",
+    }
+    return records, summary
+
+
+def format_summary(s):
+    """FileSummary.__str__ (jsonParser.py:46-75)"""
+    n = s["runs"]
+    good = s["success"] + s["faults"]
+    lines = ["", ("Summary for file %s:" % s["name"]).center(60), "",
+             "Total runs: %d" % n,
+             "Successes:  %d (%3.2f%%)" % (good, 100.0 * good / n),
+             "Errors:     %d (%3.2f%%)" % (s["errors"], 100.0 * s["errors"] / n),
+             "Faults:     %d (%3.2f%%)" % (s["faults"], 100.0 * s["faults"] / n),
+             "Timeouts:   %d (%3.2f%%)" % (s["timeouts"], 100.0 * s["timeouts"] / n),
+             "Invalid:    %d (%3.2f%%)" % (s["invalids"], 100.0 * s["invalids"] / n),
+             "Time to run: %s" % str(datetime.timedelta(seconds=int(s["wall_s"]))),
+             " (%3.6f seconds per injection)" % s["seconds_per_injection"]]
+    if s["aborts"]:
+        lines += ["Additional Data:", "Aborts:     %d (%3.2f%%)" % (s["aborts"], 100.0 * s["aborts"] / n)]
+    return "\n".join(lines)
+
+
+def write_logs(a, records, summary):
+    os.makedirs(a.log_dir, exist_ok=True)
+    now = datetime.datetime.now()
+    ts = "%d-%d-%02d_%02d-%02d" % (now.year, now.month, now.day, now.hour, now.minute)
+    prefix = os.path.join(a.log_dir, "mi355x_%s_%s" % (summary["name"], ts))
+    with open(prefix + ".log", "w") as fh:  # the UART line of every run (decoder.py:66)
+        for rec in records:
+            res = rec["result"]
+            fh.write("run %d  %s  C:%d E:%d F:%d T:%dus%s\n" % (rec["run"], json.dumps(rec["target"], sort_keys=True), res["core"],
+                                                                res["errors"], res["faults"], int(res["runtime_us"]),
+                                                                "  ABORT (FAULT_DETECTED_DWC)" if rec["class"] == "abort" else ""))
+        fh.write(format_summary(summary) + "\n")
+    with open(prefix + ".json", "w", encoding="utf-8") as fh:
+        json.dump({"summary": summary, "runs": records}, fh)
+    return prefix
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("-b", "--benchmark", default="mm", choices=sorted(BENCHES))
+    ap.add_argument("-m", "--mode", default="TMR", choices=list(MODES))
+    ap.add_argument("-t", "--runs", type=int, default=5000)
+    ap.add_argument("-s", "--section", default="registers", choices=["registers", "memory"])
+    ap.add_argument("--mem-mode", default="nomemrep", choices=["nomemrep", "default"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--side", type=int, default=9, help="mm: matrix side, one matrix per run (256 = the matrix-core engine)")
+    ap.add_argument("-l", "--log-dir", default="./logs/")
+    ap.add_argument("-n", "--no-logging", action="store_true")
+    return ap.parse_args(argv)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("-b", "--benchmark", default="mm", choices=["mm", "sha256", "aes", "crc16", "cache_test", "chsha"])
-    ap.add_argument("-m", "--mode", default="TMR", choices=list(MODES))
-    ap.add_argument("-t", "--runs", type=int, default=5000)
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--side", type=int, default=9, help="mm: matrix side (one matrix per run)")
-    a = ap.parse_args()
-
-    rng = np.random.default_rng(a.seed)
-    eng = coast_amd.Engine(0)
-    rep = MODES[a.mode]
-    nrep = max(rep, 1)
-    cfg = coast_amd.XmrConfig(rep)
-    clean = coast_amd.XmrConfig(coast_amd.UNPROTECTED)
-    g = torch.Generator(device="cuda").manual_seed(a.seed)
-    runs = a.runs
-    det = torch.zeros(1, dtype=torch.uint8, device="cuda")
-
-    if a.benchmark == "mm":
-        n = a.side
-        f = torch.randint(-2**31, 2**31, (runs, n, n), dtype=torch.int32, device="cuda", generator=g)
-        s = torch.randint(-2**31, 2**31, (runs, n, n), dtype=torch.int32, device="cuda", generator=g)
-        gold = eng.mm_batch(f, s, cfg=clean)
-        rows = [(run * n * n + int(rng.integers(0, n * n)), int(rng.integers(0, nrep)), int(rng.integers(0, 3)),
-                 int(rng.integers(0, n + 1)), int(rng.integers(0, 32))) for run in range(runs)]
-        det = torch.zeros(runs * n * n, dtype=torch.uint8, device="cuda")
-        eng.reset_stats()
-        eng.inject_faults(coast_amd.make_faults(rows))
-        out = eng.mm_batch(f, s, cfg=cfg, detected=det)
-        bad = (out != gold).reshape(runs, -1).any(dim=1)
-        flagged = det.reshape(runs, -1).any(dim=1)
-    elif a.benchmark == "sha256":
-        msgs = torch.randint(0, 256, (runs, 64), dtype=torch.uint8, device="cuda", generator=g)
-        gold = eng.sha256_batch(msgs, 64, cfg=clean)
-        rows = []
-        for run in range(runs):
-            site = int(rng.choice([coast_amd.SITE_SHA_M, coast_amd.SITE_SHA_WV, coast_amd.SITE_SHA_STATE]))
-            step = int(rng.integers(0, 3)) if site == coast_amd.SITE_SHA_STATE else int(rng.integers(0, 128))
-            rows.append((run, int(rng.integers(0, nrep)), site, step, int(rng.integers(0, 32)), int(rng.integers(0, 8))))
-        det = torch.zeros(runs, dtype=torch.uint8, device="cuda")
-        eng.reset_stats()
-        eng.inject_faults(coast_amd.make_faults(rows))
-        out = eng.sha256_batch(msgs, 64, cfg=cfg, detected=det)
-        bad = (out != gold).any(dim=1)
-        flagged = det.bool()
-    elif a.benchmark == "aes":
-        st = torch.randint(0, 256, (runs, 16), dtype=torch.uint8, device="cuda", generator=g)
-        key = torch.randint(0, 256, (runs, 16), dtype=torch.uint8, device="cuda", generator=g)
-        gs, gk = st.clone(), key.clone()
-        eng.aes128_batch(gs, gk, 0, cfg=clean)
-        rows = [(run, int(rng.integers(0, nrep)), int(rng.choice([coast_amd.SITE_AES_STATE, coast_amd.SITE_AES_KEY])),
-                 int(rng.integers(0, 11)), int(rng.integers(0, 32)), int(rng.integers(0, 4))) for run in range(runs)]
-        det = torch.zeros(runs, dtype=torch.uint8, device="cuda")
-        eng.reset_stats()
-        eng.inject_faults(coast_amd.make_faults(rows))
-        eng.aes128_batch(st, key, 0, cfg=cfg, detected=det)
-        bad = (st != gs).any(dim=1) | (key != gk).any(dim=1)
-        flagged = det.bool()
-    elif a.benchmark == "chsha":
-        ln = 192  # three data blocks + the padding block per run
-        msgs = torch.randint(0, 256, (runs, ln), dtype=torch.uint8, device="cuda", generator=g)
-        gold = eng.chsha_batch(msgs, ln, cfg=clean)
-        rows = []
-        for run in range(runs):
-            site = int(rng.choice([coast_amd.SITE_CHSHA_W, coast_amd.SITE_CHSHA_WV, coast_amd.SITE_CHSHA_DIGEST]))
-            step = int(rng.integers(0, 4)) if site == coast_amd.SITE_CHSHA_DIGEST else int(rng.integers(0, 4 * 80))
-            rows.append((run, int(rng.integers(0, nrep)), site, step, int(rng.integers(0, 32)), int(rng.integers(0, 5))))
-        det = torch.zeros(runs, dtype=torch.uint8, device="cuda")
-        eng.reset_stats()
-        eng.inject_faults(coast_amd.make_faults(rows))
-        out = eng.chsha_batch(msgs, ln, cfg=cfg, detected=det)
-        bad = (out != gold).any(dim=1)
-        flagged = det.bool()
-    elif a.benchmark == "cache_test":
-        n = 600  # data_array_elements, cacheTest.c:78
-        arr = torch.arange(n, dtype=torch.int32, device="cuda").repeat(runs, 1).contiguous()
-        gs, ge = eng.cache_test_batch(arr.clone(), cfg=clean)
-        rows = [(run, int(rng.integers(0, nrep)), int(rng.choice([coast_amd.SITE_CT_SUM, coast_amd.SITE_CT_VAL,
-                                                                  coast_amd.SITE_CT_NERR])),
-                 int(rng.integers(0, n + 1)), int(rng.integers(0, 32))) for run in range(runs)]
-        det = torch.zeros(runs, dtype=torch.uint8, device="cuda")
-        eng.reset_stats()
-        eng.inject_faults(coast_amd.make_faults(rows))
-        work = arr.clone()
-        sums, nerrs = eng.cache_test_batch(work, cfg=cfg, detected=det)
-        bad = (sums != gs) | (nerrs != ge) | (work != arr).any(dim=1)
-        flagged = det.bool()
-    else:
-        bl = 255  # the reference's maximum length (unsigned char, crc16.c:21)
-        data = torch.randint(0, 256, (runs * bl,), dtype=torch.uint8, device="cuda", generator=g)
-        gold = eng.crc16_batch(data, bl, cfg=clean)
-        rows = [(run, int(rng.integers(0, nrep)), int(rng.choice([coast_amd.SITE_CRC_CRC, coast_amd.SITE_CRC_X])),
-                 int(rng.integers(0, bl + 1)), int(rng.integers(0, 32))) for run in range(runs)]
-        det = torch.zeros(runs, dtype=torch.uint8, device="cuda")
-        eng.reset_stats()
-        eng.inject_faults(coast_amd.make_faults(rows))
-        out = eng.crc16_batch(data, bl, cfg=cfg, detected=det)
-        bad = out != gold
-        flagged = det.bool()
-
-    st_ = eng.stats()
-    bad, flagged = bad.cpu().numpy(), flagged.cpu().numpy()
-    if rep == coast_amd.DWC:
-        detected = int(flagged.sum())
-        errors = int((bad & ~flagged).sum())
-        faults = 0
-    else:
-        detected = 0
-        errors = int(bad.sum())
-        faults = int((flagged & ~bad).sum())
-    success = runs - errors - faults - detected
-    out = {"benchmark": a.benchmark, "mode": a.mode, "runs": runs, "success": success, "faults_corrected": faults,
-           "errors_sdc": errors, "dwc_detected": detected, "coverage_pct": 100.0 * (runs - errors) / runs,
-           "TMR_ERROR_CNT": st_["errors_corrected"], "__SYNC_COUNT": st_["sync_count"],
-           "fault_model": "one single-bit flip of a replica-private 32-bit register per run (injector.py:202-207)"}
-    print(json.dumps(out))
+    a = parse()
+    records, summary = run_campaign(a)
+    if not a.no_logging:
+        summary["log_prefix"] = write_logs(a, records, summary)
+    print(format_summary(summary))
+    print(json.dumps(summary))
 
 
 if __name__ == "__main__":
