@@ -17,3 +17,4 @@ SITE_AES_STATE, SITE_AES_KEY = 16, 17
 SITE_CRC_CRC, SITE_CRC_X, SITE_CRC_LEN = 24, 25, 26
 SITE_CT_SUM, SITE_CT_VAL, SITE_CT_NERR = 32, 33, 34
 SITE_CHSHA_W, SITE_CHSHA_WV, SITE_CHSHA_DIGEST = 40, 41, 42
+SITE_QS_I, SITE_QS_J, SITE_QS_PIVOT, SITE_QS_VI, SITE_QS_VJ = 48, 49, 50, 51, 52

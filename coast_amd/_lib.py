@@ -59,6 +59,8 @@ SYMBOLS = {
                                          C.POINTER(CoastCfg), C.c_void_p]),
     "coast_chsha_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_void_p,
                                     C.POINTER(CoastCfg), C.c_void_p]),
+    "coast_quicksort_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.POINTER(CoastCfg), C.c_void_p,
+                                        C.c_void_p]),
     "coast_sync_copies": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_void_p, C.c_int,
                                     C.c_void_p]),
     "coast_flip_memory": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint]),
@@ -68,6 +70,7 @@ SYMBOLS = {
     "coast_crc16_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(CoastCfg)]),
     "coast_cache_test_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(CoastCfg)]),
     "coast_chsha_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(CoastCfg)]),
+    "coast_quicksort_host": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(CoastCfg)]),
     "coast_host_inject_faults": (C.c_int, [C.c_void_p, C.c_size_t]),
     "coast_host_stats": (C.c_int, [C.POINTER(CoastStats), C.c_int]),
 }

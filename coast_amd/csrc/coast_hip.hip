@@ -25,6 +25,7 @@
 #include "vote_kernel.hip"
 #include "cache_test_kernel.hip"
 #include "chsha_kernel.hip"
+#include "quicksort_kernel.hip"
 
 using namespace coast;
 

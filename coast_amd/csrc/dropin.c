@@ -172,6 +172,26 @@ unsigned short crc16(const unsigned char *data_p, unsigned char length)
     return crc;
 }
 
+/* quick_sort(int *A, int len), tests/quicksort/quicksort.c:109: the whole recursive sort is one protected region */
+void quick_sort(int *A, int len)
+{
+    const coast_cfg cfg = dropin_cfg_counters();
+    coast_cfg q = cfg; /* the sort's indices are data: branch / address votes are its default, the -no...Sync flags its knobs */
+    q.flags &= ~(uint32_t)(COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC);
+    const char *passes = getenv("COAST_OPT_PASSES");
+    if (passes && !(q.flags & COAST_F_HOST_MEMORY_REPLICATED)) {
+        if (has_flag(passes, "-noLoadSync"))
+            q.flags |= COAST_F_NO_LOAD_SYNC;
+        if (has_flag(passes, "-noStoreAddrSync"))
+            q.flags |= COAST_F_NO_STORE_ADDR_SYNC;
+    }
+    dropin_maybe_inject();
+    const int rc = coast_quicksort_host((int32_t *)A, len < 0 ? 0u : (uint32_t)len, &q);
+    if (rc)
+        dropin_fail("quick_sort", rc);
+    dropin_account();
+}
+
 void aes_enc_dec(unsigned char *state, unsigned char *key, unsigned char dir)
 {
     const coast_cfg cfg = dropin_cfg();

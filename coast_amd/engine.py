@@ -183,6 +183,17 @@ class Engine:
                                                      _ptr(detected) if detected is not None else None))
         return sums, nerrs
 
+    def quicksort_batch(self, arrays, cfg: XmrConfig = XmrConfig(), detected=None, status=None):
+        """arrays: (n_arrays, n) int32 on the GPU, sorted IN PLACE (quick_sort, tests/quicksort/quicksort.c:109-129).
+        status (optional uint8 per array): 0 sorted, 1 watchdog, 2 stack overflow."""
+        assert arrays.is_cuda and arrays.dtype == torch.int32 and arrays.dim() == 2 and arrays.is_contiguous()
+        na, n = arrays.shape
+        cc = cfg.c()
+        self._check(self._lib.coast_quicksort_batch(self._h, _ptr(arrays), n, na, C.byref(cc),
+                                                    _ptr(detected) if detected is not None else None,
+                                                    _ptr(status) if status is not None else None))
+        return arrays
+
     # -- default mode (memory replicated x3 / x2): vote where the copies re-converge
     def sync_copies(self, copies, out=None, scrub=True, detected=None):
         """copies: 3 (TMR) or 2 (DWC) equally shaped contiguous GPU tensors holding the per-copy results of replicas=1

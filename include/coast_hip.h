@@ -135,7 +135,14 @@ enum {
     COAST_SITE_CT_NERR = 34,   /* numberOfErrors before element `step` (step == n: after the loop) */
     COAST_SITE_CHSHA_W = 40,      /* CHStone sha: schedule word W[step%80] of transform step/80, right after it is produced */
     COAST_SITE_CHSHA_WV = 41,     /* working variable index 0..4 (A..E) before round step%80 of transform step/80 */
-    COAST_SITE_CHSHA_DIGEST = 42  /* sha_info_digest[index] before transform `step` */
+    COAST_SITE_CHSHA_DIGEST = 42, /* sha_info_digest[index] before transform `step` */
+    /* quicksort: `step` counts the branch conditions the sort of this array has evaluated; the flip lands right before
+     * condition number `step` is evaluated (after the load that feeds it) */
+    COAST_SITE_QS_I = 48,     /* the left scan index i */
+    COAST_SITE_QS_J = 49,     /* the right scan index j */
+    COAST_SITE_QS_PIVOT = 50, /* the pivot */
+    COAST_SITE_QS_VI = 51,    /* the value last loaded from A[i] */
+    COAST_SITE_QS_VJ = 52     /* the value last loaded from A[j] */
 };
 
 /* One single-event upset: new = old XOR (1 << bit) on the 32-bit register holding the value
@@ -227,6 +234,18 @@ int coast_cache_test_batch(coast_ctx *ctx, int32_t *d_arrays, uint32_t n_elems, 
 int coast_chsha_batch(coast_ctx *ctx, const uint8_t *d_msgs, size_t stride, uint32_t len, size_t n_msgs,
                       uint32_t *d_digests, const coast_cfg *cfg, uint8_t *d_detected);
 
+/* quick_sort (tests/quicksort/quicksort.c:109-129, the LANL quicksort benchmark): n_arrays arrays of n_elems ints, array a at
+ * d_arrays + a*n_elems, sorted IN PLACE (ascending).  The first workload whose loop trip counts depend on the data: every
+ * evaluated branch condition (`len < 2`, `A[i] < pivot`, `A[j] > pivot`, `i >= j`) is a sync point -- the replicas of an array
+ * follow the voted direction and stay convergent -- and so are the GEP offsets of its loads / stores and the data of both
+ * stores of a swap (the reference's -noMemReplication rule set; COAST_F_NO_LOAD_SYNC / _NO_STORE_ADDR_SYNC / _NO_STORE_DATA_SYNC
+ * switch the three classes off, COAST_F_BRANCH_SYNC / _ADDR_SYNC are implied).  d_status (optional, one byte per array):
+ * 0 = sorted to the end, 1 = cut by the watchdog (a corrupted index kept a loop alive: 64 n + 1024 conditions), 2 = more than
+ * 48 pending parts (the reference's supervisor classes: timeout / stack overflow). */
+enum { COAST_QS_OK = 0, COAST_QS_WATCHDOG = 1, COAST_QS_STACK = 2 };
+int coast_quicksort_batch(coast_ctx *ctx, int32_t *d_arrays, uint32_t n_elems, size_t n_arrays, const coast_cfg *cfg,
+                          uint8_t *d_detected, uint8_t *d_status);
+
 /* ---- default-mode TMR / DWC: memory replicated as well (docs/source/passes.rst:329,337; cloning.cpp:2417-2462) ----
  * In COAST's default mode the clones of a region run on their own copies of the data and stores are not voted
  * (synchronization.cpp:211-215); values are voted where the copies re-converge -- return values, arguments of unprotected
@@ -253,6 +272,7 @@ int coast_crc16_host(const uint8_t *data, uint32_t length, uint16_t *crc, const 
 /* calc_sum's `data_array_elements` is a macro in the reference (cacheTest.c:78), so the glue TU passes it explicitly */
 int coast_cache_test_host(int32_t *array, uint32_t n_elems, int32_t *sum, uint32_t *nerr, const coast_cfg *cfg);
 int coast_chsha_host(const uint8_t *data, uint32_t len, uint32_t digest[5], const coast_cfg *cfg);
+int coast_quicksort_host(int32_t *array, uint32_t n_elems, const coast_cfg *cfg);
 /* arm single-bit flips for the NEXT single-call shim (they run on a library-owned context): lets an external harness
  * inject into an unmodified driver the way supervisor.py + GDB inject into the running benchmark */
 int coast_host_inject_faults(const coast_fault *faults, size_t k);

@@ -1069,6 +1069,180 @@ void orc_cache_test_xmr(int32_t *arrays, uint32_t n, size_t narrays, int32_t *su
 /* default mode: vote where three (two) memory copies re-converge                             */
 /* ------------------------------------------------------------------------------------------ */
 
+/* ------------------------------------------------------------------------------------------ */
+/* quicksort                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* quick_sort (tests/quicksort/quicksort.c:109-129, the Rosetta-code Hoare partition), the way the reference writes it. */
+static void qs_plain(int32_t *A, int len)
+{
+    if (len < 2)
+        return;
+    const int32_t pivot = A[len / 2];
+    int i, j;
+    for (i = 0, j = len - 1;; i++, j--) {
+        while (A[i] < pivot)
+            i++;
+        while (A[j] > pivot)
+            j--;
+        if (i >= j)
+            break;
+        const int32_t temp = A[i];
+        A[i] = A[j];
+        A[j] = temp;
+    }
+    qs_plain(A, i);
+    qs_plain(A + i, len - i);
+}
+
+void orc_quicksort_plain(int32_t *array, uint32_t n) { qs_plain(array, (int)n); }
+
+/* The protected sort of one array.  Everything the function computes with is replica-private: i, j, the pivot, the loaded
+ * values, the (base, len) of every pending call -- the recursion is an explicit per-replica stack walked in the reference's
+ * order (left part first, then the right part).  The array is memory: one copy (-noMemReplication).  Sync points, the
+ * reference's rule set for that mode applied to the source as written:
+ *   every evaluated branch condition (`len < 2`, `A[i] < pivot`, `A[j] > pivot`, `i >= j`)   synchronization.cpp:146-155
+ *   every GEP offset: A[len/2], A[i], A[j] loads (off with -noLoadSync), A[i], A[j] stores (off with -noStoreAddrSync)  :333-372
+ *   the data of both stores of a swap (off with -noStoreDataSync)                                                     :197-224
+ * `temp = A[i]` and the A[j] of `A[i] = A[j]` reuse the values the two scans loaded last (what -O3 leaves of them).
+ * The replicas of an array always take the same direction (voted, or replica 0's under DWC), so control flow -- and with it the
+ * condition counter that addresses the fault steps -- is one per array.  A corrupted index can leave the array: such loads
+ * return the replica's pivot (both scans stop), such stores are dropped; a sort that does not end within 64 n + 1024
+ * conditions, or nests deeper than ORC_QS_MAXDEPTH pending right parts, is cut (status WATCHDOG / STACK -- the reference's
+ * supervisor files those runs under timeout / stack overflow, jsonParser.py:162-186). */
+static int qs_item(int32_t *A, uint32_t n, sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    const unsigned R = c->nrep;
+    const int ls = !(c->flags & ORC_F_NO_LOAD_SYNC), ss = !(c->flags & ORC_F_NO_STORE_ADDR_SYNC);
+    uint32_t base[3] = {0, 0, 0}, len[3] = {n, n, n};
+    uint32_t stk[3][ORC_QS_MAXDEPTH][2];
+    uint32_t sp = 0, tick = 0;
+    const uint32_t cap = 64u * n + 1024u;
+    uint32_t i[3] = {0, 0, 0}, j[3] = {0, 0, 0}, pv[3] = {0, 0, 0}, vi[3] = {0, 0, 0}, vj[3] = {0, 0, 0};
+#define QS_HOOK()                                                                                              \
+    do {                                                                                                       \
+        for (size_t q_ = 0; q_ < nf; ++q_)                                                                     \
+            if (fl[q_].step == tick && fl[q_].replica < R) {                                                   \
+                uint32_t *t_ = fl[q_].site == ORC_SITE_QS_I ? i : fl[q_].site == ORC_SITE_QS_J ? j :           \
+                               fl[q_].site == ORC_SITE_QS_PIVOT ? pv : fl[q_].site == ORC_SITE_QS_VI ? vi :    \
+                               fl[q_].site == ORC_SITE_QS_VJ ? vj : NULL;                                      \
+                if (t_)                                                                                        \
+                    t_[fl[q_].replica] = flip(t_[fl[q_].replica], fl[q_].bit, 0xffffffffu);                    \
+            }                                                                                                  \
+    } while (0)
+#define QS_COND(expr0, expr1, expr2) (tick++, branch_cond(c, (expr0), R > 1 ? (expr1) : (expr0), R > 2 ? (expr2) : (expr0), 1))
+#define QS_LOAD(dst, off)                                                                                      \
+    do {                                                                                                       \
+        const uint32_t o_ = (off);                                                                             \
+        for (unsigned r_ = 0; r_ < 3; ++r_)                                                                    \
+            dst[r_] = o_ < n ? (uint32_t)A[o_] : pv[r_];                                                       \
+    } while (0)
+    for (;;) {
+        if (tick >= cap)
+            return ORC_QS_WATCHDOG;
+        QS_HOOK();
+        if (QS_COND(len[0] < 2, len[1] < 2, len[2] < 2)) {     /* if (len < 2) return;                          :110 */
+            if (sp == 0)
+                return ORC_QS_OK;
+            --sp;
+            for (unsigned r = 0; r < 3; ++r) {
+                base[r] = stk[r][sp][0];
+                len[r] = stk[r][sp][1];
+            }
+            continue;
+        }
+        {
+            const uint32_t mid[3] = {base[0] + len[0] / 2, base[1] + len[1] / 2, base[2] + len[2] / 2};
+            const uint32_t po = gep_offset(c, mid, ls);         /* pivot = A[len / 2]                            :112 */
+            for (unsigned r = 0; r < 3; ++r)
+                pv[r] = po < n ? (uint32_t)A[po] : 0u;
+        }
+        for (unsigned r = 0; r < 3; ++r) {
+            i[r] = base[r];
+            j[r] = base[r] + len[r] - 1;
+        }
+        for (;;) {                                              /* for (i = 0, j = len - 1; ; i++, j--)          :115 */
+            for (;;) {                                          /* while (A[i] < pivot) i++;                     :116 */
+                QS_LOAD(vi, gep_offset(c, i, ls));
+                QS_HOOK();
+                if (!QS_COND((int32_t)vi[0] < (int32_t)pv[0], (int32_t)vi[1] < (int32_t)pv[1], (int32_t)vi[2] < (int32_t)pv[2]) ||
+                    tick >= cap)
+                    break;
+                for (unsigned r = 0; r < 3; ++r)
+                    i[r] += 1;
+            }
+            for (;;) {                                          /* while (A[j] > pivot) j--;                     :117 */
+                QS_LOAD(vj, gep_offset(c, j, ls));
+                QS_HOOK();
+                if (!QS_COND((int32_t)vj[0] > (int32_t)pv[0], (int32_t)vj[1] > (int32_t)pv[1], (int32_t)vj[2] > (int32_t)pv[2]) ||
+                    tick >= cap)
+                    break;
+                for (unsigned r = 0; r < 3; ++r)
+                    j[r] -= 1;
+            }
+            QS_HOOK();
+            if (QS_COND((int32_t)i[0] >= (int32_t)j[0], (int32_t)i[1] >= (int32_t)j[1], (int32_t)i[2] >= (int32_t)j[2]) ||
+                tick >= cap)                                    /* if (i >= j) break;                            :119 */
+                break;
+            {                                                   /* temp = A[i]; A[i] = A[j]; A[j] = temp;   :121-123 */
+                const uint32_t oi = gep_offset(c, i, ss);
+                uint32_t d[3] = {vj[0], vj[1], vj[2]};
+                store_sync32(c, d);
+                if (oi < n)
+                    A[oi] = (int32_t)d[0];
+                const uint32_t oj = gep_offset(c, j, ss);
+                uint32_t e[3] = {vi[0], vi[1], vi[2]};
+                store_sync32(c, e);
+                if (oj < n)
+                    A[oj] = (int32_t)e[0];
+            }
+            for (unsigned r = 0; r < 3; ++r) {
+                i[r] += 1;
+                j[r] -= 1;
+            }
+        }
+        if (tick >= cap)
+            return ORC_QS_WATCHDOG;
+        if (sp == ORC_QS_MAXDEPTH)
+            return ORC_QS_STACK;
+        for (unsigned r = 0; r < 3; ++r) {                      /* quick_sort(A, i); quick_sort(A + i, len - i); :126-127 */
+            stk[r][sp][0] = i[r];
+            stk[r][sp][1] = base[r] + len[r] - i[r];
+            len[r] = i[r] - base[r];
+        }
+        ++sp;
+    }
+#undef QS_LOAD
+#undef QS_COND
+#undef QS_HOOK
+}
+
+void orc_quicksort_xmr(int32_t *arrays, uint32_t n, size_t narrays, const orc_cfg *cfg, const orc_fault *faults, size_t nfaults,
+                       orc_stats *st, uint8_t *detected, uint8_t *status)
+{
+    orc_fault *fs = sorted_faults(faults, nfaults);
+    sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0, cfg->flags};
+    size_t fp = 0;
+    for (size_t a = 0; a < narrays; ++a) {
+        while (fp < nfaults && fs[fp].item < a)
+            ++fp;
+        size_t fe = fp;
+        while (fe < nfaults && fs[fe].item == a)
+            ++fe;
+        c.detected = 0;
+        const int rc = qs_item(arrays + a * (size_t)n, n, &c, fs + fp, fe - fp);
+        if (status)
+            status[a] = (uint8_t)rc;
+        if (c.detected) {
+            st->dwc_detected += (cfg->replicas == 2);
+            if (detected)
+                detected[a] = 1;
+        }
+        fp = fe;
+    }
+    free(fs);
+}
+
 /* The exit vote of COAST's default (memory-replicated) mode over result arrays: docs/source/passes.rst:329,337 --
  * stores are not voted, values are where they leave the sphere of replication (synchronization.cpp:741-949,
  * verification.cpp:625-682).  Word-wise (32 bit): TMR vote + count (+ scrub of the copies), DWC compare. */

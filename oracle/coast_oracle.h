@@ -61,8 +61,16 @@ enum {
 
     ORC_SITE_CHSHA_W = 40,     /* CHStone sha: schedule word W[step%80] of transform step/80, right after it is produced */
     ORC_SITE_CHSHA_WV = 41,    /* working variable index 0..4 (A..E) before round step%80 of transform step/80 */
-    ORC_SITE_CHSHA_DIGEST = 42 /* sha_info_digest[index] before transform `step` */
+    ORC_SITE_CHSHA_DIGEST = 42, /* sha_info_digest[index] before transform `step` */
+    /* quicksort: `step` counts the branch conditions the sort has evaluated so far; the flip lands right before condition
+     * number `step` is evaluated (after the load that feeds it) */
+    ORC_SITE_QS_I = 48,     /* the left scan index i */
+    ORC_SITE_QS_J = 49,     /* the right scan index j */
+    ORC_SITE_QS_PIVOT = 50, /* the pivot value */
+    ORC_SITE_QS_VI = 51,    /* the value last loaded from A[i] */
+    ORC_SITE_QS_VJ = 52     /* the value last loaded from A[j] */
 };
+enum { ORC_QS_OK = 0, ORC_QS_WATCHDOG = 1, ORC_QS_STACK = 2, ORC_QS_MAXDEPTH = 48 };
 
 /* One single-bit flip.  16 bytes; identical layout to coast_fault in include/coast_hip.h. */
 typedef struct {
@@ -121,6 +129,10 @@ void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint
 /* calc_sum (tests/cache_test/cacheTest.c:101-177): n_arrays arrays of n ints, scrubbed in place; per array the sum (taken
  * BEFORE the fixes, :108) and the number of elements that were != their index (:110-111) */
 void orc_cache_test_plain(int32_t *array, uint32_t n, int32_t *sum, uint32_t *nerr);
+/* quick_sort of tests/quicksort/quicksort.c:109-129, in place; status[a] = ORC_QS_* (NULL allowed) */
+void orc_quicksort_plain(int32_t *array, uint32_t n);
+void orc_quicksort_xmr(int32_t *arrays, uint32_t n, size_t narrays, const orc_cfg *cfg, const orc_fault *faults, size_t nfaults,
+                       orc_stats *st, uint8_t *detected, uint8_t *status);
 void orc_cache_test_xmr(int32_t *arrays, uint32_t n, size_t narrays, int32_t *sums, uint32_t *nerrs, const orc_cfg *cfg,
                         const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
 

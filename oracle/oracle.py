@@ -294,6 +294,26 @@ def sync_copies(copies, scrub=True):
     return voted, cs, st.as_dict(), det
 
 
+def quicksort_plain(arr):
+    a = np.ascontiguousarray(arr, dtype=np.int32).copy()
+    lib().orc_quicksort_plain(_p(a, C.c_int32), C.c_uint32(a.shape[-1]))
+    return a
+
+
+def quicksort_xmr(arrays, replicas=3, faults=None, flags=0):
+    """arrays: (narrays, n) int32.  Returns (sorted copies, stats dict, detected per array, status per array)."""
+    a = np.ascontiguousarray(arrays, dtype=np.int32).copy()
+    na, n = a.shape
+    fl = _faults(faults)
+    st = Stats()
+    det = np.zeros(na, dtype=np.uint8)
+    status = np.zeros(na, dtype=np.uint8)
+    cfg = Cfg(replicas, 0, flags)
+    lib().orc_quicksort_xmr(_p(a, C.c_int32), C.c_uint32(n), C.c_size_t(na), C.byref(cfg), fl.ctypes.data_as(C.c_void_p),
+                            C.c_size_t(len(fl)), C.byref(st), _p(det, C.c_uint8), _p(status, C.c_uint8))
+    return a, st.as_dict(), det, status
+
+
 def cpu_tmr_mm(f, s, xor_golden):
     """Default-mode CPU-TMR restatement (timing baseline).  Returns (r, error_flag, TMR_ERROR_CNT, syncs)."""
     f = np.ascontiguousarray(f, dtype=np.uint32)
@@ -332,6 +352,13 @@ def cpu_tmr_mm_threads(f, s, xor_golden, nthreads, reps):
 
 
 # ---------------------------------------------------------------- the reference itself (oracle/_ref)
+def ref_quicksort(arr):
+    """the reference's own quick_sort (tests/quicksort/quicksort.c:109-129, compiled from where it lies)"""
+    a = np.ascontiguousarray(arr, dtype=np.int32).copy()
+    ref().ref_quicksort(_p(a, C.c_int32), C.c_int(a.shape[-1]))
+    return a
+
+
 def ref_mm(f, s, golden):
     R = ref()
     n = f.shape[-1]

@@ -157,6 +157,34 @@ def main():
     np.savez_compressed(os.path.join(HERE, "chsha_fixtures.npz"), **chv)
     out["chsha_outData"] = out_data
 
+    # ---------------- quicksort (tests/quicksort): the unmodified benchmark compiled natively; its main() never returns, so the
+    # fixture is its stdout up to and including the second acknowledge line.  The E: blocks in it are the benchmark's own:
+    # quick_sort_rev is an empty TODO (quicksort.c:131-133), so sub-tests 2 and 3 compare the sorted array with an unsorted golden.
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "qs_native")
+        subprocess.check_call(["gcc", "-O0", "-w", os.path.join(REF, "quicksort/quicksort.c"), "-o", exe])
+        p = subprocess.Popen(["stdbuf", "-oL", exe], stdout=subprocess.PIPE)
+        buf = b""
+        while True:
+            line = p.stdout.readline()
+            buf += line
+            if line.startswith(b"# 100,"):
+                break
+        p.kill()
+    out["quicksort_driver"] = {"acks": [ln.decode() for ln in buf.split(b"\r\n") if ln.startswith(b"#")],
+                               "bytes_until_ack100": len(buf), "sha256_until_ack100": hashlib.sha256(buf).hexdigest()}
+    # the reference sort on the benchmark's own first input (srand(0), 580 x rand()), as a checksum, plus random vectors
+    qv = {}
+    rng = random.Random(580)
+    for q, n in enumerate((1, 2, 3, 17, 100, 580)):
+        a = np.array([rng.randrange(-2**31, 2**31) for _ in range(n)], dtype=np.int32)
+        qv["in%d" % q] = a
+        qv["out%d" % q] = orc.ref_quicksort(a)
+    np.savez_compressed(os.path.join(HERE, "quicksort_fixtures.npz"), **qv)
+
     with open(os.path.join(HERE, "golden.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(HERE)))

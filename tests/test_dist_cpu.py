@@ -78,13 +78,16 @@ def test_bench_gpus_n_spawns_n_ranks():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env["COAST_BENCH_ECHO_RANK"] = "1"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       capture_output=True, text=True, env=env, timeout=600)
     if torch.cuda.is_available():
         pytest.skip("GPU box: covered by the gpu-marked two-rank tests")
+    for attempt in range(3):  # the rendezvous of two fresh interpreters is occasionally refused on a loaded build container
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, env=env, timeout=600)
+        err = p.stderr + p.stdout
+        if "rank 0/2" in err and "rank 1/2" in err:
+            break
     assert p.returncode != 0
-    err = p.stderr + p.stdout
-    assert "rank 0/2" in err and "rank 1/2" in err, err[-2000:]
+    assert "rank 0/2" in err and "rank 1/2" in err, err[:3000]
     assert err.count("no GPU visible") >= 2, err[-2000:]
 
 

@@ -294,3 +294,60 @@ def test_chstone_sha_golden_and_protection_model(orc, golden):
     assert (dig1[1] != clean[1]).any() and (dig1[[0, 2, 3]] == clean[[0, 2, 3]]).all()
     _, st2, det2 = orc.chsha_xmr(msgs, 192, replicas=2, faults=coast_amd.make_faults([(3, 1, 40, 5, 9)]))
     assert st2["dwc_detected"] == 1 and det2.tolist() == [0, 0, 0, 1]
+
+
+def test_quicksort_oracle_pinned_on_the_reference(orc):
+    """tests/quicksort/quicksort.c has no golden in tree (it sorts rand() data and compares two of its own sorts): the oracle's
+    restatement is pinned on the reference's quick_sort compiled from where it lies (oracle/_ref) and on sortedness, on the
+    benchmark's size (580) and the edge shapes; the protected model leaves clean runs untouched in every mode / flag set."""
+    rng = np.random.default_rng(580)
+    cases = [rng.integers(-2**31, 2**31, 580, dtype=np.int64).astype(np.int32) for _ in range(8)]
+    cases += [np.arange(580, dtype=np.int32), np.arange(580, dtype=np.int32)[::-1].copy(), np.zeros(580, np.int32),
+              rng.integers(0, 3, 580).astype(np.int32), np.array([5], np.int32), np.array([2, 1], np.int32),
+              np.array([1, 2, 1], np.int32), np.array([-2**31, 2**31 - 1, 0, -1], np.int32)]
+    have_ref = orc.ref() is not None and hasattr(orc.ref(), "ref_quicksort")
+    for a in cases:
+        want = np.sort(a)
+        assert (orc.quicksort_plain(a) == want).all()
+        if have_ref:
+            assert (orc.ref_quicksort(a) == want).all()
+    batch = np.stack(cases[:12])
+    for replicas in (3, 2, 1):
+        for flags in (0, 1, 8, 16, 1 | 8 | 16):
+            s, st, det, status = orc.quicksort_xmr(batch, replicas=replicas, flags=flags)
+            assert (s == np.sort(batch, axis=1)).all() and not status.any() and not det.any()
+            assert st["errors_corrected"] == 0 and (st["sync_count"] > 0) == (replicas > 1)
+    # every class of sync point is counted: dropping a class lowers __SYNC_COUNT
+    full = orc.quicksort_xmr(batch)[1]["sync_count"]
+    assert full > orc.quicksort_xmr(batch, flags=8)[1]["sync_count"] > orc.quicksort_xmr(batch, flags=8 | 16)[1]["sync_count"] \
+        > orc.quicksort_xmr(batch, flags=1 | 8 | 16)[1]["sync_count"] > 0
+
+
+def test_quicksort_oracle_fault_semantics(orc):
+    """a single upset in one replica never reaches the array under TMR; unprotected, the same upsets break the order or hang the
+    sort (watchdog) -- the reason the benchmark exists (quicksort.c:52-58)"""
+    rng = np.random.default_rng(1)
+    a = rng.integers(-2**31, 2**31, (150, 580), dtype=np.int64).astype(np.int32)
+    rows = [(k, int(rng.integers(0, 3)), int(rng.integers(48, 53)), int(rng.integers(0, 12000)), int(rng.integers(0, 32)))
+            for k in range(150)]
+    fl = np.zeros(len(rows), dtype=orc.FAULT_DTYPE)
+    for q, (item, rep, site, step, bit) in enumerate(rows):
+        fl[q] = (item, step, rep, site, bit, 0)
+    s, st, det, status = orc.quicksort_xmr(a, faults=fl)
+    assert (s == np.sort(a, axis=1)).all() and not status.any() and det.sum() > 50 and st["errors_corrected"] >= det.sum()
+    fl0 = fl.copy()
+    fl0["replica"] = 0
+    s, st, det, status = orc.quicksort_xmr(a, replicas=1, faults=fl0)
+    assert not (s == np.sort(a, axis=1)).all(axis=1).all() and (status == 1).any()
+    s2, st2, det2, _ = orc.quicksort_xmr(a, replicas=2, faults=fl[fl["replica"] < 2])
+    assert st2["dwc_detected"] == det2.sum() > 30
+
+
+def test_quicksort_oracle_vs_committed_reference_vectors(orc):
+    import os
+
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quicksort_fixtures.npz")))
+    for q in range(6):
+        assert (orc.quicksort_plain(fx["in%d" % q]) == fx["out%d" % q]).all()
+        s, _, _, status = orc.quicksort_xmr(fx["in%d" % q][None])
+        assert (s[0] == fx["out%d" % q]).all() and not status.any()

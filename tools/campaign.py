@@ -148,7 +148,26 @@ class CacheTest(Bench):
                 int(rng.integers(0, self.n + 1)), int(rng.integers(0, 32)))
 
 
-BENCHES = {"mm": MM, "sha256": SHA256, "aes": AES, "crc16": CRC16, "chsha": ChSha, "cache_test": CacheTest}
+class QuickSort(Bench):
+    def __init__(self, a, eng, g):
+        self.eng, self.n = eng, 580  # array_elements, tests/quicksort/quicksort.c:82
+        self.status = None
+
+    def inputs(self, runs, g):
+        return [torch.randint(-2**31, 2**31, (runs, self.n), dtype=torch.int32, device="cuda", generator=g)]
+
+    def run(self, inp, cfg, det=None):
+        work = inp[0].clone()  # quick_sort works in place
+        self.status = torch.zeros(work.shape[0], dtype=torch.uint8, device="cuda")
+        self.eng.quicksort_batch(work, cfg=cfg, detected=det, status=self.status)
+        return work
+
+    def reg_fault(self, r, nrep, rng):
+        return (r, int(rng.integers(0, nrep)), int(rng.integers(ca.SITE_QS_I, ca.SITE_QS_VJ + 1)), int(rng.integers(0, 12000)),
+                int(rng.integers(0, 32)))
+
+
+BENCHES = {"quicksort": QuickSort, "mm": MM, "sha256": SHA256, "aes": AES, "crc16": CRC16, "chsha": ChSha, "cache_test": CacheTest}
 
 
 # ------------------------------------------------------------------------------------------------ one campaign
@@ -218,11 +237,17 @@ def run_campaign(a, eng=None):
     st = eng.stats()
     bad = (out.reshape(runs, -1) != gold.reshape(runs, -1)).any(dim=1).cpu().numpy()
     flagged = det.bool().cpu().numpy()
+    hung = np.zeros(runs, dtype=bool)  # quicksort: the watchdog / stack guard cut the run (supervisor: timeout, stack overflow)
+    if getattr(bench, "status", None) is not None and a.section == "registers":
+        hung = bench.status.cpu().numpy() != 0
 
     records, counts = [], {"success": 0, "errors": 0, "faults": 0, "timeouts": 0, "invalids": 0, "aborts": 0}
     us = wall * 1e6 / runs
     for r in range(runs):
-        if rep == ca.DWC and flagged[r]:  # FAULT_DETECTED_DWC() -> abort(): the supervisor logs an abort and a timeout
+        if hung[r] and not (rep == ca.DWC and flagged[r]):
+            cls, e, f = "timeout", 0, 0
+            counts["timeouts"] += 1
+        elif rep == ca.DWC and flagged[r]:  # FAULT_DETECTED_DWC() -> abort(): the supervisor logs an abort and a timeout
             cls, e, f = "abort", 0, 0
             counts["timeouts"] += 1
             counts["aborts"] += 1
