@@ -44,6 +44,9 @@ MAC_PEAK = 30.78e12
 # ~2.05 GHz the chip sustains under MFMA load).  Peak = 2 x 2.5e15; the measured ceiling is reported next to it.
 I8_MFMA_PEAK = 5.0e15
 I8_MFMA_UBENCH = 4.25e15
+# ... on constants.  On RANDOM operand bytes (what the limbs of random matrices are) the same probe sustains 2.94-3.49 POP/s: the
+# matrix core is power-limited and clocks down to 1.4-1.66 GHz (tools/mfma_probe2, profiles/microbench_r02.txt).
+I8_MFMA_RANDOM = 3.4e15
 N_SIMD = 256 * 4
 # measured issue cost, cycles per wave-instruction at 8 waves/SIMD (profiles/microbench_r01.txt; v_bitop3 from the same probe,
 # DESIGN.md section 4.2)
@@ -280,6 +283,9 @@ class MM(Workload):
                 "bound": "mfma", "kernel": "mm_mfma_panel_kernel<3>",
                 "achieved": ops / t * 1e-12, "peak": I8_MFMA_PEAK * 1e-12, "unit": "TOP/s (int8)",
                 "frac": ops / t / I8_MFMA_PEAK, "frac_of_ubench_ceiling": ops / t / I8_MFMA_UBENCH,
+                # executed int8 ops (32/30 lane-column padding, ragged 26th column tile: x 1.083) against what the matrix core
+                # sustains on random operands at the chip's power limit
+                "executed_frac_of_random_data_ceiling": 1.0833 * ops / t / I8_MFMA_RANDOM,
                 "u32_macs_per_s": macs / t, "int8_ops_per_u32_mac": 2 * 10 * 3,
                 # SURVEY 8(d) priced this path against the VALU MAC ceiling (N^3 algorithmic MACs per matrix, x3 executed):
                 "algorithmic_macs_vs_valu_ceiling": macs / t / MAC_PEAK, "executed_macs_vs_valu_ceiling": 3.0 * macs / t / MAC_PEAK,
@@ -647,10 +653,12 @@ def extra_legs(a, eng, dist, dev, rank, world, coast_amd):
     import copy
 
     legs = {}
-    plan = [("crc16_256B", CRC16, {"block_len": 256}, 5, 2)]
+    plan = [("crc16_256B", CRC16, {"block_len": 256}, 20, 5)]
     if world == 1:
-        plan += [("crc16_255B", CRC16, {"block_len": 255}, 5, 2), ("sha256", SHA256, {}, 10, 3), ("aes", AES, {}, 20, 4)]
+        plan += [("crc16_255B", CRC16, {"block_len": 255}, 20, 5), ("sha256", SHA256, {}, 20, 5), ("aes", AES, {}, 40, 8)]
     for name, cls, over, steps, warm in plan:
+        torch.cuda.synchronize()
+        time.sleep(1.0)  # the matrix-core leg leaves the chip at its power limit: let the clocks settle before an HBM-bound leg
         b = copy.copy(a)
         b.batch, b.faults = 0, 1024
         for k, v in over.items():
