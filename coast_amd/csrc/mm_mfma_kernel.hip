@@ -187,6 +187,11 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
     int voffB[G::B_ROUNDS], dstB[G::B_ROUNDS][2];
     bool swapB;
     {
+        // pair fastest: consecutive lanes load consecutive 8-byte pieces of one tile row.  (k-quad fastest would make every store
+        // group 4 pairs x 8 k-quads = 32 distinct banks, SQ_LDS_BANK_CONFLICT 0 -- and cost 10.6 % of the kernel, 9.14 vs 8.26
+        // ms, because a load instruction's neighbouring lanes then sit in eight different rows.  Pair fastest leaves pairs 0 and
+        // 4 of a group on one bank class: two-way, absorbed by the store's 4-cycle issue; 18 % of the LDS-active cycles count as
+        // conflicts, down from 35 %, at no cost in time.)
         const int l = lane < G::CPAIR * G::KQPR ? lane : lane - G::CPAIR * G::KQPR;
         swapB = (((l % G::CPAIR) >> 1) & 1) != 0;
 #pragma unroll

@@ -10,7 +10,7 @@ mkdir -p $OUT/logs
 run() { python $ROOT/tools/campaign.py -t $RUNS -l $OUT/logs "$@" 2>/dev/null | tail -1 >> $OUT/summary.jsonl; }
 for m in NONE TMR DWC; do
   run -b mm -m $m --side 256
-  for b in mm sha256 aes crc16 chsha cache_test; do run -b $b -m $m; done
+  for b in mm sha256 aes crc16 chsha cache_test quicksort; do run -b $b -m $m; done
 done
 for b in mm crc16 sha256 aes; do
   run -b $b -m NONE -s memory
