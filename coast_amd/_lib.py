@@ -28,6 +28,21 @@ class CoastLaunchInfo(C.Structure):
                 ("fast_blocks", C.c_uint64), ("armed_faults", C.c_uint64), ("algorithmic_bytes", C.c_double)]
 
 
+class CoastCfcGraph(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("flags", C.POINTER(C.c_uint8)), ("func", C.POINTER(C.c_uint16)),
+                ("succ_begin", C.POINTER(C.c_uint32)), ("succ", C.POINTER(C.c_uint16)), ("n_calls", C.c_uint32),
+                ("call_node", C.POINTER(C.c_uint16)), ("call_entry", C.POINTER(C.c_uint16)), ("main_func", C.c_uint32)]
+
+
+class CoastCfcTables(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_buffers", C.c_uint32), ("sig", C.c_uint16 * 256), ("sig_diff", C.c_uint16 * 256),
+                ("sig_adj", C.c_uint16 * 256), ("flags", C.c_uint8 * 256), ("succ_begin", C.c_uint32 * 257),
+                ("succ", C.c_uint16 * 1024), ("call_pre_adj", C.c_uint16 * 64), ("call_post_adj", C.c_uint16 * 64)]
+
+
+CRAZYCF_PARAMS_DTYPE = np.dtype([("seed", "<i4"), ("size", "<i4"), ("times", "<i4")])
+CRAZYCF_RESULT_DTYPE = np.dtype([("total", "<i4"), ("printed", "<i4"), ("n_prints", "<u4"), ("blocks", "<u4")])
+
 ENGINE_NAMES = {0: "none", 1: "valu", 2: "matrix_core", 3: "stepwise", 4: "vote"}
 
 
@@ -61,6 +76,10 @@ SYMBOLS = {
                                     C.POINTER(CoastCfg), C.c_void_p]),
     "coast_quicksort_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.POINTER(CoastCfg), C.c_void_p,
                                         C.c_void_p]),
+    "coast_cfcss_assign": (C.c_int, [C.POINTER(CoastCfcGraph), C.POINTER(CoastCfcTables)]),
+    "coast_crazycf_graph": (C.c_int, [C.POINTER(CoastCfcGraph)]),
+    "coast_crazycf_tables": (C.c_int, [C.POINTER(CoastCfcTables)]),
+    "coast_crazycf_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]),
     "coast_sync_copies": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_void_p, C.c_int,
                                     C.c_void_p]),
     "coast_flip_memory": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint]),

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,7 @@
 #include "cache_test_kernel.hip"
 #include "chsha_kernel.hip"
 #include "quicksort_kernel.hip"
+#include "crazycf_kernel.hip"
 
 using namespace coast;
 
@@ -67,6 +69,7 @@ struct coast_ctx {
     int curBuf = 0;
 
     uint16_t *dCrcTable = nullptr; // 64 Ki x u16 two-byte-step table of the crc16 stream kernel
+    coast::CfcDevTables *dCfcTables = nullptr; // crazyCF's signature tables (coast_crazycf_batch)
     int numCUs = 256;
 
     coast_launch_info last = {};   // what the most recent protected launch dispatched to
@@ -413,6 +416,8 @@ extern "C" void coast_destroy(coast_ctx *c)
         }
     if (c->dCrcTable)
         (void)hipFree(c->dCrcTable);
+    if (c->dCfcTables)
+        (void)hipFree(c->dCfcTables);
     (void)hipFree(c->dSlots);
     (void)hipFree(c->dTotals);
     (void)hipEventDestroy(c->evArmed);
@@ -798,4 +803,6 @@ extern "C" int coast_flip_memory(coast_ctx *c, void *d_ptr, size_t byte_offset, 
 }
 
 #include "launch_others.inc"
+#include "cfcss_assign.inc"
+#include "launch_cfcss.inc"
 #include "host_shims.inc"

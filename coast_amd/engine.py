@@ -194,6 +194,20 @@ class Engine:
                                                     _ptr(status) if status is not None else None))
         return arrays
 
+    def crazycf_batch(self, params, cfcss=True, results=None, status=None):
+        """params: (n, 3) int32 on the GPU, rows of (seed, size, timesThroughWhile): n runs of tests/crazyCF/crazyCF.c's main()
+        under control-flow signatures (projects/CFCSS; cfcss=False runs them bare).  Returns (results (n, 4) int32 =
+        total, printed, n_prints, blocks; status uint8 = 0 ok, 1 FAULT_DETECTED_CFC, 2 watchdog, 3 jumped out of the program)."""
+        assert params.is_cuda and params.dtype == torch.int32 and params.dim() == 2 and params.shape[1] == 3
+        assert params.is_contiguous()
+        n = params.shape[0]
+        if results is None:
+            results = torch.zeros((n, 4), dtype=torch.int32, device=params.device)
+        if status is None:
+            status = torch.zeros(n, dtype=torch.uint8, device=params.device)
+        self._check(self._lib.coast_crazycf_batch(self._h, _ptr(params), n, _ptr(results), _ptr(status), int(bool(cfcss))))
+        return results, status
+
     # -- default mode (memory replicated x3 / x2): vote where the copies re-converge
     def sync_copies(self, copies, out=None, scrub=True, detected=None):
         """copies: 3 (TMR) or 2 (DWC) equally shaped contiguous GPU tensors holding the per-copy results of replicas=1

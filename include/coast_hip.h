@@ -19,7 +19,8 @@
 extern "C" {
 #endif
 
-#define COAST_HIP_ABI_VERSION 3 /* 2: coast_cfg.flags; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info, new flags/sites */
+#define COAST_HIP_ABI_VERSION 4 /* 2: coast_cfg.flags; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info, new flags/sites;
+                                 * 4: control-flow signatures (coast_cfcss_assign, coast_crazycf_*), additive */
 
 enum {
     COAST_OK = 0,
@@ -142,7 +143,11 @@ enum {
     COAST_SITE_QS_J = 49,     /* the right scan index j */
     COAST_SITE_QS_PIVOT = 50, /* the pivot */
     COAST_SITE_QS_VI = 51,    /* the value last loaded from A[i] */
-    COAST_SITE_QS_VJ = 52     /* the value last loaded from A[j] */
+    COAST_SITE_QS_VJ = 52,    /* the value last loaded from A[j] */
+    /* control-flow signatures (coast_crazycf_batch): `step` = how many block transitions the item has made; replica = 0 */
+    COAST_SITE_CFC_PC = 56,   /* the branch target of transition `step`: execution lands at the START of block (target ^ 1<<bit) */
+    COAST_SITE_CFC_RTS = 57,  /* BasicBlockSignatureTracker, after the leaving block stored it, before the next block checks it */
+    COAST_SITE_CFC_RTSA = 58  /* RunTimeSignatureAdjuster, same timing */
 };
 
 /* One single-event upset: new = old XOR (1 << bit) on the 32-bit register holding the value
@@ -245,6 +250,71 @@ int coast_chsha_batch(coast_ctx *ctx, const uint8_t *d_msgs, size_t stride, uint
 enum { COAST_QS_OK = 0, COAST_QS_WATCHDOG = 1, COAST_QS_STACK = 2 };
 int coast_quicksort_batch(coast_ctx *ctx, int32_t *d_arrays, uint32_t n_elems, size_t n_arrays, const coast_cfg *cfg,
                           uint8_t *d_detected, uint8_t *d_status);
+
+/* ---- CFCSS: control-flow checking by software signatures (projects/CFCSS/CFCSS.cpp, docs/source/cfcss.rst) ----
+ * The reference's second detector, a pass of its own (`opt -CFCSS`, tests/crazyCF/Makefile:3): every basic block gets a 16-bit
+ * signature, a signature difference and -- for the predecessors of branch fan-in blocks -- a run-time adjuster; two globals
+ * (BasicBlockSignatureTracker, RunTimeSignatureAdjuster) are stored at the end of every block and checked at the start of the
+ * next; a mismatch calls FAULT_DETECTED_CFC() -> abort() (CFCSS.cpp:88-105, 107-126).
+ * coast_cfcss_assign is the compile-time half (host only, no device work): the pass's signature generation for a control-flow
+ * graph -- unseeded rand() % 65536 in ascending order over the blocks (:185-200, 218-240; the glibc sequence of the
+ * reference's Linux hosts is restated inside), sigDiff / sigAdj (:438-457, 459-471), buffer blocks where the adjuster of a
+ * block with several fan-in successors cannot serve them all (:348-436, docs/source/cfcss.rst "Modifications"), the call /
+ * return handling of runOnModule (:551-643, 737-768).  The run-time half lives in the kernels: one tracker register pair per
+ * lane, checked for the whole wave with one compare per block. */
+enum { COAST_CFC_MAX_NODES = 256, COAST_CFC_MAX_SUCC = 1024, COAST_CFC_MAX_CALLS = 64 };
+enum {
+    COAST_CFC_FAN_IN = 1,  /* out: isBranchFanIn (CFCSS.cpp:234-236, 381) -- the check XORs the adjuster in */
+    COAST_CFC_CHECKED = 2, /* out: the block starts with a signature check (successors of instrumented blocks, called entries) */
+    COAST_CFC_BUFFER = 4,  /* out: an inserted buffer block */
+    COAST_CFC_SKIP = 8,    /* in/out: an error-handler block of the pass's skipList (CFCSS.h:64-66): numbered, never instrumented */
+    COAST_CFC_RET = 16     /* in/out: ends in a return */
+};
+typedef struct coast_cfc_graph {
+    uint32_t n_nodes;           /* basic blocks in module order (function by function; CFCSS.cpp:154-183) */
+    const uint8_t *flags;       /* per block: COAST_CFC_SKIP | COAST_CFC_RET */
+    const uint16_t *func;       /* per block: index of its function */
+    const uint32_t *succ_begin; /* n_nodes + 1 offsets into succ */
+    const uint16_t *succ;       /* successors in terminator operand order (br: true, false; switch: default, cases) */
+    uint32_t n_calls;           /* calls of functions defined in the module, in (block, position) order */
+    const uint16_t *call_node;  /* the calling block */
+    const uint16_t *call_entry; /* the callee's entry block */
+    uint32_t main_func;         /* returns of this function are not tracked (CFCSS.cpp:173-178) */
+} coast_cfc_graph;
+typedef struct coast_cfc_tables {
+    uint32_t n_nodes; /* input blocks + buffer blocks (appended) */
+    uint32_t n_buffers;
+    uint16_t sig[COAST_CFC_MAX_NODES];      /* stored into the tracker before the block's terminator */
+    uint16_t sig_diff[COAST_CFC_MAX_NODES]; /* XORed with the tracker by the block's entry check */
+    uint16_t sig_adj[COAST_CFC_MAX_NODES];  /* stored into the adjuster before the block's terminator */
+    uint8_t flags[COAST_CFC_MAX_NODES];
+    uint32_t succ_begin[COAST_CFC_MAX_NODES + 1];
+    uint16_t succ[COAST_CFC_MAX_SUCC]; /* terminator operands after buffer insertion */
+    uint16_t call_pre_adj[COAST_CFC_MAX_CALLS];  /* adjuster stored right before call c (after verifyCallSignatures, :645-690) */
+    uint16_t call_post_adj[COAST_CFC_MAX_CALLS]; /* adjuster re-stored after call c returns (:620-626) */
+} coast_cfc_tables;
+int coast_cfcss_assign(const coast_cfc_graph *g, coast_cfc_tables *out);
+
+/* crazyCF (tests/crazyCF/crazyCF.c, the reference's CFCSS test program: a for / switch / while / goto tangle over rand()).
+ * One work item = one run of its main() with (seed, size, timesThroughWhile) taken from d_params instead of the constants
+ * 42 / 20 / 10 (crazyCF.c:11,36,41); one lane per item, the wave executes the union of its lanes' paths block by block.
+ * result.total = `total` when the run ended, .printed / .n_prints = the value and count of "total so far" lines (:54),
+ * .blocks = block transitions made.  cfcss != 0 runs the program under the signatures of coast_crazycf_tables();
+ * d_status: COAST_CFC_OK, _DETECTED (a check failed, or the jump landed in an error handler: FAULT_DETECTED_CFC -> abort),
+ * _WATCHDOG (16 (size + times) + 256 transitions), _WILD (the jump left the program).  libc's srand / rand are the glibc
+ * TYPE_3 generator, restated on the device. */
+typedef struct coast_crazycf_params {
+    int32_t seed, size, times;
+} coast_crazycf_params;
+typedef struct coast_crazycf_result {
+    int32_t total, printed;
+    uint32_t n_prints, blocks;
+} coast_crazycf_result;
+enum { COAST_CFC_OK = 0, COAST_CFC_DETECTED = 1, COAST_CFC_WATCHDOG = 2, COAST_CFC_WILD = 3 };
+int coast_crazycf_graph(coast_cfc_graph *out);   /* the -O0 control-flow graph of crazyCF.c as this library encodes it */
+int coast_crazycf_tables(coast_cfc_tables *out); /* = coast_cfcss_assign(coast_crazycf_graph) */
+int coast_crazycf_batch(coast_ctx *ctx, const coast_crazycf_params *d_params, size_t n, coast_crazycf_result *d_results,
+                        uint8_t *d_status, int cfcss);
 
 /* ---- default-mode TMR / DWC: memory replicated as well (docs/source/passes.rst:329,337; cloning.cpp:2417-2462) ----
  * In COAST's default mode the clones of a region run on their own copies of the data and stores are not voted

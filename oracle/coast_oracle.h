@@ -68,7 +68,11 @@ enum {
     ORC_SITE_QS_J = 49,     /* the right scan index j */
     ORC_SITE_QS_PIVOT = 50, /* the pivot value */
     ORC_SITE_QS_VI = 51,    /* the value last loaded from A[i] */
-    ORC_SITE_QS_VJ = 52     /* the value last loaded from A[j] */
+    ORC_SITE_QS_VJ = 52,    /* the value last loaded from A[j] */
+    /* control-flow signatures (cfcss_oracle.c): `step` = block transitions made so far */
+    ORC_SITE_CFC_PC = 56,   /* the branch target of transition `step` */
+    ORC_SITE_CFC_RTS = 57,  /* BasicBlockSignatureTracker between the store and the next check */
+    ORC_SITE_CFC_RTSA = 58  /* RunTimeSignatureAdjuster, same timing */
 };
 enum { ORC_QS_OK = 0, ORC_QS_WATCHDOG = 1, ORC_QS_STACK = 2, ORC_QS_MAXDEPTH = 48 };
 
@@ -141,6 +145,42 @@ void orc_cache_test_xmr(int32_t *arrays, uint32_t n, size_t narrays, int32_t *su
 void orc_chsha_plain(const uint8_t *data, uint32_t len, uint32_t digest[5]);
 void orc_chsha_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nmsgs, uint32_t *digests, const orc_cfg *cfg,
                    const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
+
+/* ---- CFCSS (projects/CFCSS/CFCSS.cpp) and its test program tests/crazyCF/crazyCF.c: cfcss_oracle.c ---- */
+enum { ORC_CFC_MAX_NODES = 256, ORC_CFC_MAX_SUCC = 1024, ORC_CFC_MAX_CALLS = 64 };
+enum { ORC_CFC_FAN_IN = 1, ORC_CFC_CHECKED = 2, ORC_CFC_BUFFER = 4, ORC_CFC_SKIP = 8, ORC_CFC_RET = 16 };
+enum { ORC_CFC_OK = 0, ORC_CFC_DETECTED = 1, ORC_CFC_WATCHDOG = 2, ORC_CFC_WILD = 3 };
+typedef struct { /* same layout as coast_cfc_graph */
+    uint32_t n_nodes;
+    const uint8_t *flags;
+    const uint16_t *func;
+    const uint32_t *succ_begin;
+    const uint16_t *succ;
+    uint32_t n_calls;
+    const uint16_t *call_node;
+    const uint16_t *call_entry;
+    uint32_t main_func;
+} orc_cfc_graph;
+typedef struct { /* same layout as coast_cfc_tables */
+    uint32_t n_nodes, n_buffers;
+    uint16_t sig[ORC_CFC_MAX_NODES], sig_diff[ORC_CFC_MAX_NODES], sig_adj[ORC_CFC_MAX_NODES];
+    uint8_t flags[ORC_CFC_MAX_NODES];
+    uint32_t succ_begin[ORC_CFC_MAX_NODES + 1];
+    uint16_t succ[ORC_CFC_MAX_SUCC];
+    uint16_t call_pre_adj[ORC_CFC_MAX_CALLS], call_post_adj[ORC_CFC_MAX_CALLS];
+} orc_cfc_tables;
+typedef struct {
+    int32_t total, printed;
+    uint32_t n_prints, blocks;
+} orc_crazycf_result;
+int orc_cfcss_assign(const orc_cfc_graph *in, orc_cfc_tables *out); /* calls srand(1): the unseeded libc state */
+void orc_crazycf_graph(orc_cfc_graph *g);
+void orc_crazycf_plain(int32_t seed, int32_t size, int32_t timesThroughWhile, orc_crazycf_result *res);
+void orc_crazycf_run(const orc_cfc_tables *T, int cfcss, int32_t seed, int32_t size, int32_t times, uint64_t item,
+                     const orc_fault *fl, size_t nf, orc_crazycf_result *res, uint8_t *status);
+void orc_crazycf_batch(const orc_cfc_tables *T, int cfcss, const int32_t *params, size_t n, const orc_fault *fl, size_t nf,
+                       orc_crazycf_result *res, uint8_t *status);
+void orc_glibc_rand_seq(uint32_t seed, uint32_t *out, size_t k);
 
 /* sparse variants: evaluate only the listed items (used to check huge batches) */
 void orc_mm_xmr_items(const uint32_t *f, const uint32_t *s, int n, const uint64_t *items, size_t nitems,

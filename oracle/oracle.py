@@ -314,6 +314,118 @@ def quicksort_xmr(arrays, replicas=3, faults=None, flags=0):
     return a, st.as_dict(), det, status
 
 
+# ---- CFCSS (cfcss_oracle.c) ----
+class CfcGraph(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("flags", C.POINTER(C.c_uint8)), ("func", C.POINTER(C.c_uint16)),
+                ("succ_begin", C.POINTER(C.c_uint32)), ("succ", C.POINTER(C.c_uint16)), ("n_calls", C.c_uint32),
+                ("call_node", C.POINTER(C.c_uint16)), ("call_entry", C.POINTER(C.c_uint16)), ("main_func", C.c_uint32)]
+
+
+class CfcTables(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_buffers", C.c_uint32), ("sig", C.c_uint16 * 256), ("sig_diff", C.c_uint16 * 256),
+                ("sig_adj", C.c_uint16 * 256), ("flags", C.c_uint8 * 256), ("succ_begin", C.c_uint32 * 257),
+                ("succ", C.c_uint16 * 1024), ("call_pre_adj", C.c_uint16 * 64), ("call_post_adj", C.c_uint16 * 64)]
+
+
+CFC_FAN_IN, CFC_CHECKED, CFC_BUFFER, CFC_SKIP, CFC_RET = 1, 2, 4, 8, 16
+CFC_OK, CFC_DETECTED, CFC_WATCHDOG, CFC_WILD = 0, 1, 2, 3
+SITE_CFC_PC, SITE_CFC_RTS, SITE_CFC_RTSA = 56, 57, 58
+CRAZYCF_RESULT = np.dtype([("total", np.int32), ("printed", np.int32), ("n_prints", np.uint32), ("blocks", np.uint32)])
+
+
+def graph_to_dict(g):
+    """a ctypes graph (oracle's or the product's: same layout) as plain python"""
+    n = g.n_nodes
+    sb = [g.succ_begin[i] for i in range(n + 1)]
+    return {"n_nodes": n, "flags": [g.flags[i] for i in range(n)], "func": [g.func[i] for i in range(n)],
+            "succ": [[g.succ[e] for e in range(sb[i], sb[i + 1])] for i in range(n)],
+            "calls": [(g.call_node[c], g.call_entry[c]) for c in range(g.n_calls)], "main_func": g.main_func}
+
+
+def graph_from_dict(d, cls=None):
+    """build a ctypes graph from python lists; returns (graph, keepalive)"""
+    cls = cls or CfcGraph
+    n = d["n_nodes"]
+    flags = (C.c_uint8 * n)(*d["flags"])
+    func = (C.c_uint16 * n)(*d["func"])
+    sb, flat = [0], []
+    for sl in d["succ"]:
+        flat += list(sl)
+        sb.append(len(flat))
+    succ_begin = (C.c_uint32 * (n + 1))(*sb)
+    succ = (C.c_uint16 * max(1, len(flat)))(*flat)
+    nc = len(d["calls"])
+    cn = (C.c_uint16 * max(1, nc))(*[c[0] for c in d["calls"]])
+    ce = (C.c_uint16 * max(1, nc))(*[c[1] for c in d["calls"]])
+    g = cls(n, C.cast(flags, C.POINTER(C.c_uint8)), C.cast(func, C.POINTER(C.c_uint16)),
+            C.cast(succ_begin, C.POINTER(C.c_uint32)), C.cast(succ, C.POINTER(C.c_uint16)), nc,
+            C.cast(cn, C.POINTER(C.c_uint16)), C.cast(ce, C.POINTER(C.c_uint16)), d["main_func"])
+    return g, (flags, func, succ_begin, succ, cn, ce)
+
+
+def tables_to_dict(t):
+    n = t.n_nodes
+    sb = [t.succ_begin[i] for i in range(n + 1)]
+    return {"n_nodes": n, "n_buffers": t.n_buffers, "sig": list(t.sig[:n]), "sig_diff": list(t.sig_diff[:n]),
+            "sig_adj": list(t.sig_adj[:n]), "flags": list(t.flags[:n]),
+            "succ": [[t.succ[e] for e in range(sb[i], sb[i + 1])] for i in range(n)],
+            "call_pre_adj": list(t.call_pre_adj[:8]), "call_post_adj": list(t.call_post_adj[:8])}
+
+
+def crazycf_graph():
+    g = CfcGraph()
+    lib().orc_crazycf_graph(C.byref(g))
+    return g
+
+
+def cfcss_assign(graph):
+    """graph: CfcGraph or a dict (graph_from_dict).  Returns CfcTables.  Resets libc's rand() to its unseeded state."""
+    keep = None
+    if isinstance(graph, dict):
+        graph, keep = graph_from_dict(graph)
+    t = CfcTables()
+    rc = lib().orc_cfcss_assign(C.byref(graph), C.byref(t))
+    if rc:
+        raise RuntimeError("orc_cfcss_assign: %d" % rc)
+    del keep
+    return t
+
+
+def crazycf_plain(seed, size, times):
+    res = np.zeros(1, CRAZYCF_RESULT)
+    lib().orc_crazycf_plain(C.c_int32(seed), C.c_int32(size), C.c_int32(times), res.ctypes.data_as(C.c_void_p))
+    return int(res["total"][0]), int(res["printed"][0]), int(res["n_prints"][0])
+
+
+def crazycf_batch(params, cfcss=True, faults=None, tables=None):
+    """params: (n, 3) int32 rows of (seed, size, timesThroughWhile).  Returns (results structured array, status)."""
+    prm = np.ascontiguousarray(params, dtype=np.int32).reshape(-1, 3)
+    n = prm.shape[0]
+    if tables is None:
+        tables = cfcss_assign(crazycf_graph())
+    fl = _faults(faults)
+    res = np.zeros(n, CRAZYCF_RESULT)
+    status = np.zeros(n, np.uint8)
+    lib().orc_crazycf_batch(C.byref(tables), C.c_int(1 if cfcss else 0), _p(prm, C.c_int32), C.c_size_t(n),
+                            fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), res.ctypes.data_as(C.c_void_p),
+                            _p(status, C.c_uint8))
+    return res, status
+
+
+def glibc_rand_seq(seed, k):
+    out = np.zeros(k, np.uint32)
+    lib().orc_glibc_rand_seq(C.c_uint32(seed & 0xFFFFFFFF), _p(out, C.c_uint32), C.c_size_t(k))
+    return out
+
+
+def ref_crazycf(seed, size):
+    """crazyCF.c itself (oracle/_ref), with its srand() argument and its global `size` set; timesThroughWhile stays 10.
+    Returns (Total, total-so-far value, number of total-so-far lines)."""
+    out = (C.c_int * 3)()
+    ref().ref_crazycf(C.c_uint(seed & 0xFFFFFFFF), C.c_int(size), out)
+    return int(out[0]), int(out[1]), int(out[2])
+
+
 def cpu_tmr_mm(f, s, xor_golden):
     """Default-mode CPU-TMR restatement (timing baseline).  Returns (r, error_flag, TMR_ERROR_CNT, syncs)."""
     f = np.ascontiguousarray(f, dtype=np.uint32)

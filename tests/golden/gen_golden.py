@@ -185,6 +185,20 @@ def main():
         qv["out%d" % q] = orc.ref_quicksort(a)
     np.savez_compressed(os.path.join(HERE, "quicksort_fixtures.npz"), **qv)
 
+    # ---------------- crazyCF (tests/crazyCF, the CFCSS test program): the unmodified program compiled natively -- its two
+    # output lines -- and, through oracle/_ref's shim, a grid of (srand argument, size) with timesThroughWhile at its 10
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "crazycf_native")
+        subprocess.check_call(["gcc", "-O0", "-w", os.path.join(REF, "crazyCF/crazyCF.c"), "-o", exe])
+        out["crazycf_stdout"] = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    grid = []
+    rng = random.Random(42)
+    for seed, size in [(42, 20), (1, 1), (2, 5), (3, 6), (4, 17), (5, 18), (6, 25), (7, 26), (8, 37), (9, 38), (10, 39), (0, 64),
+                       (0x7FFFFFFF, 100), (0x80000000, 100), (0xFFFFFFFF, 50)] + [(rng.randrange(1 << 32), rng.randrange(1, 300))
+                                                                                 for _ in range(49)]:
+        grid.append([seed, size] + list(orc.ref_crazycf(seed, size)))
+    out["crazycf_grid"] = grid  # rows: srand argument, size, Total, "total so far" value, number of such lines
+
     with open(os.path.join(HERE, "golden.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(HERE)))

@@ -1469,3 +1469,121 @@ def test_campaign_quicksort(eng):
     assert t["errors"] == 0 and t["timeouts"] == 0 and t["faults"] > 100
     assert n["errors"] + n["timeouts"] > 100 and n["timeouts"] > 0   # unprotected: wrong order, or a sort that never ends
     assert m["errors"] == 0 and m["faults"] > 250
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CFCSS: control-flow signatures per wave (projects/CFCSS) on the reference's own test program, tests/crazyCF/crazyCF.c
+
+
+def _crazycf_params(rng, n):
+    prm = np.stack([rng.integers(-2**31, 2**31, n), rng.integers(0, 130, n), rng.integers(-2, 40, n)], axis=1).astype(np.int32)
+    prm[0] = (42, 20, 10)  # the source's own constants (crazyCF.c:36, 11, 41)
+    prm[1] = (7, 0, 10)
+    prm[2] = (7, 1, 0)
+    return prm
+
+
+def test_crazycf_reference_output(eng, golden):
+    """`total so far: 27` / `Total = 7`: what crazyCF.c prints when compiled unmodified (tests/golden/golden.json), and the grid
+    of (srand argument, size) runs of the reference program from oracle/_ref, with and without the signatures"""
+    import torch
+
+    grid = golden["crazycf_grid"]
+    prm = np.array([[s if s < 2**31 else s - 2**32, n, 10] for s, n, *_ in grid], dtype=np.int64).astype(np.int32)
+    for cfcss in (True, False):
+        res, st = eng.crazycf_batch(torch.from_numpy(prm).cuda(), cfcss=cfcss)
+        res, st = res.cpu().numpy(), st.cpu().numpy()
+        assert not st.any()
+        assert res[:, 0].tolist() == [r[2] for r in grid] and res[:, 1].tolist() == [r[3] for r in grid]
+        assert res[:, 2].tolist() == [r[4] for r in grid]
+    assert res[0, :3].tolist() == [7, 27, 1]
+    assert golden["crazycf_stdout"] == "total so far: %d\nTotal = %d\n" % (res[0, 1], res[0, 0])
+    assert eng.last_launch()["engine"] == "stepwise"
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
+def test_crazycf_vs_oracle_clean(eng, orc, n):
+    import torch
+
+    rng = np.random.default_rng(1000 + n)
+    prm = _crazycf_params(rng, max(n, 3))[:n]
+    for cfcss in (True, False):
+        exp, exp_st = orc.crazycf_batch(prm, cfcss=cfcss)
+        res, st = eng.crazycf_batch(torch.from_numpy(prm).cuda(), cfcss=cfcss)
+        got = res.cpu().numpy()
+        assert (st.cpu().numpy() == exp_st).all() and not exp_st.any()
+        for k, name in enumerate(("total", "printed", "n_prints", "blocks")):
+            assert (got[:, k].astype(np.int64) == exp[name].astype(np.int64)).all(), (name, cfcss)
+
+
+def test_crazycf_signature_tables_are_the_oracles(orc):
+    """the tables the kernel checks against = the oracle's restatement of the pass on the oracle's own graph"""
+    from coast_amd import cfcss
+
+    assert cfcss.crazycf_tables() == orc.tables_to_dict(orc.cfcss_assign(orc.crazycf_graph()))
+
+
+@pytest.mark.parametrize("cfcss", [True, False])
+def test_crazycf_vs_oracle_under_upsets(eng, orc, cfcss):
+    """corrupted branch targets (any bit of the 32-bit register) and upsets of the two signature globals, several per run for some
+    runs: every result word, every transition count and every status (ok / FAULT_DETECTED_CFC / watchdog / left the program)
+    equals the oracle's"""
+    import torch
+
+    import coast_amd as ca
+
+    rng = np.random.default_rng(4242 + int(cfcss))
+    n = 3000
+    prm = _crazycf_params(rng, n)
+    rows = []
+    for q in range(n):
+        for _ in range(1 if q % 7 else 2):
+            site = int(rng.choice([ca.SITE_CFC_PC, ca.SITE_CFC_PC, ca.SITE_CFC_RTS, ca.SITE_CFC_RTSA]))
+            bit = int(rng.integers(0, 6)) if rng.random() < 0.7 else int(rng.integers(0, 32))
+            rows.append((q, 0, site, int(rng.integers(0, 40 + 12 * int(prm[q][1]))), bit))
+    fl = ca.make_faults(rows)
+    exp, exp_st = orc.crazycf_batch(prm, cfcss=cfcss, faults=fl)
+    eng.inject_faults(fl)
+    res, st = eng.crazycf_batch(torch.from_numpy(prm).cuda(), cfcss=cfcss)
+    got, st = res.cpu().numpy(), st.cpu().numpy()
+    assert (st == exp_st).all(), np.nonzero(st != exp_st)[0][:10]
+    for k, name in enumerate(("total", "printed", "n_prints", "blocks")):
+        assert (got[:, k].astype(np.int64) == exp[name].astype(np.int64)).all(), name
+    assert eng.last_launch()["armed_faults"] == len(rows)
+    seen = set(exp_st.tolist())
+    if cfcss:
+        assert seen == {ca.CFC_OK, ca.CFC_DETECTED, ca.CFC_WATCHDOG, ca.CFC_WILD} or seen == {ca.CFC_OK, ca.CFC_DETECTED, ca.CFC_WILD}
+        assert (exp_st == ca.CFC_DETECTED).sum() > n // 3
+    else:
+        assert ca.CFC_WILD in seen and (exp_st == ca.CFC_DETECTED).sum() < n // 10  # only landings in an error-handler block
+    # the faults are consumed by that launch
+    res2, st2 = eng.crazycf_batch(torch.from_numpy(prm).cuda(), cfcss=cfcss)
+    assert not st2.cpu().numpy().any()
+
+
+def test_crazycf_rejects_bad_arguments(eng):
+    import torch
+
+    import coast_amd as ca
+
+    prm = torch.zeros((4, 3), dtype=torch.int32, device="cuda")
+    res = torch.zeros((4, 4), dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="NULL / misaligned"):
+        eng._check(eng._lib.coast_crazycf_batch(eng._h, prm.data_ptr(), 4, None, None, 1))
+    with pytest.raises(RuntimeError, match="NULL / misaligned"):
+        eng._check(eng._lib.coast_crazycf_batch(eng._h, prm.data_ptr() + 1, 4, res.data_ptr(), res.data_ptr(), 1))
+    assert eng._lib.coast_crazycf_batch(eng._h, None, 0, None, None, 1) == 0  # empty batch
+
+
+def test_campaign_crazycf_cfcss(eng, tmp_path):
+    """tools/campaign.py -b crazycf: one corrupted branch target (or signature-global upset) per run.  Under CFCSS the wrong
+    answers of the bare program turn into FAULT_DETECTED_CFC aborts; what is left are jumps to another legal successor."""
+    mod, a, rec, c = _campaign(["-b", "crazycf", "-m", "CFCSS", "-t", "2000", "-l", str(tmp_path)], eng)
+    _, _, _, n = _campaign(["-b", "crazycf", "-m", "NONE", "-t", "2000", "-n"], eng)
+    assert n["aborts"] < 40 and n["errors"] > 40
+    assert c["aborts"] > 200 and c["errors"] < n["errors"] // 3
+    assert c["success"] + c["errors"] + c["timeouts"] == 2000 and c["faults"] == 0
+    prefix = mod.write_logs(a, rec, c)
+    assert "ABORT (FAULT_DETECTED)" in open(prefix + ".log").read()
+    with pytest.raises(SystemExit):
+        _campaign(["-b", "mm", "-m", "CFCSS", "-t", "10", "-n"], eng)

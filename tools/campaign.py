@@ -36,7 +36,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import coast_amd as ca  # noqa: E402
 
-MODES = {"TMR": ca.TMR, "DWC": ca.DWC, "NONE": ca.UNPROTECTED}
+MODES = {"TMR": ca.TMR, "DWC": ca.DWC, "NONE": ca.UNPROTECTED, "CFCSS": ca.UNPROTECTED}  # CFCSS: -b crazycf only
 
 
 # ------------------------------------------------------------------------------------------------ benchmarks
@@ -167,7 +167,35 @@ class QuickSort(Bench):
                 int(rng.integers(0, 32)))
 
 
-BENCHES = {"quicksort": QuickSort, "mm": MM, "sha256": SHA256, "aes": AES, "crc16": CRC16, "chsha": ChSha, "cache_test": CacheTest}
+class CrazyCF(Bench):
+    """tests/crazyCF/crazyCF.c under `opt -CFCSS` (-m CFCSS) or bare (-m NONE): the upset is a corrupted branch target -- execution
+    lands at the start of block (target ^ 1 << bit), bit uniform over the 32-bit register -- or, under CFCSS, a bit of the two
+    signature globals.  A failed signature check is FAULT_DETECTED_CFC() -> abort(); a jump that leaves the program, or a run
+    the watchdog cuts, is what the supervisor files under timeouts."""
+
+    def __init__(self, a, eng, g):
+        self.eng, self.cfcss = eng, a.mode == "CFCSS"
+        self.status = None
+
+    def inputs(self, runs, g):
+        prm = torch.tensor([[42, 20, 10]], dtype=torch.int32, device="cuda").repeat(runs, 1)  # crazyCF.c:36, 11, 41
+        return [prm]
+
+    def run(self, inp, cfg, det=None):
+        res, st = self.eng.crazycf_batch(inp[0], cfcss=self.cfcss)
+        if det is not None:
+            det.copy_((st == ca.CFC_DETECTED).to(torch.uint8))
+            self.status = ((st == ca.CFC_WATCHDOG) | (st == ca.CFC_WILD)).to(torch.uint8)
+        return res[:, :3].contiguous()  # Total, the "total so far" value, how many such lines
+
+    def reg_fault(self, r, nrep, rng):
+        site = ca.SITE_CFC_PC
+        if self.cfcss and rng.random() < 0.4:
+            site = ca.SITE_CFC_RTS if rng.random() < 0.5 else ca.SITE_CFC_RTSA
+        return (r, 0, site, int(rng.integers(0, 309)), int(rng.integers(0, 32)))  # 309 block transitions in a clean run
+
+
+BENCHES = {"crazycf": CrazyCF, "quicksort": QuickSort, "mm": MM, "sha256": SHA256, "aes": AES, "crc16": CRC16, "chsha": ChSha, "cache_test": CacheTest}
 
 
 # ------------------------------------------------------------------------------------------------ one campaign
@@ -191,6 +219,11 @@ def run_campaign(a, eng=None):
     eng = eng or ca.Engine(0)
     g = torch.Generator(device="cuda").manual_seed(a.seed)
     rep = MODES[a.mode]
+    if (a.mode == "CFCSS") != (a.benchmark == "crazycf" and a.mode == "CFCSS"):
+        raise SystemExit("-m CFCSS applies to -b crazycf (the reference's CFCSS test program)")
+    if a.benchmark == "crazycf" and (a.mode not in ("CFCSS", "NONE") or a.section != "registers"):
+        raise SystemExit("-b crazycf: -m CFCSS or NONE, -s registers")
+    aborting = rep == ca.DWC or a.mode == "CFCSS"  # a detection calls the handler -> abort()
     nrep = max(rep, 1)
     runs = a.runs
     bench = BENCHES[a.benchmark](a, eng, g)
@@ -244,10 +277,10 @@ def run_campaign(a, eng=None):
     records, counts = [], {"success": 0, "errors": 0, "faults": 0, "timeouts": 0, "invalids": 0, "aborts": 0}
     us = wall * 1e6 / runs
     for r in range(runs):
-        if hung[r] and not (rep == ca.DWC and flagged[r]):
+        if hung[r] and not (aborting and flagged[r]):
             cls, e, f = "timeout", 0, 0
             counts["timeouts"] += 1
-        elif rep == ca.DWC and flagged[r]:  # FAULT_DETECTED_DWC() -> abort(): the supervisor logs an abort and a timeout
+        elif aborting and flagged[r]:  # FAULT_DETECTED_DWC() / _CFC() -> abort(): the supervisor logs an abort and a timeout
             cls, e, f = "abort", 0, 0
             counts["timeouts"] += 1
             counts["aborts"] += 1
@@ -305,7 +338,7 @@ def write_logs(a, records, summary):
             res = rec["result"]
             fh.write("run %d  %s  C:%d E:%d F:%d T:%dus%s\n" % (rec["run"], json.dumps(rec["target"], sort_keys=True), res["core"],
                                                                 res["errors"], res["faults"], int(res["runtime_us"]),
-                                                                "  ABORT (FAULT_DETECTED_DWC)" if rec["class"] == "abort" else ""))
+                                                                "  ABORT (FAULT_DETECTED)" if rec["class"] == "abort" else ""))
         fh.write(format_summary(summary) + "\n")
     with open(prefix + ".json", "w", encoding="utf-8") as fh:
         json.dump({"summary": summary, "runs": records}, fh)
