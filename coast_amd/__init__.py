@@ -19,4 +19,5 @@ SITE_CT_SUM, SITE_CT_VAL, SITE_CT_NERR = 32, 33, 34
 SITE_CHSHA_W, SITE_CHSHA_WV, SITE_CHSHA_DIGEST = 40, 41, 42
 SITE_QS_I, SITE_QS_J, SITE_QS_PIVOT, SITE_QS_VI, SITE_QS_VJ = 48, 49, 50, 51, 52
 SITE_CFC_PC, SITE_CFC_RTS, SITE_CFC_RTSA = 56, 57, 58
+SITE_CHAES_STATE, SITE_CHAES_WORD = 64, 65
 CFC_OK, CFC_DETECTED, CFC_WATCHDOG, CFC_WILD = 0, 1, 2, 3

@@ -74,6 +74,8 @@ SYMBOLS = {
                                          C.POINTER(CoastCfg), C.c_void_p]),
     "coast_chsha_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_void_p,
                                     C.POINTER(CoastCfg), C.c_void_p]),
+    "coast_chaes_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(CoastCfg),
+                                    C.c_void_p]),
     "coast_quicksort_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.POINTER(CoastCfg), C.c_void_p,
                                         C.c_void_p]),
     "coast_cfcss_assign": (C.c_int, [C.POINTER(CoastCfcGraph), C.POINTER(CoastCfcTables)]),
@@ -90,6 +92,7 @@ SYMBOLS = {
     "coast_cache_test_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(CoastCfg)]),
     "coast_chsha_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(CoastCfg)]),
     "coast_quicksort_host": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(CoastCfg)]),
+    "coast_chaes_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(CoastCfg)]),
     "coast_host_inject_faults": (C.c_int, [C.c_void_p, C.c_size_t]),
     "coast_host_stats": (C.c_int, [C.POINTER(CoastStats), C.c_int]),
 }

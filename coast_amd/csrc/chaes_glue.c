@@ -18,9 +18,10 @@ int encrypt(int statemt[32], int key[32], int type)
     static const int out_enc_statemt[16] = {0x39, 0x25, 0x84, 0x1d, 0x02, 0xdc, 0x09, 0xfb,
                                             0xdc, 0x11, 0x85, 0x97, 0x19, 0x6a, 0x0b, 0x32};
     int i;
-    coast_dropin_chstone_aes(statemt, key, type, 0);
-    nb = 4;
-    round_val = 0;
+    if (coast_dropin_chstone_aes(statemt, key, type, 0))
+        return -1;
+    nb = (type % 1000) / 32; /* the globals encrypt leaves behind (aes_enc.c:85-111): Nb, and Nr - 10 */
+    round_val = (type / 1000 > type % 1000 ? type / 1000 : type % 1000) / 32 - 4;
     printf("encrypted message \t");
     for (i = 0; i < nb * 4; ++i) {
         if (statemt[i] < 16)
@@ -37,9 +38,10 @@ int decrypt(int statemt[32], int key[32], int type)
     static const int out_dec_statemt[16] = {0x32, 0x43, 0xf6, 0xa8, 0x88, 0x5a, 0x30, 0x8d,
                                             0x31, 0x31, 0x98, 0xa2, 0xe0, 0x37, 0x07, 0x34};
     int i;
-    coast_dropin_chstone_aes(statemt, key, type, 1);
-    nb = 4;
-    round_val = 10;
+    if (coast_dropin_chstone_aes(statemt, key, type, 1))
+        return -1;
+    nb = (type % 1000) / 32; /* aes_dec.c:83-113: Nb, and Nr */
+    round_val = (type / 1000 > type % 1000 ? type / 1000 : type % 1000) / 32 + 6;
     printf("\ndecrypto message\t");
     for (i = 0; i < ((type % 1000) / 8); ++i) {
         if (statemt[i] < 16)

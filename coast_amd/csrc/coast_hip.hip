@@ -28,6 +28,7 @@
 #include "chsha_kernel.hip"
 #include "quicksort_kernel.hip"
 #include "crazycf_kernel.hip"
+#include "chaes_kernel.hip"
 
 using namespace coast;
 

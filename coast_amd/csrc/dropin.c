@@ -330,25 +330,26 @@ void coast_dropin_sha_stream(const unsigned char *indata, const int *in_i, int v
 }
 
 /* CHStone aes: encrypt / decrypt (tests/chstone/aes/aes_enc.c:67-134, aes_dec.c:66-140) keep the block and the key as one
- * byte per int.  The benchmark runs type 128128 only (aes.c:93-94: AES-128, 128-bit block); that is FIPS-197 AES-128, the
- * same function as aes_enc_dec, so the block goes through the protected AES engine (the key buffer it consumes is a copy:
- * CHStone expands the key into `word` and leaves `key` alone).  Returns the state in the caller's int array; the glue prints
- * and checks it the way the two functions do.  Other Rijndael sizes of the `type` switch are not served. */
+ * byte per int and take the Rijndael size as `type` (key bits * 1000 + block bits; the benchmark's main() runs 128128,
+ * aes.c:93-94).  All nine sizes go to the protected Rijndael kernel (coast_chaes_batch); the key array is left alone, as in the
+ * reference (KeySchedule expands it into `word`).  Returns the state in the caller's int array; the glue prints and checks it
+ * the way the two functions do. */
 int coast_dropin_chstone_aes(int *statemt, const int *key, int type, int dir)
 {
-    if (type != 128128)
-        dropin_fail("CHStone aes (only type 128128 = AES-128 is served)", COAST_EINVAL);
+    const int kb = type / 1000, bb = type % 1000;
+    if ((kb != 128 && kb != 192 && kb != 256) || (bb != 128 && bb != 192 && bb != 256))
+        return -1; /* KeySchedule's default case (aes_key.c:132-133) */
     coast_cfg cfg = dropin_cfg();
-    unsigned char st[16], k[16];
-    for (int i = 0; i < 16; ++i) {
+    unsigned char st[32], k[32];
+    for (int i = 0; i < bb / 8; ++i)
         st[i] = (unsigned char)statemt[i];
+    for (int i = 0; i < kb / 8; ++i)
         k[i] = (unsigned char)key[i];
-    }
     dropin_maybe_inject();
-    const int rc = coast_aes_enc_dec_host(st, k, (uint8_t)(dir != 0), &cfg);
+    const int rc = coast_chaes_host(st, k, type, dir, &cfg);
     if (rc)
         dropin_fail("CHStone aes", rc);
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < bb / 8; ++i)
         statemt[i] = st[i];
     dropin_account();
     return 0;

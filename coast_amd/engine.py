@@ -194,6 +194,18 @@ class Engine:
                                                     _ptr(status) if status is not None else None))
         return arrays
 
+    def chaes_batch(self, states, keys, type_, dir_=0, cfg: XmrConfig = XmrConfig(), detected=None):
+        """CHStone aes (tests/chstone/aes): Rijndael, type_ = key bits * 1000 + block bits.  states (n, 4 Nb) uint8 IN PLACE,
+        keys (n, 4 Nk) uint8 untouched."""
+        assert states.is_cuda and keys.is_cuda and states.dtype == torch.uint8 and keys.dtype == torch.uint8
+        assert states.is_contiguous() and keys.is_contiguous() and states.dim() == 2 and keys.dim() == 2
+        nk, nb = type_ // 1000 // 32, type_ % 1000 // 32
+        assert states.shape[1] == 4 * nb and keys.shape[1] == 4 * nk and states.shape[0] == keys.shape[0]
+        cc = cfg.c()
+        self._check(self._lib.coast_chaes_batch(self._h, _ptr(states), _ptr(keys), states.shape[0], int(type_), int(dir_),
+                                                C.byref(cc), _ptr(detected) if detected is not None else None))
+        return states
+
     def crazycf_batch(self, params, cfcss=True, results=None, status=None):
         """params: (n, 3) int32 on the GPU, rows of (seed, size, timesThroughWhile): n runs of tests/crazyCF/crazyCF.c's main()
         under control-flow signatures (projects/CFCSS; cfcss=False runs them bare).  Returns (results (n, 4) int32 =

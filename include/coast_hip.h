@@ -144,6 +144,10 @@ enum {
     COAST_SITE_QS_PIVOT = 50, /* the pivot */
     COAST_SITE_QS_VI = 51,    /* the value last loaded from A[i] */
     COAST_SITE_QS_VJ = 52,    /* the value last loaded from A[j] */
+    /* CHStone aes: packed state column `index` (0 .. Nb-1; row r in byte r) at round boundary `step` -- 0: region entry,
+     * r = 1 .. Nr: before the r-th (Invers)ShiftRow / ByteSub, Nr + 1: before the result is stored */
+    COAST_SITE_CHAES_STATE = 64,
+    COAST_SITE_CHAES_WORD = 65, /* expanded-key column `step` (word[0..3][step], packed), right after KeySchedule produced it */
     /* control-flow signatures (coast_crazycf_batch): `step` = how many block transitions the item has made; replica = 0 */
     COAST_SITE_CFC_PC = 56,   /* the branch target of transition `step`: execution lands at the START of block (target ^ 1<<bit) */
     COAST_SITE_CFC_RTS = 57,  /* BasicBlockSignatureTracker, after the leaving block stored it, before the next block checks it */
@@ -238,6 +242,16 @@ int coast_cache_test_batch(coast_ctx *ctx, int32_t *d_arrays, uint32_t n_elems, 
  * schedule, little-endian input words) -- bit-exact with the reference, its own test vector included. */
 int coast_chsha_batch(coast_ctx *ctx, const uint8_t *d_msgs, size_t stride, uint32_t len, size_t n_msgs,
                       uint32_t *d_digests, const coast_cfg *cfg, uint8_t *d_detected);
+
+/* CHStone aes (tests/chstone/aes; unittest/cfg/full.yml:6): encrypt (aes_enc.c:67-134) / decrypt (aes_dec.c:66-140) with
+ * KeySchedule (aes_key.c:77-165) -- full Rijndael, `type` = key bits * 1000 + block bits, all nine combinations of
+ * 128 / 192 / 256 the switch in KeySchedule knows (the benchmark's own main() runs 128128, aes.c:93-94).  n blocks: block b's
+ * state = 4 Nb bytes at d_states + 4 Nb b (column-major like statemt[], updated IN PLACE), its key = 4 Nk bytes at
+ * d_keys + 4 Nk b (left alone: KeySchedule expands it into replica-private storage).  dir = 0 encrypt, != 0 decrypt.
+ * Sync points: the result block's stores (one vote per packed column); sync_every != 0 adds the state after every round.
+ * Both arrays 4-byte aligned. */
+int coast_chaes_batch(coast_ctx *ctx, uint8_t *d_states, const uint8_t *d_keys, size_t n, int type, int dir,
+                      const coast_cfg *cfg, uint8_t *d_detected);
 
 /* quick_sort (tests/quicksort/quicksort.c:109-129, the LANL quicksort benchmark): n_arrays arrays of n_elems ints, array a at
  * d_arrays + a*n_elems, sorted IN PLACE (ascending).  The first workload whose loop trip counts depend on the data: every
@@ -343,6 +357,8 @@ int coast_crc16_host(const uint8_t *data, uint32_t length, uint16_t *crc, const 
 int coast_cache_test_host(int32_t *array, uint32_t n_elems, int32_t *sum, uint32_t *nerr, const coast_cfg *cfg);
 int coast_chsha_host(const uint8_t *data, uint32_t len, uint32_t digest[5], const coast_cfg *cfg);
 int coast_quicksort_host(int32_t *array, uint32_t n_elems, const coast_cfg *cfg);
+/* CHStone encrypt / decrypt on one block: state 4 Nb bytes (in place), key 4 Nk bytes */
+int coast_chaes_host(uint8_t *state, const uint8_t *key, int type, int dir, const coast_cfg *cfg);
 /* arm single-bit flips for the NEXT single-call shim (they run on a library-owned context): lets an external harness
  * inject into an unmodified driver the way supervisor.py + GDB inject into the running benchmark */
 int coast_host_inject_faults(const coast_fault *faults, size_t k);

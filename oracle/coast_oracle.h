@@ -69,6 +69,9 @@ enum {
     ORC_SITE_QS_PIVOT = 50, /* the pivot value */
     ORC_SITE_QS_VI = 51,    /* the value last loaded from A[i] */
     ORC_SITE_QS_VJ = 52,    /* the value last loaded from A[j] */
+    /* CHStone aes (chaes_oracle.inc) */
+    ORC_SITE_CHAES_STATE = 64, /* packed state column `index` at round boundary `step` (0 entry; r: before the r-th ShiftRow/ByteSub; Nr+1: exit) */
+    ORC_SITE_CHAES_WORD = 65,  /* expanded-key column `step`, right after KeySchedule produced it */
     /* control-flow signatures (cfcss_oracle.c): `step` = block transitions made so far */
     ORC_SITE_CFC_PC = 56,   /* the branch target of transition `step` */
     ORC_SITE_CFC_RTS = 57,  /* BasicBlockSignatureTracker between the store and the next check */
@@ -145,6 +148,12 @@ void orc_cache_test_xmr(int32_t *arrays, uint32_t n, size_t narrays, int32_t *su
 void orc_chsha_plain(const uint8_t *data, uint32_t len, uint32_t digest[5]);
 void orc_chsha_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nmsgs, uint32_t *digests, const orc_cfg *cfg,
                    const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
+
+/* CHStone aes (tests/chstone/aes): Rijndael, type = key bits * 1000 + block bits; block b = 4 Nb bytes at states + 4 Nb b (in
+ * place), its key = 4 Nk bytes at keys + 4 Nk b (left alone).  -1 = unknown type. */
+int orc_chaes_plain(uint8_t *state, const uint8_t *key, int type, int dir);
+int orc_chaes_xmr(uint8_t *states, const uint8_t *keys, size_t nblocks, int type, int dir, const orc_cfg *cfg,
+                  const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected);
 
 /* ---- CFCSS (projects/CFCSS/CFCSS.cpp) and its test program tests/crazyCF/crazyCF.c: cfcss_oracle.c ---- */
 enum { ORC_CFC_MAX_NODES = 256, ORC_CFC_MAX_SUCC = 1024, ORC_CFC_MAX_CALLS = 64 };

@@ -314,6 +314,57 @@ def quicksort_xmr(arrays, replicas=3, faults=None, flags=0):
     return a, st.as_dict(), det, status
 
 
+# ---- CHStone aes (chaes_oracle.inc) ----
+CHAES_TYPES = (128128, 128192, 128256, 192128, 192192, 192256, 256128, 256192, 256256)
+SITE_CHAES_STATE, SITE_CHAES_WORD = 64, 65
+
+
+def chaes_geom(type_):
+    nk, nb = type_ // 1000 // 32, type_ % 1000 // 32
+    return nk, nb, max(nk, nb) + 6
+
+
+def chaes_xmr(states, keys, type_, dir_=0, replicas=3, sync_every=0, faults=None, flags=0):
+    """states: (n, 4 Nb) uint8, keys: (n, 4 Nk) uint8.  Returns (states out, stats dict, detected per block)."""
+    nk, nb, _ = chaes_geom(type_)
+    s = np.ascontiguousarray(states, dtype=np.uint8).reshape(-1, 4 * nb).copy()
+    k = np.ascontiguousarray(keys, dtype=np.uint8).reshape(-1, 4 * nk)
+    n = s.shape[0]
+    assert k.shape[0] == n
+    fl = _faults(faults)
+    st = Stats()
+    det = np.zeros(n, dtype=np.uint8)
+    cfg = Cfg(replicas, sync_every, flags)
+    rc = lib().orc_chaes_xmr(_p(s, C.c_uint8), _p(k, C.c_uint8), C.c_size_t(n), C.c_int(type_), C.c_int(dir_), C.byref(cfg),
+                             fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)), C.byref(st), _p(det, C.c_uint8))
+    if rc:
+        raise ValueError("orc_chaes_xmr: unknown type %d" % type_)
+    return s, st.as_dict(), det
+
+
+def chaes_plain(state, key, type_, dir_=0):
+    s = np.ascontiguousarray(state, dtype=np.uint8).copy()
+    k = np.ascontiguousarray(key, dtype=np.uint8)
+    rc = lib().orc_chaes_plain(_p(s, C.c_uint8), _p(k, C.c_uint8), C.c_int(type_), C.c_int(dir_))
+    if rc:
+        raise ValueError("orc_chaes_plain: unknown type %d" % type_)
+    return s
+
+
+def ref_chaes(state, key, type_, dir_=0):
+    """the reference's own encrypt / decrypt (tests/chstone/aes, compiled from where it lies): one byte per int"""
+    s = np.ascontiguousarray(state, dtype=np.uint8).astype(np.int32)
+    s = np.concatenate([s, np.zeros(32 - len(s), np.int32)])
+    k = np.ascontiguousarray(key, dtype=np.uint8).astype(np.int32)
+    k = np.concatenate([k, np.zeros(32 - len(k), np.int32)])
+    rc = ref().ref_chaes(_p(s, C.c_int32), _p(k, C.c_int32), C.c_int(type_), C.c_int(dir_))
+    if rc:
+        raise ValueError("ref_chaes: type %d" % type_)
+    nb = type_ % 1000 // 32
+    assert ((s >= 0) & (s < 256)).all()
+    return s[:4 * nb].astype(np.uint8)
+
+
 # ---- CFCSS (cfcss_oracle.c) ----
 class CfcGraph(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("flags", C.POINTER(C.c_uint8)), ("func", C.POINTER(C.c_uint16)),

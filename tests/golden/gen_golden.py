@@ -185,6 +185,23 @@ def main():
         qv["out%d" % q] = orc.ref_quicksort(a)
     np.savez_compressed(os.path.join(HERE, "quicksort_fixtures.npz"), **qv)
 
+    # ---------------- CHStone aes (tests/chstone/aes): the reference's encrypt / decrypt through oracle/_ref's shim, all nine
+    # Rijndael sizes, random blocks and keys; plus the benchmark's own vector (FIPS-197 Appendix B, aes.c:95-127)
+    cav = {}
+    rng = random.Random(197)
+    for t in orc.CHAES_TYPES:
+        nk, nb, _ = orc.chaes_geom(t)
+        st = np.array([[rng.randrange(256) for _ in range(4 * nb)] for _ in range(12)], dtype=np.uint8)
+        ky = np.array([[rng.randrange(256) for _ in range(4 * nk)] for _ in range(12)], dtype=np.uint8)
+        if t == 128128:
+            st[0] = [50, 67, 246, 168, 136, 90, 48, 141, 49, 49, 152, 162, 224, 55, 7, 52]
+            ky[0] = [43, 126, 21, 22, 40, 174, 210, 166, 171, 247, 21, 136, 9, 207, 79, 60]
+        cav["st%d" % t] = st
+        cav["key%d" % t] = ky
+        cav["enc%d" % t] = np.stack([orc.ref_chaes(st[q], ky[q], t, 0) for q in range(12)])
+        cav["dec%d" % t] = np.stack([orc.ref_chaes(st[q], ky[q], t, 1) for q in range(12)])
+    np.savez_compressed(os.path.join(HERE, "chaes_fixtures.npz"), **cav)
+
     # ---------------- crazyCF (tests/crazyCF, the CFCSS test program): the unmodified program compiled natively -- its two
     # output lines -- and, through oracle/_ref's shim, a grid of (srand argument, size) with timesThroughWhile at its 10
     with tempfile.TemporaryDirectory() as td:

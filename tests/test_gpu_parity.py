@@ -1587,3 +1587,141 @@ def test_campaign_crazycf_cfcss(eng, tmp_path):
     assert "ABORT (FAULT_DETECTED)" in open(prefix + ".log").read()
     with pytest.raises(SystemExit):
         _campaign(["-b", "mm", "-m", "CFCSS", "-t", "10", "-n"], eng)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CHStone aes (tests/chstone/aes): Rijndael with nine key / block sizes, its own kernel
+
+
+def _chaes_fixtures():
+    import os
+
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chaes_fixtures.npz")))
+
+
+@pytest.mark.parametrize("type_", [128128, 128192, 128256, 192128, 192192, 192256, 256128, 256192, 256256])
+def test_chaes_reference_vectors(eng, type_):
+    """outputs of the reference's own encrypt / decrypt (oracle/_ref through tests/golden/gen_golden.py), every `type` of
+    KeySchedule's switch, every protection mode; the benchmark's FIPS-197 vector is row 0 of type 128128"""
+    import torch
+
+    import coast_amd as ca
+
+    fx = _chaes_fixtures()
+    st, ky = fx["st%d" % type_], fx["key%d" % type_]
+    for replicas in (3, 2, 1):
+        for sync_every in (0, 1):
+            cfg = ca.XmrConfig(replicas, sync_every)
+            dev, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky.copy()).cuda()
+            eng.chaes_batch(dev, dk, type_, 0, cfg)
+            assert (dev.cpu().numpy() == fx["enc%d" % type_]).all(), (replicas, sync_every)
+            assert (dk.cpu().numpy() == ky).all()  # the key array is left alone
+            eng.chaes_batch(dev, dk, type_, 1, cfg)
+            assert (dev.cpu().numpy() == st).all()
+            dev = torch.from_numpy(st.copy()).cuda()
+            eng.chaes_batch(dev, dk, type_, 1, cfg)
+            assert (dev.cpu().numpy() == fx["dec%d" % type_]).all()
+    if type_ == 128128:
+        assert fx["enc128128"][0].tobytes().hex() == "3925841d02dc09fbdc118597196a0b32"
+
+
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+@pytest.mark.parametrize("type_", [128128, 192256, 256192, 256256, 128256])
+def test_chaes_vs_oracle(eng, orc, type_, replicas):
+    """blocks, __SYNC_COUNT, TMR_ERROR_CNT, DWC flags and per-block flags equal the oracle's: clean, with the per-round sync
+    points, under -noStoreDataSync, and under random upsets of state columns and expanded-key columns (several per block)"""
+    import torch
+
+    import coast_amd as ca
+
+    nk, nb, nr = orc.chaes_geom(type_)
+    rng = np.random.default_rng(type_ + replicas)
+    n = 333
+    st = rng.integers(0, 256, (n, 4 * nb), dtype=np.uint8)
+    ky = rng.integers(0, 256, (n, 4 * nk), dtype=np.uint8)
+    for dir_ in (0, 1):
+        for sync_every, flags in ((0, 0), (1, 0), (0, ca.F_NO_STORE_DATA_SYNC)):
+            exp, exp_st, _ = orc.chaes_xmr(st, ky, type_, dir_, replicas=replicas, sync_every=sync_every, flags=flags)
+            dev, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky).cuda()
+            eng.reset_stats()
+            eng.chaes_batch(dev, dk, type_, dir_, ca.XmrConfig(replicas, sync_every, flags))
+            assert (dev.cpu().numpy() == exp).all() and _stats3(eng.stats()) == exp_st, (dir_, sync_every, flags)
+        rows = []
+        for _ in range(400):
+            q, r = int(rng.integers(0, n)), int(rng.integers(0, replicas))
+            if rng.random() < 0.5:
+                rows.append((q, r, ca.SITE_CHAES_STATE, int(rng.integers(0, nr + 2)), int(rng.integers(0, 32)), int(rng.integers(0, nb))))
+            else:
+                rows.append((q, r, ca.SITE_CHAES_WORD, int(rng.integers(0, nb * (nr + 1))), int(rng.integers(0, 32))))
+        fl = ca.make_faults(rows)
+        for sync_every, flags in ((0, 0), (1, 0), (0, ca.F_NO_STORE_DATA_SYNC)):
+            exp, exp_st, exp_det = orc.chaes_xmr(st, ky, type_, dir_, replicas=replicas, sync_every=sync_every, flags=flags, faults=fl)
+            dev, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky).cuda()
+            det = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            eng.reset_stats()
+            eng.inject_faults(fl)
+            eng.chaes_batch(dev, dk, type_, dir_, ca.XmrConfig(replicas, sync_every, flags), detected=det)
+            assert (dev.cpu().numpy() == exp).all(), (dir_, sync_every, flags)
+            assert _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all(), (dir_, sync_every, flags)
+            assert eng.last_launch()["armed_faults"] == len(rows)
+    if replicas == 3:  # one upset per block is always out-voted
+        rows = [(q, int(rng.integers(0, 3)), ca.SITE_CHAES_STATE, int(rng.integers(0, nr + 2)), int(rng.integers(0, 32)),
+                 int(rng.integers(0, nb))) for q in range(n)]
+        clean, _, _ = orc.chaes_xmr(st, ky, type_, 0, replicas=1)
+        dev, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky).cuda()
+        eng.inject_faults(ca.make_faults(rows))
+        eng.chaes_batch(dev, dk, type_, 0, ca.XmrConfig(3))
+        assert (dev.cpu().numpy() == clean).all()
+
+
+def test_chaes_rejects_bad_arguments(eng):
+    import torch
+
+    import coast_amd as ca
+
+    st = torch.zeros((4, 16), dtype=torch.uint8, device="cuda")
+    ky = torch.zeros((4, 16), dtype=torch.uint8, device="cuda")
+    cc = ca.XmrConfig(3).c()
+    import ctypes as C
+    for bad in (128129, 0, -128128, 512128, 128064):
+        assert eng._lib.coast_chaes_batch(eng._h, st.data_ptr(), ky.data_ptr(), 4, bad, 0, C.byref(cc), None) == -1
+    assert eng._lib.coast_chaes_batch(eng._h, st.data_ptr() + 1, ky.data_ptr(), 4, 128128, 0, C.byref(cc), None) == -1
+    assert eng._lib.coast_chaes_batch(eng._h, None, None, 0, 128128, 0, C.byref(cc), None) == 0
+
+
+@pytest.mark.parametrize("passes", ["-TMR -countErrors", "-DWC -noMemReplication", ""])
+def test_chaes_dropin_all_types(passes, monkeypatch):
+    """the symbol the CHStone glue binds (coast_dropin_chstone_aes, one byte per int like statemt[] / key[]) for every Rijndael
+    size, in the lane-replicated and the memory-replicated (default) mode, against the reference's outputs"""
+    import ctypes as C
+    import os
+
+    fx = _chaes_fixtures()
+    monkeypatch.setenv("COAST_OPT_PASSES", passes)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = C.CDLL(os.path.join(root, "coast_amd", "lib", "libcoast_dropin.so"))
+    fn = lib.coast_dropin_chstone_aes
+    fn.restype = C.c_int
+    for t in (128128, 128192, 192128, 256256, 192256):
+        nk, nb = t // 1000 // 32, t % 1000 // 32
+        for q in (0, 5):
+            st = (C.c_int * 32)(*[int(v) for v in fx["st%d" % t][q]])
+            ky = (C.c_int * 32)(*[int(v) for v in fx["key%d" % t][q]])
+            assert fn(st, ky, t, 0) == 0
+            assert list(st[:4 * nb]) == fx["enc%d" % t][q].tolist()
+            assert list(ky[:4 * nk]) == fx["key%d" % t][q].tolist()
+            assert fn(st, ky, t, 1) == 0
+            assert list(st[:4 * nb]) == fx["st%d" % t][q].tolist()
+    st = (C.c_int * 32)()
+    assert fn(st, st, 128000, 0) == -1  # KeySchedule's default case
+
+
+def test_campaign_chaes(eng):
+    _, _, _, t = _campaign(["-b", "chaes", "-m", "TMR", "-t", "600", "-n", "--chaes-type", "256192"], eng)
+    _, _, _, d = _campaign(["-b", "chaes", "-m", "DWC", "-t", "600", "-n", "--chaes-type", "192256"], eng)
+    _, _, _, n = _campaign(["-b", "chaes", "-m", "NONE", "-t", "600", "-n"], eng)
+    _, _, _, m = _campaign(["-b", "chaes", "-m", "TMR", "-t", "600", "-n", "-s", "memory", "--mem-mode", "default"], eng)
+    assert t["errors"] == 0 and t["faults"] > 500
+    assert d["errors"] == 0 and d["aborts"] > 500
+    assert n["errors"] > 500
+    assert m["errors"] == 0 and m["faults"] > 500

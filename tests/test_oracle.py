@@ -351,3 +351,54 @@ def test_quicksort_oracle_vs_committed_reference_vectors(orc):
         assert (orc.quicksort_plain(fx["in%d" % q]) == fx["out%d" % q]).all()
         s, _, _, status = orc.quicksort_xmr(fx["in%d" % q][None])
         assert (s[0] == fx["out%d" % q]).all() and not status.any()
+
+
+# ---- CHStone aes (tests/chstone/aes): Rijndael, nine key / block sizes ----
+def _chaes_fx():
+    import os
+
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chaes_fixtures.npz")))
+
+
+def test_chaes_oracle_matches_reference_vectors(orc):
+    """outputs of the reference's own encrypt / decrypt (oracle/_ref, tests/golden/gen_golden.py) for all nine `type`s"""
+    fx = _chaes_fx()
+    for t in orc.CHAES_TYPES:
+        out, st, det = orc.chaes_xmr(fx["st%d" % t], fx["key%d" % t], t, 0, replicas=3)
+        nk, nb, nr = orc.chaes_geom(t)
+        assert (out == fx["enc%d" % t]).all() and not det.any()
+        assert st == {"errors_corrected": 0, "sync_count": 12 * nb, "dwc_detected": 0}
+        back, _, _ = orc.chaes_xmr(out, fx["key%d" % t], t, 1, replicas=2)
+        assert (back == fx["st%d" % t]).all()
+        dec, st, _ = orc.chaes_xmr(fx["st%d" % t], fx["key%d" % t], t, 1, replicas=1, sync_every=1)
+        assert (dec == fx["dec%d" % t]).all() and st["sync_count"] == 0
+        _, st, _ = orc.chaes_xmr(fx["st%d" % t], fx["key%d" % t], t, 0, replicas=3, sync_every=1)
+        assert st["sync_count"] == 12 * nb * nr
+    # the benchmark's own test vector: FIPS-197 Appendix B (aes_enc.c:77-80)
+    assert fx["enc128128"][0].tobytes().hex() == "3925841d02dc09fbdc118597196a0b32"
+    with pytest.raises(ValueError):
+        orc.chaes_plain(np.zeros(16, np.uint8), np.zeros(16, np.uint8), 128129)
+
+
+def test_chaes_oracle_votes_out_single_upsets(orc):
+    from coast_amd import make_faults
+
+    fx = _chaes_fx()
+    rng = np.random.default_rng(3)
+    for t in (128128, 192256, 256192):
+        nk, nb, nr = orc.chaes_geom(t)
+        rows = []
+        for q in range(12):
+            if q % 2:
+                rows.append((q, int(rng.integers(0, 3)), orc.SITE_CHAES_STATE, int(rng.integers(0, nr + 2)), int(rng.integers(0, 32)),
+                             int(rng.integers(0, nb))))
+            else:
+                rows.append((q, int(rng.integers(0, 3)), orc.SITE_CHAES_WORD, int(rng.integers(0, nb * (nr + 1))),
+                             int(rng.integers(0, 32))))
+        out, st, det = orc.chaes_xmr(fx["st%d" % t], fx["key%d" % t], t, 0, replicas=3, faults=make_faults(rows))
+        assert (out == fx["enc%d" % t]).all() and det.sum() >= 10 and st["errors_corrected"] >= det.sum()
+        out1, _, _ = orc.chaes_xmr(fx["st%d" % t], fx["key%d" % t], t, 0, replicas=1, faults=make_faults([(r[0], 0) + r[2:] for r in rows]))
+        assert (out1 != fx["enc%d" % t]).any(axis=1).sum() >= 10
+        _, st2, det2 = orc.chaes_xmr(fx["st%d" % t], fx["key%d" % t], t, 0, replicas=2,
+                                     faults=make_faults([(r[0], r[1] % 2) + r[2:] for r in rows]))
+        assert st2["dwc_detected"] == det2.sum() >= 10

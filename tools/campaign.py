@@ -167,6 +167,31 @@ class QuickSort(Bench):
                 int(rng.integers(0, 32)))
 
 
+class ChAes(Bench):
+    """CHStone aes (tests/chstone/aes): one Rijndael block per run; --chaes-type picks one of the nine key / block sizes"""
+
+    def __init__(self, a, eng, g):
+        self.eng, self.type = eng, a.chaes_type
+        self.nk, self.nb = self.type // 1000 // 32, self.type % 1000 // 32
+        self.nr = max(self.nk, self.nb) + 6
+
+    def inputs(self, runs, g):
+        return [torch.randint(0, 256, (runs, 4 * self.nb), dtype=torch.uint8, device="cuda", generator=g),
+                torch.randint(0, 256, (runs, 4 * self.nk), dtype=torch.uint8, device="cuda", generator=g)]
+
+    def run(self, inp, cfg, det=None):
+        st = inp[0].clone()
+        self.eng.chaes_batch(st, inp[1], self.type, 0, cfg, detected=det)
+        return st
+
+    def reg_fault(self, r, nrep, rng):
+        if rng.random() < 0.5:
+            return (r, int(rng.integers(0, nrep)), ca.SITE_CHAES_STATE, int(rng.integers(0, self.nr + 2)), int(rng.integers(0, 32)),
+                    int(rng.integers(0, self.nb)))
+        return (r, int(rng.integers(0, nrep)), ca.SITE_CHAES_WORD, int(rng.integers(0, self.nb * (self.nr + 1))),
+                int(rng.integers(0, 32)))
+
+
 class CrazyCF(Bench):
     """tests/crazyCF/crazyCF.c under `opt -CFCSS` (-m CFCSS) or bare (-m NONE): the upset is a corrupted branch target -- execution
     lands at the start of block (target ^ 1 << bit), bit uniform over the 32-bit register -- or, under CFCSS, a bit of the two
@@ -195,7 +220,7 @@ class CrazyCF(Bench):
         return (r, 0, site, int(rng.integers(0, 309)), int(rng.integers(0, 32)))  # 309 block transitions in a clean run
 
 
-BENCHES = {"crazycf": CrazyCF, "quicksort": QuickSort, "mm": MM, "sha256": SHA256, "aes": AES, "crc16": CRC16, "chsha": ChSha, "cache_test": CacheTest}
+BENCHES = {"chaes": ChAes, "crazycf": CrazyCF, "quicksort": QuickSort, "mm": MM, "sha256": SHA256, "aes": AES, "crc16": CRC16, "chsha": ChSha, "cache_test": CacheTest}
 
 
 # ------------------------------------------------------------------------------------------------ one campaign
@@ -354,6 +379,7 @@ def parse(argv=None):
     ap.add_argument("--mem-mode", default="nomemrep", choices=["nomemrep", "default"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--side", type=int, default=9, help="mm: matrix side, one matrix per run (256 = the matrix-core engine)")
+    ap.add_argument("--chaes-type", type=int, default=128128, help="chaes: key bits * 1000 + block bits (aes_key.c:83-134)")
     ap.add_argument("-l", "--log-dir", default="./logs/")
     ap.add_argument("-n", "--no-logging", action="store_true")
     return ap.parse_args(argv)
