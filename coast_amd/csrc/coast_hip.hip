@@ -20,6 +20,7 @@
 #include "injector.hip"
 #include "mm_kernel.hip"
 #include "mm_mfma_kernel.hip"
+#include "mm_mfma_blk_kernel.hip"
 #include "sha256_kernel.hip"
 #include "aes_kernel.hip"
 #include "crc16_kernel.hip"
@@ -663,6 +664,8 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     // side 256: the int8-MFMA limb kernel, injector hooks included; COAST_MM_ENGINE=valu selects the v_mad_u64_u32 kernels
     const char *eng = getenv("COAST_MM_ENGINE");
     const bool mfma = n == 256 && !allGeneral && !(eng && !strcmp(eng, "valu"));
+    const char *tileEnv = getenv("COAST_MM_TILE"); // development: "blocks" = mm_mfma_blk_kernel (TMR), "lanes" = mm_mfma_panel_kernel
+    const bool mmBlocks = tileEnv && !strcmp(tileEnv, "blocks");
     const uint64_t nbm = (uint64_t)(n / 64) * batch; // workgroups of the panel kernel: 64 rows of one matrix each
 
     FaultTab ft;
@@ -698,6 +701,19 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     } while (0)
 #define LAUNCH_MM(R)                                                                                            \
     do {                                                                                                        \
+        if (mfma && R == 3 && mmBlocks) { /* TMR: replicas in register blocks, one wave per SIMD */              \
+            using GB = MmBlk<3>;                                                                                \
+            HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk_kernel<3>,                                 \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB::LDS_BYTES));    \
+            FaultTab ftm = ft;                                                                                  \
+            if (!have)                                                                                          \
+                ftm.list = nullptr, ftm.range = nullptr;                                                        \
+            hipLaunchKernelGGL(mm_mfma_blk_kernel<3>, dim3((uint32_t)nbm), dim3(GB::NTHR), GB::LDS_BYTES,       \
+                               c->stream, d_f, d_s, d_r, (uint32_t)nbm, ctr, ftm, d_detected);                  \
+            engine = COAST_ENGINE_MATRIX_CORE;                                                                  \
+            fastBlocks = nbm;                                                                                   \
+            break;                                                                                              \
+        }                                                                                                       \
         if (mfma) { /* armed upsets are applied and out-voted inside the panel kernel: no VALU workgroup runs */ \
             using GP = MmPanel<R>;                                                                              \
             static_assert(GP::BPM == 256 / 64, "panel geometry");                                               \

@@ -1,0 +1,404 @@
+// mm_mfma_blk_kernel.hip -- side-256 protected matrix_multiply on the matrix cores, replicas in REGISTER BLOCKS (TMR).
+//
+// Same arithmetic as mm_mfma_kernel.hip (signed-byte limb decomposition: ten int8 MFMAs per limb pair set, accumulated exactly
+// in int32) and the same workgroup geometry (64 rows of one matrix per workgroup, the rows' byte planes resident in LDS).  What
+// changes is where the replicas of an output element live.  There: NREP adjacent LANES of one accumulator register -- a wave
+// tile is 32 lane-columns = 10 logical columns for TMR, two lane-columns idle, 26 tiles for 256 columns (the last one 60 %
+// empty), dealt 7 / 7 / 6 / 6 to the four waves.  Here: the SAME lane of NREP accumulator blocks -- replica r of r[i][j] is
+// accumulator block r, fed by its own B-operand registers (read from the single LDS copy once per replica: the load is part of
+// the replicated computation, the memory is not) and accumulated by its own MFMAs:
+//     * no idle lane-columns and no ragged last tile: 16 tiles of 16 logical columns per panel, four per wave
+//     * the s slab a wave converts (16 columns x 64 k) keeps all 64 conversion lanes busy (40 there) and feeds 120 MFMAs
+//     * the voter compares registers of one lane: no cross-lane traffic; the voted tile is stored straight from the registers
+// Three replicas x four limb sums of a 64-row tile only fit the register file with v_mfma_i32_16x16x64_i8 (4 accumulator
+// registers per 16 x 16 block: 4 row blocks x 3 x 4 x 4 = 192) and one wave per SIMD; the wave hides latencies by its own
+// instruction order -- every operand register is re-read right after its last use in the step, tens of MFMAs before its next.
+// tools/mfma_probe2.hip (stepZ) measured this step shape before the kernel was written: 2.7-2.9 POP/s executed, all of it
+// useful, against 2.12 executed / 1.97 useful for the lane-replica kernel.
+//
+// Injector hooks: everything downstream of an upset is linear mod 2^32, so its exact consequence on the replica's recombined
+// word is an additive constant (mm_mfma_kernel.hip, file header); r = C0 + (C1 << 8) + ..., so the constant is placed in the
+// replica's limb-0 accumulator BEFORE the tile's first MFMA (the only point where control flow does not fight 192 live
+// accumulators for registers), the matrix core adds the products on top, and the voter sees the upset word.
+#include <type_traits>
+
+#include "xmr.hpp"
+
+namespace coast {
+
+template <int NREP> struct MmBlk {
+    static constexpr int N = 256, KS = 64, NSLAB = N / KS; // 64-deep k slabs: four steps per tile
+    static constexpr int CT = 16;                 // logical columns per wave tile
+    static constexpr int NW = 4, NTHR = 64 * NW;  // one wave per SIMD
+    static constexpr int BM = 64, BPM = N / BM, NRB = BM / 16;
+    static constexpr int NCT = N / CT;            // 16 column tiles per panel, tile t -> wave t % NW
+    static constexpr int PLANE_A = BM * N, A_PANEL = 4 * PLANE_A;
+    static constexpr int PLANE_B = CT * KS, B_BUF = 4 * PLANE_B; // plane[q][column][64 B]: 4 KB per slab
+    static constexpr int WAVE_LDS = 2 * B_BUF;    // double buffer
+    static constexpr size_t LDS_BYTES = (size_t)A_PANEL + NW * WAVE_LDS; // 96 KB
+    static constexpr int A_PER_THR = (BM * (N / 4)) / NTHR; // uint4 (four k of one row) of the panel per thread
+    static constexpr int B_ROUNDS = 2;            // staging: lane -> (column pair l % 8, k-quad l / 8 + 8 * round)
+};
+
+template <int NREP>
+__global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const uint32_t *__restrict__ F,
+                                                                           const uint32_t *__restrict__ S,
+                                                                           uint32_t *__restrict__ R, uint32_t nblocks, Counters ctr,
+                                                                           FaultTab ft, uint8_t *__restrict__ detected)
+{
+    using G = MmBlk<NREP>;
+    static_assert(NREP == 3, "the step's load / conversion slots are laid out for 120 MFMAs");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smemP[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kg = lane >> 4; // operand row / column inside a 16-block, 16-byte k group of the slab
+    uint8_t *const wbuf = smemP + G::A_PANEL + wave * G::WAVE_LDS;
+
+    const uint32_t lb = xcd_logical_block(blockIdx.x, nblocks);
+    const uint32_t mat = lb / (uint32_t)G::BPM;
+    const int row0 = (int)(lb - mat * (uint32_t)G::BPM) * G::BM;
+    constexpr size_t nn = (size_t)G::N * G::N;
+    const uint32_t *f = F + mat * nn + (size_t)row0 * G::N;
+    const uint32_t *s = S + mat * nn;
+    uint32_t *r = R + mat * nn + (size_t)row0 * G::N;
+
+    // ---- the f panel: plane[p][row][256 B], the row's sixteen 16-byte slots (slot = k / 16) at slot ^ (row & 15) -- the layout of
+    // mm_mfma_panel_kernel; a 16x16x64 fragment read (lane = row & 15, k group) finds its 16 lanes' slots in 16 different banks
+    {
+        uint4 pa[G::A_PER_THR];
+#pragma unroll
+        for (int u = 0; u < G::A_PER_THR; ++u) {
+            const int i = tid + G::NTHR * u;
+            pa[u] = *reinterpret_cast<const uint4 *>(f + (uint32_t)((i >> 6) * G::N + 4 * (i & 63)));
+        }
+#pragma unroll
+        for (int u = 0; u < G::A_PER_THR; ++u) {
+            const int i = tid + G::NTHR * u;
+            const int row = i >> 6, kq = i & 63;
+            const uint32_t y[4] = {mm_digits(pa[u].x), mm_digits(pa[u].y), mm_digits(pa[u].z), mm_digits(pa[u].w)};
+            uint32_t w[4];
+            mm_transpose4(y, w);
+            const int dst = row * G::N + (((kq >> 2) ^ (row & 15)) * 16) + (kq & 3) * 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                *reinterpret_cast<uint32_t *>(smemP + p * G::PLANE_A + dst) = w[p];
+        }
+    }
+
+    uint32_t fFirst = 0, fCount = 0;
+    if (ft.range) {
+        const uint2 rg = ft.range[lb];
+        fFirst = __builtin_amdgcn_readfirstlane(rg.x);
+        fCount = __builtin_amdgcn_readfirstlane(rg.y);
+    }
+
+    // ---- this wave's work: column tiles wave, wave + NW, ...; one pipeline step = one 64-deep k slab of one tile
+    constexpr int nTiles = G::NCT / G::NW, nIt = nTiles * G::NSLAB;
+    auto tileCol0 = [&](int it) __attribute__((always_inline)) { return (wave + G::NW * (it / G::NSLAB)) * G::CT; };
+
+    // s staging: one conversion item = four consecutive k of one column -> one word in each of the four planes; a lane owns the two
+    // columns of a pair, lane -> (pair l % 8, k-quad l / 8 + 8 * round): a dwordx2 load instruction fetches eight full tile rows
+    // (64 B each).  plane[q][column][64 B]; a column's four 16-byte slots (slot = k / 16) sit at slot ^ ((0 - column / 4) & 3), which
+    // spreads both the fragment reads (lane = column, k group) and the conversion stores over the banks; odd pairs store their
+    // two columns in the opposite order so that one store instruction covers both column parities.
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rsS =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(s), 0, (int)(nn * 4), 0x00020000);
+    int voffB[G::B_ROUNDS], dstB[G::B_ROUNDS][2];
+    const bool swapB = (lane & 1) != 0; // pair = lane % 8
+#pragma unroll
+    for (int u = 0; u < G::B_ROUNDS; ++u) {
+        const int c = 2 * (lane & 7), kq = u * 8 + (lane >> 3);
+        voffB[u] = ((4 * kq) * G::N + c) * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ch = c + (h ^ (swapB ? 1 : 0));
+            dstB[u][h] = ch * G::KS + (((kq >> 2) ^ ((0 - (ch >> 2)) & 3)) * 16) + (kq & 3) * 4;
+        }
+    }
+    auto slabOff = [&](int it) __attribute__((always_inline)) { return ((it % G::NSLAB) * G::KS * G::N + tileCol0(it)) * 4; };
+    auto rawWord = [&](const u32x2_t &v, int h) __attribute__((always_inline)) {
+        return h == 0 ? (swapB ? v[1] : v[0]) : (swapB ? v[0] : v[1]);
+    };
+
+    // fragment addresses: A row block rb, plane p, slab sl: (aOff ^ (sl * 64)) + rb * 16 * N + p * PLANE_A   (slot 4 sl + kg, swizzled)
+    const int aOff = l16 * G::N + ((kg ^ l16) * 16);
+    const int bOff = l16 * G::KS + ((kg ^ ((0 - (l16 >> 2)) & 3)) * 16);
+
+    Tally tl;
+    uint32_t detItems = 0;
+    v4i_t acc[G::NRB][NREP][4];
+    u32x2_t pbs[G::B_ROUNDS][4]; // raw s words of the NEXT slab; each round's registers are reloaded as soon as it is converted
+
+    // prologue: slab 0 converted into buffer 0, slab 1 in flight
+    {
+        const int so = slabOff(0);
+#pragma unroll
+        for (int u = 0; u < G::B_ROUNDS; ++u)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                pbs[u][kk] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[u] + kk * G::N * 4, so, 0);
+#pragma unroll
+        for (int u = 0; u < G::B_ROUNDS; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t y[4] = {mm_digits(rawWord(pbs[u][0], h)), mm_digits(rawWord(pbs[u][1], h)),
+                                       mm_digits(rawWord(pbs[u][2], h)), mm_digits(rawWord(pbs[u][3], h))};
+                uint32_t w[4];
+                mm_transpose4(y, w);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<uint32_t *>(wbuf + q * G::PLANE_B + dstB[u][h]) = w[q];
+            }
+        const int so1 = slabOff(1);
+#pragma unroll
+        for (int u = 0; u < G::B_ROUNDS; ++u)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                pbs[u][kk] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[u] + kk * G::N * 4, so1, 0);
+    }
+    __syncthreads(); // the panel (and this wave's slab 0) is complete; the waves do not meet again until the counters
+
+    // ---- tile end: recombine the limb sums, vote in-lane, store straight from the registers.  BRANCH-FREE while accumulators are
+    // alive (control flow here makes the register allocator spill accumulator tuples inside the main loop): the compare-and-select
+    // voter runs on every element, the out-voted elements are collected in a lane mask, and the per-item flags are written from
+    // that mask after the last accumulator is dead.  C/D layout of 16x16 blocks: lane -> column lane % 16, rows 4 (lane / 16) + i.
+    auto tileEnd = [&](int it) __attribute__((always_inline)) {
+        const int col = tileCol0(it) + l16;
+        uint32_t missMask = 0u; // bit rb * 4 + i: the copies of that element of this lane disagreed
+#pragma unroll
+        for (int rb = 0; rb < G::NRB; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t v[3];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    const int rs = rr < NREP ? rr : NREP - 1;
+                    v[rr] = (uint32_t)acc[rb][rs][0][i] + ((uint32_t)acc[rb][rs][1][i] << 8) + ((uint32_t)acc[rb][rs][2][i] << 16) +
+                            ((uint32_t)acc[rb][rs][3][i] << 24);
+                }
+                const bool e01 = v[0] == v[1], e02 = v[0] == v[2];
+                const uint32_t voted = (NREP == 3 && !e01) ? v[2] : v[0]; // select(a == b, a, c); DWC keeps replica 0's
+                missMask |= ((e01 && e02) ? 0u : 1u) << (rb * 4 + i);
+                r[(uint32_t)((rb * 16 + 4 * kg + i) * G::N + col)] = voted;
+            }
+        tl.syncs += 16u;
+        if (NREP == 3)
+            tl.miss += (uint32_t)__builtin_popcount(missMask);
+#pragma unroll 1
+        while (missMask) { // per-item flags of the elements that were out-voted (TMR) / caught (DWC)
+            const int idx = __builtin_ctz(missMask);
+            missMask &= missMask - 1u;
+            const int orow = (idx >> 2) * 16 + 4 * kg + (idx & 3);
+            if (NREP == 2)
+                detItems += 1;
+            if (detected)
+                detected[mat * nn + (size_t)(row0 + orow) * G::N + col] = 1;
+        }
+    };
+
+    // ---- injector hook, at the START of a tile (the accumulators of the previous tile are dead: room for control flow):
+    //     ACC, step k <= n : (p ^ m) - p,  p = sum_{k' < k} f[i][k'] s[k'][j] + the replica's earlier deltas   (k = n: p is the
+    //                        finished sum -- the flip of the register after the loop)
+    //     OPA / OPB, step k: (a ^ ma')(b ^ mb') - (a ^ ma)(b ^ mb)       (masks of this MAC before / after this upset)
+    // summed into the replica's limb-0 accumulator.  Returns whether this tile has any armed upset (wave-uniform).
+    auto tileHook = [&](int it) __attribute__((always_inline)) {
+        const int col0 = tileCol0(it);
+        bool hooked = false;
+#pragma unroll 1
+        for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
+            const int fcol = (int)(__builtin_amdgcn_readfirstlane(ft.list[q].local) & 255u);
+            hooked = hooked || (fcol >= col0 && fcol < col0 + G::CT);
+        }
+        if (!hooked)
+            return false;
+        const v4i_t zero = {0, 0, 0, 0};
+#pragma unroll
+        for (int rb = 0; rb < G::NRB; ++rb)
+#pragma unroll
+            for (int rr = 0; rr < NREP; ++rr)
+                acc[rb][rr][0] = zero;
+        uint32_t curKey = 0xffffffffu, curStep = 0xffffffffu;
+        uint32_t dsum[3] = {0u, 0u, 0u}, am[3] = {0u, 0u, 0u}, bm[3] = {0u, 0u, 0u};
+#pragma unroll 1
+        for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
+            const DevFault *fp = ft.list + q;
+            const uint32_t local = __builtin_amdgcn_readfirstlane(fp->local);
+            const int frow = (int)(local >> 8), fcol = (int)(local & 255u);
+            if (fcol < col0 || fcol >= col0 + G::CT)
+                continue;
+            const uint32_t fstep = __builtin_amdgcn_readfirstlane(fp->step);
+            const uint32_t packed = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(&fp->replica));
+            const uint32_t frep = packed & 0xffu, fsite = (packed >> 8) & 0xffu, m = 1u << ((packed >> 16) & 31u);
+            if (local != curKey) { // a new element: its replicas start from clean running deltas
+                curKey = local;
+                curStep = 0xffffffffu;
+                dsum[0] = dsum[1] = dsum[2] = 0u;
+            }
+            if (fstep != curStep) { // operand masks belong to one MAC
+                curStep = fstep;
+                am[0] = am[1] = am[2] = bm[0] = bm[1] = bm[2] = 0u;
+            }
+            const uint32_t *fr = f + frow * G::N, *sc = s + fcol;
+            const uint32_t dprev = frep == 0u ? dsum[0] : frep == 1u ? dsum[1] : dsum[2];
+            uint32_t delta = 0u;
+            if (fsite == (uint32_t)SITE_MM_ACC) {
+                const uint32_t kEnd = fstep < (uint32_t)G::N ? fstep : (uint32_t)G::N;
+                uint32_t part = 0u; // this replica's accumulator before the MAC of k == step (step >= n: after the loop)
+                for (uint32_t k = (uint32_t)lane; k < kEnd; k += 64u)
+                    part += fr[k] * sc[k * G::N];
+                const uint32_t pfx = __builtin_amdgcn_readfirstlane(wave_sum(part)) + dprev;
+                delta = (pfx ^ m) - pfx;
+            } else if (fstep < (uint32_t)G::N) {
+                const uint32_t a = __builtin_amdgcn_readfirstlane(fr[fstep]), bq = __builtin_amdgcn_readfirstlane(sc[fstep * G::N]);
+                const uint32_t ma = frep == 0u ? am[0] : frep == 1u ? am[1] : am[2];
+                const uint32_t mb = frep == 0u ? bm[0] : frep == 1u ? bm[1] : bm[2];
+                const uint32_t ma2 = fsite == (uint32_t)SITE_MM_OPA ? ma ^ m : ma, mb2 = fsite == (uint32_t)SITE_MM_OPB ? mb ^ m : mb;
+                delta = (a ^ ma2) * (bq ^ mb2) - (a ^ ma) * (bq ^ mb);
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+                    if (frep == (uint32_t)rr) {
+                        am[rr] = ma2;
+                        bm[rr] = mb2;
+                    }
+            } else {
+                continue; // an operand of a MAC that never runs
+            }
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+                if (frep == (uint32_t)rr)
+                    dsum[rr] += delta;
+            // the replica's register: panel row -> (rb, lane group, i), column -> lane, replica -> block
+            const int r16 = frow & 15;
+            const bool mineLane = lane == (r16 >> 2) * 16 + (fcol - col0);
+#pragma unroll
+            for (int rb = 0; rb < G::NRB; ++rb)
+#pragma unroll
+                for (int rr = 0; rr < NREP; ++rr)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[rb][rr][0][i] += (int)((mineLane && frep == (uint32_t)rr && (frow >> 4) == rb && (r16 & 3) == i) ? delta : 0u);
+        }
+        return true;
+    };
+
+    // ---- one pipeline step = the 120 MFMAs of slab `it` (buffer it & 1), hand-scheduled as one basic block, order: row block,
+    // replica, A plane, B plane (consecutive MFMAs never share an accumulator).  Operand registers are recycled inside the step:
+    //   a[rb]  is dead after the row block's 30 MFMAs: the NEXT slab's fragments are read into it right then (a[3]: at the start
+    //          of the next step -- first needed at its slot 90)
+    //   b[0], b[1] are dead after slots 99 / 109 (their last use is in row block 3): re-read from the other buffer, which the
+    //          conversion stages finished filling at slot 76; b[2] at the start of the next step (first needed at its slot 20)
+    // Behind the MFMAs: the 20 conversion stages of slab it + 1 (every fourth slot), and the eight loads of slab it + 2 as soon
+    // as a staging round's registers are free (after stage 9 / stage 19).
+    v4i_t a[G::NRB][4], b[NREP][4];
+    auto loadA = [&](int rb, const uint8_t *pA) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            a[rb][p] = *reinterpret_cast<const v4i_t *>(pA + p * G::PLANE_A + rb * 16 * G::N);
+    };
+    auto loadB = [&](int rr, const uint8_t *buf) __attribute__((always_inline)) {
+        int offR = bOff;
+        asm volatile("" : "+v"(offR)); // opaque copy of the offset: each replica block issues its own operand loads
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            b[rr][p] = *reinterpret_cast<const v4i_t *>(buf + offR + p * G::PLANE_B);
+    };
+    {
+        const uint8_t *pA = smemP + aOff; // slab 0
+        loadA(0, pA);
+        loadA(1, pA);
+        loadA(2, pA);
+        loadB(0, wbuf);
+        loadB(1, wbuf);
+    }
+    auto step = [&](int it, auto firstTag) __attribute__((always_inline)) {
+        constexpr int FIRST = decltype(firstTag)::value; // 0 running slab; 1 first slab of a tile; 2 first slab, limb-0 sums hold the hook's deltas
+        const int soffLoad = slabOff(it + 2); // past the end: the buffer resource returns zeros, never consumed
+        const uint8_t *pA = smemP + (aOff ^ ((it % G::NSLAB) * 64));
+        const uint8_t *pAnext = smemP + (aOff ^ (((it + 1) % G::NSLAB) * 64));
+        const uint8_t *bufCur = wbuf + (it & 1) * G::B_BUF;
+        uint8_t *bufNext = wbuf + ((it + 1) & 1) * G::B_BUF;
+        loadB(2, bufCur);
+        loadA(3, pA);
+        __builtin_amdgcn_sched_barrier(0);
+
+        uint32_t y[4], t[4], w[4];
+        auto convStage = [&](int k) __attribute__((always_inline)) {
+            const int u = k / 10, h = (k / 5) % 2, sub = k % 5;
+            if (sub == 0) {
+                y[0] = mm_digits(rawWord(pbs[u][0], h));
+                y[1] = mm_digits(rawWord(pbs[u][1], h));
+            } else if (sub == 1) {
+                y[2] = mm_digits(rawWord(pbs[u][2], h));
+                y[3] = mm_digits(rawWord(pbs[u][3], h));
+            } else if (sub == 2) {
+                t[0] = __builtin_amdgcn_perm(y[1], y[0], 0x05010400u);
+                t[1] = __builtin_amdgcn_perm(y[1], y[0], 0x07030602u);
+                t[2] = __builtin_amdgcn_perm(y[3], y[2], 0x05010400u);
+                t[3] = __builtin_amdgcn_perm(y[3], y[2], 0x07030602u);
+            } else if (sub == 3) {
+                w[0] = __builtin_amdgcn_perm(t[2], t[0], 0x05040100u);
+                w[1] = __builtin_amdgcn_perm(t[2], t[0], 0x07060302u);
+                w[2] = __builtin_amdgcn_perm(t[3], t[1], 0x05040100u);
+                w[3] = __builtin_amdgcn_perm(t[3], t[1], 0x07060302u);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<uint32_t *>(bufNext + q * G::PLANE_B + dstB[u][h]) = w[q];
+            }
+        };
+        const v4i_t zero = {0, 0, 0, 0};
+        int m = 0;
+#pragma unroll
+        for (int rb = 0; rb < G::NRB; ++rb)
+#pragma unroll
+            for (int rr = 0; rr < NREP; ++rr)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int qq = 0; qq + p < 4; ++qq) {
+                        const int q = 3 - p - qq;
+                        acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                            a[rb][p], b[rr][q], (FIRST != 0 && p == 0 && !(FIRST == 2 && q == 0)) ? zero : acc[rb][rr][p + q], 0, 0, 0);
+                        if ((m & 3) == 0 && m < 80)
+                            convStage(m / 4);
+                        if (m == 29 || m == 59 || m == 89) // a[rb] of the next slab: this row block is through
+                            loadA(m / 30, pAnext);
+                        if ((m & 3) == 1 && m >= 41 && m < 57) // staging round 0's registers are free after stage 9 (slot 36)
+                            pbs[0][(m - 41) / 4] =
+                                __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[0] + ((m - 41) / 4) * G::N * 4, soffLoad, 0);
+                        if ((m & 3) == 1 && m >= 81 && m < 97) // staging round 1: free after stage 19 (slot 76)
+                            pbs[1][(m - 81) / 4] =
+                                __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[1] + ((m - 81) / 4) * G::N * 4, soffLoad, 0);
+                        if (m == 99) {
+                            wave_lds_sync(); // the other buffer is complete (stage 19 stored at slot 76)
+                            loadB(0, bufNext);
+                        }
+                        if (m == 109)
+                            loadB(1, bufNext);
+                        ++m;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+    };
+
+#pragma unroll 1
+    for (int it0 = 0; it0 < nIt; it0 += G::NSLAB) {
+        if (fCount != 0u && tileHook(it0))
+            step(it0, std::integral_constant<int, 2>{});
+        else
+            step(it0, std::integral_constant<int, 1>{});
+        step(it0 + 1, std::integral_constant<int, 0>{});
+        step(it0 + 2, std::integral_constant<int, 0>{});
+        step(it0 + 3, std::integral_constant<int, 0>{});
+        tileEnd(it0 + G::NSLAB - 1);
+    }
+
+    __syncthreads();
+    uint32_t *sCnt = reinterpret_cast<uint32_t *>(smemP + G::A_PANEL);
+    if (tid < 4)
+        sCnt[tid] = 0;
+    __syncthreads();
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, lb);
+}
+
+} // namespace coast

@@ -122,6 +122,113 @@ template <int FLAGS> static void run_stepY(int *dD, const uint2 *g, int cus)
            ms * 1e6 / iters, mf * 65536 / (ms * 1e-3) * 1e-12, hipGetErrorString(err));
 }
 
+// (3) the same questions for v_mfma_i32_16x16x64_i8 (half the MACs per instruction, a quarter of the accumulator registers per
+// output block): pure rate, and a mock of a "replicas in register blocks" step -- wave tile 64 rows x 16 logical columns x 3
+// replicas = 4 x 3 x 4 limb sums of 4 registers (192), 64-deep k slab: 120 MFMAs, 16 A + 12 B fragment reads, the conversion of
+// a 16-column x 64-k slab (FLAGS as above).
+typedef int v4acc __attribute__((ext_vector_type(4)));
+template <int NACC, bool RND> __global__ __launch_bounds__(256, 1) void rate16(int *out, int iters)
+{
+    uint32_t s = threadIdx.x * 2654435761u + blockIdx.x * 97u + 1u;
+    v4i a[4], b[4];
+    for (int p = 0; p < 4; ++p) {
+        a[p] = RND ? (v4i){(int)rnd(s), (int)rnd(s), (int)rnd(s), (int)rnd(s)} : (v4i){1, 2, 3, 4};
+        b[p] = RND ? (v4i){(int)rnd(s), (int)rnd(s), (int)rnd(s), (int)rnd(s)} : (v4i){5, 6, 7, 8};
+    }
+    v4acc c[NACC];
+    for (int t = 0; t < NACC; ++t) c[t] = (v4acc){0};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int t = 0; t < NACC; ++t)
+            c[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t & 3], b[(t >> 2) & 3], c[t], 0, 0, 0);
+    }
+    int r = 0;
+    for (int t = 0; t < NACC; ++t) for (int e = 0; e < 4; ++e) r += c[t][e];
+    if (r == 0x12345678) out[threadIdx.x] = r;
+}
+template <int NACC, bool RND> static void run_rate16(int *dD, int cus)
+{
+    const int iters = 40000 / NACC * 4, blocks = cus;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((rate16<NACC, RND>), dim3(blocks), dim3(256), 0, 0, dD, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0); hipLaunchKernelGGL((rate16<NACC, RND>), dim3(blocks), dim3(256), 0, 0, dD, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double mf = (double)blocks * 4 * iters * NACC;
+    printf("rate16x16x64 acc=%2d %s waves/SIMD=1: %.3f ms  %.0f TOPS\n", NACC, RND ? "random" : "const ", ms, mf * 32768 / (ms * 1e-3) * 1e-12);
+}
+template <int FLAGS> __global__ __launch_bounds__(256, 1) void stepZ(int *out, const uint2 *g, int iters)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t s = threadIdx.x * 2654435761u + blockIdx.x * 97u + 1u;
+    for (int i = threadIdx.x; i < 36864; i += 256) reinterpret_cast<uint32_t *>(lds)[i] = rnd(s);
+    __syncthreads();
+    v4i a[4][4], b[3][4]; // [row block][plane], [replica][plane]
+    for (int k = 0; k < 4; ++k) for (int p = 0; p < 4; ++p)
+        a[k][p] = (v4i){(int)rnd(s), (int)rnd(s), (int)rnd(s), (int)rnd(s)};
+    for (int k = 0; k < 3; ++k) for (int p = 0; p < 4; ++p)
+        b[k][p] = (v4i){(int)rnd(s), (int)rnd(s), (int)rnd(s), (int)rnd(s)};
+    v4acc c[48];
+    for (int t = 0; t < 48; ++t) c[t] = (v4acc){0};
+    uint32_t x[8];
+    for (int t = 0; t < 8; ++t) x[t] = rnd(s);
+    uint2 gl[8] = {};
+    const unsigned char *pa = lds + (lane & 15) * 64 + (lane >> 4) * 16;
+    unsigned char *pw = lds + 131072 + wave * 4096 + lane * 4;
+    auto body = [&](int i) __attribute__((always_inline)) {
+        int m = 0;
+        // order: row block, A plane, replica, B plane; operands of a (row block, replica) pair are re-read right after its last use
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int q = 0; q + p < 4; ++q) {
+                        c[(rb * 3 + rr) * 4 + p + q] =
+                            __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rb][p], b[rr][q], c[(rb * 3 + rr) * 4 + p + q], 0, 0, 0);
+                        if ((FLAGS & 1) && m % 4 == 3 && m / 4 < 28) { // 16 A + 12 B fragment reads per step, spread
+                            const int k = m / 4;
+                            if (k < 16)
+                                a[(k / 4 + 3) & 3][k & 3] = *reinterpret_cast<const v4i *>(pa + (k & 3) * 16384 + ((i + 1) & 3) * 4096 + (k / 4) * 1024);
+                            else
+                                b[(k - 16) / 4][(k - 16) & 3] = *reinterpret_cast<const v4i *>(pa + 65536 + ((k - 16) & 3) * 1024 + ((i + 1) & 1) * 4096);
+                        }
+                        if ((FLAGS & 2) && m < 80) { // 80 conversion VALU: 16 words per lane x (2 digit ops + 2 perms) + address
+                            x[m % 8] = __builtin_amdgcn_perm(x[m % 8], x[(m + 3) % 8] + gl[m % 8].x, 0x05010400u);
+                        }
+                        if ((FLAGS & 4) && m % 4 == 1 && m < 64)
+                            *reinterpret_cast<uint32_t *>(pw + (m / 4) * 256 + ((i + 1) & 1) * 8192) = x[m % 8];
+                        if ((FLAGS & 8) && m >= 90 && m < 98)
+                            gl[m - 90] = g[(size_t)((i * 8 + (m - 90)) & 1023) * 4096 + blockIdx.x * 64 + lane];
+                        ++m;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+    };
+    for (int i = 0; i < iters; ++i)
+        body(i);
+    int r = 0;
+    for (int t = 0; t < 48; ++t) for (int e = 0; e < 4; ++e) r += c[t][e];
+    for (int t = 0; t < 8; ++t) r += (int)x[t];
+    if (r == 0x12345678) out[threadIdx.x] = r;
+}
+template <int FLAGS> static void run_stepZ(int *dD, const uint2 *g, int cus)
+{
+    const int iters = 2000, blocks = cus;
+    hipFuncSetAttribute((const void *)stepZ<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(stepZ<FLAGS>, dim3(blocks), dim3(256), 160 * 1024, 0, dD, g, 10);
+    hipDeviceSynchronize();
+    hipError_t err = hipGetLastError();
+    hipEventRecord(e0); hipLaunchKernelGGL(stepZ<FLAGS>, dim3(blocks), dim3(256), 160 * 1024, 0, dD, g, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double mf = (double)blocks * 4 * iters * 120;
+    printf("stepZ flags=%2d (16x16x64, 120 MFMAs = 60 big ones per step) 1 wave/SIMD: %.1f ns per step, %.0f TOPS  [%s]\n", FLAGS,
+           ms * 1e6 / iters, mf * 32768 / (ms * 1e-3) * 1e-12, hipGetErrorString(err));
+}
+
 int main()
 {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
@@ -130,6 +237,8 @@ int main()
     run_rate<4, false, 1>(dD, cus); run_rate<4, true, 1>(dD, cus); run_rate<8, true, 1>(dD, cus); run_rate<16, true, 1>(dD, cus);
     run_rate<4, false, 2>(dD, cus); run_rate<4, true, 2>(dD, cus); run_rate<8, true, 2>(dD, cus);
     uint2 *g; hipMalloc(&g, (size_t)1024 * 4096 * 8 + 65536 * 8); hipMemset(g, 0x5a, (size_t)1024 * 4096 * 8);
+    run_rate16<16, false>(dD, cus); run_rate16<16, true>(dD, cus); run_rate16<48, true>(dD, cus);
+    run_stepZ<0>(dD, g, cus); run_stepZ<1>(dD, g, cus); run_stepZ<3>(dD, g, cus); run_stepZ<7>(dD, g, cus); run_stepZ<15>(dD, g, cus);
     run_stepY<0>(dD, g, cus); run_stepY<1>(dD, g, cus); run_stepY<3>(dD, g, cus); run_stepY<7>(dD, g, cus); run_stepY<15>(dD, g, cus);
     return 0;
 }
