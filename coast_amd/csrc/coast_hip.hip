@@ -708,8 +708,8 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
             FaultTab ftm = ft;                                                                                  \
             if (!have)                                                                                          \
                 ftm.list = nullptr, ftm.range = nullptr;                                                        \
-            hipLaunchKernelGGL(mm_mfma_blk_kernel<3>, dim3((uint32_t)nbm), dim3(GB::NTHR), GB::LDS_BYTES,       \
-                               c->stream, d_f, d_s, d_r, (uint32_t)nbm, ctr, ftm, d_detected);                  \
+            hipLaunchKernelGGL(mm_mfma_blk_kernel<3>, dim3((uint32_t)batch), dim3(GB::NTHR), GB::LDS_BYTES,     \
+                               c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);                \
             engine = COAST_ENGINE_MATRIX_CORE;                                                                  \
             fastBlocks = nbm;                                                                                   \
             break;                                                                                              \

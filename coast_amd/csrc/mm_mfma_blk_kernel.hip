@@ -1,19 +1,24 @@
 // mm_mfma_blk_kernel.hip -- side-256 protected matrix_multiply on the matrix cores, replicas in REGISTER BLOCKS (TMR).
 //
 // Same arithmetic as mm_mfma_kernel.hip (signed-byte limb decomposition: ten int8 MFMAs per limb pair set, accumulated exactly
-// in int32) and the same workgroup geometry (64 rows of one matrix per workgroup, the rows' byte planes resident in LDS).  What
-// changes is where the replicas of an output element live.  There: NREP adjacent LANES of one accumulator register -- a wave
-// tile is 32 lane-columns = 10 logical columns for TMR, two lane-columns idle, 26 tiles for 256 columns (the last one 60 %
-// empty), dealt 7 / 7 / 6 / 6 to the four waves.  Here: the SAME lane of NREP accumulator blocks -- replica r of r[i][j] is
-// accumulator block r, fed by its own B-operand registers (read from the single LDS copy once per replica: the load is part of
-// the replicated computation, the memory is not) and accumulated by its own MFMAs:
-//     * no idle lane-columns and no ragged last tile: 16 tiles of 16 logical columns per panel, four per wave
+// in int32).  What changes is where the replicas of an output element live.  There: NREP adjacent LANES of one accumulator
+// register -- a wave tile is 32 lane-columns = 10 logical columns for TMR, two lane-columns idle, 26 tiles for 256 columns (the
+// last one 60 % empty), dealt 7 / 7 / 6 / 6 to the four waves.  Here: the SAME lane of NREP accumulator blocks -- replica r of
+// r[i][j] is accumulator block r, fed by its own B-operand registers (read from the single LDS copy once per replica: the load
+// is part of the replicated computation, the memory is not) and accumulated by its own MFMAs:
+//     * no idle lane-columns and no ragged last tile: 16 tiles of 16 logical columns per 64-row panel, four per wave
 //     * the s slab a wave converts (16 columns x 64 k) keeps all 64 conversion lanes busy (40 there) and feeds 120 MFMAs
 //     * the voter compares registers of one lane: no cross-lane traffic; the voted tile is stored straight from the registers
 // Three replicas x four limb sums of a 64-row tile only fit the register file with v_mfma_i32_16x16x64_i8 (4 accumulator
-// registers per 16 x 16 block: 4 row blocks x 3 x 4 x 4 = 192) and one wave per SIMD; the wave hides latencies by its own
-// instruction order -- every operand register is re-read right after its last use in the step, tens of MFMAs before its next.
-// tools/mfma_probe2.hip (stepZ) measured this step shape before the kernel was written: 2.7-2.9 POP/s executed, all of it
+// registers per 16 x 16 block: 4 row blocks x 3 x 4 x 4 = 192) and one wave per SIMD.  With nobody else on the SIMD the wave has
+// to hide every latency by its own instruction order:
+//     * every operand register is re-read right after its last use in the step, tens of MFMAs before its next
+//     * a workgroup owns a whole MATRIX (four 64-row panels, one after the other): the next panel's rows of f are fetched and
+//       converted into a second LDS panel buffer in the background of the current panel's steps (one 16-byte piece per thread
+//       and step), so the load -> convert -> barrier prologue is paid once per matrix, not once per panel
+//     * the vote and the stores of a tile's row blocks 0..2 run behind the MFMAs of the tile's last step (a row block's sums are
+//       final 30 MFMAs before the next one's); only row block 3 is left for after the step
+// tools/mfma_probe2.hip (stepZ) measured the step shape before the kernel was written: 2.7-2.9 POP/s executed, all of it
 // useful, against 2.12 executed / 1.97 useful for the lane-replica kernel.
 //
 // Injector hooks: everything downstream of an upset is linear mod 2^32, so its exact consequence on the replica's recombined
@@ -21,23 +26,34 @@
 // replica's limb-0 accumulator BEFORE the tile's first MFMA (the only point where control flow does not fight 192 live
 // accumulators for registers), the matrix core adds the products on top, and the voter sees the upset word.
 #include <type_traits>
+#include <utility>
 
 #include "xmr.hpp"
 
 namespace coast {
 
+// f(integral_constant<int, 0>), f(<1>), ...: a loop whose index is a constant in every iteration's own instantiation (the step's
+// 120 slots are too big for `#pragma unroll` to take -- its cost estimate runs before the slot tests fold away)
+template <class Fn, int... Is> __device__ __forceinline__ void for_each_index(std::integer_sequence<int, Is...>, Fn &&fn)
+{
+    (fn(std::integral_constant<int, Is>{}), ...);
+}
+
 template <int NREP> struct MmBlk {
     static constexpr int N = 256, KS = 64, NSLAB = N / KS; // 64-deep k slabs: four steps per tile
     static constexpr int CT = 16;                 // logical columns per wave tile
     static constexpr int NW = 4, NTHR = 64 * NW;  // one wave per SIMD
-    static constexpr int BM = 64, BPM = N / BM, NRB = BM / 16;
+    static constexpr int BM = 64, NPANEL = N / BM, NRB = BM / 16;
     static constexpr int NCT = N / CT;            // 16 column tiles per panel, tile t -> wave t % NW
-    static constexpr int PLANE_A = BM * N, A_PANEL = 4 * PLANE_A;
-    static constexpr int PLANE_B = CT * KS, B_BUF = 4 * PLANE_B; // plane[q][column][64 B]: 4 KB per slab
+    static constexpr int TPW = NCT / NW;          // tiles per wave and panel
+    static constexpr int SPP = TPW * NSLAB;       // steps per panel (16)
+    static constexpr int PLANE_A = BM * N, A_PANEL = 4 * PLANE_A; // 64 KB, two of them
+    static constexpr int PLANE_B = CT * KS, B_BUF = 4 * PLANE_B;  // plane[q][column][64 B]: 4 KB per slab
     static constexpr int WAVE_LDS = 2 * B_BUF;    // double buffer
-    static constexpr size_t LDS_BYTES = (size_t)A_PANEL + NW * WAVE_LDS; // 96 KB
-    static constexpr int A_PER_THR = (BM * (N / 4)) / NTHR; // uint4 (four k of one row) of the panel per thread
+    static constexpr size_t LDS_BYTES = (size_t)2 * A_PANEL + NW * WAVE_LDS; // 160 KB: the whole CU
+    static constexpr int A_PER_THR = (BM * (N / 4)) / NTHR; // uint4 (four k of one row) of a panel per thread = SPP
     static constexpr int B_ROUNDS = 2;            // staging: lane -> (column pair l % 8, k-quad l / 8 + 8 * round)
+    static_assert(A_PER_THR == SPP, "one background piece of the next panel per step");
 };
 
 template <int NREP>
@@ -52,49 +68,53 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, kg = lane >> 4; // operand row / column inside a 16-block, 16-byte k group of the slab
-    uint8_t *const wbuf = smemP + G::A_PANEL + wave * G::WAVE_LDS;
+    uint8_t *const wbuf = smemP + 2 * G::A_PANEL + wave * G::WAVE_LDS;
 
-    const uint32_t lb = xcd_logical_block(blockIdx.x, nblocks);
-    const uint32_t mat = lb / (uint32_t)G::BPM;
-    const int row0 = (int)(lb - mat * (uint32_t)G::BPM) * G::BM;
+    const uint32_t mat = xcd_logical_block(blockIdx.x, nblocks); // one workgroup per matrix
     constexpr size_t nn = (size_t)G::N * G::N;
-    const uint32_t *f = F + mat * nn + (size_t)row0 * G::N;
+    const uint32_t *f = F + mat * nn;
     const uint32_t *s = S + mat * nn;
-    uint32_t *r = R + mat * nn + (size_t)row0 * G::N;
+    uint32_t *r = R + mat * nn;
+    const __amdgpu_buffer_rsrc_t rsF =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(f), 0, (int)(nn * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(s), 0, (int)(nn * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(r, 0, (int)(nn * 4), 0x00020000);
+    const int voffR = ((4 * ((tid & 63) >> 4)) * G::N + (tid & 15)) * 4; // C/D layout: lane -> column lane % 16, rows 4 (lane / 16) + i
 
-    // ---- the f panel: plane[p][row][256 B], the row's sixteen 16-byte slots (slot = k / 16) at slot ^ (row & 15) -- the layout of
-    // mm_mfma_panel_kernel; a 16x16x64 fragment read (lane = row & 15, k group) finds its 16 lanes' slots in 16 different banks
+    // ---- f panels: plane[p][row][256 B], the row's sixteen 16-byte slots (slot = k / 16) at slot ^ (row & 15) -- the layout of
+    // mm_mfma_panel_kernel; a 16x16x64 fragment read (lane = row & 15, k group) finds its 16 lanes' slots in 16 different banks.
+    // Piece j of a panel for thread t: row 4 j + t / 64, k-quad t % 64.  Panel 0 is converted here, panels 1..3 in the background.
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const int voffF = ((tid >> 6) * G::N + 4 * (tid & 63)) * 4;
+    auto panelDst = [&](int j) __attribute__((always_inline)) {
+        const int row = 4 * j + (tid >> 6), kq = tid & 63;
+        return row * G::N + (((kq >> 2) ^ (row & 15)) * 16) + (kq & 3) * 4;
+    };
     {
-        uint4 pa[G::A_PER_THR];
+        u32x4_t pa[G::A_PER_THR];
+#pragma unroll
+        for (int u = 0; u < G::A_PER_THR; ++u)
+            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffF, u * 4 * G::N * 4, 0);
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u) {
-            const int i = tid + G::NTHR * u;
-            pa[u] = *reinterpret_cast<const uint4 *>(f + (uint32_t)((i >> 6) * G::N + 4 * (i & 63)));
-        }
-#pragma unroll
-        for (int u = 0; u < G::A_PER_THR; ++u) {
-            const int i = tid + G::NTHR * u;
-            const int row = i >> 6, kq = i & 63;
-            const uint32_t y[4] = {mm_digits(pa[u].x), mm_digits(pa[u].y), mm_digits(pa[u].z), mm_digits(pa[u].w)};
+            const uint32_t y[4] = {mm_digits(pa[u][0]), mm_digits(pa[u][1]), mm_digits(pa[u][2]), mm_digits(pa[u][3])};
             uint32_t w[4];
             mm_transpose4(y, w);
-            const int dst = row * G::N + (((kq >> 2) ^ (row & 15)) * 16) + (kq & 3) * 4;
+            const int dst = panelDst(u);
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 *reinterpret_cast<uint32_t *>(smemP + p * G::PLANE_A + dst) = w[p];
         }
     }
+    // background piece in flight: piece (g + 1) % 16 of panel (g + 1) / 16 + 1 is loaded during step g and converted during step
+    // g + 1; past the matrix the buffer resource returns zeros (the last panel's "next panel" is never read)
+    auto bgOff = [&](int g) __attribute__((always_inline)) { return (((g >> 4) + 1) * G::BM + 4 * (g & 15)) * G::N * 4; };
+    u32x4_t bgRaw = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffF, bgOff(0), 0);
 
-    uint32_t fFirst = 0, fCount = 0;
-    if (ft.range) {
-        const uint2 rg = ft.range[lb];
-        fFirst = __builtin_amdgcn_readfirstlane(rg.x);
-        fCount = __builtin_amdgcn_readfirstlane(rg.y);
-    }
-
-    // ---- this wave's work: column tiles wave, wave + NW, ...; one pipeline step = one 64-deep k slab of one tile
-    constexpr int nTiles = G::NCT / G::NW, nIt = nTiles * G::NSLAB;
-    auto tileCol0 = [&](int it) __attribute__((always_inline)) { return (wave + G::NW * (it / G::NSLAB)) * G::CT; };
+    // ---- this wave's work: per panel the column tiles wave, wave + NW, ...; one pipeline step = one 64-deep k slab of one tile;
+    // g = step number inside the matrix (0 .. 63): panel g / 16, tile (g / 4) % 4, slab g % 4
+    auto tileCol0 = [&](int g) __attribute__((always_inline)) { return (wave + G::NW * ((g >> 2) & 3)) * G::CT; };
 
     // s staging: one conversion item = four consecutive k of one column -> one word in each of the four planes; a lane owns the two
     // columns of a pair, lane -> (pair l % 8, k-quad l / 8 + 8 * round): a dwordx2 load instruction fetches eight full tile rows
@@ -102,8 +122,6 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     // spreads both the fragment reads (lane = column, k group) and the conversion stores over the banks; odd pairs store their
     // two columns in the opposite order so that one store instruction covers both column parities.
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-    const __amdgpu_buffer_rsrc_t rsS =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(s), 0, (int)(nn * 4), 0x00020000);
     int voffB[G::B_ROUNDS], dstB[G::B_ROUNDS][2];
     const bool swapB = (lane & 1) != 0; // pair = lane % 8
 #pragma unroll
@@ -116,7 +134,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
             dstB[u][h] = ch * G::KS + (((kq >> 2) ^ ((0 - (ch >> 2)) & 3)) * 16) + (kq & 3) * 4;
         }
     }
-    auto slabOff = [&](int it) __attribute__((always_inline)) { return ((it % G::NSLAB) * G::KS * G::N + tileCol0(it)) * 4; };
+    auto slabOff = [&](int g) __attribute__((always_inline)) { return ((g & 3) * G::KS * G::N + tileCol0(g)) * 4; };
     auto rawWord = [&](const u32x2_t &v, int h) __attribute__((always_inline)) {
         return h == 0 ? (swapB ? v[1] : v[0]) : (swapB ? v[0] : v[1]);
     };
@@ -124,6 +142,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     // fragment addresses: A row block rb, plane p, slab sl: (aOff ^ (sl * 64)) + rb * 16 * N + p * PLANE_A   (slot 4 sl + kg, swizzled)
     const int aOff = l16 * G::N + ((kg ^ l16) * 16);
     const int bOff = l16 * G::KS + ((kg ^ ((0 - (l16 >> 2)) & 3)) * 16);
+    auto panelA = [&](int g) __attribute__((always_inline)) { return smemP + ((g >> 4) & 1) * G::A_PANEL + (aOff ^ ((g & 3) * 64)); };
 
     Tally tl;
     uint32_t detItems = 0;
@@ -157,43 +176,44 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
             for (int kk = 0; kk < 4; ++kk)
                 pbs[u][kk] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[u] + kk * G::N * 4, so1, 0);
     }
-    __syncthreads(); // the panel (and this wave's slab 0) is complete; the waves do not meet again until the counters
+    __syncthreads(); // panel 0 (and this wave's slab 0) is complete
 
-    // ---- tile end: recombine the limb sums, vote in-lane, store straight from the registers.  BRANCH-FREE while accumulators are
-    // alive (control flow here makes the register allocator spill accumulator tuples inside the main loop): the compare-and-select
-    // voter runs on every element, the out-voted elements are collected in a lane mask, and the per-item flags are written from
-    // that mask after the last accumulator is dead.  C/D layout of 16x16 blocks: lane -> column lane % 16, rows 4 (lane / 16) + i.
-    auto tileEnd = [&](int it) __attribute__((always_inline)) {
-        const int col = tileCol0(it) + l16;
-        uint32_t missMask = 0u; // bit rb * 4 + i: the copies of that element of this lane disagreed
-#pragma unroll
-        for (int rb = 0; rb < G::NRB; ++rb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t v[3];
-#pragma unroll
-                for (int rr = 0; rr < 3; ++rr) {
-                    const int rs = rr < NREP ? rr : NREP - 1;
-                    v[rr] = (uint32_t)acc[rb][rs][0][i] + ((uint32_t)acc[rb][rs][1][i] << 8) + ((uint32_t)acc[rb][rs][2][i] << 16) +
-                            ((uint32_t)acc[rb][rs][3][i] << 24);
-                }
-                const bool e01 = v[0] == v[1], e02 = v[0] == v[2];
-                const uint32_t voted = (NREP == 3 && !e01) ? v[2] : v[0]; // select(a == b, a, c); DWC keeps replica 0's
-                missMask |= ((e01 && e02) ? 0u : 1u) << (rb * 4 + i);
-                r[(uint32_t)((rb * 16 + 4 * kg + i) * G::N + col)] = voted;
-            }
+    // ---- tile end, BRANCH-FREE while accumulators are alive (control flow makes the register allocator spill accumulator tuples
+    // inside the main loop): the compare-and-select voter runs on every element, the out-voted elements are collected in a lane
+    // mask, the per-item flags are written from that mask once the accumulators are dead.  One element = five small stages so
+    // that they can sit behind MFMAs: recombine replica 0 / 1 / 2, vote, store.  C/D layout of 16x16 blocks: lane -> column
+    // lane % 16, rows 4 (lane / 16) + i.
+    uint32_t missMask = 0u, teV[3], teVoted = 0u;
+    auto teStage = [&](int g, auto rbTag, auto kTag) __attribute__((always_inline)) {
+        constexpr int rb = decltype(rbTag)::value, k = decltype(kTag)::value;
+        constexpr int i = k / 5, sub = k % 5;
+        if constexpr (sub < 3) {
+            constexpr int rs = sub < NREP ? sub : NREP - 1;
+            teV[sub] = (uint32_t)acc[rb][rs][0][i] + ((uint32_t)acc[rb][rs][1][i] << 8) + ((uint32_t)acc[rb][rs][2][i] << 16) +
+                       ((uint32_t)acc[rb][rs][3][i] << 24);
+        } else if constexpr (sub == 3) {
+            const bool e01 = teV[0] == teV[1], e02 = teV[0] == teV[2];
+            teVoted = (NREP == 3 && !e01) ? teV[2] : teV[0]; // select(a == b, a, c); DWC keeps replica 0's
+            missMask |= ((e01 && e02) ? 0u : 1u) << (rb * 4 + i);
+        } else {
+            // one per-lane offset for the whole kernel; the element's row / the tile's column are a scalar offset
+            __builtin_amdgcn_raw_buffer_store_b32(teVoted, rsR, voffR, (((g >> 4) * G::BM + rb * 16 + i) * G::N + tileCol0(g)) * 4, 0);
+        }
+    };
+    auto tileFlags = [&](int g) __attribute__((always_inline)) { // after the tile's last accumulator is dead
         tl.syncs += 16u;
         if (NREP == 3)
             tl.miss += (uint32_t)__builtin_popcount(missMask);
+        const int col = tileCol0(g) + l16;
 #pragma unroll 1
         while (missMask) { // per-item flags of the elements that were out-voted (TMR) / caught (DWC)
             const int idx = __builtin_ctz(missMask);
             missMask &= missMask - 1u;
-            const int orow = (idx >> 2) * 16 + 4 * kg + (idx & 3);
+            const int orow = (g >> 4) * G::BM + (idx >> 2) * 16 + 4 * kg + (idx & 3);
             if (NREP == 2)
                 detItems += 1;
             if (detected)
-                detected[mat * nn + (size_t)(row0 + orow) * G::N + col] = 1;
+                detected[mat * nn + (size_t)orow * G::N + col] = 1;
         }
     };
 
@@ -202,8 +222,9 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     //                        finished sum -- the flip of the register after the loop)
     //     OPA / OPB, step k: (a ^ ma')(b ^ mb') - (a ^ ma)(b ^ mb)       (masks of this MAC before / after this upset)
     // summed into the replica's limb-0 accumulator.  Returns whether this tile has any armed upset (wave-uniform).
-    auto tileHook = [&](int it) __attribute__((always_inline)) {
-        const int col0 = tileCol0(it);
+    uint32_t fFirst = 0, fCount = 0; // armed upsets of the current panel: {first, count} in the injector's table
+    auto tileHook = [&](int g) __attribute__((always_inline)) {
+        const int col0 = tileCol0(g), prow0 = (g >> 4) * G::BM;
         bool hooked = false;
 #pragma unroll 1
         for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
@@ -239,7 +260,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
                 curStep = fstep;
                 am[0] = am[1] = am[2] = bm[0] = bm[1] = bm[2] = 0u;
             }
-            const uint32_t *fr = f + frow * G::N, *sc = s + fcol;
+            const uint32_t *fr = f + (prow0 + frow) * G::N, *sc = s + fcol;
             const uint32_t dprev = frep == 0u ? dsum[0] : frep == 1u ? dsum[1] : dsum[2];
             uint32_t delta = 0u;
             if (fsite == (uint32_t)SITE_MM_ACC) {
@@ -282,21 +303,25 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
         return true;
     };
 
-    // ---- one pipeline step = the 120 MFMAs of slab `it` (buffer it & 1), hand-scheduled as one basic block, order: row block,
+    // ---- one pipeline step = the 120 MFMAs of slab `g` (buffer g & 1), hand-scheduled as one basic block, order: row block,
     // replica, A plane, B plane (consecutive MFMAs never share an accumulator).  Operand registers are recycled inside the step:
-    //   a[rb]  is dead after the row block's 30 MFMAs: the NEXT slab's fragments are read into it right then (a[3]: at the start
-    //          of the next step -- first needed at its slot 90)
+    //   a      two sets of four planes: row block rb uses set rb & 1 for its 30 MFMAs, and the set is re-read right behind them --
+    //          with row block rb + 2 of this slab, then with row block 0 / 1 of the next one (row block 0: not in a panel's last
+    //          step, the next panel is handed over at a barrier first; row block 1: at the start of the next step)
     //   b[0], b[1] are dead after slots 99 / 109 (their last use is in row block 3): re-read from the other buffer, which the
     //          conversion stages finished filling at slot 76; b[2] at the start of the next step (first needed at its slot 20)
-    // Behind the MFMAs: the 20 conversion stages of slab it + 1 (every fourth slot), and the eight loads of slab it + 2 as soon
-    // as a staging round's registers are free (after stage 9 / stage 19).
-    v4i_t a[G::NRB][4], b[NREP][4];
-    auto loadA = [&](int rb, const uint8_t *pA) __attribute__((always_inline)) {
+    // Behind the MFMAs: the 20 conversion stages of slab g + 1 (every fourth slot up to 76), the eight loads of slab g + 2 as
+    // soon as a staging round's registers are free (after stage 9 / stage 19), the background piece of the next f panel (five
+    // stages from slot 82), and in a tile's last step the tile end of row blocks 0 .. 2.
+    v4i_t a[2][4], b[NREP][4]; // row block rb's A fragments live in set rb & 1
+    auto loadA = [&](auto rbTag, const uint8_t *pA) __attribute__((always_inline)) {
+        constexpr int rb = decltype(rbTag)::value;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            a[rb][p] = *reinterpret_cast<const v4i_t *>(pA + p * G::PLANE_A + rb * 16 * G::N);
+            a[rb & 1][p] = *reinterpret_cast<const v4i_t *>(pA + p * G::PLANE_A + rb * 16 * G::N);
     };
-    auto loadB = [&](int rr, const uint8_t *buf) __attribute__((always_inline)) {
+    auto loadB = [&](auto rrTag, const uint8_t *buf) __attribute__((always_inline)) {
+        constexpr int rr = decltype(rrTag)::value;
         int offR = bOff;
         asm volatile("" : "+v"(offR)); // opaque copy of the offset: each replica block issues its own operand loads
 #pragma unroll
@@ -304,101 +329,152 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
             b[rr][p] = *reinterpret_cast<const v4i_t *>(buf + offR + p * G::PLANE_B);
     };
     {
-        const uint8_t *pA = smemP + aOff; // slab 0
-        loadA(0, pA);
-        loadA(1, pA);
-        loadA(2, pA);
-        loadB(0, wbuf);
-        loadB(1, wbuf);
+        loadA(std::integral_constant<int, 0>{}, panelA(0));
+        loadB(std::integral_constant<int, 0>{}, wbuf);
+        loadB(std::integral_constant<int, 1>{}, wbuf);
     }
-    auto step = [&](int it, auto firstTag) __attribute__((always_inline)) {
+    auto step = [&](int g, auto firstTag, auto lastTag) __attribute__((always_inline)) {
         constexpr int FIRST = decltype(firstTag)::value; // 0 running slab; 1 first slab of a tile; 2 first slab, limb-0 sums hold the hook's deltas
-        const int soffLoad = slabOff(it + 2); // past the end: the buffer resource returns zeros, never consumed
-        const uint8_t *pA = smemP + (aOff ^ ((it % G::NSLAB) * 64));
-        const uint8_t *pAnext = smemP + (aOff ^ (((it + 1) % G::NSLAB) * 64));
-        const uint8_t *bufCur = wbuf + (it & 1) * G::B_BUF;
-        uint8_t *bufNext = wbuf + ((it + 1) & 1) * G::B_BUF;
-        loadB(2, bufCur);
-        loadA(3, pA);
+        constexpr int LAST = decltype(lastTag)::value;   // 0; 1 last slab of a tile; 2 last slab of a panel's last tile
+        const int soffLoad = slabOff(g + 2);
+        const uint8_t *pA = panelA(g);
+        const uint8_t *pAnext = panelA(g + 1);
+        const uint8_t *bufCur = wbuf + (g & 1) * G::B_BUF;
+        uint8_t *bufNext = wbuf + ((g + 1) & 1) * G::B_BUF;
+        uint8_t *bgDst = smemP + (((g >> 4) + 1) & 1) * G::A_PANEL + panelDst(g & 15);
+        const int bgNext = bgOff(g + 1);
+        loadB(std::integral_constant<int, 2>{}, bufCur);
+        loadA(std::integral_constant<int, 1>{}, pA); // set 1 is free since the previous step's last slot; first needed at slot 30
         __builtin_amdgcn_sched_barrier(0);
 
-        uint32_t y[4], t[4], w[4];
-        auto convStage = [&](int k) __attribute__((always_inline)) {
-            const int u = k / 10, h = (k / 5) % 2, sub = k % 5;
-            if (sub == 0) {
-                y[0] = mm_digits(rawWord(pbs[u][0], h));
-                y[1] = mm_digits(rawWord(pbs[u][1], h));
-            } else if (sub == 1) {
-                y[2] = mm_digits(rawWord(pbs[u][2], h));
-                y[3] = mm_digits(rawWord(pbs[u][3], h));
-            } else if (sub == 2) {
-                t[0] = __builtin_amdgcn_perm(y[1], y[0], 0x05010400u);
-                t[1] = __builtin_amdgcn_perm(y[1], y[0], 0x07030602u);
-                t[2] = __builtin_amdgcn_perm(y[3], y[2], 0x05010400u);
-                t[3] = __builtin_amdgcn_perm(y[3], y[2], 0x07030602u);
-            } else if (sub == 3) {
-                w[0] = __builtin_amdgcn_perm(t[2], t[0], 0x05040100u);
-                w[1] = __builtin_amdgcn_perm(t[2], t[0], 0x07060302u);
-                w[2] = __builtin_amdgcn_perm(t[3], t[1], 0x05040100u);
-                w[3] = __builtin_amdgcn_perm(t[3], t[1], 0x07060302u);
-            } else {
+        uint32_t y[4], t[4];
+        uint32_t (&w)[4] = y; // the transposed words replace the digit words
+        auto digits4 = [&](uint32_t x0, uint32_t x1, auto halfTag) __attribute__((always_inline)) {
+            constexpr int hf = decltype(halfTag)::value;
+            y[2 * hf] = mm_digits(x0);
+            y[2 * hf + 1] = mm_digits(x1);
+        };
+        auto perm1 = [&]() __attribute__((always_inline)) {
+            t[0] = __builtin_amdgcn_perm(y[1], y[0], 0x05010400u);
+            t[1] = __builtin_amdgcn_perm(y[1], y[0], 0x07030602u);
+            t[2] = __builtin_amdgcn_perm(y[3], y[2], 0x05010400u);
+            t[3] = __builtin_amdgcn_perm(y[3], y[2], 0x07030602u);
+        };
+        auto perm2 = [&]() __attribute__((always_inline)) {
+            w[0] = __builtin_amdgcn_perm(t[2], t[0], 0x05040100u);
+            w[1] = __builtin_amdgcn_perm(t[2], t[0], 0x07060302u);
+            w[2] = __builtin_amdgcn_perm(t[3], t[1], 0x05040100u);
+            w[3] = __builtin_amdgcn_perm(t[3], t[1], 0x07060302u);
+        };
+        auto convStage = [&](auto kTag) __attribute__((always_inline)) { // s slab g + 1: (round u, the column handled h-th) in five stages
+            constexpr int k = decltype(kTag)::value, u = k / 10, h = (k / 5) % 2, sub = k % 5;
+            if constexpr (sub == 0)
+                digits4(rawWord(pbs[u][0], h), rawWord(pbs[u][1], h), std::integral_constant<int, 0>{});
+            else if constexpr (sub == 1)
+                digits4(rawWord(pbs[u][2], h), rawWord(pbs[u][3], h), std::integral_constant<int, 1>{});
+            else if constexpr (sub == 2)
+                perm1();
+            else if constexpr (sub == 3)
+                perm2();
+            else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<uint32_t *>(bufNext + q * G::PLANE_B + dstB[u][h]) = w[q];
             }
         };
-        const v4i_t zero = {0, 0, 0, 0};
-        int m = 0;
-#pragma unroll
-        for (int rb = 0; rb < G::NRB; ++rb)
-#pragma unroll
-            for (int rr = 0; rr < NREP; ++rr)
+        auto bgStage = [&](auto subTag) __attribute__((always_inline)) { // the piece of the next panel loaded during the previous step
+            constexpr int sub = decltype(subTag)::value;
+            if constexpr (sub == 0)
+                digits4(bgRaw[0], bgRaw[1], std::integral_constant<int, 0>{});
+            else if constexpr (sub == 1) {
+                digits4(bgRaw[2], bgRaw[3], std::integral_constant<int, 1>{});
+                bgRaw = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffF, bgNext, 0); // the registers are free: next piece
+            } else if constexpr (sub == 2)
+                perm1();
+            else if constexpr (sub == 3)
+                perm2();
+            else {
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int qq = 0; qq + p < 4; ++qq) {
-                        const int q = 3 - p - qq;
-                        acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
-                            a[rb][p], b[rr][q], (FIRST != 0 && p == 0 && !(FIRST == 2 && q == 0)) ? zero : acc[rb][rr][p + q], 0, 0, 0);
-                        if ((m & 3) == 0 && m < 80)
-                            convStage(m / 4);
-                        if (m == 29 || m == 59 || m == 89) // a[rb] of the next slab: this row block is through
-                            loadA(m / 30, pAnext);
-                        if ((m & 3) == 1 && m >= 41 && m < 57) // staging round 0's registers are free after stage 9 (slot 36)
-                            pbs[0][(m - 41) / 4] =
-                                __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[0] + ((m - 41) / 4) * G::N * 4, soffLoad, 0);
-                        if ((m & 3) == 1 && m >= 81 && m < 97) // staging round 1: free after stage 19 (slot 76)
-                            pbs[1][(m - 81) / 4] =
-                                __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[1] + ((m - 81) / 4) * G::N * 4, soffLoad, 0);
-                        if (m == 99) {
-                            wave_lds_sync(); // the other buffer is complete (stage 19 stored at slot 76)
-                            loadB(0, bufNext);
-                        }
-                        if (m == 109)
-                            loadB(1, bufNext);
-                        ++m;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    *reinterpret_cast<uint32_t *>(bgDst + p * G::PLANE_A) = w[p];
+            }
+        };
+        const v4i_t zero = {0, 0, 0, 0};
+        // slot m of the step: row block m / 30, replica (m % 30) / 10, then (A plane p, B plane q) in the order 3 2 1 0 | 3 2 1 | 3 2 | 3
+        auto slot = [&](auto mTag) __attribute__((always_inline)) {
+            constexpr int m = decltype(mTag)::value;
+            constexpr int rb = m / 30, rr = (m % 30) / 10, j = m % 10;
+            constexpr int p = j < 4 ? 0 : j < 7 ? 1 : j < 9 ? 2 : 3;
+            constexpr int qq = j - (p == 0 ? 0 : p == 1 ? 4 : p == 2 ? 7 : 9);
+            constexpr int q = 3 - p - qq;
+            constexpr bool fromZero = FIRST != 0 && p == 0 && !(FIRST == 2 && q == 0);
+            acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rb & 1][p], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
+            if constexpr ((m & 3) == 0 && m < 80)
+                convStage(std::integral_constant<int, m / 4>{});
+            if constexpr ((m & 7) == 2 && m >= 82)
+                bgStage(std::integral_constant<int, (m - 82) / 8>{});
+            if constexpr (m == 29 || m == 59) // the set this row block used is free: row block rb + 2 of this slab
+                loadA(std::integral_constant<int, m / 30 + 2>{}, pA);
+            if constexpr (LAST != 2 && m == 89) // row block 0 of the next slab (not across a panel hand-over)
+                loadA(std::integral_constant<int, 0>{}, pAnext);
+            if constexpr ((m & 3) == 1 && m >= 41 && m < 57) // staging round 0's registers are free after stage 9 (slot 36)
+                pbs[0][(m - 41) / 4] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[0] + ((m - 41) / 4) * G::N * 4, soffLoad, 0);
+            if constexpr ((m & 3) == 1 && m >= 81 && m < 97) // staging round 1: free after stage 19 (slot 76)
+                pbs[1][(m - 81) / 4] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[1] + ((m - 81) / 4) * G::N * 4, soffLoad, 0);
+            if constexpr (m == 99) {
+                wave_lds_sync(); // the other buffer is complete (stage 19 stored at slot 76)
+                loadB(std::integral_constant<int, 0>{}, bufNext);
+            }
+            if constexpr (m == 109)
+                loadB(std::integral_constant<int, 1>{}, bufNext);
+            if constexpr (LAST != 0 && m >= 31 && m <= 110 && (m - 31) % 30 < 20) // tile end of the row block that finished at slot 30 (rb + 1) - 1
+                teStage(g, std::integral_constant<int, (m - 31) / 30>{}, std::integral_constant<int, (m - 31) % 30>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for_each_index(std::make_integer_sequence<int, 120>{}, slot);
+        if constexpr (LAST != 0)
+            for_each_index(std::make_integer_sequence<int, 20>{},
+                           [&](auto kTag) __attribute__((always_inline)) { teStage(g, std::integral_constant<int, G::NRB - 1>{}, kTag); });
     };
 
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>;
 #pragma unroll 1
-    for (int it0 = 0; it0 < nIt; it0 += G::NSLAB) {
-        if (fCount != 0u && tileHook(it0))
-            step(it0, std::integral_constant<int, 2>{});
-        else
-            step(it0, std::integral_constant<int, 1>{});
-        step(it0 + 1, std::integral_constant<int, 0>{});
-        step(it0 + 2, std::integral_constant<int, 0>{});
-        step(it0 + 3, std::integral_constant<int, 0>{});
-        tileEnd(it0 + G::NSLAB - 1);
+    for (int pi = 0; pi < G::NPANEL; ++pi) {
+        if (ft.range) {
+            const uint2 rg = ft.range[mat * (uint32_t)G::NPANEL + (uint32_t)pi];
+            fFirst = __builtin_amdgcn_readfirstlane(rg.x);
+            fCount = __builtin_amdgcn_readfirstlane(rg.y);
+        }
+        if (pi > 0) { // hand-over: every wave has stored its pieces of this panel (the last one during the previous step)
+            __syncthreads();
+            loadA(std::integral_constant<int, 0>{}, panelA(pi * G::SPP));
+        }
+#pragma unroll 1
+        for (int tile = 0; tile < G::TPW; ++tile) {
+            const int g0 = pi * G::SPP + tile * G::NSLAB;
+            if (fCount != 0u && tileHook(g0))
+                step(g0, T2{}, T0{});
+            else
+                step(g0, T1{}, T0{});
+#pragma unroll 1
+            for (int g = g0 + 1; g < g0 + 3; ++g)
+                step(g, T0{}, T0{});
+            if (tile == G::TPW - 1)
+                step(g0 + 3, T0{}, T2{});
+            else
+                step(g0 + 3, T0{}, T1{});
+            tileFlags(g0);
+        }
     }
 
     __syncthreads();
-    uint32_t *sCnt = reinterpret_cast<uint32_t *>(smemP + G::A_PANEL);
+    uint32_t *sCnt = reinterpret_cast<uint32_t *>(wbuf - wave * G::WAVE_LDS);
     if (tid < 4)
         sCnt[tid] = 0;
     __syncthreads();
-    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, lb);
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, mat);
 }
 
 } // namespace coast
