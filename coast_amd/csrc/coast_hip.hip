@@ -703,13 +703,21 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     do {                                                                                                        \
         if (mfma && R == 3 && mmBlocks) { /* TMR: replicas in register blocks, one wave per SIMD */              \
             using GB = MmBlk<3>;                                                                                \
-            HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk_kernel<3>,                                 \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB::LDS_BYTES));    \
             FaultTab ftm = ft;                                                                                  \
             if (!have)                                                                                          \
                 ftm.list = nullptr, ftm.range = nullptr;                                                        \
-            hipLaunchKernelGGL(mm_mfma_blk_kernel<3>, dim3((uint32_t)batch), dim3(GB::NTHR), GB::LDS_BYTES,     \
-                               c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);                \
+            const uint32_t gridB = (uint32_t)std::min<uint64_t>((uint64_t)batch, (uint64_t)c->numCUs);          \
+            if (d_detected) {                                                                                   \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk_kernel<3, true>,                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB::LDS_BYTES)); \
+                hipLaunchKernelGGL((mm_mfma_blk_kernel<3, true>), dim3(gridB), dim3(GB::NTHR), GB::LDS_BYTES,   \
+                                   c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);            \
+            } else {                                                                                            \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk_kernel<3, false>,                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB::LDS_BYTES)); \
+                hipLaunchKernelGGL((mm_mfma_blk_kernel<3, false>), dim3(gridB), dim3(GB::NTHR), GB::LDS_BYTES,  \
+                                   c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);            \
+            }                                                                                                   \
             engine = COAST_ENGINE_MATRIX_CORE;                                                                  \
             fastBlocks = nbm;                                                                                   \
             break;                                                                                              \

@@ -13,9 +13,10 @@
 // registers per 16 x 16 block: 4 row blocks x 3 x 4 x 4 = 192) and one wave per SIMD.  With nobody else on the SIMD the wave has
 // to hide every latency by its own instruction order:
 //     * every operand register is re-read right after its last use in the step, tens of MFMAs before its next
-//     * a workgroup owns a whole MATRIX (four 64-row panels, one after the other): the next panel's rows of f are fetched and
-//       converted into a second LDS panel buffer in the background of the current panel's steps (one 16-byte piece per thread
-//       and step), so the load -> convert -> barrier prologue is paid once per matrix, not once per panel
+//     * a workgroup is persistent (one per CU) and takes whole matrices, four 64-row panels each: the next panel's rows of f --
+//       of this matrix or the next one -- are fetched and converted into a second LDS panel buffer in the background of the
+//       current panel's steps (one 16-byte piece per thread and step), and the s pipeline runs straight across the matrix
+//       boundary, so the load -> convert -> barrier prologue is paid once per workgroup, not once per panel
 //     * the vote and the stores of a tile's row blocks 0..2 run behind the MFMAs of the tile's last step (a row block's sums are
 //       final 30 MFMAs before the next one's); only row block 3 is left for after the step
 // tools/mfma_probe2.hip (stepZ) measured the step shape before the kernel was written: 2.7-2.9 POP/s executed, all of it
@@ -30,6 +31,9 @@
 
 #include "xmr.hpp"
 
+#ifndef COAST_BLK_KNOCK
+#define COAST_BLK_KNOCK 0 // development: 1 tile end replaced by a checksum of the accumulators, 2 no background panel, 4 no s conversion
+#endif
 namespace coast {
 
 // f(integral_constant<int, 0>), f(<1>), ...: a loop whose index is a constant in every iteration's own instantiation (the step's
@@ -56,7 +60,7 @@ template <int NREP> struct MmBlk {
     static_assert(A_PER_THR == SPP, "one background piece of the next panel per step");
 };
 
-template <int NREP>
+template <int NREP, bool FLAGS>
 __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const uint32_t *__restrict__ F,
                                                                            const uint32_t *__restrict__ S,
                                                                            uint32_t *__restrict__ R, uint32_t nblocks, Counters ctr,
@@ -70,17 +74,23 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     const int l16 = lane & 15, kg = lane >> 4; // operand row / column inside a 16-block, 16-byte k group of the slab
     uint8_t *const wbuf = smemP + 2 * G::A_PANEL + wave * G::WAVE_LDS;
 
-    const uint32_t mat = xcd_logical_block(blockIdx.x, nblocks); // one workgroup per matrix
+    // A workgroup is persistent: matrices blockIdx.x, blockIdx.x + gridDim.x, ... one after the other, with the load / convert
+    // pipelines running straight across the matrix boundaries ("cur" = the matrix being multiplied, "next" = the one after it).
     constexpr size_t nn = (size_t)G::N * G::N;
-    const uint32_t *f = F + mat * nn;
-    const uint32_t *s = S + mat * nn;
-    uint32_t *r = R + mat * nn;
-    const __amdgpu_buffer_rsrc_t rsF =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(f), 0, (int)(nn * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsS =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(s), 0, (int)(nn * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(r, 0, (int)(nn * 4), 0x00020000);
+    uint32_t mat = blockIdx.x;
+    const uint32_t *f = F + mat * nn, *s = S + mat * nn;
+    auto rsrcOf = [&](const void *base, bool live, int bytes) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(live ? base : (const void *)F), 0, live ? bytes : 0, 0x00020000);
+    };
+    auto nextLive = [&]() __attribute__((always_inline)) { return mat + gridDim.x < nblocks; };
+    __amdgpu_buffer_rsrc_t rsF = rsrcOf(f, true, (int)(nn * 4)), rsS = rsrcOf(s, true, (int)(nn * 4));
+    __amdgpu_buffer_rsrc_t rsFnext = rsrcOf(F + (mat + gridDim.x) * nn, nextLive(), (int)(nn * 4)); // empty past the batch: reads give 0
+    __amdgpu_buffer_rsrc_t rsSnext = rsrcOf(S + (mat + gridDim.x) * nn, nextLive(), (int)(nn * 4));
+    __amdgpu_buffer_rsrc_t rsR = rsrcOf(R + mat * nn, true, (int)(nn * 4));
     const int voffR = ((4 * ((tid & 63) >> 4)) * G::N + (tid & 15)) * 4; // C/D layout: lane -> column lane % 16, rows 4 (lane / 16) + i
+    // per-item flags (FLAGS): one byte per element; the range check drops the stores of the lanes whose element agreed (their
+    // offset is pushed out of range): no branch
+    __amdgpu_buffer_rsrc_t rsD = rsrcOf(detected + mat * nn, FLAGS && detected != nullptr, (int)nn);
 
     // ---- f panels: plane[p][row][256 B], the row's sixteen 16-byte slots (slot = k / 16) at slot ^ (row & 15) -- the layout of
     // mm_mfma_panel_kernel; a 16x16x64 fragment read (lane = row & 15, k group) finds its 16 lanes' slots in 16 different banks.
@@ -107,10 +117,14 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
                 *reinterpret_cast<uint32_t *>(smemP + p * G::PLANE_A + dst) = w[p];
         }
     }
-    // background piece in flight: piece (g + 1) % 16 of panel (g + 1) / 16 + 1 is loaded during step g and converted during step
-    // g + 1; past the matrix the buffer resource returns zeros (the last panel's "next panel" is never read)
-    auto bgOff = [&](int g) __attribute__((always_inline)) { return (((g >> 4) + 1) * G::BM + 4 * (g & 15)) * G::N * 4; };
-    u32x4_t bgRaw = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffF, bgOff(0), 0);
+    // background pieces in flight: piece g % 16 of panel g / 16 + 1 is loaded during step g - 2 and converted during step g; panel 4
+    // (g >= 48) is panel 0 of the NEXT matrix, and steps 64, 65 are the next matrix's steps 0, 1
+    auto bgLoad = [&](int g) __attribute__((always_inline)) {
+        const int pnl = (g >> 4) + 1;
+        return __builtin_amdgcn_raw_buffer_load_b128(pnl >= G::NPANEL ? rsFnext : rsF, voffF,
+                                                     ((pnl & 3) * G::BM + 4 * (g & 15)) * G::N * 4, 0);
+    };
+    u32x4_t bgRaw[2] = {bgLoad(0), bgLoad(1)}; // two pieces in flight: piece g lives in set g & 1, reloaded with piece g + 2
 
     // ---- this wave's work: per panel the column tiles wave, wave + NW, ...; one pipeline step = one 64-deep k slab of one tile;
     // g = step number inside the matrix (0 .. 63): panel g / 16, tile (g / 4) % 4, slab g % 4
@@ -119,25 +133,24 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     // s staging: one conversion item = four consecutive k of one column -> one word in each of the four planes; a lane owns the two
     // columns of a pair, lane -> (pair l % 8, k-quad l / 8 + 8 * round): a dwordx2 load instruction fetches eight full tile rows
     // (64 B each).  plane[q][column][64 B]; a column's four 16-byte slots (slot = k / 16) sit at slot ^ ((0 - column / 4) & 3), which
-    // spreads both the fragment reads (lane = column, k group) and the conversion stores over the banks; odd pairs store their
-    // two columns in the opposite order so that one store instruction covers both column parities.
+    // spreads both the fragment reads (lane = column, k group) and the conversion stores (eight columns of one parity x four
+    // k-quads per 32 lanes) over the banks.
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-    int voffB[G::B_ROUNDS], dstB[G::B_ROUNDS][2];
-    const bool swapB = (lane & 1) != 0; // pair = lane % 8
+    int voffB, dstB[G::B_ROUNDS][2]; // staging round u loads 32 u rows further down: that goes into the scalar offset
+    constexpr int kRoundOff = 8 * 4 * G::N * 4;
 #pragma unroll
     for (int u = 0; u < G::B_ROUNDS; ++u) {
         const int c = 2 * (lane & 7), kq = u * 8 + (lane >> 3);
-        voffB[u] = ((4 * kq) * G::N + c) * 4;
+        if (u == 0)
+            voffB = ((4 * kq) * G::N + c) * 4;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int ch = c + (h ^ (swapB ? 1 : 0));
+            const int ch = c + h;
             dstB[u][h] = ch * G::KS + (((kq >> 2) ^ ((0 - (ch >> 2)) & 3)) * 16) + (kq & 3) * 4;
         }
     }
     auto slabOff = [&](int g) __attribute__((always_inline)) { return ((g & 3) * G::KS * G::N + tileCol0(g)) * 4; };
-    auto rawWord = [&](const u32x2_t &v, int h) __attribute__((always_inline)) {
-        return h == 0 ? (swapB ? v[1] : v[0]) : (swapB ? v[0] : v[1]);
-    };
+    auto rawWord = [&](const u32x2_t &v, int h) __attribute__((always_inline)) { return v[h]; };
 
     // fragment addresses: A row block rb, plane p, slab sl: (aOff ^ (sl * 64)) + rb * 16 * N + p * PLANE_A   (slot 4 sl + kg, swizzled)
     const int aOff = l16 * G::N + ((kg ^ l16) * 16);
@@ -147,34 +160,44 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     Tally tl;
     uint32_t detItems = 0;
     v4i_t acc[G::NRB][NREP][4];
-    u32x2_t pbs[G::B_ROUNDS][4]; // raw s words of the NEXT slab; each round's registers are reloaded as soon as it is converted
+    // raw s words in flight, two slabs deep: slab G lives in set G & 1; a step converts slab g + 1 and reloads each staging round's
+    // registers with slab g + 3 as soon as the round is converted -- almost two steps for the data to arrive (one step is not enough:
+    // every step then opened with a wait for memory, 15 % of the kernel).  The set index is a compile-time constant: the slab
+    // position inside a tile fixes the parity.
+    u32x2_t pbs[2][G::B_ROUNDS][4];
 
-    // prologue: slab 0 converted into buffer 0, slab 1 in flight
+    // prologue: slab 0 converted into buffer 0, slabs 1 and 2 in flight
     {
         const int so = slabOff(0);
 #pragma unroll
         for (int u = 0; u < G::B_ROUNDS; ++u)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                pbs[u][kk] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[u] + kk * G::N * 4, so, 0);
+                pbs[0][u][kk] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB + kk * G::N * 4, so + u * kRoundOff, 0);
+        const int so1 = slabOff(1);
+#pragma unroll
+        for (int u = 0; u < G::B_ROUNDS; ++u)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                pbs[1][u][kk] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB + kk * G::N * 4, so1 + u * kRoundOff, 0);
 #pragma unroll
         for (int u = 0; u < G::B_ROUNDS; ++u)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint32_t y[4] = {mm_digits(rawWord(pbs[u][0], h)), mm_digits(rawWord(pbs[u][1], h)),
-                                       mm_digits(rawWord(pbs[u][2], h)), mm_digits(rawWord(pbs[u][3], h))};
+                const uint32_t y[4] = {mm_digits(rawWord(pbs[0][u][0], h)), mm_digits(rawWord(pbs[0][u][1], h)),
+                                       mm_digits(rawWord(pbs[0][u][2], h)), mm_digits(rawWord(pbs[0][u][3], h))};
                 uint32_t w[4];
                 mm_transpose4(y, w);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<uint32_t *>(wbuf + q * G::PLANE_B + dstB[u][h]) = w[q];
             }
-        const int so1 = slabOff(1);
+        const int so2 = slabOff(2);
 #pragma unroll
         for (int u = 0; u < G::B_ROUNDS; ++u)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                pbs[u][kk] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[u] + kk * G::N * 4, so1, 0);
+                pbs[0][u][kk] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB + kk * G::N * 4, so2 + u * kRoundOff, 0);
     }
     __syncthreads(); // panel 0 (and this wave's slab 0) is complete
 
@@ -183,38 +206,35 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     // mask, the per-item flags are written from that mask once the accumulators are dead.  One element = five small stages so
     // that they can sit behind MFMAs: recombine replica 0 / 1 / 2, vote, store.  C/D layout of 16x16 blocks: lane -> column
     // lane % 16, rows 4 (lane / 16) + i.
-    uint32_t missMask = 0u, teV[3], teVoted = 0u;
+    uint32_t teV[3], teVoted = 0u, teMiss = 0u;
     auto teStage = [&](int g, auto rbTag, auto kTag) __attribute__((always_inline)) {
         constexpr int rb = decltype(rbTag)::value, k = decltype(kTag)::value;
         constexpr int i = k / 5, sub = k % 5;
         if constexpr (sub < 3) {
             constexpr int rs = sub < NREP ? sub : NREP - 1;
-            teV[sub] = (uint32_t)acc[rb][rs][0][i] + ((uint32_t)acc[rb][rs][1][i] << 8) + ((uint32_t)acc[rb][rs][2][i] << 16) +
-                       ((uint32_t)acc[rb][rs][3][i] << 24);
+            teV[sub] = (((((uint32_t)acc[rb][rs][3][i] << 8) + (uint32_t)acc[rb][rs][2][i]) << 8) + (uint32_t)acc[rb][rs][1][i] << 8) +
+                       (uint32_t)acc[rb][rs][0][i]; // three v_lshl_add_u32
         } else if constexpr (sub == 3) {
             const bool e01 = teV[0] == teV[1], e02 = teV[0] == teV[2];
             teVoted = (NREP == 3 && !e01) ? teV[2] : teV[0]; // select(a == b, a, c); DWC keeps replica 0's
-            missMask |= ((e01 && e02) ? 0u : 1u) << (rb * 4 + i);
+            teMiss = (e01 && e02) ? 0u : 1u;
+            if (NREP == 3)
+                tl.miss += teMiss; // TMR_ERROR_CNT
+            else
+                detItems += teMiss;
         } else {
             // one per-lane offset for the whole kernel; the element's row / the tile's column are a scalar offset
-            __builtin_amdgcn_raw_buffer_store_b32(teVoted, rsR, voffR, (((g >> 4) * G::BM + rb * 16 + i) * G::N + tileCol0(g)) * 4, 0);
+            const int erow = (g >> 4) * G::BM + rb * 16 + i;
+            __builtin_amdgcn_raw_buffer_store_b32(teVoted, rsR, voffR, (erow * G::N + tileCol0(g)) * 4, 0);
+            if constexpr (FLAGS)
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)1, rsD, teMiss ? (voffR >> 2) : 0x40000000, erow * G::N + tileCol0(g), 0);
         }
     };
-    auto tileFlags = [&](int g) __attribute__((always_inline)) { // after the tile's last accumulator is dead
-        tl.syncs += 16u;
-        if (NREP == 3)
-            tl.miss += (uint32_t)__builtin_popcount(missMask);
-        const int col = tileCol0(g) + l16;
-#pragma unroll 1
-        while (missMask) { // per-item flags of the elements that were out-voted (TMR) / caught (DWC)
-            const int idx = __builtin_ctz(missMask);
-            missMask &= missMask - 1u;
-            const int orow = (g >> 4) * G::BM + (idx >> 2) * 16 + 4 * kg + (idx & 3);
-            if (NREP == 2)
-                detItems += 1;
-            if (detected)
-                detected[mat * nn + (size_t)orow * G::N + col] = 1;
-        }
+    // row block 3's sums are final with the step's last MFMA: its tile end runs after the step.  (Moving it behind the first MFMAs of
+    // the next tile's first step was measured: slower -- a slot only has room for about five VALU instructions.)
+    auto flushRb3 = [&](int g) __attribute__((always_inline)) {
+        for_each_index(std::make_integer_sequence<int, 20>{},
+                       [&](auto kTag) __attribute__((always_inline)) { teStage(g, std::integral_constant<int, G::NRB - 1>{}, kTag); });
     };
 
     // ---- injector hook, at the START of a tile (the accumulators of the previous tile are dead: room for control flow):
@@ -303,48 +323,49 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
         return true;
     };
 
-    // ---- one pipeline step = the 120 MFMAs of slab `g` (buffer g & 1), hand-scheduled as one basic block, order: row block,
-    // replica, A plane, B plane (consecutive MFMAs never share an accumulator).  Operand registers are recycled inside the step:
-    //   a      two sets of four planes: row block rb uses set rb & 1 for its 30 MFMAs, and the set is re-read right behind them --
-    //          with row block rb + 2 of this slab, then with row block 0 / 1 of the next one (row block 0: not in a panel's last
-    //          step, the next panel is handed over at a barrier first; row block 1: at the start of the next step)
-    //   b[0], b[1] are dead after slots 99 / 109 (their last use is in row block 3): re-read from the other buffer, which the
-    //          conversion stages finished filling at slot 76; b[2] at the start of the next step (first needed at its slot 20)
-    // Behind the MFMAs: the 20 conversion stages of slab g + 1 (every fourth slot up to 76), the eight loads of slab g + 2 as
-    // soon as a staging round's registers are free (after stage 9 / stage 19), the background piece of the next f panel (five
-    // stages from slot 82), and in a tile's last step the tile end of row blocks 0 .. 2.
-    v4i_t a[2][4], b[NREP][4]; // row block rb's A fragments live in set rb & 1
-    auto loadA = [&](auto rbTag, const uint8_t *pA) __attribute__((always_inline)) {
-        constexpr int rb = decltype(rbTag)::value;
+    // ---- one pipeline step = the 120 MFMAs of slab `g` (buffer g & 1), hand-scheduled as one basic block.  Order: row block, A
+    // plane p, B plane q (3 - p down to 0), replica -- three consecutive MFMAs share both operands' planes and never an accumulator.
+    // Operand registers are refreshed in place, each right behind its last use:
+    //   a[p]      plane p of the current row block (12 / 9 / 6 / 3 MFMAs); behind its block it is re-read with plane p of the next row
+    //             block -- of this slab, or of row block 0 of the next slab (not across a panel hand-over: after the barrier)
+    //   b[rr][q]  used in every row block; its last use in the step is in row block 3, A plane 3 - q: re-read there from the other slab
+    //             buffer (filled by slot 76); the next step needs b[.][3] first and b[.][0] last, the order in which they come free
+    // Behind the MFMAs: the 20 conversion stages of slab g + 1 (every fourth slot up to 76), the loads of slab g + 3 as soon as a
+    // staging round's registers are free (after stage 9 / stage 19), the background piece of the next f panel (five stages from
+    // slot 82), and in a tile's last step the tile end of row blocks 0 .. 2.
+    v4i_t a[4], b[NREP][4];
+    int bOffR[NREP]; // opaque copies of the B fragment offset: each replica block issues its own operand loads
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            a[rb & 1][p] = *reinterpret_cast<const v4i_t *>(pA + p * G::PLANE_A + rb * 16 * G::N);
-    };
-    auto loadB = [&](auto rrTag, const uint8_t *buf) __attribute__((always_inline)) {
-        constexpr int rr = decltype(rrTag)::value;
-        int offR = bOff;
-        asm volatile("" : "+v"(offR)); // opaque copy of the offset: each replica block issues its own operand loads
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            b[rr][p] = *reinterpret_cast<const v4i_t *>(buf + offR + p * G::PLANE_B);
-    };
-    {
-        loadA(std::integral_constant<int, 0>{}, panelA(0));
-        loadB(std::integral_constant<int, 0>{}, wbuf);
-        loadB(std::integral_constant<int, 1>{}, wbuf);
+    for (int rr = 0; rr < NREP; ++rr) {
+        bOffR[rr] = bOff;
+        asm volatile("" : "+v"(bOffR[rr]));
     }
-    auto step = [&](int g, auto firstTag, auto lastTag) __attribute__((always_inline)) {
+    auto loadA = [&](auto pTag, int rb, const uint8_t *pA) __attribute__((always_inline)) {
+        constexpr int p = decltype(pTag)::value;
+        a[p] = *reinterpret_cast<const v4i_t *>(pA + p * G::PLANE_A + rb * 16 * G::N);
+    };
+    auto loadB = [&](auto rrTag, auto qTag, const uint8_t *buf) __attribute__((always_inline)) {
+        constexpr int rr = decltype(rrTag)::value, q = decltype(qTag)::value;
+        b[rr][q] = *reinterpret_cast<const v4i_t *>(buf + bOffR[rr] + q * G::PLANE_B);
+    };
+    auto loadAllA = [&](const uint8_t *pA) __attribute__((always_inline)) { // row block 0 of a panel's first slab
+        for_each_index(std::make_integer_sequence<int, 4>{}, [&](auto pTag) __attribute__((always_inline)) { loadA(pTag, 0, pA); });
+    };
+    loadAllA(panelA(0));
+    for_each_index(std::make_integer_sequence<int, NREP * 4>{}, [&](auto kTag) __attribute__((always_inline)) {
+        constexpr int k = decltype(kTag)::value;
+        loadB(std::integral_constant<int, k / 4>{}, std::integral_constant<int, k % 4>{}, wbuf);
+    });
+    auto step = [&](int g, auto firstTag, auto lastTag, auto parTag) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(parTag)::value, CS = PAR ^ 1; // g & 1; the set that holds slab g + 1 (converted now, reloaded with slab g + 3)
         constexpr int FIRST = decltype(firstTag)::value; // 0 running slab; 1 first slab of a tile; 2 first slab, limb-0 sums hold the hook's deltas
-        constexpr int LAST = decltype(lastTag)::value;   // 0; 1 last slab of a tile; 2 last slab of a panel's last tile
-        const int soffLoad = slabOff(g + 2);
+        constexpr int LAST = decltype(lastTag)::value;   // 1: last slab of a tile
+        const int soffLoad = slabOff(g + 3);
+        const __amdgpu_buffer_rsrc_t rsLoad = g + 3 >= G::NPANEL * G::SPP ? rsSnext : rsS; // steps 64 ..: the next matrix
         const uint8_t *pA = panelA(g);
         const uint8_t *pAnext = panelA(g + 1);
-        const uint8_t *bufCur = wbuf + (g & 1) * G::B_BUF;
         uint8_t *bufNext = wbuf + ((g + 1) & 1) * G::B_BUF;
         uint8_t *bgDst = smemP + (((g >> 4) + 1) & 1) * G::A_PANEL + panelDst(g & 15);
-        const int bgNext = bgOff(g + 1);
-        loadB(std::integral_constant<int, 2>{}, bufCur);
-        loadA(std::integral_constant<int, 1>{}, pA); // set 1 is free since the previous step's last slot; first needed at slot 30
         __builtin_amdgcn_sched_barrier(0);
 
         uint32_t y[4], t[4];
@@ -369,9 +390,9 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
         auto convStage = [&](auto kTag) __attribute__((always_inline)) { // s slab g + 1: (round u, the column handled h-th) in five stages
             constexpr int k = decltype(kTag)::value, u = k / 10, h = (k / 5) % 2, sub = k % 5;
             if constexpr (sub == 0)
-                digits4(rawWord(pbs[u][0], h), rawWord(pbs[u][1], h), std::integral_constant<int, 0>{});
+                digits4(rawWord(pbs[CS][u][0], h), rawWord(pbs[CS][u][1], h), std::integral_constant<int, 0>{});
             else if constexpr (sub == 1)
-                digits4(rawWord(pbs[u][2], h), rawWord(pbs[u][3], h), std::integral_constant<int, 1>{});
+                digits4(rawWord(pbs[CS][u][2], h), rawWord(pbs[CS][u][3], h), std::integral_constant<int, 1>{});
             else if constexpr (sub == 2)
                 perm1();
             else if constexpr (sub == 3)
@@ -385,10 +406,10 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
         auto bgStage = [&](auto subTag) __attribute__((always_inline)) { // the piece of the next panel loaded during the previous step
             constexpr int sub = decltype(subTag)::value;
             if constexpr (sub == 0)
-                digits4(bgRaw[0], bgRaw[1], std::integral_constant<int, 0>{});
+                digits4(bgRaw[PAR][0], bgRaw[PAR][1], std::integral_constant<int, 0>{});
             else if constexpr (sub == 1) {
-                digits4(bgRaw[2], bgRaw[3], std::integral_constant<int, 1>{});
-                bgRaw = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffF, bgNext, 0); // the registers are free: next piece
+                digits4(bgRaw[PAR][2], bgRaw[PAR][3], std::integral_constant<int, 1>{});
+                bgRaw[PAR] = bgLoad(g + 2); // the registers are free: the piece two steps ahead
             } else if constexpr (sub == 2)
                 perm1();
             else if constexpr (sub == 3)
@@ -400,73 +421,95 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
             }
         };
         const v4i_t zero = {0, 0, 0, 0};
-        // slot m of the step: row block m / 30, replica (m % 30) / 10, then (A plane p, B plane q) in the order 3 2 1 0 | 3 2 1 | 3 2 | 3
+        // slot m of the step: row block m / 30; inside it A plane p = 0 (12 slots), 1 (9), 2 (6), 3 (3); inside that B plane q from
+        // 3 - p down to 0, three replicas each
         auto slot = [&](auto mTag) __attribute__((always_inline)) {
             constexpr int m = decltype(mTag)::value;
-            constexpr int rb = m / 30, rr = (m % 30) / 10, j = m % 10;
-            constexpr int p = j < 4 ? 0 : j < 7 ? 1 : j < 9 ? 2 : 3;
-            constexpr int qq = j - (p == 0 ? 0 : p == 1 ? 4 : p == 2 ? 7 : 9);
-            constexpr int q = 3 - p - qq;
+            constexpr int rb = m / 30, j = m % 30;
+            constexpr int p = j < 12 ? 0 : j < 21 ? 1 : j < 27 ? 2 : 3;
+            constexpr int jj = j - (p == 0 ? 0 : p == 1 ? 12 : p == 2 ? 21 : 27);
+            constexpr int q = 3 - p - jj / 3, rr = jj % 3;
             constexpr bool fromZero = FIRST != 0 && p == 0 && !(FIRST == 2 && q == 0);
-            acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rb & 1][p], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
-            if constexpr ((m & 3) == 0 && m < 80)
-                convStage(std::integral_constant<int, m / 4>{});
-            if constexpr ((m & 7) == 2 && m >= 82)
-                bgStage(std::integral_constant<int, (m - 82) / 8>{});
-            if constexpr (m == 29 || m == 59) // the set this row block used is free: row block rb + 2 of this slab
-                loadA(std::integral_constant<int, m / 30 + 2>{}, pA);
-            if constexpr (LAST != 2 && m == 89) // row block 0 of the next slab (not across a panel hand-over)
-                loadA(std::integral_constant<int, 0>{}, pAnext);
-            if constexpr ((m & 3) == 1 && m >= 41 && m < 57) // staging round 0's registers are free after stage 9 (slot 36)
-                pbs[0][(m - 41) / 4] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[0] + ((m - 41) / 4) * G::N * 4, soffLoad, 0);
-            if constexpr ((m & 3) == 1 && m >= 81 && m < 97) // staging round 1: free after stage 19 (slot 76)
-                pbs[1][(m - 81) / 4] = __builtin_amdgcn_raw_buffer_load_b64(rsS, voffB[1] + ((m - 81) / 4) * G::N * 4, soffLoad, 0);
-            if constexpr (m == 99) {
-                wave_lds_sync(); // the other buffer is complete (stage 19 stored at slot 76)
-                loadB(std::integral_constant<int, 0>{}, bufNext);
+            acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[p], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
+            if constexpr (jj == 3 * (4 - p) - 1) // the plane's block is through: the next row block's (across a panel hand-over the
+                                                 // read is early and is repeated behind the barrier)
+                loadA(std::integral_constant<int, p>{}, (rb + 1) % G::NRB, rb == G::NRB - 1 ? pAnext : pA);
+            if constexpr (rb == G::NRB - 1 && jj < 3) { // last use of b[rr][3 - p] in this step
+                if constexpr (m == 90)
+                    wave_lds_sync(); // the other buffer is complete (stage 19 stored at slot 76)
+                loadB(std::integral_constant<int, rr>{}, std::integral_constant<int, 3 - p>{}, bufNext);
             }
-            if constexpr (m == 109)
-                loadB(std::integral_constant<int, 1>{}, bufNext);
-            if constexpr (LAST != 0 && m >= 31 && m <= 110 && (m - 31) % 30 < 20) // tile end of the row block that finished at slot 30 (rb + 1) - 1
-                teStage(g, std::integral_constant<int, (m - 31) / 30>{}, std::integral_constant<int, (m - 31) % 30>{});
+            if constexpr (!(COAST_BLK_KNOCK & 4) && (m & 3) == 0 && m < 80)
+                convStage(std::integral_constant<int, m / 4>{});
+            if constexpr (!(COAST_BLK_KNOCK & 2) && (m & 7) == 2 && m >= 82)
+                bgStage(std::integral_constant<int, (m - 82) / 8>{});
+            if constexpr ((m & 3) == 1 && m >= 41 && m < 57) // staging round 0's registers are free after stage 9 (slot 36)
+                pbs[CS][0][(m - 41) / 4] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + ((m - 41) / 4) * G::N * 4, soffLoad, 0);
+            if constexpr ((m & 3) == 1 && m >= 81 && m < 97) // staging round 1: free after stage 19 (slot 76)
+                pbs[CS][1][(m - 81) / 4] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + ((m - 81) / 4) * G::N * 4, soffLoad + kRoundOff, 0);
+            // tile end of the row block that finished at slot 30 (rb + 1) - 1: its 20 stages in two of every three slots (a slot has
+            // room for about five VALU instructions behind its MFMA before the next MFMA is held up)
+            if constexpr (!(COAST_BLK_KNOCK & 1) && LAST != 0 && m >= 31 && (m - 31) % 30 < 29 && ((m - 31) % 30) % 3 != 2)
+                teStage(g, std::integral_constant<int, (m - 31) / 30>{},
+                        std::integral_constant<int, (m - 31) % 30 - ((m - 31) % 30) / 3>{});
             __builtin_amdgcn_sched_barrier(0);
         };
         for_each_index(std::make_integer_sequence<int, 120>{}, slot);
-        if constexpr (LAST != 0)
-            for_each_index(std::make_integer_sequence<int, 20>{},
-                           [&](auto kTag) __attribute__((always_inline)) { teStage(g, std::integral_constant<int, G::NRB - 1>{}, kTag); });
     };
 
     using T0 = std::integral_constant<int, 0>;
     using T1 = std::integral_constant<int, 1>;
     using T2 = std::integral_constant<int, 2>;
+    for (bool firstMatrix = true;; firstMatrix = false) {
 #pragma unroll 1
-    for (int pi = 0; pi < G::NPANEL; ++pi) {
-        if (ft.range) {
-            const uint2 rg = ft.range[mat * (uint32_t)G::NPANEL + (uint32_t)pi];
-            fFirst = __builtin_amdgcn_readfirstlane(rg.x);
-            fCount = __builtin_amdgcn_readfirstlane(rg.y);
-        }
-        if (pi > 0) { // hand-over: every wave has stored its pieces of this panel (the last one during the previous step)
-            __syncthreads();
-            loadA(std::integral_constant<int, 0>{}, panelA(pi * G::SPP));
-        }
+        for (int pi = 0; pi < G::NPANEL; ++pi) {
+            if (ft.range) {
+                const uint2 rg = ft.range[mat * (uint32_t)G::NPANEL + (uint32_t)pi];
+                fFirst = __builtin_amdgcn_readfirstlane(rg.x);
+                fCount = __builtin_amdgcn_readfirstlane(rg.y);
+            }
+            if (pi > 0 || !firstMatrix) { // hand-over: every wave has stored its pieces of this panel (the last one during the previous step)
+                __syncthreads();
+                loadAllA(panelA(pi * G::SPP));
+            }
 #pragma unroll 1
-        for (int tile = 0; tile < G::TPW; ++tile) {
-            const int g0 = pi * G::SPP + tile * G::NSLAB;
-            if (fCount != 0u && tileHook(g0))
-                step(g0, T2{}, T0{});
-            else
-                step(g0, T1{}, T0{});
-#pragma unroll 1
-            for (int g = g0 + 1; g < g0 + 3; ++g)
-                step(g, T0{}, T0{});
-            if (tile == G::TPW - 1)
-                step(g0 + 3, T0{}, T2{});
-            else
-                step(g0 + 3, T0{}, T1{});
-            tileFlags(g0);
+            for (int tile = 0; tile < G::TPW; ++tile) {
+                const int g0 = pi * G::SPP + tile * G::NSLAB;
+                tl.syncs += 16u;
+                if (fCount != 0u && tileHook(g0)) // armed upsets in this tile (wave-uniform, rare)
+                    step(g0, T2{}, T0{}, T0{});
+                else
+                    step(g0, T1{}, T0{}, T0{});
+                step(g0 + 1, T0{}, T0{}, T1{});
+                step(g0 + 2, T0{}, T0{}, T0{});
+                step(g0 + 3, T0{}, T1{}, T1{});
+                if (!(COAST_BLK_KNOCK & 1))
+                    flushRb3(g0 + 3);
+                else { // keep the MFMAs alive
+                    int sum = 0;
+#pragma unroll
+                    for (int rb = 0; rb < G::NRB; ++rb)
+#pragma unroll
+                        for (int rr = 0; rr < NREP; ++rr)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                sum += acc[rb][rr][t][0] ^ acc[rb][rr][t][1] ^ acc[rb][rr][t][2] ^ acc[rb][rr][t][3];
+                    if (sum == 0x12345678)
+                        tl.miss += 1;
+                }
+            }
         }
+        if (!nextLive())
+            break;
+        mat += gridDim.x; // the pipelines are already inside this matrix: its slab 0 is converted, its panel 0 on its way into LDS
+        f = F + mat * nn;
+        s = S + mat * nn;
+        rsF = rsFnext;
+        rsS = rsSnext;
+        rsFnext = rsrcOf(F + (mat + gridDim.x) * nn, nextLive(), (int)(nn * 4));
+        rsSnext = rsrcOf(S + (mat + gridDim.x) * nn, nextLive(), (int)(nn * 4));
+        rsR = rsrcOf(R + mat * nn, true, (int)(nn * 4));
+        rsD = rsrcOf(detected + mat * nn, FLAGS && detected != nullptr, (int)nn);
     }
 
     __syncthreads();
@@ -474,7 +517,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     if (tid < 4)
         sCnt[tid] = 0;
     __syncthreads();
-    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, mat);
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
 }
 
 } // namespace coast

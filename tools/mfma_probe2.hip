@@ -196,8 +196,18 @@ template <int FLAGS> __global__ __launch_bounds__(256, 1) void stepZ(int *out, c
                             else
                                 b[(k - 16) / 4][(k - 16) & 3] = *reinterpret_cast<const v4i *>(pa + 65536 + ((k - 16) & 3) * 1024 + ((i + 1) & 1) * 4096);
                         }
-                        if ((FLAGS & 2) && m < 80) { // 80 conversion VALU: 16 words per lane x (2 digit ops + 2 perms) + address
+                        if ((FLAGS & 2) && !(FLAGS & 16) && m < 80) { // 160 VALU spread: 2 per slot
                             x[m % 8] = __builtin_amdgcn_perm(x[m % 8], x[(m + 3) % 8] + gl[m % 8].x, 0x05010400u);
+                        }
+                        if ((FLAGS & 16) && m < 80 && m % 4 == 0) { // the same 160 VALU in bursts: 8 every fourth slot
+#pragma unroll
+                            for (int z = 0; z < 4; ++z)
+                                x[(m + z) % 8] = __builtin_amdgcn_perm(x[(m + z) % 8], x[(m + z + 3) % 8] + gl[(m + z) % 8].x, 0x05010400u);
+                        }
+                        if ((FLAGS & 32) && m < 80 && m % 4 == 0) { // bursts of 6 (120 VALU): what a conversion stage issues
+#pragma unroll
+                            for (int z = 0; z < 3; ++z)
+                                x[(m + z) % 8] = __builtin_amdgcn_perm(x[(m + z) % 8], x[(m + z + 3) % 8] + gl[(m + z) % 8].x, 0x05010400u);
                         }
                         if ((FLAGS & 4) && m % 4 == 1 && m < 64)
                             *reinterpret_cast<uint32_t *>(pw + (m / 4) * 256 + ((i + 1) & 1) * 8192) = x[m % 8];
@@ -234,11 +244,13 @@ int main()
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     int *dD; hipMalloc(&dD, 4096);
     const int cus = p.multiProcessorCount;
+    if (getenv("PROBE_ALL")) {
     run_rate<4, false, 1>(dD, cus); run_rate<4, true, 1>(dD, cus); run_rate<8, true, 1>(dD, cus); run_rate<16, true, 1>(dD, cus);
     run_rate<4, false, 2>(dD, cus); run_rate<4, true, 2>(dD, cus); run_rate<8, true, 2>(dD, cus);
+    }
     uint2 *g; hipMalloc(&g, (size_t)1024 * 4096 * 8 + 65536 * 8); hipMemset(g, 0x5a, (size_t)1024 * 4096 * 8);
     run_rate16<16, false>(dD, cus); run_rate16<16, true>(dD, cus); run_rate16<48, true>(dD, cus);
-    run_stepZ<0>(dD, g, cus); run_stepZ<1>(dD, g, cus); run_stepZ<3>(dD, g, cus); run_stepZ<7>(dD, g, cus); run_stepZ<15>(dD, g, cus);
+    run_stepZ<1>(dD, g, cus); run_stepZ<3>(dD, g, cus); run_stepZ<17>(dD, g, cus); run_stepZ<33>(dD, g, cus); run_stepZ<15>(dD, g, cus); run_stepZ<29>(dD, g, cus);
     run_stepY<0>(dD, g, cus); run_stepY<1>(dD, g, cus); run_stepY<3>(dD, g, cus); run_stepY<7>(dD, g, cus); run_stepY<15>(dD, g, cus);
     return 0;
 }
