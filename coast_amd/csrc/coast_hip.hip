@@ -664,8 +664,10 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     // side 256: the int8-MFMA limb kernel, injector hooks included; COAST_MM_ENGINE=valu selects the v_mad_u64_u32 kernels
     const char *eng = getenv("COAST_MM_ENGINE");
     const bool mfma = n == 256 && !allGeneral && !(eng && !strcmp(eng, "valu"));
-    const char *tileEnv = getenv("COAST_MM_TILE"); // development: "blocks" = mm_mfma_blk_kernel (TMR), "lanes" = mm_mfma_panel_kernel
-    const bool mmBlocks = tileEnv && !strcmp(tileEnv, "blocks");
+    // TMR: replicas in register blocks (mm_mfma_blk_kernel); COAST_MM_TILE=lanes selects the lane-replica kernel (mm_mfma_panel_kernel),
+    // which also serves DWC and the unprotected mode
+    const char *tileEnv = getenv("COAST_MM_TILE");
+    const bool mmBlocks = !(tileEnv && !strcmp(tileEnv, "lanes"));
     const uint64_t nbm = (uint64_t)(n / 64) * batch; // workgroups of the panel kernel: 64 rows of one matrix each
 
     FaultTab ft;

@@ -97,10 +97,9 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     // Piece j of a panel for thread t: row 4 j + t / 64, k-quad t % 64.  Panel 0 is converted here, panels 1..3 in the background.
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     const int voffF = ((tid >> 6) * G::N + 4 * (tid & 63)) * 4;
-    auto panelDst = [&](int j) __attribute__((always_inline)) {
-        const int row = 4 * j + (tid >> 6), kq = tid & 63;
-        return row * G::N + (((kq >> 2) ^ (row & 15)) * 16) + (kq & 3) * 4;
-    };
+    // piece j: row 4 j + w (w = wave < 4), so row & 15 = 4 (j & 3) | w and the swizzle splits into a per-thread and a per-piece part
+    const int panelDst0 = (tid >> 6) * G::N + ((((tid & 63) >> 2) ^ (tid >> 6)) * 16) + (tid & 3) * 4;
+    auto panelDst = [&](int j) __attribute__((always_inline)) { return (panelDst0 ^ ((j & 3) * 64)) + j * 4 * G::N; };
     {
         u32x4_t pa[G::A_PER_THR];
 #pragma unroll
