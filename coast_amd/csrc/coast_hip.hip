@@ -708,7 +708,8 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
             FaultTab ftm = ft;                                                                                  \
             if (!have)                                                                                          \
                 ftm.list = nullptr, ftm.range = nullptr;                                                        \
-            const uint32_t gridB = (uint32_t)std::min<uint64_t>((uint64_t)batch, (uint64_t)c->numCUs);          \
+            /* one workgroup per CU; four of them (one XCD) share a matrix */                                    \
+            const uint32_t gridB = 4u * (uint32_t)std::min<uint64_t>((uint64_t)batch, (uint64_t)(c->numCUs / 4)); \
             if (d_detected) {                                                                                   \
                 HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk_kernel<3, true>,                       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB::LDS_BYTES)); \

@@ -13,10 +13,10 @@
 // registers per 16 x 16 block: 4 row blocks x 3 x 4 x 4 = 192) and one wave per SIMD.  With nobody else on the SIMD the wave has
 // to hide every latency by its own instruction order:
 //     * every operand register is re-read right after its last use in the step, tens of MFMAs before its next
-//     * a workgroup is persistent (one per CU) and takes whole matrices, four 64-row panels each: the next panel's rows of f --
-//       of this matrix or the next one -- are fetched and converted into a second LDS panel buffer in the background of the
-//       current panel's steps (one 16-byte piece per thread and step), and the s pipeline runs straight across the matrix
-//       boundary, so the load -> convert -> barrier prologue is paid once per workgroup, not once per panel
+//     * a workgroup is persistent (one per CU) and takes one 64-row panel position of a sequence of matrices: the next
+//       matrix's rows of f are fetched and converted into a second LDS panel buffer in the background of the current panel's
+//       steps (one 16-byte piece per thread and step), and the s pipeline runs straight across the matrix boundary, so the
+//       load -> convert -> barrier prologue is paid once per workgroup, not once per panel
 //     * the vote and the stores of a tile's row blocks 0..2 run behind the MFMAs of the tile's last step (a row block's sums are
 //       final 30 MFMAs before the next one's); only row block 3 is left for after the step
 // tools/mfma_probe2.hip (stepZ) measured the step shape before the kernel was written: 2.7-2.9 POP/s executed, all of it
@@ -32,7 +32,7 @@
 #include "xmr.hpp"
 
 #ifndef COAST_BLK_KNOCK
-#define COAST_BLK_KNOCK 0 // development: 1 tile end replaced by a checksum of the accumulators, 2 no background panel, 4 no s conversion
+#define COAST_BLK_KNOCK 0 // development timing knock-outs (results wrong): 1 no tile end, 2 no background panel, 4 no s conversion
 #endif
 namespace coast {
 
@@ -74,23 +74,30 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     const int l16 = lane & 15, kg = lane >> 4; // operand row / column inside a 16-block, 16-byte k group of the slab
     uint8_t *const wbuf = smemP + 2 * G::A_PANEL + wave * G::WAVE_LDS;
 
-    // A workgroup is persistent: matrices blockIdx.x, blockIdx.x + gridDim.x, ... one after the other, with the load / convert
-    // pipelines running straight across the matrix boundaries ("cur" = the matrix being multiplied, "next" = the one after it).
+    // A workgroup is persistent and owns ONE 64-row panel position: panel `pnl` of matrices mat0, mat0 + stride, mat0 + 2 stride, ...
+    // ("items"), with the load / convert pipelines running straight across the item boundaries.  The four panels of a matrix
+    // are taken by four workgroups of the same XCD at about the same time (workgroups go round-robin over the 8 XCDs), so the
+    // matrix's s -- which every one of them streams in full -- comes out of that XCD's L2 three times out of four.
     constexpr size_t nn = (size_t)G::N * G::N;
-    uint32_t mat = blockIdx.x;
-    const uint32_t *f = F + mat * nn, *s = S + mat * nn;
+    const uint32_t stride = gridDim.x / G::NPANEL; // matrices in flight
+    const bool xcdMap = (gridDim.x % 32u) == 0u;
+    const uint32_t slotX = blockIdx.x >> 3; // position inside the XCD
+    const uint32_t mat0 = xcdMap ? (blockIdx.x & 7u) * (gridDim.x >> 5) + (slotX >> 2) : blockIdx.x >> 2;
+    const int pnl = (int)(xcdMap ? slotX & 3u : blockIdx.x & 3u);
+    auto matOf = [&](int item) __attribute__((always_inline)) { return mat0 + (uint32_t)item * stride; };
     auto rsrcOf = [&](const void *base, bool live, int bytes) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(live ? base : (const void *)F), 0, live ? bytes : 0, 0x00020000);
     };
-    auto nextLive = [&]() __attribute__((always_inline)) { return mat + gridDim.x < nblocks; };
-    __amdgpu_buffer_rsrc_t rsF = rsrcOf(f, true, (int)(nn * 4)), rsS = rsrcOf(s, true, (int)(nn * 4));
-    __amdgpu_buffer_rsrc_t rsFnext = rsrcOf(F + (mat + gridDim.x) * nn, nextLive(), (int)(nn * 4)); // empty past the batch: reads give 0
-    __amdgpu_buffer_rsrc_t rsSnext = rsrcOf(S + (mat + gridDim.x) * nn, nextLive(), (int)(nn * 4));
-    __amdgpu_buffer_rsrc_t rsR = rsrcOf(R + mat * nn, true, (int)(nn * 4));
+    // the item's f / s as buffers; past the batch an empty one: reads give 0 (the pipelines run two steps ahead of the last item)
+    auto rsFof = [&](int item) __attribute__((always_inline)) { return rsrcOf(F + matOf(item) * nn, matOf(item) < nblocks, (int)(nn * 4)); };
+    auto rsSof = [&](int item) __attribute__((always_inline)) { return rsrcOf(S + matOf(item) * nn, matOf(item) < nblocks, (int)(nn * 4)); };
+    const uint32_t *f = F + mat0 * nn, *s = S + mat0 * nn; // the current item's, for the injector hook
+    const __amdgpu_buffer_rsrc_t rsF = rsFof(0), rsS = rsSof(0);
+    __amdgpu_buffer_rsrc_t rsR = rsrcOf(R + mat0 * nn, true, (int)(nn * 4));
     const int voffR = ((4 * ((tid & 63) >> 4)) * G::N + (tid & 15)) * 4; // C/D layout: lane -> column lane % 16, rows 4 (lane / 16) + i
     // per-item flags (FLAGS): one byte per element; the range check drops the stores of the lanes whose element agreed (their
     // offset is pushed out of range): no branch
-    __amdgpu_buffer_rsrc_t rsD = rsrcOf(detected + mat * nn, FLAGS && detected != nullptr, (int)nn);
+    __amdgpu_buffer_rsrc_t rsD = rsrcOf(detected + mat0 * nn, FLAGS && detected != nullptr, (int)nn);
 
     // ---- f panels: plane[p][row][256 B], the row's sixteen 16-byte slots (slot = k / 16) at slot ^ (row & 15) -- the layout of
     // mm_mfma_panel_kernel; a 16x16x64 fragment read (lane = row & 15, k group) finds its 16 lanes' slots in 16 different banks.
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
         u32x4_t pa[G::A_PER_THR];
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u)
-            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffF, u * 4 * G::N * 4, 0);
+            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffF, (pnl * G::BM + u * 4) * G::N * 4, 0);
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u) {
             const uint32_t y[4] = {mm_digits(pa[u][0]), mm_digits(pa[u][1]), mm_digits(pa[u][2]), mm_digits(pa[u][3])};
@@ -116,17 +123,14 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
                 *reinterpret_cast<uint32_t *>(smemP + p * G::PLANE_A + dst) = w[p];
         }
     }
-    // background pieces in flight: piece g % 16 of panel g / 16 + 1 is loaded during step g - 2 and converted during step g; panel 4
-    // (g >= 48) is panel 0 of the NEXT matrix, and steps 64, 65 are the next matrix's steps 0, 1
+    // background pieces in flight: piece g % 16 of the NEXT item's panel is loaded during step g - 2 and converted during step g
+    // (g = step number in the workgroup's life: item g / 16, tile (g / 4) % 4, slab g % 4)
     auto bgLoad = [&](int g) __attribute__((always_inline)) {
-        const int pnl = (g >> 4) + 1;
-        return __builtin_amdgcn_raw_buffer_load_b128(pnl >= G::NPANEL ? rsFnext : rsF, voffF,
-                                                     ((pnl & 3) * G::BM + 4 * (g & 15)) * G::N * 4, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(rsFof((g >> 4) + 1), voffF, (pnl * G::BM + 4 * (g & 15)) * G::N * 4, 0);
     };
     u32x4_t bgRaw[2] = {bgLoad(0), bgLoad(1)}; // two pieces in flight: piece g lives in set g & 1, reloaded with piece g + 2
 
-    // ---- this wave's work: per panel the column tiles wave, wave + NW, ...; one pipeline step = one 64-deep k slab of one tile;
-    // g = step number inside the matrix (0 .. 63): panel g / 16, tile (g / 4) % 4, slab g % 4
+    // ---- this wave's work: per item the column tiles wave, wave + NW, ...; one pipeline step = one 64-deep k slab of one tile
     auto tileCol0 = [&](int g) __attribute__((always_inline)) { return (wave + G::NW * ((g >> 2) & 3)) * G::CT; };
 
     // s staging: one conversion item = four consecutive k of one column -> one word in each of the four planes; a lane owns the two
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
                 detItems += teMiss;
         } else {
             // one per-lane offset for the whole kernel; the element's row / the tile's column are a scalar offset
-            const int erow = (g >> 4) * G::BM + rb * 16 + i;
+            const int erow = pnl * G::BM + rb * 16 + i;
             __builtin_amdgcn_raw_buffer_store_b32(teVoted, rsR, voffR, (erow * G::N + tileCol0(g)) * 4, 0);
             if constexpr (FLAGS)
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)1, rsD, teMiss ? (voffR >> 2) : 0x40000000, erow * G::N + tileCol0(g), 0);
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     // summed into the replica's limb-0 accumulator.  Returns whether this tile has any armed upset (wave-uniform).
     uint32_t fFirst = 0, fCount = 0; // armed upsets of the current panel: {first, count} in the injector's table
     auto tileHook = [&](int g) __attribute__((always_inline)) {
-        const int col0 = tileCol0(g), prow0 = (g >> 4) * G::BM;
+        const int col0 = tileCol0(g), prow0 = pnl * G::BM;
         bool hooked = false;
 #pragma unroll 1
         for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
         constexpr int FIRST = decltype(firstTag)::value; // 0 running slab; 1 first slab of a tile; 2 first slab, limb-0 sums hold the hook's deltas
         constexpr int LAST = decltype(lastTag)::value;   // 1: last slab of a tile
         const int soffLoad = slabOff(g + 3);
-        const __amdgpu_buffer_rsrc_t rsLoad = g + 3 >= G::NPANEL * G::SPP ? rsSnext : rsS; // steps 64 ..: the next matrix
+        const __amdgpu_buffer_rsrc_t rsLoad = rsSof((g + 3) >> 4); // the last three steps of an item load the next item's s
         const uint8_t *pA = panelA(g);
         const uint8_t *pAnext = panelA(g + 1);
         uint8_t *bufNext = wbuf + ((g + 1) & 1) * G::B_BUF;
@@ -459,56 +463,36 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     using T0 = std::integral_constant<int, 0>;
     using T1 = std::integral_constant<int, 1>;
     using T2 = std::integral_constant<int, 2>;
-    for (bool firstMatrix = true;; firstMatrix = false) {
 #pragma unroll 1
-        for (int pi = 0; pi < G::NPANEL; ++pi) {
-            if (ft.range) {
-                const uint2 rg = ft.range[mat * (uint32_t)G::NPANEL + (uint32_t)pi];
-                fFirst = __builtin_amdgcn_readfirstlane(rg.x);
-                fCount = __builtin_amdgcn_readfirstlane(rg.y);
-            }
-            if (pi > 0 || !firstMatrix) { // hand-over: every wave has stored its pieces of this panel (the last one during the previous step)
-                __syncthreads();
-                loadAllA(panelA(pi * G::SPP));
-            }
-#pragma unroll 1
-            for (int tile = 0; tile < G::TPW; ++tile) {
-                const int g0 = pi * G::SPP + tile * G::NSLAB;
-                tl.syncs += 16u;
-                if (fCount != 0u && tileHook(g0)) // armed upsets in this tile (wave-uniform, rare)
-                    step(g0, T2{}, T0{}, T0{});
-                else
-                    step(g0, T1{}, T0{}, T0{});
-                step(g0 + 1, T0{}, T0{}, T1{});
-                step(g0 + 2, T0{}, T0{}, T0{});
-                step(g0 + 3, T0{}, T1{}, T1{});
-                if (!(COAST_BLK_KNOCK & 1))
-                    flushRb3(g0 + 3);
-                else { // keep the MFMAs alive
-                    int sum = 0;
-#pragma unroll
-                    for (int rb = 0; rb < G::NRB; ++rb)
-#pragma unroll
-                        for (int rr = 0; rr < NREP; ++rr)
-#pragma unroll
-                            for (int t = 0; t < 4; ++t)
-                                sum += acc[rb][rr][t][0] ^ acc[rb][rr][t][1] ^ acc[rb][rr][t][2] ^ acc[rb][rr][t][3];
-                    if (sum == 0x12345678)
-                        tl.miss += 1;
-                }
-            }
+    for (int item = 0; matOf(item) < nblocks; ++item) {
+        const uint32_t mat = matOf(item);
+        if (ft.range) {
+            const uint2 rg = ft.range[mat * (uint32_t)G::NPANEL + (uint32_t)pnl];
+            fFirst = __builtin_amdgcn_readfirstlane(rg.x);
+            fCount = __builtin_amdgcn_readfirstlane(rg.y);
         }
-        if (!nextLive())
-            break;
-        mat += gridDim.x; // the pipelines are already inside this matrix: its slab 0 is converted, its panel 0 on its way into LDS
-        f = F + mat * nn;
-        s = S + mat * nn;
-        rsF = rsFnext;
-        rsS = rsSnext;
-        rsFnext = rsrcOf(F + (mat + gridDim.x) * nn, nextLive(), (int)(nn * 4));
-        rsSnext = rsrcOf(S + (mat + gridDim.x) * nn, nextLive(), (int)(nn * 4));
-        rsR = rsrcOf(R + mat * nn, true, (int)(nn * 4));
-        rsD = rsrcOf(detected + mat * nn, FLAGS && detected != nullptr, (int)nn);
+        if (item > 0) { // hand-over: every wave has stored its pieces of this item's panel (the last one during the previous step)
+            __syncthreads();
+            loadAllA(panelA(item * G::SPP));
+            f = F + mat * nn;
+            s = S + mat * nn;
+            rsR = rsrcOf(R + mat * nn, true, (int)(nn * 4));
+            rsD = rsrcOf(detected + mat * nn, FLAGS && detected != nullptr, (int)nn);
+        }
+#pragma unroll 1
+        for (int tile = 0; tile < G::TPW; ++tile) {
+            const int g0 = item * G::SPP + tile * G::NSLAB;
+            tl.syncs += 16u;
+            if (fCount != 0u && tileHook(g0)) // armed upsets in this tile (wave-uniform, rare)
+                step(g0, T2{}, T0{}, T0{});
+            else
+                step(g0, T1{}, T0{}, T0{});
+            step(g0 + 1, T0{}, T0{}, T1{});
+            step(g0 + 2, T0{}, T0{}, T0{});
+            step(g0 + 3, T0{}, T1{}, T1{});
+            if (!(COAST_BLK_KNOCK & 1))
+                flushRb3(g0 + 3);
+        }
     }
 
     __syncthreads();
