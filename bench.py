@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's headline metric on MI355X: protected elems/sec + corrected-fault count,
-matrixMultiply TMR (configs[1]: 256x256 uint32, 3-lane replicate + vote), 1..8 GPUs of one node.
+matrixMultiply TMR (configs[1]: 256x256 uint32, 3 replicas + vote), 1..8 GPUs of one node.
 
 A step = one pass of the protected hot path over one batch of synthetic inputs that are already resident in HBM:
 arm the on-device injector with a seeded fault list, run the protected kernel on this GPU's shard of independent
@@ -47,6 +47,8 @@ I8_MFMA_UBENCH = 4.25e15
 # ... on constants.  On RANDOM operand bytes (what the limbs of random matrices are) the same probe sustains 2.94-3.49 POP/s: the
 # matrix core is power-limited and clocks down to 1.4-1.66 GHz (tools/mfma_probe2, profiles/microbench_r02.txt).
 I8_MFMA_RANDOM = 3.4e15
+# v_mfma_i32_16x16x64_i8, one wave per SIMD, 16 / 48 independent accumulators: 2.54-2.76 POP/s on constants and on random bytes
+I8_MFMA_16X16_UBENCH = 2.755e15
 N_SIMD = 256 * 4
 # measured issue cost, cycles per wave-instruction at 8 waves/SIMD (profiles/microbench_r01.txt; v_bitop3 from the same probe,
 # DESIGN.md section 4.2)
@@ -259,14 +261,22 @@ class MM(Workload):
         return bool(torch.equal(chk, self.r[:2]))
 
     def config(self, world):
-        return {"workload": "matrixMultiply %dx%d uint32 TMR (3-lane replicate + vote), batch %d matrices/GPU, "
-                            "%d injected single-bit faults/GPU/step" % (self.n, self.n, self.batch, len(self.faults)),
-                "side": self.n, "batch_per_gpu": self.batch, "replicas": 3, "engine": self.engine(),
-                "parallelism": "dp%d (independent matrices)" % world}
+        cfg = {"workload": "matrixMultiply %dx%d uint32 TMR (3 replicas + vote), batch %d matrices/GPU, "
+                           "%d injected single-bit faults/GPU/step" % (self.n, self.n, self.batch, len(self.faults)),
+               "side": self.n, "batch_per_gpu": self.batch, "replicas": 3, "engine": self.engine(),
+               "parallelism": "dp%d (independent matrices)" % world}
+        if self.engine() == "mfma":
+            cfg["tile"] = self.tile()  # where the replicas live on the matrix core (coast_hip.hip LAUNCH_MM)
+        return cfg
 
     def engine(self):
         """which kernel coast_mm_batch dispatches to (coast_hip.hip LAUNCH_MM): side 256 runs on the matrix cores"""
         return "mfma" if self.n == 256 and os.environ.get("COAST_MM_ENGINE") != "valu" else "valu"
+
+    @staticmethod
+    def tile():
+        """blocks: mm_mfma_blk_kernel (replica = accumulator block, in-lane vote); lanes: mm_mfma_panel_kernel (COAST_MM_TILE=lanes)"""
+        return "lanes" if os.environ.get("COAST_MM_TILE") == "lanes" else "blocks"
 
     def roofline(self, kern_ms):
         n, batch = self.n, self.batch
@@ -279,6 +289,22 @@ class MM(Workload):
             # a wrapping 32-bit MAC = 10 signed-byte limb products (p+q <= 3), per replica: the int8 work the protected
             # computation needs on the matrix core (lane padding 32/30 and ragged tiles are NOT counted)
             ops = 2.0 * macs * 10 * 3
+            if self.tile() == "blocks":
+                return dict(hbm, **{
+                    "bound": "mfma", "kernel": "mm_mfma_blk_kernel<3, false>",
+                    "achieved": ops / t * 1e-12, "peak": I8_MFMA_PEAK * 1e-12, "unit": "TOP/s (int8)",
+                    "frac": ops / t / I8_MFMA_PEAK,
+                    # v_mfma_i32_16x16x64_i8 issued back to back by one wave per SIMD: 2.54-2.76 POP/s, constants or random
+                    # bytes alike -- issue-bound, not power-bound (tools/mfma_probe2 rate16x16x64, profiles/microbench_r02.txt).
+                    # Every executed MFMA is useful here (no lane padding, no ragged tile).
+                    "frac_of_ubench_ceiling": ops / t / I8_MFMA_16X16_UBENCH,
+                    "u32_macs_per_s": macs / t, "int8_ops_per_u32_mac": 2 * 10 * 3,
+                    "algorithmic_macs_vs_valu_ceiling": macs / t / MAC_PEAK, "executed_macs_vs_valu_ceiling": 3.0 * macs / t / MAC_PEAK,
+                    "note": "r = sum_k f*s mod 2^32 as ten int8 GEMMs of signed-byte limbs on v_mfma_i32_16x16x64_i8, the three replicas "
+                            "in three accumulator blocks of the same lane (own B-operand registers, own MFMAs), voted in-lane; one "
+                            "wave per SIMD (192 accumulator registers); achieved = 2*N^3*10*3 int8 ops per matrix / kernel time; "
+                            "peak = 2x the bf16 dense peak (MI355X_MICROARCH.md: I8 runs at ~2x bf16 rate)",
+                })
             return dict(hbm, **{
                 "bound": "mfma", "kernel": "mm_mfma_panel_kernel<3>",
                 "achieved": ops / t * 1e-12, "peak": I8_MFMA_PEAK * 1e-12, "unit": "TOP/s (int8)",
