@@ -135,10 +135,13 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
 
     // s staging: one conversion item = four consecutive k of one column -> one word in each of the four planes; a lane owns the two
     // columns of a pair, lane -> (pair l % 8, k-quad l / 8 + 8 * round): a dwordx2 load instruction fetches eight full tile rows
-    // (64 B each).  plane[q][column][64 B]; a column's four 16-byte slots (slot = k / 16) sit at slot ^ ((0 - column / 4) & 3), which
-    // spreads both the fragment reads (lane = column, k group) and the conversion stores (eight columns of one parity x four
-    // k-quads per 32 lanes) over the banks.
+    // (64 B each).  A plane holds one 64-byte row per column, column c in row (c % 8) * 2 + c / 8, its four 16-byte slots (slot =
+    // k / 16) at slot ^ ((c / 2) % 4): the fragment reads (ds_read_b128: lane = column, k group; 64 banks, lane groups of 16) and
+    // the conversion stores (ds_write_b32: the eight columns of one parity x four k-quads per 32 lanes; 32 banks) are both
+    // conflict-free -- checked by enumeration, SQ_LDS_BANK_CONFLICT agrees.
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    auto colRow = [](int c) { return ((c & 7) << 1) | (c >> 3); }; // column c's 64-byte row in a plane
+    auto colSwz = [](int c) { return (c >> 1) & 3; };               // XORed onto its 16-byte slot number
     int voffB, dstB[G::B_ROUNDS][2]; // staging round u loads 32 u rows further down: that goes into the scalar offset
     constexpr int kRoundOff = 8 * 4 * G::N * 4;
 #pragma unroll
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ch = c + h;
-            dstB[u][h] = ch * G::KS + (((kq >> 2) ^ ((0 - (ch >> 2)) & 3)) * 16) + (kq & 3) * 4;
+            dstB[u][h] = colRow(ch) * G::KS + (((kq >> 2) ^ colSwz(ch)) * 16) + (kq & 3) * 4;
         }
     }
     auto slabOff = [&](int g) __attribute__((always_inline)) { return ((g & 3) * G::KS * G::N + tileCol0(g)) * 4; };
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
 
     // fragment addresses: A row block rb, plane p, slab sl: (aOff ^ (sl * 64)) + rb * 16 * N + p * PLANE_A   (slot 4 sl + kg, swizzled)
     const int aOff = l16 * G::N + ((kg ^ l16) * 16);
-    const int bOff = l16 * G::KS + ((kg ^ ((0 - (l16 >> 2)) & 3)) * 16);
+    const int bOff = colRow(l16) * G::KS + ((kg ^ colSwz(l16)) * 16);
     auto panelA = [&](int g) __attribute__((always_inline)) { return smemP + ((g >> 4) & 1) * G::A_PANEL + (aOff ^ ((g & 3) * 64)); };
 
     Tally tl;
