@@ -495,6 +495,14 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
             step(g0 + 3, T0{}, T1{}, T1{});
             if (!(COAST_BLK_KNOCK & 1))
                 flushRb3(g0 + 3);
+            else { // keep every MFMA alive: one element of every accumulator, one store per tile
+                uint32_t x = 0;
+                for_each_index(std::make_integer_sequence<int, G::NRB * NREP * 4>{}, [&](auto kTag) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kTag)::value;
+                    x ^= (uint32_t)acc[k / (NREP * 4)][(k / 4) % NREP][k % 4][0];
+                });
+                __builtin_amdgcn_raw_buffer_store_b32(x, rsR, voffR, (pnl * G::BM * G::N + tileCol0(g0)) * 4, 0);
+            }
         }
     }
 
