@@ -97,7 +97,11 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     const int voffR = ((4 * ((tid & 63) >> 4)) * G::N + (tid & 15)) * 4; // C/D layout: lane -> column lane % 16, rows 4 (lane / 16) + i
     // per-item flags (FLAGS): one byte per element; the range check drops the stores of the lanes whose element agreed (their
     // offset is pushed out of range): no branch
-    __amdgpu_buffer_rsrc_t rsD = rsrcOf(detected + mat0 * nn, FLAGS && detected != nullptr, (int)nn);
+    auto flagsOf = [&](uint32_t m) __attribute__((always_inline)) { // per-item flags of matrix m; none: an empty buffer
+        const bool on = FLAGS && detected != nullptr;
+        return rsrcOf(on ? detected + m * nn : (const uint8_t *)F, on, (int)nn);
+    };
+    __amdgpu_buffer_rsrc_t rsD = flagsOf(mat0);
 
     // ---- f panels: plane[p][row][256 B], the row's sixteen 16-byte slots (slot = k / 16) at slot ^ (row & 15) -- the layout of
     // mm_mfma_panel_kernel; a 16x16x64 fragment read (lane = row & 15, k group) finds its 16 lanes' slots in 16 different banks.
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
             f = F + mat * nn;
             s = S + mat * nn;
             rsR = rsrcOf(R + mat * nn, true, (int)(nn * 4));
-            rsD = rsrcOf(detected + mat * nn, FLAGS && detected != nullptr, (int)nn);
+            rsD = flagsOf(mat);
         }
 #pragma unroll 1
         for (int tile = 0; tile < G::TPW; ++tile) {

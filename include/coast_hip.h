@@ -204,8 +204,9 @@ int coast_inject_faults(coast_ctx *ctx, const coast_fault *faults, size_t k);
 /* matrix_multiply (tests/mm_common/mm_common_tmr.c:3-20; LANL variant tests/matrixMultiply/matrixMultiply.c:95-112):
  * `batch` independent n x n row-major uint32 products, r = (uint32) sum_k f[i][k]*s[k][j].
  * n == 256 (the benchmark's side) runs on the int8 matrix cores (exact signed-byte limb decomposition of the 32-bit
- * products; armed upsets are applied to the replica's lane and out-voted inside that kernel); every other side, and
- * n == 256 under COAST_MM_ENGINE=valu, on the VALU kernels.  Same words, counters and flags.  f, s, r: 16-byte aligned
+ * products; TMR: the three replicas in three accumulator blocks of one lane, voted in-lane; DWC / unprotected: replicas in
+ * adjacent lanes; armed upsets are applied to the replica's accumulator and out-voted inside that kernel); every other side,
+ * and n == 256 under COAST_MM_ENGINE=valu, on the VALU kernels.  Same words, counters and flags.  f, s, r: 16-byte aligned
  * when n is a multiple of 4.
  * d_detected (all batch entry points): optional, one byte per work item, set to 1 where a sync point of that item saw
  * unequal copies -- DWC: the compare that would have called FAULT_DETECTED_DWC(); TMR: a value was out-voted (the per-item
