@@ -1725,3 +1725,42 @@ def test_campaign_chaes(eng):
     assert d["errors"] == 0 and d["aborts"] > 500
     assert n["errors"] > 500
     assert m["errors"] == 0 and m["faults"] > 500
+
+
+@pytest.mark.parametrize("batch", [1, 2, 5, 63, 64, 65, 130, 200])
+def test_mm_256_register_block_kernel_batch_shapes(eng, orc, batch, monkeypatch):
+    """the persistent TMR kernel (a workgroup = one panel position of matrices m, m + 64, ...): batches that leave panel groups
+    empty, end in the middle of a stride, or give every workgroup several items -- outputs equal the lane-replica kernel's
+    (COAST_MM_TILE=lanes) word for word, upsets in first and later items are out-voted, flagged per item and counted, and a sparse
+    sample equals the oracle"""
+    import torch
+
+    import coast_amd as ca
+
+    n = 256
+    g = torch.Generator(device="cuda").manual_seed(batch)
+    f = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device="cuda", generator=g)
+    s = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device="cuda", generator=g)
+    rng = np.random.default_rng(batch)
+    items = np.unique(np.concatenate([rng.integers(0, batch * n * n, 40), [0, batch * n * n - 1, (batch - 1) * n * n + 64 * n + 17]]))
+    rows = [(int(it), int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, n + 1)), int(rng.integers(0, 32)))
+            for it in items]
+    fl = ca.make_faults(rows)
+    det = torch.zeros(batch * n * n, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    r = eng.mm_batch(f, s, detected=det)
+    st = eng.stats()
+    assert eng.last_launch()["engine"] == "matrix_core" and eng.last_launch()["general_blocks"] == 0
+    monkeypatch.setenv("COAST_MM_TILE", "lanes")
+    det2 = torch.zeros_like(det)
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    r2 = eng.mm_batch(f, s, detected=det2)
+    st2 = eng.stats()
+    assert torch.equal(r, r2) and torch.equal(det, det2)
+    assert _stats3(st) == _stats3(st2) and st["sync_count"] == batch * n * n
+    assert int(det.sum()) == st["errors_corrected"] > 0
+    fh, sh = _host(f, np.uint32), _host(s, np.uint32)
+    exp, _, _ = orc.mm_xmr_items(fh, sh, items.astype(np.uint64))
+    assert (_host(r, np.uint32).reshape(-1)[items] == exp).all()
