@@ -21,6 +21,7 @@
 #include "mm_kernel.hip"
 #include "mm_mfma_kernel.hip"
 #include "mm_mfma_blk_kernel.hip"
+#include "mm_mfma_blk2_kernel.hip"
 #include "sha256_kernel.hip"
 #include "aes_kernel.hip"
 #include "crc16_kernel.hip"
@@ -668,6 +669,7 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     // which also serves DWC and the unprotected mode
     const char *tileEnv = getenv("COAST_MM_TILE");
     const bool mmBlocks = !(tileEnv && !strcmp(tileEnv, "lanes"));
+    const bool mmBlocks2 = tileEnv && !strcmp(tileEnv, "blocks2"); // two waves per SIMD (mm_mfma_blk2_kernel)
     const uint64_t nbm = (uint64_t)(n / 64) * batch; // workgroups of the panel kernel: 64 rows of one matrix each
 
     FaultTab ft;
@@ -710,7 +712,20 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
                 ftm.list = nullptr, ftm.range = nullptr;                                                        \
             /* one workgroup per CU; four of them (one XCD) share a matrix */                                    \
             const uint32_t gridB = 4u * (uint32_t)std::min<uint64_t>((uint64_t)batch, (uint64_t)(c->numCUs / 4)); \
-            if (d_detected) {                                                                                   \
+            if (mmBlocks2) {                                                                                    \
+                using G2 = MmBlk2<3>;                                                                           \
+                if (d_detected) {                                                                               \
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk2_kernel<3, true>,                  \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
+                    hipLaunchKernelGGL((mm_mfma_blk2_kernel<3, true>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
+                                       c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);        \
+                } else {                                                                                        \
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk2_kernel<3, false>,                 \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
+                    hipLaunchKernelGGL((mm_mfma_blk2_kernel<3, false>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
+                                       c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);        \
+                }                                                                                               \
+            } else if (d_detected) {                                                                            \
                 HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk_kernel<3, true>,                       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB::LDS_BYTES)); \
                 hipLaunchKernelGGL((mm_mfma_blk_kernel<3, true>), dim3(gridB), dim3(GB::NTHR), GB::LDS_BYTES,   \

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
         constexpr int i = k / 5, sub = k % 5;
         if constexpr (sub < 3) {
             constexpr int rs = sub < NREP ? sub : NREP - 1;
-            teV[sub] = (((((uint32_t)acc[rb][rs][3][i] << 8) + (uint32_t)acc[rb][rs][2][i]) << 8) + (uint32_t)acc[rb][rs][1][i] << 8) +
+            teV[sub] = ((((((uint32_t)acc[rb][rs][3][i] << 8) + (uint32_t)acc[rb][rs][2][i]) << 8) + (uint32_t)acc[rb][rs][1][i]) << 8) +
                        (uint32_t)acc[rb][rs][0][i]; // three v_lshl_add_u32
         } else if constexpr (sub == 3) {
             const bool e01 = teV[0] == teV[1], e02 = teV[0] == teV[2];
