@@ -275,8 +275,10 @@ class MM(Workload):
 
     @staticmethod
     def tile():
-        """blocks: mm_mfma_blk_kernel (replica = accumulator block, in-lane vote); lanes: mm_mfma_panel_kernel (COAST_MM_TILE=lanes)"""
-        return "lanes" if os.environ.get("COAST_MM_TILE") == "lanes" else "blocks"
+        """blocks2 (default): mm_mfma_blk2_kernel (replica = accumulator block, in-lane vote, two waves per SIMD); blocks:
+        mm_mfma_blk_kernel (the same with one wave per SIMD, COAST_MM_TILE=blocks); lanes: mm_mfma_panel_kernel (COAST_MM_TILE=lanes)"""
+        t = os.environ.get("COAST_MM_TILE")
+        return t if t in ("lanes", "blocks") else "blocks2"
 
     def roofline(self, kern_ms):
         n, batch = self.n, self.batch
@@ -289,9 +291,10 @@ class MM(Workload):
             # a wrapping 32-bit MAC = 10 signed-byte limb products (p+q <= 3), per replica: the int8 work the protected
             # computation needs on the matrix core (lane padding 32/30 and ragged tiles are NOT counted)
             ops = 2.0 * macs * 10 * 3
-            if self.tile() == "blocks":
+            if self.tile() != "lanes":
+                two = self.tile() == "blocks2"
                 return dict(hbm, **{
-                    "bound": "mfma", "kernel": "mm_mfma_blk_kernel<3, false>",
+                    "bound": "mfma", "kernel": "mm_mfma_blk2_kernel<3, false>" if two else "mm_mfma_blk_kernel<3, false>",
                     "achieved": ops / t * 1e-12, "peak": I8_MFMA_PEAK * 1e-12, "unit": "TOP/s (int8)",
                     "frac": ops / t / I8_MFMA_PEAK,
                     # v_mfma_i32_16x16x64_i8 issued back to back by one wave per SIMD: 2.54-2.76 POP/s, constants or random
@@ -301,8 +304,10 @@ class MM(Workload):
                     "u32_macs_per_s": macs / t, "int8_ops_per_u32_mac": 2 * 10 * 3,
                     "algorithmic_macs_vs_valu_ceiling": macs / t / MAC_PEAK, "executed_macs_vs_valu_ceiling": 3.0 * macs / t / MAC_PEAK,
                     "note": "r = sum_k f*s mod 2^32 as ten int8 GEMMs of signed-byte limbs on v_mfma_i32_16x16x64_i8, the three replicas "
-                            "in three accumulator blocks of the same lane (own B-operand registers, own MFMAs), voted in-lane; one "
-                            "wave per SIMD (192 accumulator registers); achieved = 2*N^3*10*3 int8 ops per matrix / kernel time; "
+                            "in three accumulator blocks of the same lane (own B-operand registers, own MFMAs), voted in-lane; "
+                            + ("two waves per SIMD, each with half the tile's rows (96 accumulator registers)" if two else
+                               "one wave per SIMD (192 accumulator registers)") +
+                            "; achieved = 2*N^3*10*3 int8 ops per matrix / kernel time; "
                             "peak = 2x the bf16 dense peak (MI355X_MICROARCH.md: I8 runs at ~2x bf16 rate)",
                 })
             return dict(hbm, **{

@@ -665,11 +665,12 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     // side 256: the int8-MFMA limb kernel, injector hooks included; COAST_MM_ENGINE=valu selects the v_mad_u64_u32 kernels
     const char *eng = getenv("COAST_MM_ENGINE");
     const bool mfma = n == 256 && !allGeneral && !(eng && !strcmp(eng, "valu"));
-    // TMR: replicas in register blocks (mm_mfma_blk_kernel); COAST_MM_TILE=lanes selects the lane-replica kernel (mm_mfma_panel_kernel),
-    // which also serves DWC and the unprotected mode
+    // TMR: replicas in register blocks, two waves per SIMD (mm_mfma_blk2_kernel); COAST_MM_TILE=blocks selects its one-wave-per-SIMD
+    // predecessor (mm_mfma_blk_kernel), COAST_MM_TILE=lanes the lane-replica kernel (mm_mfma_panel_kernel), which also serves DWC and
+    // the unprotected mode
     const char *tileEnv = getenv("COAST_MM_TILE");
     const bool mmBlocks = !(tileEnv && !strcmp(tileEnv, "lanes"));
-    const bool mmBlocks2 = tileEnv && !strcmp(tileEnv, "blocks2"); // two waves per SIMD (mm_mfma_blk2_kernel)
+    const bool mmBlocks2 = !(tileEnv && !strcmp(tileEnv, "blocks"));
     const uint64_t nbm = (uint64_t)(n / 64) * batch; // workgroups of the panel kernel: 64 rows of one matrix each
 
     FaultTab ft;
@@ -705,7 +706,7 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     } while (0)
 #define LAUNCH_MM(R)                                                                                            \
     do {                                                                                                        \
-        if (mfma && R == 3 && mmBlocks) { /* TMR: replicas in register blocks, one wave per SIMD */              \
+        if (mfma && R == 3 && mmBlocks) { /* TMR: replicas in register blocks */              \
             using GB = MmBlk<3>;                                                                                \
             FaultTab ftm = ft;                                                                                  \
             if (!have)                                                                                          \

@@ -9,6 +9,17 @@
 // converting: wave H converts slab g + 1 during the steps with g % 2 == H (and the background f piece in the others), so each
 // slab is still converted once per pair and the conversion work per wave halves.  One workgroup barrier per step, in its middle:
 // the converter is through by slot 28, the fragments of the next slab are read behind it.
+//
+// Tile end inside the steps: a wave's first row block is final after slot 29 of the tile's last step and is voted and stored behind
+// that step's remaining 30 MFMAs; its second row block leaves behind the first 30 MFMAs of the NEXT tile's first step (across an
+// item hand-over through the previous item's buffer resources), before slot 30 restarts its sums.  Only the very last tile's second
+// row block is flushed in the open.  The first step of all therefore votes a tile that does not exist: zeroed accumulators (equal
+// replicas, nothing counted) and a zero-sized buffer resource (stores dropped).
+//
+// Register budget: 256 VGPRs per wave at two waves per SIMD, no AGPRs to spill into.  Any per-lane constant that stayed live across
+// the steps and got spilled came back through scratch -- and its s_waitcnt vmcnt(0) drained the two-slab-deep s prefetch (a variant
+// with ~40 spilled registers ran 8-13 ms instead of 6.6).  The rarely used ones (f piece offsets, panel destinations, store offsets)
+// are recomputed from a fresh lane id at their point of use instead: 0 VGPR spills in the step bodies.
 #include <type_traits>
 #include <utility>
 
@@ -61,7 +72,18 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
     const uint32_t *f = F + mat0 * nn, *s = S + mat0 * nn;
     const __amdgpu_buffer_rsrc_t rsF = rsFof(0), rsS = rsSof(0);
     __amdgpu_buffer_rsrc_t rsR = rsrcOf(R + mat0 * nn, true, (int)(nn * 4));
-    const int voffR = ((4 * kg) * G::N + l16) * 4;
+    // per-lane constants that are needed once or twice per step are recomputed from a fresh lane id where they are used: every
+    // register that stays live across the steps is one the allocator has to take from the accumulators' neighbourhood (a spilled
+    // constant comes back through scratch, and its s_waitcnt vmcnt(0) drains the s prefetches)
+    auto freshLane = []() __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    auto voffRof = [&]() __attribute__((always_inline)) {
+        const int l = freshLane();
+        return ((4 * (l >> 4)) * G::N + (l & 15)) * 4;
+    };
     auto flagsOf = [&](uint32_t m) __attribute__((always_inline)) {
         const bool on = FLAGS && detected != nullptr;
         return rsrcOf(on ? detected + m * nn : (const uint8_t *)F, on, (int)nn);
@@ -70,14 +92,18 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
 
     // ---- f panels: piece j of a panel for thread t (512 threads): row 8 j + t / 64, k-quad t % 64
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    const int voffF = ((tid >> 6) * G::N + 4 * (tid & 63)) * 4;
-    const int panelDst0 = (tid >> 6) * G::N + ((((tid & 63) >> 2) ^ (tid >> 6)) * 16) + (tid & 3) * 4; // row & 15 = 8 (j & 1) | t / 64
-    auto panelDst = [&](int j) __attribute__((always_inline)) { return (panelDst0 ^ ((j & 1) * 128)) + j * 8 * G::N; };
+    const int soffFw = wv * G::N * 4; // the wave's row of a piece goes into the scalar offset
+    auto voffFof = [&]() __attribute__((always_inline)) { return freshLane() * 16; };
+    auto panelDst = [&](int j) __attribute__((always_inline)) { // row & 15 = 8 (j & 1) | t / 64
+        const int l = freshLane();
+        const int d0 = wv * G::N + (((l >> 2) ^ wv) * 16) + (l & 3) * 4;
+        return (d0 ^ ((j & 1) * 128)) + j * 8 * G::N;
+    };
     {
         u32x4_t pa[G::A_PER_THR];
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u)
-            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffF, (pnl * G::BM + u * 8) * G::N * 4, 0);
+            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffFof(), soffFw + (pnl * G::BM + u * 8) * G::N * 4, 0);
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u) {
             const uint32_t y[4] = {mm_digits(pa[u][0]), mm_digits(pa[u][1]), mm_digits(pa[u][2]), mm_digits(pa[u][3])};
@@ -91,7 +117,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
     }
     // background piece of step g (a step in which this wave is not converting s): piece (g % 16) / 2 of the next item's panel
     auto bgLoad = [&](int g) __attribute__((always_inline)) {
-        return __builtin_amdgcn_raw_buffer_load_b128(rsFof((g >> 4) + 1), voffF, (pnl * G::BM + 8 * ((g & 15) >> 1)) * G::N * 4, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(rsFof((g >> 4) + 1), voffFof(), soffFw + (pnl * G::BM + 8 * ((g & 15) >> 1)) * G::N * 4, 0);
     };
 
     auto tileCol0 = [&](int g) __attribute__((always_inline)) { return (wave + G::NLANE * ((g >> 2) & 3)) * G::CT; };
@@ -119,6 +145,13 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
         Tally tl;
         uint32_t detItems = 0;
         v4i_t acc[2][NREP][4]; // row blocks 2 H and 2 H + 1
+#pragma unroll
+        for (int rbz = 0; rbz < 2; ++rbz)
+#pragma unroll
+            for (int rz = 0; rz < NREP; ++rz)
+#pragma unroll
+                for (int pz = 0; pz < 4; ++pz)
+                    acc[rbz][rz][pz] = v4i_t{0, 0, 0, 0}; // the first step votes a tile that does not exist: equal replicas, stores out of range
         // raw s words of this wave's next conversion: wave H converts slab g + 1 in the steps with g % 2 == H, i.e. the slabs of
         // one parity; behind each staging round it reloads the registers with the slab two further on -- two steps to arrive
         u32x2_t pbs[G::B_ROUNDS][4];
@@ -156,7 +189,8 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
 
         // ---- tile end (branch-free, see mm_mfma_blk_kernel): this wave's two row blocks
         uint32_t teV[3], teVoted = 0u, teMiss = 0u;
-        auto teStage = [&](int g, auto rbTag, auto kTag) __attribute__((always_inline)) {
+        __amdgpu_buffer_rsrc_t rsRp = rsrcOf(R, false, 0), rsDp = rsRp; // where the previous tile's second row block goes (nowhere before the first tile)
+        auto teStage = [&](int g, int voffR, auto rbTag, auto kTag) __attribute__((always_inline)) {
             constexpr int rb = decltype(rbTag)::value, k = decltype(kTag)::value;
             constexpr int i = k / 5, sub = k % 5;
             if constexpr (sub < 3) {
@@ -173,15 +207,15 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
                     detItems += teMiss;
             } else {
                 const int erow = pnl * G::BM + (2 * H + rb) * 16 + i;
-                __builtin_amdgcn_raw_buffer_store_b32(teVoted, rsR, voffR, (erow * G::N + tileCol0(g)) * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(teVoted, rb == 0 ? rsR : rsRp, voffR, (erow * G::N + tileCol0(g)) * 4, 0);
                 if constexpr (FLAGS)
-                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)1, rsD, teMiss ? (voffR >> 2) : 0x40000000, erow * G::N + tileCol0(g), 0);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)1, rb == 0 ? rsD : rsDp, teMiss ? (voffR >> 2) : 0x40000000, erow * G::N + tileCol0(g), 0);
             }
         };
         auto flushTile = [&](int g) __attribute__((always_inline)) {
-            for_each_index(std::make_integer_sequence<int, 40>{}, [&](auto kTag) __attribute__((always_inline)) {
-                constexpr int k = decltype(kTag)::value;
-                teStage(g, std::integral_constant<int, k / 20>{}, std::integral_constant<int, k % 20>{});
+            const int voffR = voffRof();
+            for_each_index(std::make_integer_sequence<int, 20>{}, [&](auto kTag) __attribute__((always_inline)) {
+                teStage(g, voffR, std::integral_constant<int, 1>{}, kTag); // the first row block's went out inside the last step
             });
         };
 
@@ -289,7 +323,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
             loadB(std::integral_constant<int, k / 4>{}, std::integral_constant<int, k % 4>{}, wbuf);
         });
         auto step = [&](int g, auto firstTag, auto posTag) __attribute__((always_inline)) {
-            constexpr int FIRST = decltype(firstTag)::value; // 1: first slab of a tile, the sums start from zero
+            constexpr int FIRST = decltype(firstTag)::value; // 1: first slab of a tile: the previous tile's second row block goes out, then the sums start from zero
             constexpr int POS = decltype(posTag)::value;     // g % 4
             constexpr bool DUTY = (POS & 1) == H;            // this wave converts slab g + 1 now; otherwise its background f piece
             const int soffLoad = slabOff(g + 3);
@@ -298,6 +332,9 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
             const uint8_t *pAnext = panelA(g + 1);
             uint8_t *bufNext = wbuf + ((g + 1) & 1) * G::B_BUF;
             uint8_t *bgDst = smemP + (((g >> 4) + 1) & 1) * G::A_PANEL + panelDst((g & 15) >> 1);
+            int voffR = 0;
+            if constexpr (FIRST != 0 || POS == 3)
+                voffR = voffRof();
             __builtin_amdgcn_sched_barrier(0);
 
             uint32_t y[4], t[4];
@@ -375,6 +412,10 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
                     pbs[1][(m - 31) / 2] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + ((m - 31) / 2) * G::N * 4, soffLoad + kRoundOff, 0);
                 if constexpr (!DUTY && (m & 3) == 0 && m < 20)
                     bgStage(std::integral_constant<int, m / 4>{});
+                if constexpr (POS == 3 && m >= 30 && (m - 30) % 3 != 2) // last slab: the first row block's sums are final after slot 29
+                    teStage(g, voffR, std::integral_constant<int, 0>{}, std::integral_constant<int, (m - 30) - (m - 30) / 3>{});
+                if constexpr (FIRST != 0 && m < 30 && m % 3 != 1) // the previous tile's second row block, before slot 30 restarts its sums
+                    teStage(g - 1, voffR, std::integral_constant<int, 1>{}, std::integral_constant<int, m - (m + 2) / 3>{});
                 __builtin_amdgcn_sched_barrier(0);
             };
             for_each_index(std::make_integer_sequence<int, 60>{}, slot);
@@ -384,6 +425,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
         using T1 = std::integral_constant<int, 1>;
         using T2 = std::integral_constant<int, 2>;
         using T3 = std::integral_constant<int, 3>;
+        int gLast = 3;
 #pragma unroll 1
         for (int item = 0; matOf(item) < nblocks; ++item) {
             const uint32_t mat = matOf(item);
@@ -404,15 +446,18 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
             for (int tile = 0; tile < G::TPW; ++tile) {
                 const int g0 = item * G::SPP + tile * G::NSLAB;
                 tl.syncs += 8u;
-                step(g0, T1{}, T0{});
+                step(g0, T1{}, T0{}); // + the previous tile's second row block (the previous item's resources at a hand-over)
+                rsRp = rsR;
+                rsDp = rsD;
                 step(g0 + 1, T0{}, T1{});
                 step(g0 + 2, T0{}, T2{});
-                step(g0 + 3, T0{}, T3{});
-                if (fCount != 0u) // armed upsets in this panel (wave-uniform, rare): their deltas go on top of the finished limb-0 sums
+                if (fCount != 0u) // armed upsets in this panel (wave-uniform, rare): their deltas go on top of the running limb-0 sums
                     tileHook(g0);
-                flushTile(g0 + 3);
+                step(g0 + 3, T0{}, T3{}); // + this tile's first row block
+                gLast = g0 + 3;
             }
         }
+        flushTile(gLast); // the last tile's second row block: nothing left to hide it behind
 
         __syncthreads();
         uint32_t *sCnt = reinterpret_cast<uint32_t *>(smemP + 2 * G::A_PANEL);

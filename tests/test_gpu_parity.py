@@ -1727,9 +1727,11 @@ def test_campaign_chaes(eng):
     assert m["errors"] == 0 and m["faults"] > 500
 
 
+@pytest.mark.parametrize("tile", ["blocks2", "blocks"])
 @pytest.mark.parametrize("batch", [1, 2, 5, 63, 64, 65, 130, 200])
-def test_mm_256_register_block_kernel_batch_shapes(eng, orc, batch, monkeypatch):
-    """the persistent TMR kernel (a workgroup = one panel position of matrices m, m + 64, ...): batches that leave panel groups
+def test_mm_256_register_block_kernel_batch_shapes(eng, orc, batch, tile, monkeypatch):
+    """the persistent TMR kernels (two waves per SIMD -- the default -- and one wave per SIMD, COAST_MM_TILE=blocks; a workgroup =
+    one panel position of matrices m, m + 64, ...): batches that leave panel groups
     empty, end in the middle of a stride, or give every workgroup several items -- outputs equal the lane-replica kernel's
     (COAST_MM_TILE=lanes) word for word, upsets in first and later items are out-voted, flagged per item and counted, and a sparse
     sample equals the oracle"""
@@ -1747,11 +1749,17 @@ def test_mm_256_register_block_kernel_batch_shapes(eng, orc, batch, monkeypatch)
             for it in items]
     fl = ca.make_faults(rows)
     det = torch.zeros(batch * n * n, dtype=torch.uint8, device="cuda")
+    monkeypatch.setenv("COAST_MM_TILE", tile)
     eng.reset_stats()
     eng.inject_faults(fl)
     r = eng.mm_batch(f, s, detected=det)
     st = eng.stats()
     assert eng.last_launch()["engine"] == "matrix_core" and eng.last_launch()["general_blocks"] == 0
+    # the same launch without the per-item flag array (the other template instance: no flag stores)
+    eng.reset_stats()
+    eng.inject_faults(fl)
+    r0 = eng.mm_batch(f, s)
+    assert torch.equal(r, r0) and _stats3(eng.stats()) == _stats3(st)
     monkeypatch.setenv("COAST_MM_TILE", "lanes")
     det2 = torch.zeros_like(det)
     eng.reset_stats()
