@@ -49,6 +49,8 @@ I8_MFMA_UBENCH = 4.25e15
 I8_MFMA_RANDOM = 3.4e15
 # v_mfma_i32_16x16x64_i8, one wave per SIMD, 16 / 48 independent accumulators: 2.54-2.76 POP/s on constants and on random bytes
 I8_MFMA_16X16_UBENCH = 2.755e15
+# ... and with two waves per SIMD (24 accumulators each, mm_mfma_blk2_kernel's regime): 4.58 POP/s on constants, 3.71 on random bytes
+I8_MFMA_16X16_UBENCH_2W = 3.711e15
 N_SIMD = 256 * 4
 # measured issue cost, cycles per wave-instruction at 8 waves/SIMD (profiles/microbench_r01.txt; v_bitop3 from the same probe,
 # DESIGN.md section 4.2)
@@ -298,9 +300,10 @@ class MM(Workload):
                     "achieved": ops / t * 1e-12, "peak": I8_MFMA_PEAK * 1e-12, "unit": "TOP/s (int8)",
                     "frac": ops / t / I8_MFMA_PEAK,
                     # v_mfma_i32_16x16x64_i8 issued back to back by one wave per SIMD: 2.54-2.76 POP/s, constants or random
-                    # bytes alike -- issue-bound, not power-bound (tools/mfma_probe2 rate16x16x64, profiles/microbench_r02.txt).
-                    # Every executed MFMA is useful here (no lane padding, no ragged tile).
-                    "frac_of_ubench_ceiling": ops / t / I8_MFMA_16X16_UBENCH,
+                    # bytes alike -- issue-bound, not power-bound; by two waves per SIMD: 3.71 POP/s on random bytes
+                    # (tools/mfma_probe2 rate16x16x64, profiles/microbench_r02.txt).  Every executed MFMA is useful here
+                    # (no lane padding, no ragged tile).
+                    "frac_of_ubench_ceiling": ops / t / (I8_MFMA_16X16_UBENCH_2W if two else I8_MFMA_16X16_UBENCH),
                     "u32_macs_per_s": macs / t, "int8_ops_per_u32_mac": 2 * 10 * 3,
                     "algorithmic_macs_vs_valu_ceiling": macs / t / MAC_PEAK, "executed_macs_vs_valu_ceiling": 3.0 * macs / t / MAC_PEAK,
                     "note": "r = sum_k f*s mod 2^32 as ten int8 GEMMs of signed-byte limbs on v_mfma_i32_16x16x64_i8, the three replicas "

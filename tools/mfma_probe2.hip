@@ -127,7 +127,7 @@ template <int FLAGS> static void run_stepY(int *dD, const uint2 *g, int cus)
 // replicas = 4 x 3 x 4 limb sums of 4 registers (192), 64-deep k slab: 120 MFMAs, 16 A + 12 B fragment reads, the conversion of
 // a 16-column x 64-k slab (FLAGS as above).
 typedef int v4acc __attribute__((ext_vector_type(4)));
-template <int NACC, bool RND> __global__ __launch_bounds__(256, 1) void rate16(int *out, int iters)
+template <int NACC, bool RND, int WPS = 1> __global__ __launch_bounds__(256 * WPS, 1) void rate16(int *out, int iters)
 {
     uint32_t s = threadIdx.x * 2654435761u + blockIdx.x * 97u + 1u;
     v4i a[4], b[4];
@@ -146,16 +146,16 @@ template <int NACC, bool RND> __global__ __launch_bounds__(256, 1) void rate16(i
     for (int t = 0; t < NACC; ++t) for (int e = 0; e < 4; ++e) r += c[t][e];
     if (r == 0x12345678) out[threadIdx.x] = r;
 }
-template <int NACC, bool RND> static void run_rate16(int *dD, int cus)
+template <int NACC, bool RND, int WPS = 1> static void run_rate16(int *dD, int cus)
 {
     const int iters = 40000 / NACC * 4, blocks = cus;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((rate16<NACC, RND>), dim3(blocks), dim3(256), 0, 0, dD, 10);
+    hipLaunchKernelGGL((rate16<NACC, RND, WPS>), dim3(blocks), dim3(256 * WPS), 0, 0, dD, 10);
     hipDeviceSynchronize();
-    hipEventRecord(e0); hipLaunchKernelGGL((rate16<NACC, RND>), dim3(blocks), dim3(256), 0, 0, dD, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventRecord(e0); hipLaunchKernelGGL((rate16<NACC, RND, WPS>), dim3(blocks), dim3(256 * WPS), 0, 0, dD, iters); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double mf = (double)blocks * 4 * iters * NACC;
-    printf("rate16x16x64 acc=%2d %s waves/SIMD=1: %.3f ms  %.0f TOPS\n", NACC, RND ? "random" : "const ", ms, mf * 32768 / (ms * 1e-3) * 1e-12);
+    const double mf = (double)blocks * 4 * WPS * iters * NACC;
+    printf("rate16x16x64 acc=%2d %s waves/SIMD=%d: %.3f ms  %.0f TOPS\n", NACC, RND ? "random" : "const ", WPS, ms, mf * 32768 / (ms * 1e-3) * 1e-12);
 }
 template <int FLAGS> __global__ __launch_bounds__(256, 1) void stepZ(int *out, const uint2 *g, int iters)
 {
@@ -250,6 +250,9 @@ int main()
     }
     uint2 *g; hipMalloc(&g, (size_t)1024 * 4096 * 8 + 65536 * 8); hipMemset(g, 0x5a, (size_t)1024 * 4096 * 8);
     run_rate16<16, false>(dD, cus); run_rate16<16, true>(dD, cus); run_rate16<48, true>(dD, cus);
+    run_rate16<24, true, 1>(dD, cus); run_rate16<24, false, 2>(dD, cus); run_rate16<24, true, 2>(dD, cus); // two waves per SIMD: mm_mfma_blk2_kernel's regime
+    if (getenv("PROBE_RATE16_ONLY"))
+        return 0;
     run_stepZ<1>(dD, g, cus); run_stepZ<3>(dD, g, cus); run_stepZ<17>(dD, g, cus); run_stepZ<33>(dD, g, cus); run_stepZ<15>(dD, g, cus); run_stepZ<29>(dD, g, cus);
     run_stepY<0>(dD, g, cus); run_stepY<1>(dD, g, cus); run_stepY<3>(dD, g, cus); run_stepY<7>(dD, g, cus); run_stepY<15>(dD, g, cus);
     return 0;
