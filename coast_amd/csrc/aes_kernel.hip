@@ -427,6 +427,267 @@ __global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restric
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------ bank-replicated tables
+// The T-table kernels above are LDS-bound and half of their LDS cycles are bank conflicts: the 16 distinct blocks of a DWC
+// lane group hit 32 banks at random (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 46 %, 4.1 cycles per lookup instead of 2;
+// profiles/r02_aes_rocprofv3_summary.txt).  For large batches the tables are therefore REPLICATED: copy c of entry v sits at
+// word v * 16 + c, i.e. in bank c + 16 (v & 1), and the lanes of block slot q read copy q % 16 -- the replicas of a block
+// share a copy (same address: broadcast), different blocks of a 32-lane group can never meet on a bank, whatever their
+// indices.  Still one shared read-only copy set per workgroup, outside the sphere of replication like the tables above.
+// 64 KiB (encryption) / 112 KiB (decryption) of LDS, so the kernels are persistent: 1024-thread workgroups, waves
+// grid-stride over tiles, tables filled once per workgroup.  The byte tables ride along instead of conflicting beside them:
+//   encryption  S[v] is byte 1 of Te_0[v] (= (2S, S, S, 3S)): key schedule and last round look up Te_0 and pick the byte
+//               with v_perm_b32;
+//   decryption  Td_0 and Tis_0 are stored as 8-byte pairs {Td_0[v], rsbox[v] * 0x01010101} / {Tis_0[v], S[v] * 0x01010101}
+//               and read with ds_read_b64 (same 2 LDS cycles as a dword read): the key-schedule word and its InvMixColumns
+//               image come out of ONE lookup per byte (Tis_r = Tis_0 rotated by r bytes), the last round reads the .y halves.
+constexpr int kAesCopies = 16;
+constexpr int kAesRepThreads = 1024;
+constexpr int kAesTabWords = 256 * kAesCopies; // one replicated dword table: 16 KiB
+constexpr size_t kAesEncRepLds = (size_t)4 * kAesTabWords * 4 + 16;
+constexpr size_t kAesDecRepLds = (size_t)(3 + 2 + 2) * kAesTabWords * 4 + 16;
+
+__device__ __forceinline__ uint32_t aes_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32
+// bytes 0..3 = byte 1 of t0..t3
+__device__ __forceinline__ uint32_t aes_pick_b1(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3)
+{
+    return __builtin_amdgcn_perm(t1, t0, 0x0c0c0501u) | __builtin_amdgcn_perm(t3, t2, 0x05010c0cu);
+}
+// byte i of the result = byte i of yi (the yi carry one byte value in all four positions)
+__device__ __forceinline__ uint32_t aes_pick_rep(uint32_t y0, uint32_t y1, uint32_t y2, uint32_t y3)
+{
+    return aes_bfi(0x000000ffu, y0, aes_bfi(0x0000ff00u, y1, aes_bfi(0x00ff0000u, y2, y3)));
+}
+// LDS byte offset of this lane's copy of table entry x.byte[B]: entries are 1 << SH bytes apart (16 copies of a dword: SH = 6, of
+// an 8-byte pair: SH = 7), cOff = copy * entry size < 1 << SH, so the OR is an add: one shift and one v_and_or_b32 per lookup
+template <int B, int SH> __device__ __forceinline__ uint32_t aes_rep_off(uint32_t x, uint32_t cOff)
+{
+    uint32_t a;
+    if constexpr (8 * B >= SH)
+        a = x >> (8 * B - SH);
+    else
+        a = x << (SH - 8 * B);
+    return (a & (0xffu << SH)) | cOff;
+}
+__device__ __forceinline__ uint32_t aes_rotl8(uint32_t x, int bytes) { return __builtin_amdgcn_alignbit(x, x, 32 - 8 * bytes); }
+
+template <int NREP>
+__global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
+                                                                        uint64_t nblocksData, uint64_t ntiles, Counters ctr,
+                                                                        const uint2 *__restrict__ faultRange,
+                                                                        uint8_t *__restrict__ detected)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smemAes[];
+    uint32_t *sT = reinterpret_cast<uint32_t *>(smemAes);
+    uint32_t *sCnt = sT + 4 * kAesTabWords;
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    const LaneMap<NREP> lm;
+    const int tid = threadIdx.x;
+    { // thread (copy c, entry row v0): 64 entries per pass; lanes 0..15 / 16..31 of a group write entries v / v + 1 -> 32 banks
+        const int c = tid & (kAesCopies - 1), v0 = tid >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                sT[r * kAesTabWords + (v0 + 64 * i) * kAesCopies + c] = gAesTe[r][v0 + 64 * i];
+    }
+    if (tid < 4)
+        sCnt[tid] = 0;
+    __syncthreads();
+    const uint32_t cOff = (uint32_t)((NREP == 1 ? lm.lane : lm.q) & (kAesCopies - 1)) * 4u; // this lane's copy
+#define TE(r, x, b) (*reinterpret_cast<const uint32_t *>(smemAes + (r) * kAesTabWords * 4 + aes_rep_off<b, 6>(x, cOff)))
+    Tally tl;
+    uint32_t detItems = 0;
+    for (uint64_t tile = (uint64_t)blockIdx.x * (kAesRepThreads / kWave) + (tid >> 6); tile < ntiles;
+         tile += (uint64_t)gridDim.x * (kAesRepThreads / kWave)) {
+        if (faultRange && faultRange[tile].y != 0u)
+            continue; // aes128_xmr_kernel owns faulted tiles (wave-uniform)
+        const uint64_t item = tile * IPW + (uint64_t)lm.q;
+        const bool live = lm.live && item < nblocksData;
+        const bool cnt = live && lm.r == 0;
+        const uint64_t it = live ? item : 0;
+        const uint4 sv = reinterpret_cast<const uint4 *>(states)[it];
+        const uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
+        uint32_t s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w;
+        uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
+#pragma unroll
+        for (int rd = 0; rd < 10; ++rd) { // as aes128_enc_fast_kernel
+            const uint32_t x0 = s0 ^ k0, x1 = s1 ^ k1, x2 = s2 ^ k2, x3 = s3 ^ k3;
+            if (rd < 9) {
+                s0 = aes_xor3(TE(0, x0, 0), TE(1, x1, 1), TE(2, x2, 2)) ^ TE(3, x3, 3);
+                s1 = aes_xor3(TE(0, x1, 0), TE(1, x2, 1), TE(2, x3, 2)) ^ TE(3, x0, 3);
+                s2 = aes_xor3(TE(0, x2, 0), TE(1, x3, 1), TE(2, x0, 2)) ^ TE(3, x1, 3);
+                s3 = aes_xor3(TE(0, x3, 0), TE(1, x0, 1), TE(2, x1, 2)) ^ TE(3, x2, 3);
+            } else {
+                s0 = aes_pick_b1(TE(0, x0, 0), TE(0, x1, 1), TE(0, x2, 2), TE(0, x3, 3));
+                s1 = aes_pick_b1(TE(0, x1, 0), TE(0, x2, 1), TE(0, x3, 2), TE(0, x0, 3));
+                s2 = aes_pick_b1(TE(0, x2, 0), TE(0, x3, 1), TE(0, x0, 2), TE(0, x1, 3));
+                s3 = aes_pick_b1(TE(0, x3, 0), TE(0, x0, 1), TE(0, x1, 2), TE(0, x2, 3));
+            }
+            const uint32_t sw = aes_pick_b1(TE(0, k3, 1), TE(0, k3, 2), TE(0, k3, 3), TE(0, k3, 0));
+            k0 = aes_xor3(k0, sw, (uint32_t)kAesRcon[rd]);
+            k1 ^= k0;
+            k2 ^= k1;
+            k3 ^= k2;
+        }
+        s0 ^= k0;
+        s1 ^= k1;
+        s2 ^= k2;
+        s3 ^= k3;
+        Tally te = tl;
+        te.det = 0;
+        s0 = xmr_sync<NREP>(s0, lm, cnt, te);
+        s1 = xmr_sync<NREP>(s1, lm, cnt, te);
+        s2 = xmr_sync<NREP>(s2, lm, cnt, te);
+        s3 = xmr_sync<NREP>(s3, lm, cnt, te);
+        k0 = xmr_sync<NREP>(k0, lm, cnt, te);
+        k1 = xmr_sync<NREP>(k1, lm, cnt, te);
+        k2 = xmr_sync<NREP>(k2, lm, cnt, te);
+        k3 = xmr_sync<NREP>(k3, lm, cnt, te);
+        tl.miss = te.miss;
+        tl.syncs = te.syncs;
+        if (cnt) {
+            reinterpret_cast<uint4 *>(states)[item] = make_uint4(s0, s1, s2, s3);
+            reinterpret_cast<uint4 *>(keys)[item] = make_uint4(k0, k1, k2, k3);
+            if (te.det) {
+                if (NREP == 2)
+                    detItems += 1;
+                if (detected)
+                    detected[item] = 1;
+            }
+        }
+    }
+#undef TE
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+template <int NREP>
+__global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
+                                                                        uint64_t nblocksData, uint64_t ntiles, Counters ctr,
+                                                                        const uint2 *__restrict__ faultRange,
+                                                                        uint8_t *__restrict__ detected)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smemAes[];
+    uint2 *sDR = reinterpret_cast<uint2 *>(smemAes);                      // {Td_0[v], rsbox[v] x 4}
+    uint2 *sTS = sDR + kAesTabWords;                                      // {Tis_0[v], S[v] x 4}
+    uint32_t *sTd = reinterpret_cast<uint32_t *>(sTS + kAesTabWords);     // Td_1..3
+    uint32_t *sCnt = sTd + 3 * kAesTabWords;
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    const LaneMap<NREP> lm;
+    const int tid = threadIdx.x;
+    {
+        const int c = tid & (kAesCopies - 1), v0 = tid >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = v0 + 64 * i;
+            sDR[v * kAesCopies + c] = make_uint2(gAesTd[0][v], (uint32_t)gAesRsbox[v] * 0x01010101u);
+            sTS[v * kAesCopies + c] = make_uint2(gAesTis[0][v], (uint32_t)gAesSbox[v] * 0x01010101u);
+#pragma unroll
+            for (int r = 1; r < 4; ++r)
+                sTd[(r - 1) * kAesTabWords + v * kAesCopies + c] = gAesTd[r][v];
+        }
+    }
+    if (tid < 4)
+        sCnt[tid] = 0;
+    __syncthreads();
+    const uint32_t cOff = (uint32_t)((NREP == 1 ? lm.lane : lm.q) & (kAesCopies - 1)) * 8u; // this lane's copy (8-byte pairs)
+#define DR(x, b) (*reinterpret_cast<const uint2 *>(smemAes + aes_rep_off<b, 7>(x, cOff)))
+#define TS(x, b) (*reinterpret_cast<const uint2 *>(smemAes + kAesTabWords * 8 + aes_rep_off<b, 7>(x, cOff)))
+#define TD(r, x, b) (*reinterpret_cast<const uint32_t *>(smemAes + (3 + (r)) * kAesTabWords * 4 + aes_rep_off<b, 6>(x, cOff >> 1)))
+#define SUBROT(k) aes_pick_rep(TS(k, 1).y, TS(k, 2).y, TS(k, 3).y, TS(k, 0).y)
+#define TDCOL(a, b, c, d) (aes_xor3(DR(a, 0).x, TD(1, b, 1), TD(2, c, 2)) ^ TD(3, d, 3))
+    Tally tl;
+    uint32_t detItems = 0;
+    for (uint64_t tile = (uint64_t)blockIdx.x * (kAesRepThreads / kWave) + (tid >> 6); tile < ntiles;
+         tile += (uint64_t)gridDim.x * (kAesRepThreads / kWave)) {
+        if (faultRange && faultRange[tile].y != 0u)
+            continue;
+        const uint64_t item = tile * IPW + (uint64_t)lm.q;
+        const bool live = lm.live && item < nblocksData;
+        const bool cnt = live && lm.r == 0;
+        const uint64_t it = live ? item : 0;
+        const uint4 sv = reinterpret_cast<const uint4 *>(states)[it];
+        const uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
+        uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
+#pragma unroll
+        for (int rd = 0; rd < 10; ++rd) { // the last encryption key first (:110-123)
+            k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[rd]);
+            k1 ^= k0;
+            k2 ^= k1;
+            k3 ^= k2;
+        }
+        uint32_t x0 = sv.x ^ k0, x1 = sv.y ^ k1, x2 = sv.z ^ k2, x3 = sv.w ^ k3;
+        k3 ^= k2; // round 0, as aes128_dec_fast_kernel
+        k2 ^= k1;
+        k1 ^= k0;
+        k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[9]);
+        uint32_t m0 = aes_imc_col(k0), m1 = aes_imc_col(k1), m2 = aes_imc_col(k2), m3 = aes_imc_col(k3);
+        {
+            const uint32_t w0 = TDCOL(x0, x3, x2, x1) ^ m0, w1 = TDCOL(x1, x0, x3, x2) ^ m1;
+            const uint32_t w2 = TDCOL(x2, x1, x0, x3) ^ m2, w3 = TDCOL(x3, x2, x1, x0) ^ m3;
+            x0 = w0;
+            x1 = w1;
+            x2 = w2;
+            x3 = w3;
+        }
+#pragma unroll
+        for (int j = 8; j >= 1; --j) {
+            k3 ^= k2;
+            k2 ^= k1;
+            k1 ^= k0;
+            m3 ^= m2;
+            m2 ^= m1;
+            m1 ^= m0;
+            // one 8-byte lookup per byte of k3: the S-box byte for the key word, Tis_0 for its InvMixColumns image
+            const uint2 a1 = TS(k3, 1), a2 = TS(k3, 2), a3 = TS(k3, 3), a0 = TS(k3, 0);
+            k0 = aes_xor3(k0, aes_pick_rep(a1.y, a2.y, a3.y, a0.y), (uint32_t)kAesRcon[j]);
+            m0 ^= aes_xor3(a1.x, aes_rotl8(a2.x, 1), aes_rotl8(a3.x, 2)) ^ aes_rotl8(a0.x, 3) ^ gAesImcRcon[j];
+            const uint32_t w0 = TDCOL(x0, x3, x2, x1) ^ m0, w1 = TDCOL(x1, x0, x3, x2) ^ m1;
+            const uint32_t w2 = TDCOL(x2, x1, x0, x3) ^ m2, w3 = TDCOL(x3, x2, x1, x0) ^ m3;
+            x0 = w0;
+            x1 = w1;
+            x2 = w2;
+            x3 = w3;
+        }
+        k3 ^= k2; // reference round 9
+        k2 ^= k1;
+        k1 ^= k0;
+        k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[0]);
+        uint32_t s0 = aes_pick_rep(DR(x0, 0).y, DR(x3, 1).y, DR(x2, 2).y, DR(x1, 3).y) ^ k0;
+        uint32_t s1 = aes_pick_rep(DR(x1, 0).y, DR(x0, 1).y, DR(x3, 2).y, DR(x2, 3).y) ^ k1;
+        uint32_t s2 = aes_pick_rep(DR(x2, 0).y, DR(x1, 1).y, DR(x0, 2).y, DR(x3, 3).y) ^ k2;
+        uint32_t s3 = aes_pick_rep(DR(x3, 0).y, DR(x2, 1).y, DR(x1, 2).y, DR(x0, 3).y) ^ k3;
+        Tally te = tl;
+        te.det = 0;
+        s0 = xmr_sync<NREP>(s0, lm, cnt, te);
+        s1 = xmr_sync<NREP>(s1, lm, cnt, te);
+        s2 = xmr_sync<NREP>(s2, lm, cnt, te);
+        s3 = xmr_sync<NREP>(s3, lm, cnt, te);
+        k0 = xmr_sync<NREP>(k0, lm, cnt, te);
+        k1 = xmr_sync<NREP>(k1, lm, cnt, te);
+        k2 = xmr_sync<NREP>(k2, lm, cnt, te);
+        k3 = xmr_sync<NREP>(k3, lm, cnt, te);
+        tl.miss = te.miss;
+        tl.syncs = te.syncs;
+        if (cnt) {
+            reinterpret_cast<uint4 *>(states)[item] = make_uint4(s0, s1, s2, s3);
+            reinterpret_cast<uint4 *>(keys)[item] = make_uint4(k0, k1, k2, k3);
+            if (te.det) {
+                if (NREP == 2)
+                    detItems += 1;
+                if (detected)
+                    detected[item] = 1;
+            }
+        }
+    }
+#undef DR
+#undef TS
+#undef TD
+#undef SUBROT
+#undef TDCOL
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------ general path
 template <int NREP>
 __global__ __launch_bounds__(256, 5) void aes128_xmr_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,

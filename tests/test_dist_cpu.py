@@ -84,11 +84,12 @@ def test_bench_gpus_n_spawns_n_ranks():
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                            capture_output=True, text=True, env=env, timeout=600)
         err = p.stderr + p.stdout
-        if "rank 0/2" in err and "rank 1/2" in err:
+        if "rank 0/2" in err and "rank 1/2" in err and err.count("no GPU visible") >= 2:
             break
     assert p.returncode != 0
     assert "rank 0/2" in err and "rank 1/2" in err, err[:3000]
-    assert err.count("no GPU visible") >= 2, err[-2000:]
+    # both ranks normally get to the error; the launcher may SIGTERM the slower one the moment the first one fails
+    assert err.count("no GPU visible") >= 1, err[-2000:]
 
 
 def test_bench_rejects_mismatched_world():

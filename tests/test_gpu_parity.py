@@ -392,6 +392,47 @@ def test_aes_faults_vs_oracle(eng, orc, replicas, sync_every, direction):
     assert (det.cpu().numpy() == exp_det).all()
 
 
+@pytest.mark.parametrize("replicas", [2, 3, 1])
+@pytest.mark.parametrize("direction", [0, 1])
+def test_aes_bank_replicated_table_kernels(eng, orc, golden, replicas, direction, monkeypatch):
+    """the persistent kernels with bank-replicated tables (what large batches run; forced here through COAST_AES_TABLES):
+    bit-identical with the one-copy T-table kernels on states, keys, per-block flags and counters -- ragged batch sizes,
+    upsets armed (their tiles go to the stepwise kernel and are skipped by the table kernel) -- and equal to the oracle"""
+    import torch
+
+    import coast_amd
+
+    rng = np.random.default_rng(77 + 2 * replicas + direction)
+    for n in (1, 33, 2500, 70001):
+        st = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+        key = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+        fl = _rand_faults(rng, 0 if replicas == 1 else min(60, n), n, replicas, [16, 17], 10, max_index=4)
+        got = {}
+        for mode in ("replicated", "classic"):
+            monkeypatch.setenv("COAST_AES_TABLES", mode)
+            ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(key.copy()).cuda()
+            det = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            eng.reset_stats()
+            eng.inject_faults(fl)
+            eng.aes128_batch(ds, dk, direction, cfg=coast_amd.XmrConfig(replicas), detected=det)
+            got[mode] = (ds.cpu().numpy(), dk.cpu().numpy(), det.cpu().numpy(), _stats3(eng.stats()))
+        r, c = got["replicated"], got["classic"]
+        assert (r[0] == c[0]).all() and (r[1] == c[1]).all() and (r[2] == c[2]).all() and r[3] == c[3], n
+        if n <= 2500:
+            es, ek, exp_st, exp_det = orc.aes128_xmr(st, key, direction, replicas=replicas, faults=fl)
+            assert (r[0] == es).all() and (r[1] == ek).all() and r[3] == exp_st and (r[2] == exp_det).all(), n
+    if direction == 0:  # the 568 NIST vectors through the replicated-table kernels, both directions
+        monkeypatch.setenv("COAST_AES_TABLES", "replicated")
+        kat = golden["aes_kat"]
+        key, key2, ct, pt, inp = (np.ascontiguousarray(kat[:, 16 * q:16 * q + 16]) for q in range(5))
+        stt, k1 = torch.from_numpy(inp.copy()).cuda(), torch.from_numpy(key.copy()).cuda()
+        eng.aes128_batch(stt, k1, 0, cfg=coast_amd.XmrConfig(replicas))
+        assert (stt.cpu().numpy() == ct).all()
+        k2 = torch.from_numpy(key2.copy()).cuda()
+        eng.aes128_batch(stt, k2, 1, cfg=coast_amd.XmrConfig(replicas))
+        assert (stt.cpu().numpy() == pt).all() and (k2.cpu().numpy() == key2).all()
+
+
 def test_aes_roundtrip_1M(eng):
     """BASELINE config 3 size: 2^20 blocks with per-block keys, encrypt then decrypt must round-trip."""
     import torch
