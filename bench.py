@@ -455,9 +455,11 @@ class AES(Workload):
     unit = "blocks/s"
     dtype = "u8"
     kernels_per_step = 1
-    # LDS lookups of one block per replica lane (tools/instr_mix.py on the compiled kernels): encryption 147 ds_read_b32 (four
-    # T-tables x 4 columns x 9 rounds + last round) + 56 ds_read_u8 (S-box: key schedule, last round); decryption 179 + 84
-    LOOKUPS = {0: 147 + 56, 1: 179 + 84}
+    # LDS lookups of one block per replica lane (tools/instr_mix.py on the compiled kernels).  One-copy tables: encryption 147
+    # ds_read_b32 (four T-tables x 4 columns x 9 rounds + last round) + 56 ds_read_u8 (S-box: key schedule, last round);
+    # decryption 179 + 84.  Bank-replicated tables (what 1 Mi DWC blocks run): encryption 203 ds_read_b32 (the S-box bytes come
+    # out of Te_0 entries), decryption 199 ds_read_b32 + 32 ds_read_b64 ({Tis_0, S} pairs: one lookup per key-schedule byte)
+    LOOKUPS = {0: 203, 1: 199 + 32}
 
     def __init__(self, a, eng, dev, rank, coast_amd):
         self.n = a.batch or (1 << 20)
@@ -504,13 +506,14 @@ class AES(Workload):
     def roofline(self, kern_ms):
         t = kern_ms * 1e-3
         look = 0.5 * (self.LOOKUPS[0] + self.LOOKUPS[1]) * 2  # per block: mean of the enc / dec steps, x 2 replica lanes
-        return {"bound": "lds", "kernel": "aes128_enc_fast_kernel<2> / aes128_dec_fast_kernel<2> (alternating)",
+        return {"bound": "lds", "kernel": "aes128_enc_rep_kernel<2> / aes128_dec_rep_kernel<2> (alternating)",
                 "achieved": self.n * look / t * 1e-12, "peak": LDS_LOOKUP_PEAK * 1e-12,
                 "unit": "T lane-lookups/s (LDS: 32 conflict-free 4-byte lookups per clock per CU at 2.4 GHz)",
                 "frac": self.n * look / t / LDS_LOOKUP_PEAK, "lookups_per_block_lane": self.LOOKUPS, "kernel_ms": kern_ms,
                 "hbm_achieved_GBs": self.n * 64 / t * 1e-9, "algorithmic_bytes": float(self.n) * 64,
-                "note": "random table indices: replicas broadcast, distinct blocks conflict on banks, so the conflict-free "
-                        "peak is an upper bound no table kernel reaches; 1 Mi blocks are a 60-80 us launch"}
+                "note": "bank-replicated tables: the lookups are conflict-free, the kernels are bound by the two address "
+                        "instructions per lookup instead (VALU); 1 Mi blocks are a 55-80 us launch, and the step also carries "
+                        "the stepwise kernel on the armed-fault tiles (side stream) and the key restore copy"}
 
     def cpu(self):
         return cpu_baseline_items("aes")
