@@ -61,7 +61,20 @@ def sources():
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """(Re)build in-tree when the library is missing or was compiled from other sources.  One builder at a time: the N ranks of a
+    multi-GPU launch all come through here, and on a stale tree they must not compile into the same file concurrently."""
+    import fcntl
+
     os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     want = source_hash()
     stale = force or not os.path.exists(LIB) or not _stamp_ok(want)
     if stale:
