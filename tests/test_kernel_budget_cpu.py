@@ -1,0 +1,138 @@
+"""CPU checks of the compiled hot kernels and of the evidence that bench.py cites -- no GPU needed (hipcc cross-compiles gfx950).
+
+Register allocation decides the speed of the matrix-core kernels: a spilled VGPR inside the MFMA loop comes back through scratch and
+its `s_waitcnt vmcnt(0)` drains the operand prefetch (variants of mm_mfma_blk2_kernel with 35-117 spilled registers ran 7.9-13.4 ms
+instead of 6.6, profiles/r02d_mm_blk2_ab_spills.txt).  These tests compile the kernels alone and hold the budget: registers, spills,
+scratch, the number of MFMAs the step bodies issue, occupancy of the LDS-table kernels.  They also hold the bench's pointers: every
+profiles/ file that traffic.json or bench.py names exists, every kernel name bench.py reports is a kernel in the sources."""
+import json
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "coast_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+TU = r'''
+#include "coast_hip.h"
+#include <hip/hip_runtime.h>
+#include "xmr.hpp"
+#include "injector.hip"
+#include "mm_kernel.hip"
+#include "mm_mfma_kernel.hip"
+#include "mm_mfma_blk_kernel.hip"
+#include "mm_mfma_blk2_kernel.hip"
+#include "aes_kernel.hip"
+#include "crc16_kernel.hip"
+namespace coast {
+#define MMARGS const uint32_t *, const uint32_t *, uint32_t *, uint32_t, Counters, FaultTab, uint8_t *
+template __global__ void mm_mfma_blk2_kernel<3, true>(MMARGS);
+template __global__ void mm_mfma_blk2_kernel<3, false>(MMARGS);
+template __global__ void mm_mfma_blk_kernel<3, true>(MMARGS);
+template __global__ void mm_mfma_blk_kernel<3, false>(MMARGS);
+#define AESARGS uint8_t *, uint8_t *, uint64_t, uint64_t, Counters, const uint2 *, uint8_t *
+template __global__ void aes128_enc_rep_kernel<2>(AESARGS);
+template __global__ void aes128_dec_rep_kernel<2>(AESARGS);
+#define CRCARGS const uint8_t *, uint32_t, uint64_t, uint16_t *, const uint16_t *, uint64_t, Counters, const uint2 *, uint8_t *
+template __global__ void crc16_stream_kernel<3, 2, true>(CRCARGS);
+template __global__ void crc16_stream_kernel<3, 1, false>(CRCARGS);
+}
+'''
+
+
+@pytest.fixture(scope="module")
+def compiled(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not found")
+    d = tmp_path_factory.mktemp("budget")
+    src = str(d / "budget_tu.hip")  # outside the source tree: coast_amd/csrc is content-hashed into the library
+    with open(src, "w") as fh:
+        fh.write(TU)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-I", CSRC, "-I", os.path.join(ROOT, "include")]
+    rem = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(d / "t.o")], capture_output=True,
+                         text=True, timeout=900)
+    assert rem.returncode == 0, rem.stderr[-3000:]
+    asm = d / "t.s"
+    subprocess.check_call(cmd + ["-S", src, "-o", str(asm)], stderr=subprocess.DEVNULL, timeout=900)
+    usage = {}
+    cur = None
+    for line in rem.stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = usage.setdefault(subprocess.check_output(["c++filt", m.group(1)], text=True).strip(), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z /\[\]]+): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    text = asm.read_text()
+    bodies = {}
+    for m in re.finditer(r"^(_ZN5coast\w+):[^\n]*\n(.*?)\n\s+s_endpgm", text, flags=re.S | re.M):
+        bodies[subprocess.check_output(["c++filt", m.group(1)], text=True).strip()] = m.group(2)
+    return usage, bodies
+
+
+def _find(table, prefix):
+    hits = [k for k in table if k.startswith(prefix)]
+    assert len(hits) == 1, (prefix, sorted(table))
+    return table[hits[0]]
+
+
+@pytest.mark.parametrize("flags", ["true", "false"])
+def test_mm_register_block_kernels_fit_their_register_files(compiled, flags):
+    usage, bodies = compiled
+    # two waves per SIMD: 256 VGPRs, no AGPRs; the default TMR kernel
+    u2 = _find(usage, "void coast::mm_mfma_blk2_kernel<3, %s>" % flags)
+    assert u2["VGPRs"] <= 256 and u2["AGPRs"] == 0 and u2["Occupancy [waves/SIMD]"] == 2
+    # the armed-upset hook (cold, wave-uniform branch) may park a few registers; the step bodies must not
+    assert u2["VGPRs Spill"] <= 8, u2
+    b2 = _find(bodies, "void coast::mm_mfma_blk2_kernel<3, %s>" % flags)
+    # 4 step variants x 60 MFMAs x 2 row halves: every k-slab of a tile issues its 120 MFMAs once
+    assert len(re.findall(r"v_mfma_i32_16x16x64_i8", b2)) == 480
+    assert len(re.findall(r"scratch_load", b2)) <= 8
+    # one wave per SIMD: accumulators in AGPRs, nothing spilled
+    u1 = _find(usage, "void coast::mm_mfma_blk_kernel<3, %s>" % flags)
+    assert u1["VGPRs Spill"] == 0 and u1["Occupancy [waves/SIMD]"] == 1 and u1["VGPRs"] <= 256 and u1["AGPRs"] <= 256
+
+
+def test_lds_table_kernels_keep_their_occupancy(compiled):
+    usage, bodies = compiled
+    enc = _find(usage, "void coast::aes128_enc_rep_kernel<2>")
+    dec = _find(usage, "void coast::aes128_dec_rep_kernel<2>")
+    # encryption: two 1024-thread workgroups per CU (64 KiB of tables each) need <= 64 registers per lane
+    assert enc["VGPRs"] <= 64 and enc["VGPRs Spill"] == 0 and enc["Occupancy [waves/SIMD]"] == 8
+    assert dec["VGPRs"] <= 128 and dec["VGPRs Spill"] == 0
+    # lookups per block: encryption 203 dword reads; decryption 199 dword + 32 eight-byte pair reads (bench.py AES.LOOKUPS)
+    be, bd = _find(bodies, "void coast::aes128_enc_rep_kernel<2>"), _find(bodies, "void coast::aes128_dec_rep_kernel<2>")
+    assert (len(re.findall(r"ds_read_b32", be)), len(re.findall(r"ds_read_b64", be))) == (203, 0)
+    assert (len(re.findall(r"ds_read_b32", bd)), len(re.findall(r"ds_read_b64", bd))) == (199, 32)
+    for name in ("void coast::crc16_stream_kernel<3, 2, true>", "void coast::crc16_stream_kernel<3, 1, false>"):
+        u = _find(usage, name)  # 1024-thread persistent workgroups: 128 registers per lane
+        assert u["VGPRs"] <= 128 and u["VGPRs Spill"] == 0, (name, u)
+
+
+def test_bench_lookup_counts_match_the_compiled_kernels():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.AES.LOOKUPS == {0: 203, 1: 199 + 32}
+
+
+def test_evidence_pointers_resolve():
+    """every profiles/ file that traffic.json or bench.py cites is tracked here, every kernel bench.py names is in the sources"""
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    cited = set()
+    for rec in traffic.values():
+        cited.update(re.findall(r"profiles/[\w./-]+\.(?:txt|json)", rec.get("source", "")))
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    cited.update(re.findall(r"profiles/[\w./-]+\.(?:txt|json)", bench))
+    for f in sorted(cited):
+        assert os.path.exists(os.path.join(ROOT, f)), "cited evidence %s is missing" % f
+    sources = "".join(open(os.path.join(CSRC, f)).read() for f in os.listdir(CSRC) if f.endswith((".hip", ".inc")))
+    for kern in set(re.findall(r"\b((?:mm|aes128|crc16|sha256|chsha|cache_test)_\w*kernel)\b", bench)):
+        assert re.search(r"\b%s\b" % kern, sources), "bench.py names %s, which is not a kernel in coast_amd/csrc" % kern
