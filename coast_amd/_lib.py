@@ -24,7 +24,7 @@ class CoastStats(C.Structure):
 
 
 class CoastLaunchInfo(C.Structure):
-    _fields_ = [("engine", C.c_uint32), ("reserved", C.c_uint32), ("general_blocks", C.c_uint64),
+    _fields_ = [("engine", C.c_uint32), ("hooked_blocks", C.c_uint32), ("general_blocks", C.c_uint64),
                 ("fast_blocks", C.c_uint64), ("armed_faults", C.c_uint64), ("algorithmic_bytes", C.c_double)]
 
 

@@ -65,13 +65,47 @@ def build(force: bool = False, verbose: bool = False) -> str:
     multi-GPU launch all come through here, and on a stale tree they must not compile into the same file concurrently."""
     import fcntl
 
-    os.makedirs(LIBDIR, exist_ok=True)
-    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+    try:
+        os.makedirs(LIBDIR, exist_ok=True)
+        lock = open(os.path.join(LIBDIR, ".build.lock"), "w")
+    except OSError:
+        # read-only install: nothing can be (re)built here; a current library is still usable, a stale one is refused below
+        if os.path.exists(LIB) and _stamp_ok(source_hash()) and not force:
+            return LIB
+        raise
+    with lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             return _build_locked(force, verbose)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_examples(force: bool, stale: bool, verbose: bool) -> None:
+    """The C host examples (tests run them on the GPU box).  Best effort: libcoast_hip.so resolves RCCL at first use, so a host
+    without RCCL development files or gcc must still be able to load the library -- a failed demo link is a warning."""
+    import warnings
+
+    inc = os.path.join(HERE, "..", "include")
+    demo_src = os.path.join(HERE, "..", "examples", "host_c_demo.c")
+    demo = os.path.join(HERE, "..", "examples", "host_c_demo")
+    mg_src = os.path.join(HERE, "..", "examples", "multi_gpu_c_demo.c")
+    mg = os.path.join(HERE, "..", "examples", "multi_gpu_c_demo")
+    jobs = []
+    if os.path.exists(demo_src) and os.path.exists(DROPIN_OBJ) and (force or _newer(demo, [demo_src, DROPIN_OBJ, LIB])):
+        jobs.append(["gcc", "-std=gnu11", "-O2", "-Dside=4", demo_src, os.path.join(CSRC, "mm_glue.c"), DROPIN_OBJ,
+                     "-L", LIBDIR, "-lcoast_hip", "-Wl,-rpath,$ORIGIN/../coast_amd/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", demo])
+    if os.path.exists(mg_src) and (force or stale or _newer(mg, [mg_src, LIB])):
+        jobs.append(["gcc", "-std=gnu11", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", inc, mg_src,
+                     "-L", LIBDIR, "-lcoast_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl",
+                     "-Wl,-rpath,$ORIGIN/../coast_amd/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", mg])
+    for cmd in jobs:
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+        except (OSError, subprocess.CalledProcessError) as e:
+            warnings.warn("coast_amd.build: example %s not built (%s); the library itself is unaffected" % (cmd[-1], e))
 
 
 def _build_locked(force: bool, verbose: bool) -> str:
@@ -92,19 +126,7 @@ def _build_locked(force: bool, verbose: bool) -> str:
         subprocess.check_call(cmd)
         subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=gnu11", "-I", os.path.join(HERE, "..", "include"), "-c",
                                dropin_src, "-o", DROPIN_OBJ])
-    demo_src = os.path.join(HERE, "..", "examples", "host_c_demo.c")
-    demo = os.path.join(HERE, "..", "examples", "host_c_demo")
-    if os.path.exists(demo_src) and os.path.exists(DROPIN_OBJ) and (force or _newer(demo, [demo_src, DROPIN_OBJ, LIB])):
-        subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Dside=4", demo_src, os.path.join(CSRC, "mm_glue.c"), DROPIN_OBJ,
-                               "-L", LIBDIR, "-lcoast_hip", "-Wl,-rpath,$ORIGIN/../coast_amd/lib",
-                               "-Wl,-rpath,/opt/rocm/lib", "-o", demo])
-    mg_src = os.path.join(HERE, "..", "examples", "multi_gpu_c_demo.c")
-    mg = os.path.join(HERE, "..", "examples", "multi_gpu_c_demo")
-    if os.path.exists(mg_src) and (force or stale or _newer(mg, [mg_src, LIB])):
-        subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                               "-I", os.path.join(HERE, "..", "include"), mg_src, "-L", LIBDIR, "-lcoast_hip",
-                               "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-Wl,-rpath,$ORIGIN/../coast_amd/lib",
-                               "-Wl,-rpath,/opt/rocm/lib", "-o", mg])
+    _build_examples(force, stale, verbose)
     return LIB
 
 

@@ -18,6 +18,8 @@
 //                           and InvMix(round key) follows the inverse key schedule through a second table set.
 //   aes128_xmr_kernel       byte-at-a-time exactly as written in the reference, both directions, injector hooks and
 //                           per-round sync points; runs faulted tiles (side stream) and sync_every != 0.
+#include <type_traits>
+
 #include "xmr.hpp"
 
 namespace coast {
@@ -194,11 +196,44 @@ __device__ __forceinline__ uint32_t aes_xor3(uint32_t a, uint32_t b, uint32_t c)
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 }
 
+// Injector hook of the lean kernels: XOR masks of the upsets that are due at the start of main-loop round `rd` (10: after the
+// loop) in this lane's copy of the state / running key, as column dwords (byte r of column c = state[4c + r], so bit b of dword
+// `index` is bit b % 8 of byte 4 index + b / 8: the same flip aes128_xmr_kernel applies to its byte registers).  Only tiles that
+// own an armed fault come here (wave-uniform test on the range table).
+struct AesDue { // XOR masks for the four state columns and the four key columns
+    uint32_t s0 = 0u, s1 = 0u, s2 = 0u, s3 = 0u, k0 = 0u, k1 = 0u, k2 = 0u, k3 = 0u;
+};
+__device__ __forceinline__ AesDue aes_due_masks(const FaultTab &ft, uint2 fr, uint32_t rd, int slot, int rep, bool laneLive)
+{
+    AesDue d;
+    for (uint32_t q = 0; q < fr.y; ++q) {
+        const DevFault *fp = ft.list + fr.x + q;
+        const uint32_t packed = *reinterpret_cast<const uint32_t *>(&fp->replica); // replica, site, bit, index
+        if (fp->step != rd || (int)fp->local != slot || (int)(packed & 0xffu) != rep || !laneLive)
+            continue;
+        const uint32_t site = (packed >> 8) & 0xffu, m = 1u << ((packed >> 16) & 31u), c = (packed >> 24) & 3u;
+        const uint32_t ms = site == (uint32_t)SITE_AES_STATE ? m : 0u, mk = site == (uint32_t)SITE_AES_KEY ? m : 0u;
+        d.s0 ^= c == 0u ? ms : 0u, d.s1 ^= c == 1u ? ms : 0u, d.s2 ^= c == 2u ? ms : 0u, d.s3 ^= c == 3u ? ms : 0u;
+        d.k0 ^= c == 0u ? mk : 0u, d.k1 ^= c == 1u ? mk : 0u, d.k2 ^= c == 2u ? mk : 0u, d.k3 ^= c == 3u ? mk : 0u;
+    }
+    return d;
+}
+
+__device__ __forceinline__ uint2 aes_tile_faults(const FaultTab &ft, uint64_t tile)
+{
+    uint2 fr = make_uint2(0u, 0u);
+    if (ft.range) {
+        const uint2 rg = ft.range[tile];
+        fr.x = __builtin_amdgcn_readfirstlane(rg.x);
+        fr.y = __builtin_amdgcn_readfirstlane(rg.y);
+    }
+    return fr;
+}
+
 template <int NREP>
 __global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
                                                               uint64_t nblocksData, uint64_t ntiles, Counters ctr,
-                                                              const uint2 *__restrict__ faultRange,
-                                                              uint8_t *__restrict__ detected)
+                                                              FaultTab ft, uint8_t *__restrict__ detected)
 {
     __shared__ uint32_t sTe[4][256];
     __shared__ uint8_t sSb[256];
@@ -215,9 +250,8 @@ __global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restric
     __syncthreads();
 
     const uint64_t tile = (uint64_t)blockIdx.x * 4 + (tid >> 6);
-    bool skip = tile >= ntiles;
-    if (!skip && faultRange)
-        skip = faultRange[tile].y != 0u; // aes128_xmr_kernel owns faulted tiles
+    const bool skip = tile >= ntiles;
+    const uint2 fr = skip ? make_uint2(0u, 0u) : aes_tile_faults(ft, tile); // this tile's armed upsets (wave-uniform)
     const uint64_t item = tile * IPW + (uint64_t)lm.q;
     const bool live = !skip && lm.live && item < nblocksData;
     const bool cnt = live && lm.r == 0;
@@ -231,28 +265,47 @@ __global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restric
 #define B1(x) (((x) >> 8) & 0xffu)
 #define B2(x) (((x) >> 16) & 0xffu)
 #define B3(x) ((x) >> 24)
+    // The ten rounds, instantiated twice: HOOKED = a tile that owns armed upsets applies the flips that are due at the start of
+    // each round (and after the loop) to this lane's state / key registers; everything downstream -- the remaining rounds, the
+    // sync points, the counters, the stores -- is the code every other tile runs.
+    auto rounds = [&](auto hookTag) __attribute__((always_inline)) {
+        constexpr bool HOOKED = decltype(hookTag)::value;
+        auto hook = [&](int rd) __attribute__((always_inline)) {
+            if constexpr (HOOKED) {
+                const AesDue d = aes_due_masks(ft, fr, (uint32_t)rd, lm.q, lm.r, lm.live);
+                s0 ^= d.s0, s1 ^= d.s1, s2 ^= d.s2, s3 ^= d.s3;
+                k0 ^= d.k0, k1 ^= d.k1, k2 ^= d.k2, k3 ^= d.k3;
+            }
+        };
 #pragma unroll
-    for (int rd = 0; rd < 10; ++rd) {
-        const uint32_t x0 = s0 ^ k0, x1 = s1 ^ k1, x2 = s2 ^ k2, x3 = s3 ^ k3; // state[i] ^ key[i]       (:144-146)
-        if (rd < 9) { // SubBytes, ShiftRows (row r of column j comes from column j+r, :148-166), MixColumns (:168-185)
-            s0 = aes_xor3(sTe[0][B0(x0)], sTe[1][B1(x1)], sTe[2][B2(x2)]) ^ sTe[3][B3(x3)];
-            s1 = aes_xor3(sTe[0][B0(x1)], sTe[1][B1(x2)], sTe[2][B2(x3)]) ^ sTe[3][B3(x0)];
-            s2 = aes_xor3(sTe[0][B0(x2)], sTe[1][B1(x3)], sTe[2][B2(x0)]) ^ sTe[3][B3(x1)];
-            s3 = aes_xor3(sTe[0][B0(x3)], sTe[1][B1(x0)], sTe[2][B2(x1)]) ^ sTe[3][B3(x2)];
-        } else { // last round: no MixColumns
-            s0 = (uint32_t)sSb[B0(x0)] | ((uint32_t)sSb[B1(x1)] << 8) | ((uint32_t)sSb[B2(x2)] << 16) | ((uint32_t)sSb[B3(x3)] << 24);
-            s1 = (uint32_t)sSb[B0(x1)] | ((uint32_t)sSb[B1(x2)] << 8) | ((uint32_t)sSb[B2(x3)] << 16) | ((uint32_t)sSb[B3(x0)] << 24);
-            s2 = (uint32_t)sSb[B0(x2)] | ((uint32_t)sSb[B1(x3)] << 8) | ((uint32_t)sSb[B2(x0)] << 16) | ((uint32_t)sSb[B3(x1)] << 24);
-            s3 = (uint32_t)sSb[B0(x3)] | ((uint32_t)sSb[B1(x0)] << 8) | ((uint32_t)sSb[B2(x1)] << 16) | ((uint32_t)sSb[B3(x2)] << 24);
+        for (int rd = 0; rd < 10; ++rd) {
+            hook(rd);
+            const uint32_t x0 = s0 ^ k0, x1 = s1 ^ k1, x2 = s2 ^ k2, x3 = s3 ^ k3; // state[i] ^ key[i]       (:144-146)
+            if (rd < 9) { // SubBytes, ShiftRows (row r of column j comes from column j+r, :148-166), MixColumns (:168-185)
+                s0 = aes_xor3(sTe[0][B0(x0)], sTe[1][B1(x1)], sTe[2][B2(x2)]) ^ sTe[3][B3(x3)];
+                s1 = aes_xor3(sTe[0][B0(x1)], sTe[1][B1(x2)], sTe[2][B2(x3)]) ^ sTe[3][B3(x0)];
+                s2 = aes_xor3(sTe[0][B0(x2)], sTe[1][B1(x3)], sTe[2][B2(x0)]) ^ sTe[3][B3(x1)];
+                s3 = aes_xor3(sTe[0][B0(x3)], sTe[1][B1(x0)], sTe[2][B2(x1)]) ^ sTe[3][B3(x2)];
+            } else { // last round: no MixColumns
+                s0 = (uint32_t)sSb[B0(x0)] | ((uint32_t)sSb[B1(x1)] << 8) | ((uint32_t)sSb[B2(x2)] << 16) | ((uint32_t)sSb[B3(x3)] << 24);
+                s1 = (uint32_t)sSb[B0(x1)] | ((uint32_t)sSb[B1(x2)] << 8) | ((uint32_t)sSb[B2(x3)] << 16) | ((uint32_t)sSb[B3(x0)] << 24);
+                s2 = (uint32_t)sSb[B0(x2)] | ((uint32_t)sSb[B1(x3)] << 8) | ((uint32_t)sSb[B2(x0)] << 16) | ((uint32_t)sSb[B3(x1)] << 24);
+                s3 = (uint32_t)sSb[B0(x3)] | ((uint32_t)sSb[B1(x0)] << 8) | ((uint32_t)sSb[B2(x1)] << 16) | ((uint32_t)sSb[B3(x2)] << 24);
+            }
+            // key schedule (:220-226): key[0..3] ^= sbox[key[13,14,15,12]] (^ Rcon on byte 0), then key[i] ^= key[i-4]
+            const uint32_t sw = (uint32_t)sSb[B1(k3)] | ((uint32_t)sSb[B2(k3)] << 8) | ((uint32_t)sSb[B3(k3)] << 16) |
+                                ((uint32_t)sSb[B0(k3)] << 24);
+            k0 = aes_xor3(k0, sw, (uint32_t)kAesRcon[rd]);
+            k1 ^= k0;
+            k2 ^= k1;
+            k3 ^= k2;
         }
-        // key schedule (:220-226): key[0..3] ^= sbox[key[13,14,15,12]] (^ Rcon on byte 0), then key[i] ^= key[i-4]
-        const uint32_t sw = (uint32_t)sSb[B1(k3)] | ((uint32_t)sSb[B2(k3)] << 8) | ((uint32_t)sSb[B3(k3)] << 16) |
-                            ((uint32_t)sSb[B0(k3)] << 24);
-        k0 = aes_xor3(k0, sw, (uint32_t)kAesRcon[rd]);
-        k1 ^= k0;
-        k2 ^= k1;
-        k3 ^= k2;
-    }
+        hook(10);
+    };
+    if (fr.y != 0u)
+        rounds(std::true_type{});
+    else
+        rounds(std::false_type{});
 #undef B0
 #undef B1
 #undef B2
@@ -302,11 +355,28 @@ __device__ __forceinline__ uint32_t aes_imc_col(uint32_t x) // InvMixColumns of 
     return aes_xtime4(y ^ r8) ^ aes_xor3(r8, __builtin_amdgcn_alignbit(y, y, 16), __builtin_amdgcn_alignbit(y, y, 24));
 }
 
+// Injector hook of the decryption kernels.  At the start of reference round rd = 1..9 the lean kernels hold the state as
+// x = InvMixColumns(state) (the first thing that round does to it, :168-175) and carry m = InvMixColumns(key) beside the key:
+// a flipped state register becomes x ^= InvMix(mask) -- exact, the transformation is linear -- and a flipped key register
+// keeps its image consistent, m ^= InvMix(mask).  Rounds 0 (nothing mixed yet) and 10 (after the loop) flip the registers as they are.
+#define AES_DEC_HOOK(rd, mixedState, haveM)                                                                       \
+    do {                                                                                                          \
+        if constexpr (HOOKED) {                                                                                   \
+            const AesDue d_ = aes_due_masks(ft, fr, (uint32_t)(rd), lm.q, lm.r, lm.live);                         \
+            if (mixedState)                                                                                       \
+                x0 ^= aes_imc_col(d_.s0), x1 ^= aes_imc_col(d_.s1), x2 ^= aes_imc_col(d_.s2), x3 ^= aes_imc_col(d_.s3); \
+            else                                                                                                  \
+                x0 ^= d_.s0, x1 ^= d_.s1, x2 ^= d_.s2, x3 ^= d_.s3;                                               \
+            k0 ^= d_.k0, k1 ^= d_.k1, k2 ^= d_.k2, k3 ^= d_.k3;                                                   \
+            if (haveM)                                                                                            \
+                m0 ^= aes_imc_col(d_.k0), m1 ^= aes_imc_col(d_.k1), m2 ^= aes_imc_col(d_.k2), m3 ^= aes_imc_col(d_.k3); \
+        }                                                                                                         \
+    } while (0)
+
 template <int NREP>
 __global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
                                                               uint64_t nblocksData, uint64_t ntiles, Counters ctr,
-                                                              const uint2 *__restrict__ faultRange,
-                                                              uint8_t *__restrict__ detected)
+                                                              FaultTab ft, uint8_t *__restrict__ detected)
 {
     __shared__ uint32_t sTd[4][256];
     __shared__ uint32_t sTis[4][256];
@@ -328,9 +398,8 @@ __global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restric
     __syncthreads();
 
     const uint64_t tile = (uint64_t)blockIdx.x * 4 + (tid >> 6);
-    bool skip = tile >= ntiles;
-    if (!skip && faultRange)
-        skip = faultRange[tile].y != 0u; // aes128_xmr_kernel owns faulted tiles
+    const bool skip = tile >= ntiles;
+    const uint2 fr = skip ? make_uint2(0u, 0u) : aes_tile_faults(ft, tile); // this tile's armed upsets (wave-uniform)
     const uint64_t item = tile * IPW + (uint64_t)lm.q;
     const bool live = !skip && lm.live && item < nblocksData;
     const bool cnt = live && lm.r == 0;
@@ -338,71 +407,87 @@ __global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restric
     const uint4 sv = reinterpret_cast<const uint4 *>(states)[it];
     const uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
     uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
+    uint32_t x0, x1, x2, x3; // the state; after the loop: the plaintext columns
 
 #define B0(x) ((x) & 0xffu)
 #define B1(x) (((x) >> 8) & 0xffu)
 #define B2(x) (((x) >> 16) & 0xffu)
 #define B3(x) ((x) >> 24)
 #define SUBROT(k) ((uint32_t)sSb[B1(k)] | ((uint32_t)sSb[B2(k)] << 8) | ((uint32_t)sSb[B3(k)] << 16) | ((uint32_t)sSb[B0(k)] << 24))
-    // the last encryption key first (:110-123)
+    // instantiated twice, as in aes128_enc_fast_kernel: HOOKED = a tile that owns armed upsets
+    auto rounds = [&](auto hookTag) __attribute__((always_inline)) {
+        constexpr bool HOOKED = decltype(hookTag)::value;
+        uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
+        // the last encryption key first (:110-123)
 #pragma unroll
-    for (int rd = 0; rd < 10; ++rd) {
-        k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[rd]);
-        k1 ^= k0;
-        k2 ^= k1;
-        k3 ^= k2;
-    }
-    uint32_t x0 = sv.x ^ k0, x1 = sv.y ^ k1, x2 = sv.z ^ k2, x3 = sv.w ^ k3; // first AddRoundKey (:126-128)
+        for (int rd = 0; rd < 10; ++rd) {
+            k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[rd]);
+            k1 ^= k0;
+            k2 ^= k1;
+            k3 ^= k2;
+        }
+        x0 = sv.x ^ k0, x1 = sv.y ^ k1, x2 = sv.z ^ k2, x3 = sv.w ^ k3; // first AddRoundKey (:126-128)
+        AES_DEC_HOOK(0, false, false);
 
-    // round 0: inverse key schedule to round key 9, no InvMixColumns on the state yet
-    k3 ^= k2;
-    k2 ^= k1;
-    k1 ^= k0;
-    k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[9]);
-    uint32_t m0 = aes_imc_col(k0), m1 = aes_imc_col(k1), m2 = aes_imc_col(k2), m3 = aes_imc_col(k3); // InvMix(key 9)
-    {   // InvShiftRows: row r of column j comes from column j-r (:188-207); rsbox ^ key, then next round's InvMixColumns
-        const uint32_t w0 = aes_xor3(sTd[0][B0(x0)], sTd[1][B1(x3)], sTd[2][B2(x2)]) ^ sTd[3][B3(x1)] ^ m0;
-        const uint32_t w1 = aes_xor3(sTd[0][B0(x1)], sTd[1][B1(x0)], sTd[2][B2(x3)]) ^ sTd[3][B3(x2)] ^ m1;
-        const uint32_t w2 = aes_xor3(sTd[0][B0(x2)], sTd[1][B1(x1)], sTd[2][B2(x0)]) ^ sTd[3][B3(x3)] ^ m2;
-        const uint32_t w3 = aes_xor3(sTd[0][B0(x3)], sTd[1][B1(x2)], sTd[2][B2(x1)]) ^ sTd[3][B3(x0)] ^ m3;
-        x0 = w0;
-        x1 = w1;
-        x2 = w2;
-        x3 = w3;
-    }
-#pragma unroll
-    for (int j = 8; j >= 1; --j) { // reference rounds 1..8: key j+1 -> key j, state through Td
+        // round 0: inverse key schedule to round key 9, no InvMixColumns on the state yet
         k3 ^= k2;
         k2 ^= k1;
         k1 ^= k0;
-        m3 ^= m2;
-        m2 ^= m1;
-        m1 ^= m0;
-        k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[j]);
-        m0 ^= aes_xor3(sTis[0][B1(k3)], sTis[1][B2(k3)], sTis[2][B3(k3)]) ^ sTis[3][B0(k3)] ^ gAesImcRcon[j];
-        const uint32_t w0 = aes_xor3(sTd[0][B0(x0)], sTd[1][B1(x3)], sTd[2][B2(x2)]) ^ sTd[3][B3(x1)] ^ m0;
-        const uint32_t w1 = aes_xor3(sTd[0][B0(x1)], sTd[1][B1(x0)], sTd[2][B2(x3)]) ^ sTd[3][B3(x2)] ^ m1;
-        const uint32_t w2 = aes_xor3(sTd[0][B0(x2)], sTd[1][B1(x1)], sTd[2][B2(x0)]) ^ sTd[3][B3(x3)] ^ m2;
-        const uint32_t w3 = aes_xor3(sTd[0][B0(x3)], sTd[1][B1(x2)], sTd[2][B2(x1)]) ^ sTd[3][B3(x0)] ^ m3;
-        x0 = w0;
-        x1 = w1;
-        x2 = w2;
-        x3 = w3;
-    }
-    // reference round 9: key 1 -> cipher key, InvShiftRows, rsbox ^ key (x already carries this round's InvMixColumns)
-    k3 ^= k2;
-    k2 ^= k1;
-    k1 ^= k0;
-    k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[0]);
-    uint32_t s0 = ((uint32_t)sRsb[B0(x0)] | ((uint32_t)sRsb[B1(x3)] << 8) | ((uint32_t)sRsb[B2(x2)] << 16) | ((uint32_t)sRsb[B3(x1)] << 24)) ^ k0;
-    uint32_t s1 = ((uint32_t)sRsb[B0(x1)] | ((uint32_t)sRsb[B1(x0)] << 8) | ((uint32_t)sRsb[B2(x3)] << 16) | ((uint32_t)sRsb[B3(x2)] << 24)) ^ k1;
-    uint32_t s2 = ((uint32_t)sRsb[B0(x2)] | ((uint32_t)sRsb[B1(x1)] << 8) | ((uint32_t)sRsb[B2(x0)] << 16) | ((uint32_t)sRsb[B3(x3)] << 24)) ^ k2;
-    uint32_t s3 = ((uint32_t)sRsb[B0(x3)] | ((uint32_t)sRsb[B1(x2)] << 8) | ((uint32_t)sRsb[B2(x1)] << 16) | ((uint32_t)sRsb[B3(x0)] << 24)) ^ k3;
+        k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[9]);
+        m0 = aes_imc_col(k0), m1 = aes_imc_col(k1), m2 = aes_imc_col(k2), m3 = aes_imc_col(k3); // InvMix(key 9)
+        {   // InvShiftRows: row r of column j comes from column j-r (:188-207); rsbox ^ key, then next round's InvMixColumns
+            const uint32_t w0 = aes_xor3(sTd[0][B0(x0)], sTd[1][B1(x3)], sTd[2][B2(x2)]) ^ sTd[3][B3(x1)] ^ m0;
+            const uint32_t w1 = aes_xor3(sTd[0][B0(x1)], sTd[1][B1(x0)], sTd[2][B2(x3)]) ^ sTd[3][B3(x2)] ^ m1;
+            const uint32_t w2 = aes_xor3(sTd[0][B0(x2)], sTd[1][B1(x1)], sTd[2][B2(x0)]) ^ sTd[3][B3(x3)] ^ m2;
+            const uint32_t w3 = aes_xor3(sTd[0][B0(x3)], sTd[1][B1(x2)], sTd[2][B2(x1)]) ^ sTd[3][B3(x0)] ^ m3;
+            x0 = w0;
+            x1 = w1;
+            x2 = w2;
+            x3 = w3;
+        }
+#pragma unroll
+        for (int j = 8; j >= 1; --j) { // reference rounds 1..8: key j+1 -> key j, state through Td
+            AES_DEC_HOOK(9 - j, true, true);
+            k3 ^= k2;
+            k2 ^= k1;
+            k1 ^= k0;
+            m3 ^= m2;
+            m2 ^= m1;
+            m1 ^= m0;
+            k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[j]);
+            m0 ^= aes_xor3(sTis[0][B1(k3)], sTis[1][B2(k3)], sTis[2][B3(k3)]) ^ sTis[3][B0(k3)] ^ gAesImcRcon[j];
+            const uint32_t w0 = aes_xor3(sTd[0][B0(x0)], sTd[1][B1(x3)], sTd[2][B2(x2)]) ^ sTd[3][B3(x1)] ^ m0;
+            const uint32_t w1 = aes_xor3(sTd[0][B0(x1)], sTd[1][B1(x0)], sTd[2][B2(x3)]) ^ sTd[3][B3(x2)] ^ m1;
+            const uint32_t w2 = aes_xor3(sTd[0][B0(x2)], sTd[1][B1(x1)], sTd[2][B2(x0)]) ^ sTd[3][B3(x3)] ^ m2;
+            const uint32_t w3 = aes_xor3(sTd[0][B0(x3)], sTd[1][B1(x2)], sTd[2][B2(x1)]) ^ sTd[3][B3(x0)] ^ m3;
+            x0 = w0;
+            x1 = w1;
+            x2 = w2;
+            x3 = w3;
+        }
+        // reference round 9: key 1 -> cipher key, InvShiftRows, rsbox ^ key (x already carries this round's InvMixColumns)
+        AES_DEC_HOOK(9, true, false);
+        k3 ^= k2;
+        k2 ^= k1;
+        k1 ^= k0;
+        k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[0]);
+        const uint32_t p0 = ((uint32_t)sRsb[B0(x0)] | ((uint32_t)sRsb[B1(x3)] << 8) | ((uint32_t)sRsb[B2(x2)] << 16) | ((uint32_t)sRsb[B3(x1)] << 24)) ^ k0;
+        const uint32_t p1 = ((uint32_t)sRsb[B0(x1)] | ((uint32_t)sRsb[B1(x0)] << 8) | ((uint32_t)sRsb[B2(x3)] << 16) | ((uint32_t)sRsb[B3(x2)] << 24)) ^ k1;
+        const uint32_t p2 = ((uint32_t)sRsb[B0(x2)] | ((uint32_t)sRsb[B1(x1)] << 8) | ((uint32_t)sRsb[B2(x0)] << 16) | ((uint32_t)sRsb[B3(x3)] << 24)) ^ k2;
+        const uint32_t p3 = ((uint32_t)sRsb[B0(x3)] | ((uint32_t)sRsb[B1(x2)] << 8) | ((uint32_t)sRsb[B2(x1)] << 16) | ((uint32_t)sRsb[B3(x0)] << 24)) ^ k3;
+        x0 = p0, x1 = p1, x2 = p2, x3 = p3;
+        AES_DEC_HOOK(10, false, false);
+    };
+    if (fr.y != 0u)
+        rounds(std::true_type{});
+    else
+        rounds(std::false_type{});
 #undef SUBROT
 #undef B0
 #undef B1
 #undef B2
 #undef B3
+    uint32_t s0 = x0, s1 = x1, s2 = x2, s3 = x3;
 
     Tally tl;
     s0 = xmr_sync<NREP>(s0, lm, cnt, tl); // in-place stores of state and key: store-data sync
@@ -474,8 +559,7 @@ __device__ __forceinline__ uint32_t aes_rotl8(uint32_t x, int bytes) { return __
 template <int NREP>
 __global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
                                                                         uint64_t nblocksData, uint64_t ntiles, Counters ctr,
-                                                                        const uint2 *__restrict__ faultRange,
-                                                                        uint8_t *__restrict__ detected)
+                                                                        FaultTab ft, uint8_t *__restrict__ detected)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smemAes[];
     uint32_t *sT = reinterpret_cast<uint32_t *>(smemAes);
@@ -500,8 +584,7 @@ __global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8
     uint32_t detItems = 0;
     for (uint64_t tile = (uint64_t)blockIdx.x * (kAesRepThreads / kWave) + (tid >> 6); tile < ntiles;
          tile += (uint64_t)gridDim.x * (kAesRepThreads / kWave)) {
-        if (faultRange && faultRange[tile].y != 0u)
-            continue; // aes128_xmr_kernel owns faulted tiles (wave-uniform)
+        const uint2 fr = aes_tile_faults(ft, tile); // this tile's armed upsets (wave-uniform)
         const uint64_t item = tile * IPW + (uint64_t)lm.q;
         const bool live = lm.live && item < nblocksData;
         const bool cnt = live && lm.r == 0;
@@ -510,26 +593,42 @@ __global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8
         const uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
         uint32_t s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w;
         uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
+        auto rounds = [&](auto hookTag) __attribute__((always_inline)) { // as aes128_enc_fast_kernel, HOOKED included
+            constexpr bool HOOKED = decltype(hookTag)::value;
+            auto hook = [&](int rd) __attribute__((always_inline)) {
+                if constexpr (HOOKED) {
+                    const AesDue d = aes_due_masks(ft, fr, (uint32_t)rd, lm.q, lm.r, lm.live);
+                    s0 ^= d.s0, s1 ^= d.s1, s2 ^= d.s2, s3 ^= d.s3;
+                    k0 ^= d.k0, k1 ^= d.k1, k2 ^= d.k2, k3 ^= d.k3;
+                }
+            };
 #pragma unroll
-        for (int rd = 0; rd < 10; ++rd) { // as aes128_enc_fast_kernel
-            const uint32_t x0 = s0 ^ k0, x1 = s1 ^ k1, x2 = s2 ^ k2, x3 = s3 ^ k3;
-            if (rd < 9) {
-                s0 = aes_xor3(TE(0, x0, 0), TE(1, x1, 1), TE(2, x2, 2)) ^ TE(3, x3, 3);
-                s1 = aes_xor3(TE(0, x1, 0), TE(1, x2, 1), TE(2, x3, 2)) ^ TE(3, x0, 3);
-                s2 = aes_xor3(TE(0, x2, 0), TE(1, x3, 1), TE(2, x0, 2)) ^ TE(3, x1, 3);
-                s3 = aes_xor3(TE(0, x3, 0), TE(1, x0, 1), TE(2, x1, 2)) ^ TE(3, x2, 3);
-            } else {
-                s0 = aes_pick_b1(TE(0, x0, 0), TE(0, x1, 1), TE(0, x2, 2), TE(0, x3, 3));
-                s1 = aes_pick_b1(TE(0, x1, 0), TE(0, x2, 1), TE(0, x3, 2), TE(0, x0, 3));
-                s2 = aes_pick_b1(TE(0, x2, 0), TE(0, x3, 1), TE(0, x0, 2), TE(0, x1, 3));
-                s3 = aes_pick_b1(TE(0, x3, 0), TE(0, x0, 1), TE(0, x1, 2), TE(0, x2, 3));
+            for (int rd = 0; rd < 10; ++rd) {
+                hook(rd);
+                const uint32_t x0 = s0 ^ k0, x1 = s1 ^ k1, x2 = s2 ^ k2, x3 = s3 ^ k3;
+                if (rd < 9) {
+                    s0 = aes_xor3(TE(0, x0, 0), TE(1, x1, 1), TE(2, x2, 2)) ^ TE(3, x3, 3);
+                    s1 = aes_xor3(TE(0, x1, 0), TE(1, x2, 1), TE(2, x3, 2)) ^ TE(3, x0, 3);
+                    s2 = aes_xor3(TE(0, x2, 0), TE(1, x3, 1), TE(2, x0, 2)) ^ TE(3, x1, 3);
+                    s3 = aes_xor3(TE(0, x3, 0), TE(1, x0, 1), TE(2, x1, 2)) ^ TE(3, x2, 3);
+                } else {
+                    s0 = aes_pick_b1(TE(0, x0, 0), TE(0, x1, 1), TE(0, x2, 2), TE(0, x3, 3));
+                    s1 = aes_pick_b1(TE(0, x1, 0), TE(0, x2, 1), TE(0, x3, 2), TE(0, x0, 3));
+                    s2 = aes_pick_b1(TE(0, x2, 0), TE(0, x3, 1), TE(0, x0, 2), TE(0, x1, 3));
+                    s3 = aes_pick_b1(TE(0, x3, 0), TE(0, x0, 1), TE(0, x1, 2), TE(0, x2, 3));
+                }
+                const uint32_t sw = aes_pick_b1(TE(0, k3, 1), TE(0, k3, 2), TE(0, k3, 3), TE(0, k3, 0));
+                k0 = aes_xor3(k0, sw, (uint32_t)kAesRcon[rd]);
+                k1 ^= k0;
+                k2 ^= k1;
+                k3 ^= k2;
             }
-            const uint32_t sw = aes_pick_b1(TE(0, k3, 1), TE(0, k3, 2), TE(0, k3, 3), TE(0, k3, 0));
-            k0 = aes_xor3(k0, sw, (uint32_t)kAesRcon[rd]);
-            k1 ^= k0;
-            k2 ^= k1;
-            k3 ^= k2;
-        }
+            hook(10);
+        };
+        if (fr.y != 0u)
+            rounds(std::true_type{});
+        else
+            rounds(std::false_type{});
         s0 ^= k0;
         s1 ^= k1;
         s2 ^= k2;
@@ -564,8 +663,7 @@ __global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8
 template <int NREP>
 __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
                                                                         uint64_t nblocksData, uint64_t ntiles, Counters ctr,
-                                                                        const uint2 *__restrict__ faultRange,
-                                                                        uint8_t *__restrict__ detected)
+                                                                        FaultTab ft, uint8_t *__restrict__ detected)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smemAes[];
     uint2 *sDR = reinterpret_cast<uint2 *>(smemAes);                      // {Td_0[v], rsbox[v] x 4}
@@ -600,8 +698,7 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
     uint32_t detItems = 0;
     for (uint64_t tile = (uint64_t)blockIdx.x * (kAesRepThreads / kWave) + (tid >> 6); tile < ntiles;
          tile += (uint64_t)gridDim.x * (kAesRepThreads / kWave)) {
-        if (faultRange && faultRange[tile].y != 0u)
-            continue;
+        const uint2 fr = aes_tile_faults(ft, tile); // this tile's armed upsets (wave-uniform)
         const uint64_t item = tile * IPW + (uint64_t)lm.q;
         const bool live = lm.live && item < nblocksData;
         const bool cnt = live && lm.r == 0;
@@ -609,54 +706,69 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
         const uint4 sv = reinterpret_cast<const uint4 *>(states)[it];
         const uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
         uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
+        uint32_t x0, x1, x2, x3;
+        auto rounds = [&](auto hookTag) __attribute__((always_inline)) { // as aes128_dec_fast_kernel, HOOKED included
+            constexpr bool HOOKED = decltype(hookTag)::value;
+            uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
 #pragma unroll
-        for (int rd = 0; rd < 10; ++rd) { // the last encryption key first (:110-123)
-            k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[rd]);
-            k1 ^= k0;
-            k2 ^= k1;
-            k3 ^= k2;
-        }
-        uint32_t x0 = sv.x ^ k0, x1 = sv.y ^ k1, x2 = sv.z ^ k2, x3 = sv.w ^ k3;
-        k3 ^= k2; // round 0, as aes128_dec_fast_kernel
-        k2 ^= k1;
-        k1 ^= k0;
-        k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[9]);
-        uint32_t m0 = aes_imc_col(k0), m1 = aes_imc_col(k1), m2 = aes_imc_col(k2), m3 = aes_imc_col(k3);
-        {
-            const uint32_t w0 = TDCOL(x0, x3, x2, x1) ^ m0, w1 = TDCOL(x1, x0, x3, x2) ^ m1;
-            const uint32_t w2 = TDCOL(x2, x1, x0, x3) ^ m2, w3 = TDCOL(x3, x2, x1, x0) ^ m3;
-            x0 = w0;
-            x1 = w1;
-            x2 = w2;
-            x3 = w3;
-        }
-#pragma unroll
-        for (int j = 8; j >= 1; --j) {
-            k3 ^= k2;
+            for (int rd = 0; rd < 10; ++rd) { // the last encryption key first (:110-123)
+                k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[rd]);
+                k1 ^= k0;
+                k2 ^= k1;
+                k3 ^= k2;
+            }
+            x0 = sv.x ^ k0, x1 = sv.y ^ k1, x2 = sv.z ^ k2, x3 = sv.w ^ k3;
+            AES_DEC_HOOK(0, false, false);
+            k3 ^= k2; // round 0
             k2 ^= k1;
             k1 ^= k0;
-            m3 ^= m2;
-            m2 ^= m1;
-            m1 ^= m0;
-            // one 8-byte lookup per byte of k3: the S-box byte for the key word, Tis_0 for its InvMixColumns image
-            const uint2 a1 = TS(k3, 1), a2 = TS(k3, 2), a3 = TS(k3, 3), a0 = TS(k3, 0);
-            k0 = aes_xor3(k0, aes_pick_rep(a1.y, a2.y, a3.y, a0.y), (uint32_t)kAesRcon[j]);
-            m0 ^= aes_xor3(a1.x, aes_rotl8(a2.x, 1), aes_rotl8(a3.x, 2)) ^ aes_rotl8(a0.x, 3) ^ gAesImcRcon[j];
-            const uint32_t w0 = TDCOL(x0, x3, x2, x1) ^ m0, w1 = TDCOL(x1, x0, x3, x2) ^ m1;
-            const uint32_t w2 = TDCOL(x2, x1, x0, x3) ^ m2, w3 = TDCOL(x3, x2, x1, x0) ^ m3;
-            x0 = w0;
-            x1 = w1;
-            x2 = w2;
-            x3 = w3;
-        }
-        k3 ^= k2; // reference round 9
-        k2 ^= k1;
-        k1 ^= k0;
-        k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[0]);
-        uint32_t s0 = aes_pick_rep(DR(x0, 0).y, DR(x3, 1).y, DR(x2, 2).y, DR(x1, 3).y) ^ k0;
-        uint32_t s1 = aes_pick_rep(DR(x1, 0).y, DR(x0, 1).y, DR(x3, 2).y, DR(x2, 3).y) ^ k1;
-        uint32_t s2 = aes_pick_rep(DR(x2, 0).y, DR(x1, 1).y, DR(x0, 2).y, DR(x3, 3).y) ^ k2;
-        uint32_t s3 = aes_pick_rep(DR(x3, 0).y, DR(x2, 1).y, DR(x1, 2).y, DR(x0, 3).y) ^ k3;
+            k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[9]);
+            m0 = aes_imc_col(k0), m1 = aes_imc_col(k1), m2 = aes_imc_col(k2), m3 = aes_imc_col(k3);
+            {
+                const uint32_t w0 = TDCOL(x0, x3, x2, x1) ^ m0, w1 = TDCOL(x1, x0, x3, x2) ^ m1;
+                const uint32_t w2 = TDCOL(x2, x1, x0, x3) ^ m2, w3 = TDCOL(x3, x2, x1, x0) ^ m3;
+                x0 = w0;
+                x1 = w1;
+                x2 = w2;
+                x3 = w3;
+            }
+#pragma unroll
+            for (int j = 8; j >= 1; --j) {
+                AES_DEC_HOOK(9 - j, true, true);
+                k3 ^= k2;
+                k2 ^= k1;
+                k1 ^= k0;
+                m3 ^= m2;
+                m2 ^= m1;
+                m1 ^= m0;
+                // one 8-byte lookup per byte of k3: the S-box byte for the key word, Tis_0 for its InvMixColumns image
+                const uint2 a1 = TS(k3, 1), a2 = TS(k3, 2), a3 = TS(k3, 3), a0 = TS(k3, 0);
+                k0 = aes_xor3(k0, aes_pick_rep(a1.y, a2.y, a3.y, a0.y), (uint32_t)kAesRcon[j]);
+                m0 ^= aes_xor3(a1.x, aes_rotl8(a2.x, 1), aes_rotl8(a3.x, 2)) ^ aes_rotl8(a0.x, 3) ^ gAesImcRcon[j];
+                const uint32_t w0 = TDCOL(x0, x3, x2, x1) ^ m0, w1 = TDCOL(x1, x0, x3, x2) ^ m1;
+                const uint32_t w2 = TDCOL(x2, x1, x0, x3) ^ m2, w3 = TDCOL(x3, x2, x1, x0) ^ m3;
+                x0 = w0;
+                x1 = w1;
+                x2 = w2;
+                x3 = w3;
+            }
+            AES_DEC_HOOK(9, true, false);
+            k3 ^= k2; // reference round 9
+            k2 ^= k1;
+            k1 ^= k0;
+            k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[0]);
+            const uint32_t p0 = aes_pick_rep(DR(x0, 0).y, DR(x3, 1).y, DR(x2, 2).y, DR(x1, 3).y) ^ k0;
+            const uint32_t p1 = aes_pick_rep(DR(x1, 0).y, DR(x0, 1).y, DR(x3, 2).y, DR(x2, 3).y) ^ k1;
+            const uint32_t p2 = aes_pick_rep(DR(x2, 0).y, DR(x1, 1).y, DR(x0, 2).y, DR(x3, 3).y) ^ k2;
+            const uint32_t p3 = aes_pick_rep(DR(x3, 0).y, DR(x2, 1).y, DR(x1, 2).y, DR(x0, 3).y) ^ k3;
+            x0 = p0, x1 = p1, x2 = p2, x3 = p3;
+            AES_DEC_HOOK(10, false, false);
+        };
+        if (fr.y != 0u)
+            rounds(std::true_type{});
+        else
+            rounds(std::false_type{});
+        uint32_t s0 = x0, s1 = x1, s2 = x2, s3 = x3;
         Tally te = tl;
         te.det = 0;
         s0 = xmr_sync<NREP>(s0, lm, cnt, te);
@@ -687,6 +799,8 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
 #undef TDCOL
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
 }
+
+#undef AES_DEC_HOOK
 
 // ------------------------------------------------------------------------------------------------ general path
 template <int NREP>

@@ -262,11 +262,14 @@ int arm_faults_impl(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *g
 // (or the pool is full), so block on the stragglers.
 int profile_fold(coast_ctx *c, bool wait)
 {
-    size_t keep = 0;
-    for (size_t i = 0; i < c->evPending.size(); ++i) {
+    size_t keep = 0, i = 0;
+    int rc = COAST_OK;
+    for (; i < c->evPending.size(); ++i) {
         coast_ctx::EvPair e = c->evPending[i];
-        if (wait)
-            HIP_TRY(c, hipEventSynchronize(e.b));
+        if (wait && hipEventSynchronize(e.b) != hipSuccess) {
+            rc = fail(c, COAST_EHIP, "hipEventSynchronize failed on a timing event");
+            break;
+        }
         float ms = 0.f;
         const hipError_t q = hipEventElapsedTime(&ms, e.a, e.b);
         if (q == hipSuccess) {
@@ -276,15 +279,23 @@ int profile_fold(coast_ctx *c, bool wait)
             (void)hipGetLastError();
             c->evPending[keep++] = e;
         } else {
-            return fail(c, COAST_EHIP, "hipEventElapsedTime failed: %s", hipGetErrorString(q));
+            rc = fail(c, COAST_EHIP, "hipEventElapsedTime failed: %s", hipGetErrorString(q));
+            break;
         }
     }
+    // on an error the unprocessed tail stays pending (compacted): nothing is listed twice, nothing is reused while pending
+    for (; i < c->evPending.size(); ++i)
+        c->evPending[keep++] = c->evPending[i];
     c->evPending.resize(keep);
-    return COAST_OK;
+    return rc;
 }
 
 int profile_begin(coast_ctx *c)
 {
+    if (c->evOpen && !c->evPending.empty()) { // the previous launch failed between its bracket's two records: the pair's `b`
+        c->evFree.push_back(c->evPending.back()); // was never recorded and would poison every later fold
+        c->evPending.pop_back();
+    }
     c->evOpen = false;
     if (!c->profiling)
         return COAST_OK;
@@ -299,9 +310,15 @@ int profile_begin(coast_ctx *c)
         c->evFree.pop_back();
     } else {
         HIP_TRY(c, hipEventCreate(&e.a));
-        HIP_TRY(c, hipEventCreate(&e.b));
+        if (hipEventCreate(&e.b) != hipSuccess) {
+            (void)hipEventDestroy(e.a);
+            return fail(c, COAST_EHIP, "hipEventCreate failed");
+        }
     }
-    HIP_TRY(c, hipEventRecord(e.a, c->stream));
+    if (hipEventRecord(e.a, c->stream) != hipSuccess) {
+        c->evFree.push_back(e);
+        return fail(c, COAST_EHIP, "hipEventRecord failed on a timing event");
+    }
     c->evPending.push_back(e);
     c->evOpen = true;
     return COAST_OK;
@@ -507,6 +524,11 @@ extern "C" int coast_read_stats(coast_ctx *c, coast_stats *out)
     out->sync_count = h[1];
     out->dwc_detected = h[2];
     out->launches = h[3];
+    if (c->evOpen && !c->evPending.empty()) { // a failed launch left its bracket open: drop it (see profile_begin)
+        c->evFree.push_back(c->evPending.back());
+        c->evPending.pop_back();
+        c->evOpen = false;
+    }
     rc = profile_fold(c, true); // the stream is idle: every bracket has closed
     if (rc)
         return rc;
@@ -543,6 +565,7 @@ extern "C" int coast_reset_stats(coast_ctx *c)
     for (coast_ctx::EvPair &e : c->evPending)
         c->evFree.push_back(e);
     c->evPending.clear();
+    c->evOpen = false;
     c->kernelMs = 0.0;
     c->hbmBytes = 0.0;
     return COAST_OK;
@@ -672,6 +695,8 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     const bool mmBlocks = !(tileEnv && !strcmp(tileEnv, "lanes"));
     const bool mmBlocks2 = !(tileEnv && !strcmp(tileEnv, "blocks"));
     const uint64_t nbm = (uint64_t)(n / 64) * batch; // workgroups of the panel kernel: 64 rows of one matrix each
+    if (mfma && nbm > 0x7fffffffull)
+        return fail(c, COAST_EINVAL, "coast_mm_batch: %llu workgroups exceed the grid limit", (unsigned long long)nbm);
 
     FaultTab ft;
     int have = 0;
@@ -712,7 +737,7 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
             if (!have)                                                                                          \
                 ftm.list = nullptr, ftm.range = nullptr;                                                        \
             /* one workgroup per CU; four of them (one XCD) share a matrix */                                    \
-            const uint32_t gridB = 4u * (uint32_t)std::min<uint64_t>((uint64_t)batch, (uint64_t)(c->numCUs / 4)); \
+            const uint32_t gridB = 4u * (uint32_t)std::min<uint64_t>((uint64_t)batch, (uint64_t)std::max(1, c->numCUs / 4)); \
             if (mmBlocks2) {                                                                                    \
                 using G2 = MmBlk2<3>;                                                                           \
                 if (d_detected) {                                                                               \

@@ -9,7 +9,9 @@
 // `while (length--)` loop-condition sync, crc16.c:25).
 //
 // Two kernels:
-//   crc16_stream_kernel   the HBM-streaming path (any block_len, no fault in the tile, mandatory sync only).
+//   crc16_stream_kernel   the HBM-streaming path (any block_len, mandatory sync point only).  A tile that owns an armed
+//                         upset walks its blocks byte by byte with the injector hooks INSIDE this kernel (wave-uniform
+//                         branch), so the flipped crc meets this kernel's own return-value sync, counter gate and store.
 //                         The byte-serial update costs ~9 VALU ops per byte per replica -- 3 replicas would cap the
 //                         chip near 2 TB/s -- so two update steps are folded into ONE lookup: for W = (b0<<8)|b1,
 //                         crc' = T16[crc ^ W] (both byte steps depend on crc and the data only through crc ^ W; derived
@@ -26,8 +28,8 @@
 //                         alignment costs no instruction.  The tail (block_len % 4 bytes) comes out of the same
 //                         registers: one more pair lookup and / or one byte-serial step.
 //   crc16_general_kernel  byte-serial, exactly as written in crc16.c, with the injector hooks and the optional
-//                         per-V-bytes votes; one wave per tile; runs the tiles that own an armed fault (side stream) or
-//                         every tile when the stream path does not apply.
+//                         per-V-bytes votes; one wave per tile; every tile when the launch asks for sync_every != 0 or
+//                         COAST_F_BRANCH_SYNC.
 #include "xmr.hpp"
 
 namespace coast {
@@ -59,10 +61,41 @@ constexpr int kCrcTableBytes = 65536 * 2;
 __device__ __forceinline__ uint32_t crc_perm_sel(uint32_t sh) { return 0x00010203u + 0x01010101u * sh; }
 __device__ __forceinline__ uint32_t crc_be32(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
+// crc16() byte by byte as written (crc16.c:25-29) with the injector hooks: a flip of the lane's crc register before byte `step`
+// (step == length: after the loop), of its temporary x right after `x ^= x >> 4`.  Used by both kernels for the tiles that own
+// an armed fault.
+__device__ __forceinline__ uint32_t crc16_bytes_hooked(const uint8_t *p, uint32_t blockLen, const FaultTab &ft, uint2 fr, int slot,
+                                                       int rep, bool laneLive)
+{
+    uint32_t crc = 0xFFFFu;
+    for (uint32_t t = 0; t < blockLen; ++t) {
+        uint32_t xm = 0u;
+        for (uint32_t q = 0; q < fr.y; ++q) {
+            const DevFault df = ft.list[fr.x + q];
+            if (df.step != t || (int)df.local != slot || (int)df.replica != rep || !laneLive)
+                continue;
+            if (df.site == SITE_CRC_CRC)
+                crc = flip_bit(crc, df.bit, 0xffffu);
+            else if (df.site == SITE_CRC_X)
+                xm ^= (1u << (df.bit & 31u)) & 0xffu;
+        }
+        uint32_t x = ((crc >> 8) ^ (uint32_t)p[t]) & 0xffu;
+        x ^= x >> 4;
+        x ^= xm;
+        crc = ((crc << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xffffu;
+    }
+    for (uint32_t q = 0; q < fr.y; ++q) {
+        const DevFault df = ft.list[fr.x + q];
+        if (df.step == blockLen && df.site == SITE_CRC_CRC && (int)df.local == slot && (int)df.replica == rep && laneLive)
+            crc = flip_bit(crc, df.bit, 0xffffu);
+    }
+    return crc;
+}
+
 template <int NREP, int NT, bool ALIGNED>
 __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
     const uint8_t *__restrict__ data, uint32_t blockLen, uint64_t nblocksData, uint16_t *__restrict__ crcs,
-    const uint16_t *__restrict__ t16g, uint64_t ntiles, Counters ctr, const uint2 *__restrict__ faultRange,
+    const uint16_t *__restrict__ t16g, uint64_t ntiles, uint64_t ntilesWalk, Counters ctr, FaultTab ft,
     uint8_t *__restrict__ detected)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smemRaw[];
@@ -102,7 +135,7 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
     for (uint64_t tileBase = wave0 * NT; tileBase < ntiles; tileBase += wavesTotal * NT) {
         // NT independent tiles per wave: NT dependent lookup chains in flight per lane
         const uint8_t *p[NT];
-        bool liveT[NT], cntT[NT];
+        bool liveT[NT], cntT[NT], slowT[NT];
         uint64_t itemT[NT];
         uint32_t crc[NT], sel[NT];
         uint32_t cur[NT][16], nxt[NT][16]; // one 64-byte batch of the block's dword stream, and the batch after it
@@ -123,18 +156,26 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const uint64_t tile = tileBase + j;
-            bool skip = tile >= ntiles;
-            if (!skip && faultRange)
-                skip = faultRange[tile].y != 0u; // crc16_general_kernel owns faulted tiles
+            const bool skip = tile >= ntiles;
+            // a tile that owns an armed upset, or one of the stream's last tiles (rows that are not 16-byte aligned are read as
+            // the dword-aligned chunks that cover them: < 20 bytes past the row), is walked byte by byte below -- wave-uniform
+            slowT[j] = !skip && (tile >= ntilesWalk ||
+                                 (ft.range && __builtin_amdgcn_readfirstlane(ft.range[tile].y) != 0u));
             itemT[j] = tile * IPW + (uint64_t)lm.q;
             liveT[j] = !skip && lm.live && itemT[j] < nblocksData;
             cntT[j] = liveT[j] && lm.r == 0;
-            const uint8_t *row = data + (liveT[j] ? itemT[j] : 0) * (uint64_t)blockLen;
+            // the lookup walk of a lane that has no block of its own (or whose tile is walked byte by byte) reads row 0
+            const uint8_t *row = data + ((liveT[j] && !slowT[j]) ? itemT[j] : 0) * (uint64_t)blockLen;
             const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(row) & 3u);
             p[j] = row - sh;
             sel[j] = crc_perm_sel(sh);
             crc[j] = 0xFFFFu;
         }
+        bool anyWalk = false; // wave-uniform: some tile of this round takes the lookup walk
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            anyWalk = anyWalk || (tileBase + j < ntiles && !slowT[j]);
+        if (anyWalk) {
         if constexpr (ALIGNED) { // rows are whole 16-byte chunks: exact loads, the byte swap is a plain v_perm
             const uint32_t nbatch = blockLen >> 6, rem = blockLen & 63u;
             uint4 c4[NT][4], n4[NT][4];
@@ -262,6 +303,7 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
             }
         }
         }
+        } // anyWalk
 #undef CRC_NEXT
 #undef CRC_WINDOW_INIT
 #undef CRC_LOAD_BATCH
@@ -269,6 +311,16 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
 #undef CRC_LOAD_CHUNK
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+            if (slowT[j]) { // the flips land in this lane's own crc / x registers; the sync point below is the one every tile meets
+                uint2 fr = make_uint2(0u, 0u);
+                if (ft.range) {
+                    const uint2 rg = ft.range[tileBase + j];
+                    fr.x = __builtin_amdgcn_readfirstlane(rg.x);
+                    fr.y = __builtin_amdgcn_readfirstlane(rg.y);
+                }
+                crc[j] = crc16_bytes_hooked(data + (liveT[j] ? itemT[j] : 0) * (uint64_t)blockLen, liveT[j] ? blockLen : 0u, ft,
+                                            fr, lm.q, lm.r, lm.live);
+            }
             Tally te = tl;
             te.det = 0;
             const uint32_t voted = xmr_sync<NREP>(crc[j], lm, cntT[j], te); // return-value sync
@@ -294,15 +346,12 @@ __global__ __launch_bounds__(64) void crc16_general_kernel(const uint8_t *__rest
                                                            uint64_t nblocksData, uint16_t *__restrict__ crcs,
                                                            uint32_t syncEvery, Counters ctr, FaultTab ft,
                                                            const uint32_t *__restrict__ tileList,
-                                                           uint8_t *__restrict__ detected, uint32_t tileBase = 0u,
-                                                           uint32_t unlessFaulted = 0u)
+                                                           uint8_t *__restrict__ detected)
 {
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
     const LaneMap<NREP> lm;
-    const uint32_t tile = tileList ? tileList[blockIdx.x] : tileBase + blockIdx.x;
-    if (unlessFaulted && ft.range && ft.range[tile].y != 0u)
-        return; // the launch over the armed-fault tiles has this one
+    const uint32_t tile = tileList ? tileList[blockIdx.x] : blockIdx.x;
     const int slot = lm.q;
     const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
     const bool live = lm.live && item < nblocksData;

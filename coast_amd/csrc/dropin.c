@@ -144,7 +144,10 @@ static void dropin_maybe_inject(void)
 
 static void dropin_fail(const char *what, int rc)
 {
-    fprintf(stderr, "libcoast_dropin: %s failed with code %d (no GPU / no CPU fallback)\n", what, rc);
+    if (rc == COAST_ETIMEOUT) /* the reference program would hang here and the supervisor would file a timeout */
+        fprintf(stderr, "libcoast_dropin: %s did not terminate (watchdog / recursion stack limit)\n", what);
+    else
+        fprintf(stderr, "libcoast_dropin: %s failed with code %d (no GPU / no CPU fallback)\n", what, rc);
     abort();
 }
 

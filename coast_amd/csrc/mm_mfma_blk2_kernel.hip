@@ -143,6 +143,9 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
     auto run = [&](auto hTag) __attribute__((always_inline)) {
         constexpr int H = decltype(hTag)::value;
         Tally tl;
+        // every lane executes exactly four votes on a tile that does not exist (the first step's look-back at zeroed accumulators;
+        // in a workgroup without an item, the final flush): they are the only votes not in the schedule
+        tl.syncs = 0u - 4u;
         uint32_t detItems = 0;
         v4i_t acc[2][NREP][4]; // row blocks 2 H and 2 H + 1
 #pragma unroll
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
                 const bool e01 = teV[0] == teV[1], e02 = teV[0] == teV[2];
                 teVoted = (NREP == 3 && !e01) ? teV[2] : teV[0];
                 teMiss = (e01 && e02) ? 0u : 1u;
+                tl.syncs += 1u; // __SYNC_COUNT is counted where the vote happens: a tile whose vote were skipped would be missed
                 if (NREP == 3)
                     tl.miss += teMiss;
                 else
@@ -445,7 +449,6 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
 #pragma unroll 1
             for (int tile = 0; tile < G::TPW; ++tile) {
                 const int g0 = item * G::SPP + tile * G::NSLAB;
-                tl.syncs += 8u;
                 step(g0, T1{}, T0{}); // + the previous tile's second row block (the previous item's resources at a hand-over)
                 rsRp = rsR;
                 rsDp = rsD;

@@ -72,7 +72,12 @@ __global__ __launch_bounds__(64) void quicksort_kernel(int32_t *__restrict__ arr
 
     Tally tl;
     uint32_t base = 0u, len = live ? n : 0u, sp = 0u, tick = 0u, st = kQsOk;
-    const uint32_t cap = 64u * n + 1024u;
+    // the watchdog (the supervisor's timeout) guards sorts an armed upset can derail; a clean sort always terminates, and a
+    // legitimate bad-pivot order may take ~n^2 conditions, so an array without an armed upset runs without it
+    bool armedItem = false;
+    for (uint32_t q = 0; q < fr.y; ++q)
+        armedItem = armedItem || (int)ft.list[fr.x + q].local == slot;
+    const uint32_t cap = armedItem ? 64u * n + 1024u : 0xffffffffu;
     uint32_t i = 0u, j = 0u, pv = 0u, vi = 0u, vj = 0u;
     auto hook = [&]() __attribute__((always_inline)) {
         for (uint32_t q = 0; q < fr.y; ++q) {

@@ -11,10 +11,14 @@
 // compression per replica (rotates are v_alignbit_b32, 3-input xor / ch / maj are one v_bitop3_b32 each).
 //
 // Two kernels:
-//   sha256_fast_kernel     tiles no armed fault points at: 64 rounds fully unrolled with rotating register names,
-//                          whole 64-byte blocks loaded as 4 x dwordx4 per lane.
-//   sha256_general_kernel  tiles that own an armed fault (side stream), or every tile when the message array is not
-//                          4-byte aligned: round-at-a-time with the injector hooks.
+//   sha256_fast_kernel     every tile of an aligned batch: 64 rounds fully unrolled with rotating register names, whole
+//                          64-byte blocks loaded as 4 x dwordx4 per lane.  A tile that owns an armed fault (wave-uniform test
+//                          on the injector's range table) runs its compressions a round at a time with the injector hooks
+//                          instead -- inside this kernel, so the flipped register meets this kernel's own sync points, lane
+//                          map, counter gate and stores (round 2 handed such tiles to the kernel below and the voter here
+//                          never saw unequal copies).
+//   sha256_general_kernel  message arrays that are not 4-byte aligned, -noStoreDataSync, and the byte loop with its counters
+//                          inside the sphere of replication (COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC).
 #include "xmr.hpp"
 
 namespace coast {
@@ -138,98 +142,7 @@ __device__ __forceinline__ void sha_compress_unrolled(uint32_t st[8], uint32_t m
     st[7] += h;
 }
 
-// one wave per tile; requires 4-byte aligned message rows (stride % 4 == 0, base % 4 == 0); VEC16: rows 16-byte aligned
-template <int NREP, bool VEC16>
-__global__ __launch_bounds__(256) void sha256_fast_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
-                                                          uint64_t nmsgs, uint8_t *__restrict__ digests,
-                                                          uint64_t ntiles, Counters ctr,
-                                                          const uint2 *__restrict__ faultRange,
-                                                          uint8_t *__restrict__ detected)
-{
-    __shared__ uint32_t sCnt[4];
-    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
-    const LaneMap<NREP> lm;
-    if (threadIdx.x < 4)
-        sCnt[threadIdx.x] = 0;
-    __syncthreads();
-
-    const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    bool skip = tile >= ntiles;
-    if (!skip && faultRange)
-        skip = faultRange[tile].y != 0u; // sha256_general_kernel owns faulted tiles
-    const uint64_t item = tile * IPW + (uint64_t)lm.q;
-    const bool live = !skip && lm.live && item < nmsgs;
-    const bool cnt = live && lm.r == 0;
-    const uint8_t *msg = msgs + (live ? item : 0) * stride;
-
-    uint32_t st[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
-                      0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u}; // :107-114
-    Tally tl;
-    const uint32_t nfull = len >> 6, rem = len & 63u;
-    const uint32_t ncomp = nfull + (rem < 56u ? 1u : 2u);
-
-    for (uint32_t c = 0; c < ncomp; ++c) {
-        uint32_t m[16];
-        if (c < nfull) { // a whole data block
-            if (VEC16) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(msg + (size_t)c * 64);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const uint4 q = src[v];
-                    m[4 * v + 0] = bswap32(q.x);
-                    m[4 * v + 1] = bswap32(q.y);
-                    m[4 * v + 2] = bswap32(q.z);
-                    m[4 * v + 3] = bswap32(q.w);
-                }
-            } else {
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(msg + (size_t)c * 64);
-#pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    m[t] = bswap32(src[t]);
-            }
-        } else { // tail / padding blocks (:129-164).  A message of k * 64 bytes ends with a block that holds no data: its 16
-                 // words and 48 schedule words depend on `len` alone, yet they are computed here, per replica lane, like
-                 // every other block -- in the reference that expansion sits inside the triplicated sha256_transform (:49-63),
-                 // so it belongs inside the sphere of replication (round 1 expanded it once on the host).
-            const bool last = (c + 1u == ncomp);
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-                m[t] = sha_word(msg, len, c, t, true, last);
-        }
-        sha_compress_unrolled(st, m);
-#pragma unroll
-        for (int w = 0; w < 8; ++w) // ctx_state[w] += ... are stores: store-data sync
-            st[w] = xmr_sync<NREP>(st[w], lm, cnt, tl);
-    }
-    uint32_t dg[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w)
-        dg[w] = bswap32(xmr_sync<NREP>(st[w], lm, cnt, tl)); // digest words voted before the store (:169-178)
-
-    uint32_t detItems = 0;
-    if (cnt) {
-        uint8_t *out = digests + item * 32u;
-        if ((reinterpret_cast<uintptr_t>(digests) & 15u) == 0u) {
-            reinterpret_cast<uint4 *>(out)[0] = make_uint4(dg[0], dg[1], dg[2], dg[3]);
-            reinterpret_cast<uint4 *>(out)[1] = make_uint4(dg[4], dg[5], dg[6], dg[7]);
-        } else {
-#pragma unroll
-            for (int w = 0; w < 8; ++w)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    out[4 * w + b] = (uint8_t)(dg[w] >> (8 * b));
-        }
-        if (tl.det) { // unequal copies seen at a sync point of this message (DWC: detected, TMR: corrected)
-            if (NREP == 2)
-                detItems = 1;
-            if (detected)
-                detected[item] = 1;
-        }
-    }
-    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------------ general path
+// ------------------------------------------------------------------------------------------------ injector hooks
 #define SHA_ROUND(T, MW)                                                                                        \
     do {                                                                                                        \
         const uint32_t ep0_ = rotr32(v[0], 2) ^ rotr32(v[0], 13) ^ rotr32(v[0], 22);                            \
@@ -308,6 +221,106 @@ __device__ __forceinline__ void sha_state_hook(uint32_t st[8], uint32_t step, co
     }
 }
 
+// one wave per tile; requires 4-byte aligned message rows (stride % 4 == 0, base % 4 == 0); VEC16: rows 16-byte aligned
+template <int NREP, bool VEC16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void sha256_fast_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
+                                                          uint64_t nmsgs, uint8_t *__restrict__ digests,
+                                                          uint64_t ntiles, Counters ctr, FaultTab ft,
+                                                          uint8_t *__restrict__ detected)
+{
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    const LaneMap<NREP> lm;
+    if (threadIdx.x < 4)
+        sCnt[threadIdx.x] = 0;
+    __syncthreads();
+
+    const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool skip = tile >= ntiles;
+    uint2 fr = make_uint2(0u, 0u); // this tile's armed faults (the same for the whole wave): {first, count} in ft.list
+    if (!skip && ft.range) {
+        fr = ft.range[tile]; // left in vector registers: the hooks' loop state would otherwise cost the unrolled rounds SGPRs
+    }
+    const uint64_t item = tile * IPW + (uint64_t)lm.q;
+    const bool live = !skip && lm.live && item < nmsgs;
+    const bool cnt = live && lm.r == 0;
+    const uint8_t *msg = msgs + (live ? item : 0) * stride;
+
+    uint32_t st[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
+                      0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u}; // :107-114
+    Tally tl;
+    const uint32_t nfull = len >> 6, rem = len & 63u;
+    const uint32_t ncomp = nfull + (rem < 56u ? 1u : 2u);
+
+    for (uint32_t c = 0; c < ncomp; ++c) {
+        uint32_t m[16];
+        if (c < nfull) { // a whole data block
+            if (VEC16) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(msg + (size_t)c * 64);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const uint4 q = src[v];
+                    m[4 * v + 0] = bswap32(q.x);
+                    m[4 * v + 1] = bswap32(q.y);
+                    m[4 * v + 2] = bswap32(q.z);
+                    m[4 * v + 3] = bswap32(q.w);
+                }
+            } else {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(msg + (size_t)c * 64);
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    m[t] = bswap32(src[t]);
+            }
+        } else { // tail / padding blocks (:129-164).  A message of k * 64 bytes ends with a block that holds no data: its 16
+                 // words and 48 schedule words depend on `len` alone, yet they are computed here, per replica lane, like
+                 // every other block -- in the reference that expansion sits inside the triplicated sha256_transform (:49-63),
+                 // so it belongs inside the sphere of replication (round 1 expanded it once on the host).
+            const bool last = (c + 1u == ncomp);
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                m[t] = sha_word(msg, len, c, t, true, last);
+        }
+        if (fr.y != 0u) { // a tile with armed upsets: the same compression a round at a time, flips applied where they are due
+            sha_state_hook(st, c, ft, fr, lm.q, lm.r, lm.live);
+            sha_compress_hooked(st, m, c, ft, fr, lm.q, lm.r, lm.live);
+        } else {
+            sha_compress_unrolled(st, m);
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w) // ctx_state[w] += ... are stores: store-data sync
+            st[w] = xmr_sync<NREP>(st[w], lm, cnt, tl);
+    }
+    if (fr.y != 0u)
+        sha_state_hook(st, ncomp, ft, fr, lm.q, lm.r, lm.live); // step == ncompress: a ctx_state word before the digest
+    uint32_t dg[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+        dg[w] = bswap32(xmr_sync<NREP>(st[w], lm, cnt, tl)); // digest words voted before the store (:169-178)
+
+    uint32_t detItems = 0;
+    if (cnt) {
+        uint8_t *out = digests + item * 32u;
+        if ((reinterpret_cast<uintptr_t>(digests) & 15u) == 0u) {
+            reinterpret_cast<uint4 *>(out)[0] = make_uint4(dg[0], dg[1], dg[2], dg[3]);
+            reinterpret_cast<uint4 *>(out)[1] = make_uint4(dg[4], dg[5], dg[6], dg[7]);
+        } else {
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    out[4 * w + b] = (uint8_t)(dg[w] >> (8 * b));
+        }
+        if (tl.det) { // unequal copies seen at a sync point of this message (DWC: detected, TMR: corrected)
+            if (NREP == 2)
+                detItems = 1;
+            if (detected)
+                detected[item] = 1;
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------ general path
 // sha256_hash with its byte loop as written (sha256_common_tmr.c:119-127), for COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC: the loop
 // counter `i` and `ctx_datalen` are replica-private registers of the lane; ctx_data[64] is memory -- one copy per message, in
 // LDS, written by the original store (replica 0's lane) at the voted or at its own offset; ctx_bitlen likewise.  Mirrors

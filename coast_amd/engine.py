@@ -111,7 +111,7 @@ class Engine:
         """What the most recent protected launch dispatched to (coast_last_launch_info)."""
         li = _lib.CoastLaunchInfo()
         self._check(self._lib.coast_last_launch_info(self._h, C.byref(li)))
-        return {"engine": _lib.ENGINE_NAMES.get(int(li.engine), str(li.engine)), "general_blocks": int(li.general_blocks),
+        return {"engine": _lib.ENGINE_NAMES.get(int(li.engine), str(li.engine)), "general_blocks": int(li.general_blocks), "hooked_blocks": int(li.hooked_blocks),
                 "fast_blocks": int(li.fast_blocks), "armed_faults": int(li.armed_faults),
                 "algorithmic_bytes": float(li.algorithmic_bytes)}
 

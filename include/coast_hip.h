@@ -27,7 +27,9 @@ enum {
     COAST_EINVAL = -1, /* bad argument (NULL pointer, replicas not in {1,2,3}, size overflow ...) */
     COAST_EHIP = -2,   /* a HIP runtime call failed */
     COAST_ENODEV = -3, /* no gfx950 device */
-    COAST_ENOMEM = -4
+    COAST_ENOMEM = -4,
+    COAST_ETIMEOUT = -5 /* a single-call shim's region did not end: quicksort's watchdog or recursion-stack limit (the class the
+                         * reference's supervisor files under timeout); the caller's array is left as it was */
 };
 
 /* Protection mode.  replicas = 3 is what `opt -TMR` selects (projects/TMR/TMR.cpp:33, DP.run(M,3)),
@@ -108,8 +110,8 @@ enum {
 };
 typedef struct coast_launch_info {
     uint32_t engine;         /* COAST_ENGINE_* */
-    uint32_t reserved;
-    uint64_t general_blocks; /* workgroups / tiles run by the stepwise (hooked) kernel */
+    uint32_t hooked_blocks;  /* of fast_blocks: tiles / workgroups of the lean kernel that own an armed fault and applied it themselves */
+    uint64_t general_blocks; /* workgroups / tiles run by a stepwise kernel (sync_every, flags, unaligned input) */
     uint64_t fast_blocks;    /* workgroups / tiles run by the lean kernel */
     uint64_t armed_faults;   /* single-bit flips the launch consumed */
     double algorithmic_bytes;

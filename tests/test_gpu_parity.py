@@ -397,7 +397,7 @@ def test_aes_faults_vs_oracle(eng, orc, replicas, sync_every, direction):
 def test_aes_bank_replicated_table_kernels(eng, orc, golden, replicas, direction, monkeypatch):
     """the persistent kernels with bank-replicated tables (what large batches run; forced here through COAST_AES_TABLES):
     bit-identical with the one-copy T-table kernels on states, keys, per-block flags and counters -- ragged batch sizes,
-    upsets armed (their tiles go to the stepwise kernel and are skipped by the table kernel) -- and equal to the oracle"""
+    upsets armed (applied inside the table kernels) -- and equal to the oracle"""
     import torch
 
     import coast_amd
@@ -480,6 +480,153 @@ def test_crc16_faults_vs_oracle(eng, orc, block_len, replicas, sync_every):
     assert _stats3(eng.stats()) == exp_st
     assert (det.cpu().numpy() == exp_det).all()
 
+
+
+# ------------------------------------------------------------------------------------------------ lean kernels vote on real disagreement
+def _named_hits(item, site, step, bit, index, other_bit):
+    """single hit / the same flip in two replicas (select(a==b, a, c) keeps the WRONG pair) / two different flips (replica 2 wins
+    only if it is clean) / all three replicas / a flip and its cancellation -- (label, rows)"""
+    f = lambda r, b=bit: (item, r, site, step, b, index)
+    return [("r0", [f(0)]), ("r1", [f(1)]), ("r2", [f(2)]), ("r0r1_same", [f(0), f(1)]), ("r0r2_same", [f(0), f(2)]),
+            ("r1r2_same", [f(1), f(2)]), ("r0r1_diff", [f(0), f(1, other_bit)]), ("all3_same", [f(0), f(1), f(2)]),
+            ("all3_diff", [f(0), f(1, other_bit), f(2, (other_bit + 7) % 32)]), ("r1_twice", [f(1), f(1)])]
+
+
+def _lean_launch_checks(eng, nfaulted_tiles, nfaults):
+    li = eng.last_launch()
+    assert li["engine"] == "valu" and li["general_blocks"] == 0, li       # no stepwise twin ran
+    assert li["hooked_blocks"] == nfaulted_tiles and li["armed_faults"] == nfaults, li
+
+
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+@pytest.mark.parametrize("length,stride", [(64, 64), (10, 12), (150, 152), (119, 128)])
+def test_sha256_fast_kernel_votes_on_its_own_upsets(eng, orc, replicas, length, stride):
+    """sha256_fast_kernel (both the 16-byte and the 4-byte row variants) applies the armed flips itself -- every
+    site, first / middle / last round, state words before each compression and before the digest -- and its own xmr_sync calls see
+    the unequal copies: digests, counters and per-message flags equal the oracle's, no stepwise workgroup runs."""
+    import torch
+
+    import coast_amd
+
+    rng = np.random.default_rng(1234 + length + replicas)
+    ipw = 64 // replicas
+    nm = 5 * ipw + 3  # a ragged last tile
+    msgs = rng.integers(0, 256, (nm, stride), dtype=np.uint8)
+    ncomp = length // 64 + (1 if length % 64 < 56 else 2)
+    cases = []
+    for item, (site, step, index) in zip(
+            [0, 1, ipw - 1, ipw, 2 * ipw + 5, 3 * ipw, 4 * ipw + 1, nm - 1, 7, 9, 11],
+            [(8, 0, 0), (8, 15, 0), (8, 16, 0), (8, ncomp * 64 - 1, 0), (9, 0, 0), (9, 33, 7), (9, ncomp * 64 - 1, 4),
+             (10, 0, 3), (10, ncomp, 5), (10, ncomp - 1, 0), (8, 63, 0)]):
+        for label, rows in _named_hits(item, site, step, int(rng.integers(0, 32)), index, int(rng.integers(0, 32))):
+            rows = [r for r in rows if r[1] < replicas]
+            if rows:
+                cases.append((label, site, rows))
+    # every case alone (its own launch), then all of them at once
+    for label, site, rows in cases + [("all", 0, [r for c in cases for r in c[2]])]:
+        fl = coast_amd.make_faults(rows)
+        exp, exp_st, exp_det = orc.sha256_xmr(msgs, length, replicas=replicas, faults=fl)
+        det = torch.zeros(nm, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        got = eng.sha256_batch(torch.from_numpy(msgs).cuda(), length, cfg=coast_amd.XmrConfig(replicas), detected=det).cpu().numpy()
+        _lean_launch_checks(eng, len({r[0] // ipw for r in rows}), len(rows))
+        assert (got == exp).all(), (label, site)
+        assert _stats3(eng.stats()) == exp_st, (label, site, rows)
+        assert (det.cpu().numpy() == exp_det).all(), (label, site)
+        if replicas == 3 and label in ("r0", "r1", "r2"):
+            assert exp_st["errors_corrected"] >= 1 and got[rows[0][0]].tobytes() == hashlib.sha256(msgs[rows[0][0], :length].tobytes()).digest()
+
+
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+@pytest.mark.parametrize("direction", [0, 1])
+@pytest.mark.parametrize("tables", ["classic", "replicated"])
+def test_aes_lean_kernels_vote_on_their_own_upsets(eng, orc, replicas, direction, tables, monkeypatch):
+    """the four lean AES kernels (one-copy and bank-replicated tables, both directions) apply the armed flips at their round
+    boundaries themselves (decryption: through InvMixColumns, where the kernel keeps the state in that image) and their own sync
+    points see the unequal copies: states, keys, counters and flags equal the oracle's, no stepwise workgroup runs."""
+    import torch
+
+    import coast_amd
+
+    monkeypatch.setenv("COAST_AES_TABLES", tables)
+    rng = np.random.default_rng(99 + 2 * replicas + direction)
+    ipw = 64 // replicas
+    n = 18 * ipw + 5  # more tiles than one persistent workgroup's 16 waves
+    st = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    key = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    cases = []
+    item = 0
+    for site in (16, 17):
+        for step in range(0, 11):
+            for label, rows in _named_hits(item % n, site, step, int(rng.integers(0, 32)), int(rng.integers(0, 4)), int(rng.integers(0, 32))):
+                rows = [r for r in rows if r[1] < replicas]
+                if rows and (label in ("r0", "r1", "r2", "r0r1_same", "all3_diff") or step in (0, 5, 9, 10)):
+                    cases.append((label, site, step, rows))
+            item += ipw // 2 + 1
+    launches = [c[3] for c in cases[::7]] + [[r for c in cases for r in c[3]]]  # a sample alone, then everything at once
+    for rows in launches:
+        fl = coast_amd.make_faults(rows)
+        es, ek, exp_st, exp_det = orc.aes128_xmr(st, key, direction, replicas=replicas, faults=fl)
+        ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(key.copy()).cuda()
+        det = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        eng.aes128_batch(ds, dk, direction, cfg=coast_amd.XmrConfig(replicas), detected=det)
+        _lean_launch_checks(eng, len({r[0] // ipw for r in rows}), len(rows))
+        assert (ds.cpu().numpy() == es).all() and (dk.cpu().numpy() == ek).all(), rows[:4]
+        assert _stats3(eng.stats()) == exp_st, rows[:4]
+        assert (det.cpu().numpy() == exp_det).all()
+    if replicas == 3:  # every single-replica upset is out-voted: the batch equals the clean run
+        rows = [c[3][0] for c in cases if c[0] in ("r0", "r1", "r2")]
+        ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(key.copy()).cuda()
+        eng.reset_stats()
+        eng.inject_faults(coast_amd.make_faults(rows))
+        eng.aes128_batch(ds, dk, direction, cfg=coast_amd.XmrConfig(3))
+        cs, ck, _, _ = orc.aes128_xmr(st, key, direction, replicas=1)
+        assert (ds.cpu().numpy() == cs).all() and (dk.cpu().numpy() == ck).all() and eng.stats()["errors_corrected"] > 0
+
+
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+@pytest.mark.parametrize("block_len,nt", [(256, 2), (256, 1), (255, 1), (255, 2), (64, 2), (13, 2), (129, 1), (1, 2)])
+def test_crc16_stream_kernel_votes_on_its_own_upsets(eng, orc, replicas, block_len, nt, monkeypatch):
+    """crc16_stream_kernel<R, NT, ALIGNED> walks a tile that owns an armed upset byte by byte itself (and, for rows that are not
+    16-byte aligned, the stream's last tiles): crcs, counters and flags equal the oracle's for every site and step class, single /
+    double / triple hits; no stepwise workgroup runs (the side-stream twin of round 2 is gone)."""
+    import torch
+
+    import coast_amd
+
+    monkeypatch.setenv("COAST_CRC_NT", str(nt))
+    rng = np.random.default_rng(4321 + block_len + replicas + nt)
+    ipw = 64 // replicas
+    nb = 40 * ipw + 7  # 41 tiles: more than one round of a 16-wave workgroup at NT = 2
+    data = rng.integers(0, 256, (nb, block_len), dtype=np.uint8)
+    cases = []
+    steps = sorted({0, 1, block_len // 2, block_len - 1, block_len})
+    item = 0
+    for site in (24, 25):
+        for step in steps:
+            if site == 25 and step == block_len:
+                continue
+            for label, rows in _named_hits(item % nb, site, step, int(rng.integers(0, 16)), 0, int(rng.integers(0, 16))):
+                rows = [r for r in rows if r[1] < replicas]
+                if rows:
+                    cases.append((label, rows))
+            item += ipw + 3
+    cases.append(("last_block", [(nb - 1, 0, 24, 0, 3, 0)]))
+    launches = [c[1] for c in cases[::5]] + [[r for c in cases for r in c[1]]]
+    for rows in launches:
+        fl = coast_amd.make_faults(rows)
+        exp, exp_st, exp_det = orc.crc16_xmr(data, block_len, replicas=replicas, faults=fl)
+        det = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        got = _host(eng.crc16_batch(torch.from_numpy(data).cuda(), block_len, cfg=coast_amd.XmrConfig(replicas), detected=det), np.uint16)
+        _lean_launch_checks(eng, len({r[0] // ipw for r in rows}), len(rows))
+        assert (got == exp).all(), rows[:4]
+        assert _stats3(eng.stats()) == exp_st, rows[:4]
+        assert (det.cpu().numpy() == exp_det).all()
 
 @pytest.mark.parametrize("block_len", [2, 3, 4, 5, 7, 15, 17, 63, 65, 67, 127, 191, 192, 252, 253, 254, 255, 257, 319, 1000])
 def test_crc16_stream_every_alignment_and_tail(eng, orc, block_len):

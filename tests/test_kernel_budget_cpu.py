@@ -26,6 +26,7 @@ TU = r'''
 #include "mm_mfma_kernel.hip"
 #include "mm_mfma_blk_kernel.hip"
 #include "mm_mfma_blk2_kernel.hip"
+#include "sha256_kernel.hip"
 #include "aes_kernel.hip"
 #include "crc16_kernel.hip"
 namespace coast {
@@ -34,10 +35,13 @@ template __global__ void mm_mfma_blk2_kernel<3, true>(MMARGS);
 template __global__ void mm_mfma_blk2_kernel<3, false>(MMARGS);
 template __global__ void mm_mfma_blk_kernel<3, true>(MMARGS);
 template __global__ void mm_mfma_blk_kernel<3, false>(MMARGS);
-#define AESARGS uint8_t *, uint8_t *, uint64_t, uint64_t, Counters, const uint2 *, uint8_t *
+#define AESARGS uint8_t *, uint8_t *, uint64_t, uint64_t, Counters, FaultTab, uint8_t *
 template __global__ void aes128_enc_rep_kernel<2>(AESARGS);
 template __global__ void aes128_dec_rep_kernel<2>(AESARGS);
-#define CRCARGS const uint8_t *, uint32_t, uint64_t, uint16_t *, const uint16_t *, uint64_t, Counters, const uint2 *, uint8_t *
+template __global__ void aes128_enc_fast_kernel<3>(AESARGS);
+template __global__ void aes128_dec_fast_kernel<3>(AESARGS);
+template __global__ void sha256_fast_kernel<3, true>(const uint8_t *, size_t, uint32_t, uint64_t, uint8_t *, uint64_t, Counters, FaultTab, uint8_t *);
+#define CRCARGS const uint8_t *, uint32_t, uint64_t, uint16_t *, const uint16_t *, uint64_t, uint64_t, Counters, FaultTab, uint8_t *
 template __global__ void crc16_stream_kernel<3, 2, true>(CRCARGS);
 template __global__ void crc16_stream_kernel<3, 1, false>(CRCARGS);
 }
@@ -92,7 +96,11 @@ def test_mm_register_block_kernels_fit_their_register_files(compiled, flags):
     b2 = _find(bodies, "void coast::mm_mfma_blk2_kernel<3, %s>" % flags)
     # 4 step variants x 60 MFMAs x 2 row halves: every k-slab of a tile issues its 120 MFMAs once
     assert len(re.findall(r"v_mfma_i32_16x16x64_i8", b2)) == 480
-    assert len(re.findall(r"scratch_load", b2)) <= 8
+    assert len(re.findall(r"scratch_load", b2)) <= 12
+    # ... and inside the tile loops (the basic blocks that hold the MFMAs) at most the one reload per tile of a tally register
+    for blk in re.split(r"\n\.LBB\d+_\d+:", b2):
+        if len(re.findall(r"v_mfma_i32_16x16x64_i8", blk)) >= 60:
+            assert len(re.findall(r"scratch_load", blk)) <= 1 and not re.search(r"scratch_store", blk)
     # one wave per SIMD: accumulators in AGPRs, nothing spilled
     u1 = _find(usage, "void coast::mm_mfma_blk_kernel<3, %s>" % flags)
     assert u1["VGPRs Spill"] == 0 and u1["Occupancy [waves/SIMD]"] == 1 and u1["VGPRs"] <= 256 and u1["AGPRs"] <= 256
@@ -105,13 +113,29 @@ def test_lds_table_kernels_keep_their_occupancy(compiled):
     # encryption: two 1024-thread workgroups per CU (64 KiB of tables each) need <= 64 registers per lane
     assert enc["VGPRs"] <= 64 and enc["VGPRs Spill"] == 0 and enc["Occupancy [waves/SIMD]"] == 8
     assert dec["VGPRs"] <= 128 and dec["VGPRs Spill"] == 0
-    # lookups per block: encryption 203 dword reads; decryption 199 dword + 32 eight-byte pair reads (bench.py AES.LOOKUPS)
+    # lookups per block: encryption 203 dword reads; decryption 199 dword + 32 eight-byte pair reads (bench.py AES.LOOKUPS).  The
+    # rounds are instantiated twice -- clean tiles, and tiles that own an armed upset (injector hooks between the same rounds)
     be, bd = _find(bodies, "void coast::aes128_enc_rep_kernel<2>"), _find(bodies, "void coast::aes128_dec_rep_kernel<2>")
-    assert (len(re.findall(r"ds_read_b32", be)), len(re.findall(r"ds_read_b64", be))) == (203, 0)
-    assert (len(re.findall(r"ds_read_b32", bd)), len(re.findall(r"ds_read_b64", bd))) == (199, 32)
+    # (the compiler may sink a few lookups of the last round below the join of the two instantiations)
+    ne, nd, nd64 = len(re.findall(r"ds_read_b32", be)), len(re.findall(r"ds_read_b32", bd)), len(re.findall(r"ds_read_b64", bd))
+    assert 2 * 203 - 8 <= ne <= 2 * 203 and not re.search(r"ds_read_b64", be), ne
+    assert 2 * 199 - 8 <= nd <= 2 * 199 + 16 and 2 * 32 - 4 <= nd64 <= 2 * 32, (nd, nd64)
     for name in ("void coast::crc16_stream_kernel<3, 2, true>", "void coast::crc16_stream_kernel<3, 1, false>"):
         u = _find(usage, name)  # 1024-thread persistent workgroups: 128 registers per lane
         assert u["VGPRs"] <= 128 and u["VGPRs Spill"] == 0, (name, u)
+
+
+def test_injector_hooks_cost_the_lean_kernels_nothing(compiled):
+    """round 3: the lean sha256 / aes / crc16 kernels carry their own injector hooks (a tile that owns an armed upset takes a
+    wave-uniform branch).  The hooks must not put the kernels on scratch, and must not take occupancy from the clean path."""
+    usage, _ = compiled
+    sha = _find(usage, "void coast::sha256_fast_kernel<3, true>")
+    assert sha["VGPRs"] <= 64 and sha["Occupancy [waves/SIMD]"] == 8 and sha["ScratchSize [bytes/lane]"] == 0, sha
+    for name in ("aes128_enc_fast_kernel<3>", "aes128_dec_fast_kernel<3>", "aes128_enc_rep_kernel<2>", "aes128_dec_rep_kernel<2>",
+                 "crc16_stream_kernel<3, 2, true>", "crc16_stream_kernel<3, 1, false>"):
+        u = _find(usage, "void coast::" + name)
+        assert u["ScratchSize [bytes/lane]"] == 0 and u["VGPRs Spill"] == 0, (name, u)
+    assert _find(usage, "void coast::aes128_enc_fast_kernel<3>")["VGPRs"] <= 64
 
 
 def test_bench_lookup_counts_match_the_compiled_kernels():
