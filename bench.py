@@ -250,17 +250,34 @@ class MM(Workload):
         # one accumulator upset in one replica of K distinct output elements: each must be out-voted and counted once
         rng = np.random.default_rng(99 + rank)
         items = rng.choice(batch * n * n, a.faults, replace=False)
-        self.faults = coast_amd.make_faults([(int(it), int(rng.integers(0, 3)), coast_amd.SITE_MM_ACC,
-                                              int(rng.integers(0, n + 1)), int(rng.integers(0, 32))) for it in items])
+        self.fault_rows = [(int(it), int(rng.integers(0, 3)), coast_amd.SITE_MM_ACC, int(rng.integers(0, n + 1)),
+                            int(rng.integers(0, 32))) for it in items]
+        self.faults = coast_amd.make_faults(self.fault_rows)
         self.units_per_step = batch * n * n
 
     def launch(self):
         self.eng.mm_batch(self.f, self.s, out=self.r, cfg=self.cfg)
 
     def check(self):
-        chk = self.eng.mm_batch(self.f[:2].contiguous(), self.s[:2].contiguous(),
-                                cfg=self.ca.XmrConfig(self.ca.UNPROTECTED))
-        return bool(torch.equal(chk, self.r[:2]))
+        """Every element an upset was armed on, plus a random sample of 64 Ki others, against sum_k f[i][k] * s[k][j] mod 2^32
+        computed by torch in int64 (wrap-around keeps the low word exact) -- independent of the engine's own kernels.  A vote
+        that let an upset through, or stored the wrong copy, fails here."""
+        n, nn = self.n, self.n * self.n
+        rng = np.random.default_rng(4242)
+        items = np.concatenate([np.array([int(f[0]) for f in self.fault_rows], dtype=np.int64),
+                                rng.integers(0, self.batch * nn, 65536, dtype=np.int64)])
+        it = torch.from_numpy(items).to(self.f.device)
+        b, i, j = it // nn, (it % nn) // n, it % n
+        ok = True
+        for lo in range(0, it.numel(), 8192):
+            sl = slice(lo, lo + 8192)
+            fr = self.f[b[sl], i[sl], :].to(torch.int64) & 0xFFFFFFFF
+            sc = self.s[b[sl], :, j[sl]].to(torch.int64) & 0xFFFFFFFF
+            want = (fr * sc).sum(-1) & 0xFFFFFFFF
+            got = self.r[b[sl], i[sl], j[sl]].to(torch.int64) & 0xFFFFFFFF
+            ok = ok and bool(torch.equal(want, got))
+        self.checked = {"faulted_elements": len(self.fault_rows), "sampled_elements": 65536, "reference": "torch int64 dot products"}
+        return ok
 
     def config(self, world):
         cfg = {"workload": "matrixMultiply %dx%d uint32 TMR (3 replicas + vote), batch %d matrices/GPU, "
@@ -361,18 +378,31 @@ class CRC16(Workload):
         self.eng = eng
         rng = np.random.default_rng(7 + rank)
         items = rng.choice(self.nb, a.faults, replace=False)
-        self.faults = coast_amd.make_faults([(int(it), int(rng.integers(0, 3)), coast_amd.SITE_CRC_CRC,
-                                              int(rng.integers(0, self.bl + 1)), int(rng.integers(0, 16))) for it in items])
+        self.fault_rows = [(int(it), int(rng.integers(0, 3)), coast_amd.SITE_CRC_CRC, int(rng.integers(0, self.bl + 1)),
+                            int(rng.integers(0, 16))) for it in items]
+        self.faults = coast_amd.make_faults(self.fault_rows)
         self.units_per_step = self.nb * self.bl * 1e-9  # GB
 
     def launch(self):
         self.eng.crc16_batch(self.data, self.bl, out=self.out, cfg=self.cfg)
 
     def check(self):
-        import coast_amd
-
-        ref = self.eng.crc16_batch(self.data[: 4096 * self.bl], self.bl, cfg=coast_amd.XmrConfig(coast_amd.UNPROTECTED))
-        return bool(torch.equal(ref, self.out[:4096]))
+        """every block an upset was armed on, the first 4096 and the last 64 blocks of the stream, against the byte-serial
+        recurrence of tests/crc16/crc16.c:25-29 evaluated with numpy on the host -- independent of the engine's kernels"""
+        idx = np.unique(np.concatenate([np.array([int(f[0]) for f in self.fault_rows], dtype=np.int64), np.arange(4096),
+                                        np.arange(self.nb - 64, self.nb)]))
+        idx = idx[(idx >= 0) & (idx < self.nb)]
+        it = torch.from_numpy(idx).to(self.data.device)
+        rows = self.data.view(-1)[(it[:, None] * self.bl + torch.arange(self.bl, device=self.data.device)[None, :])].cpu().numpy()
+        crc = np.full(rows.shape[0], 0xFFFF, dtype=np.uint32)
+        for t in range(self.bl):
+            x = ((crc >> 8) ^ rows[:, t]) & 0xFF
+            x ^= x >> 4
+            crc = ((crc << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xFFFF
+        got = self.out[it].cpu().numpy().view(np.uint16).astype(np.uint32)
+        self.checked = {"faulted_blocks": len(self.fault_rows), "other_blocks": int(rows.shape[0] - len(self.fault_rows)),
+                        "reference": "numpy byte-serial crc16"}
+        return bool((got == crc).all())
 
     def config(self, world):
         return {"workload": "crc16 %d-byte blocks TMR, %.1f GiB/GPU stream, %d injected single-bit faults/GPU/step"
@@ -417,6 +447,7 @@ class SHA256(Workload):
             site = int(rng.choice([coast_amd.SITE_SHA_M, coast_amd.SITE_SHA_WV, coast_amd.SITE_SHA_STATE]))
             step = int(rng.integers(0, 3)) if site == coast_amd.SITE_SHA_STATE else int(rng.integers(0, 128))
             rows.append((int(it), int(rng.integers(0, 3)), site, step, int(rng.integers(0, 32)), int(rng.integers(0, 8))))
+        self.fault_rows = rows
         self.faults = coast_amd.make_faults(rows)
         self.units_per_step = self.nm
 
@@ -426,9 +457,14 @@ class SHA256(Workload):
     def check(self):
         import hashlib
 
-        m = self.msgs[:64].cpu().numpy()
-        d = self.out[:64].cpu().numpy()
-        return all(hashlib.sha256(m[i].tobytes()).digest() == d[i].tobytes() for i in range(64))
+        idx = np.unique(np.concatenate([np.array([int(f[0]) for f in self.fault_rows], dtype=np.int64), np.arange(256),
+                                        np.arange(self.nm - 64, self.nm)]))
+        it = torch.from_numpy(idx).to(self.msgs.device)
+        m = self.msgs[it].cpu().numpy()
+        d = self.out[it].cpu().numpy()
+        self.checked = {"faulted_messages": len(self.fault_rows), "other_messages": int(len(idx) - len(self.fault_rows)),
+                        "reference": "hashlib.sha256"}
+        return all(hashlib.sha256(m[i].tobytes()).digest() == d[i].tobytes() for i in range(len(idx)))
 
     def config(self, world):
         return {"workload": "sha256 %d x 64-byte messages TMR + on-device injector (%d faults/GPU/step)"
@@ -443,6 +479,10 @@ class SHA256(Workload):
         return {"bound": "valu", "kernel": "sha256_fast_kernel<3,true>", "achieved": self.nm / t * 1e-9,
                 "peak": ceiling * 1e-9, "unit": "G msgs/s (instruction-mix issue ceiling at 2.4 GHz)", "frac": self.nm / t / ceiling,
                 "cycles_per_wave_of_21_msgs": cyc, "instruction_mix": self.MIX, "issue_cycles": CYC, "kernel_ms": kern_ms,
+                # the same count against the guide's neutral full-rate VALU figure (256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T
+                # lane-ops/s, MI355X_MICROARCH.md): 3 replica lanes x sum(MIX) instructions per message
+                "valu_lane_ops_per_s": self.nm / t * 3 * sum(self.MIX.values()),
+                "frac_of_fullrate_valu": self.nm / t * 3 * sum(self.MIX.values()) / (N_SIMD * 32 * CLK),
                 "hbm_achieved_GBs": self.nm * 96 / t * 1e-9, "algorithmic_bytes": float(self.nm) * 96}
 
     def cpu(self):
@@ -511,9 +551,9 @@ class AES(Workload):
                 "unit": "T lane-lookups/s (LDS: 32 conflict-free 4-byte lookups per clock per CU at 2.4 GHz)",
                 "frac": self.n * look / t / LDS_LOOKUP_PEAK, "lookups_per_block_lane": self.LOOKUPS, "kernel_ms": kern_ms,
                 "hbm_achieved_GBs": self.n * 64 / t * 1e-9, "algorithmic_bytes": float(self.n) * 64,
-                "note": "bank-replicated tables: the lookups are conflict-free, the kernels are bound by the two address "
-                        "instructions per lookup instead (VALU); 1 Mi blocks are a 55-80 us launch, and the step also carries "
-                        "the stepwise kernel on the armed-fault tiles (side stream) and the key restore copy"}
+                "note": "bank-replicated tables: the lookups are conflict-free, the kernels are bound by the address "
+                        "instructions per lookup instead (VALU); 1 Mi blocks are a 55-80 us launch (the armed upsets are applied "
+                        "inside it), and the step also carries the key restore copy"}
 
     def cpu(self):
         return cpu_baseline_items("aes")
@@ -678,8 +718,12 @@ def result_fields(wl, run, a, world, steps, warmup, with_cpu):
         "corrected_faults": tot[0], "dwc_detected": tot[2], "injected_faults": len(wl.faults) * steps * world,
         "sync_count": tot[1], "outputs_match_unprotected": wl.check(),
         "voted_by": run["launch_info"]["engine"], "stepwise_blocks_last_launch": run["launch_info"]["general_blocks"],
+        # tiles / workgroups of the lean kernel that owned an armed upset and applied, voted and counted it themselves
+        "hooked_blocks_last_launch": run["launch_info"]["hooked_blocks"],
         "roofline": roof,
     }
+    if getattr(wl, "checked", None):
+        out["outputs_checked"] = wl.checked
     if with_cpu:
         out["cpu_baseline"] = wl.cpu()
     return out
@@ -754,6 +798,21 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
         else:
             dist.init_process_group(backend)
+    elif os.environ.get("COAST_BENCH_FORCE_DIST"):
+        # one rank, but through the multi-GPU code path: init_process_group("nccl", device_id=...), the device-tensor all_reduce of
+        # the fault counters and the barriers all run on RCCL (a 1-GPU box can execute what the 8-GPU run executes per rank)
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        torch.cuda.set_device(0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group(backend, rank=0, world_size=1)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -767,8 +826,8 @@ def main():
     out = None
     if rank == 0:
         out = result_fields(wl, run, a, world, a.steps, a.warmup, with_cpu=(world == 1 and not a.no_cpu_baseline))
-        out["collective"] = ("%s all_reduce(SUM) of 4 x int64 fault counters per step, %d ranks" % (backend, world)) if world > 1 \
-            else "none (1 rank)"
+        out["collective"] = ("%s all_reduce(SUM) of 4 x int64 fault counters per step, %d rank%s" % (backend, world, "s" if world > 1 else "")) \
+            if dist else "none (1 rank)"
     if a.workload == "mm" and not a.no_extra:
         wl.free()
         legs = extra_legs(a, eng, dist, dev, rank, world, coast_amd)

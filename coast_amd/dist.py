@@ -19,7 +19,7 @@ def shard_range(n_items: int, rank: int, world: int):
 def allreduce_counters(engine, dist=None, group=None) -> torch.Tensor:
     """Global {errors_corrected, sync_count, dwc_detected, launches}.  Local totals stay untouched (cumulative)."""
     tot = engine.counters.clone()
-    if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist is not None and dist.is_initialized():  # also at world size 1: the same RCCL call the N-rank job issues
         if tot.is_cuda and dist.get_backend(group) == "gloo":  # dry runs of the rank logic without RCCL: stage through the host
             host = tot.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)

@@ -1286,6 +1286,20 @@ def test_bench_two_ranks_crc16_stream_sharded():
     assert two["outputs_match_unprotected"]
 
 
+def test_bench_rccl_path_on_one_rank():
+    """the multi-GPU code path of bench.py executed on hardware -- init_process_group("nccl", device_id=...),
+    the barriers and the all_reduce of the engine's device-resident counter tensor run on RCCL with one rank (what each of the N
+    ranks of the driver's scaling run executes); the counters that come back are the engine's own."""
+    out = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "64", "--faults", "256", "--no-extra",
+                      "--no-cpu-baseline"], env_extra={"COAST_BENCH_FORCE_DIST": "1"})
+    assert out["n_gpus"] == 1 and out["collective"].startswith("nccl all_reduce"), out["collective"]
+    assert out["corrected_faults"] == out["injected_faults"] == 3 * 256 and out["outputs_match_unprotected"]
+    crc = _run_bench(["--gpus", "1", "--workload", "crc16", "--batch", "65536", "--steps", "2", "--warmup", "1", "--no-extra",
+                      "--no-cpu-baseline"], env_extra={"COAST_BENCH_FORCE_DIST": "1"})
+    assert crc["collective"].startswith("nccl all_reduce") and crc["corrected_faults"] > 0 and crc["stepwise_blocks_last_launch"] == 0
+    assert crc["hooked_blocks_last_launch"] > 0 and crc["outputs_match_unprotected"]
+
+
 def test_multi_gpu_c_host_rccl_allreduce():
     """examples/multi_gpu_c_demo.c: plain C host, one coast_ctx per visible GPU, coast_allreduce_counters over RCCL
     (ncclCommInitAll).  With one GPU the communicator has one rank; the call path (fold -> ncclAllReduce on the context's
