@@ -114,7 +114,7 @@ int fail(coast_ctx *ctx, int code, const char *fmt, ...)
 
 unsigned long long *totals_of(coast_ctx *c) { return c->dBound ? c->dBound : c->dTotals; }
 
-// `indexedOk`: this kernel implements the index-in-the-sphere-of-replication flags (sha256, crc16)
+// `indexedOk`: this kernel implements the index-in-the-sphere-of-replication flags (mm, sha256, crc16)
 int check_cfg(coast_ctx *ctx, const coast_cfg *cfg, bool indexedOk = false)
 {
     if (!ctx)
@@ -125,8 +125,8 @@ int check_cfg(coast_ctx *ctx, const coast_cfg *cfg, bool indexedOk = false)
     if (cfg->flags & ~((uint32_t)COAST_F_NO_STORE_DATA_SYNC | indexed))
         return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: unknown bits", cfg->flags);
     if ((cfg->flags & indexed) && !indexedOk)
-        return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC are implemented for sha256 "
-                                       "and crc16 (the kernels whose reference source walks a data-dependent counter)", cfg->flags);
+        return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC are implemented for mm, sha256 "
+                                       "and crc16 (quicksort votes its indices by default)", cfg->flags);
     if ((cfg->flags & (COAST_F_NO_LOAD_SYNC | COAST_F_NO_STORE_ADDR_SYNC)) && !(cfg->flags & COAST_F_ADDR_SYNC))
         return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: -noLoadSync / -noStoreAddrSync qualify COAST_F_ADDR_SYNC", cfg->flags);
     return COAST_OK;
@@ -167,8 +167,16 @@ int arm_faults_impl(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *g
     dv.reserve(guard.taken.size());
     for (const coast_fault &f : guard.taken) {
         DevFault d;
-        if (dec(f, geom, d))
+        if (f.replica == COAST_REPLICA_ALL) { // common-mode upset: the same flip in every replica's copy (the decoder drops
+            for (uint8_t r = 0; r < 3; ++r) { // replica numbers the launch does not have)
+                coast_fault fr = f;
+                fr.replica = r;
+                if (dec(fr, geom, d))
+                    dv.push_back(d);
+            }
+        } else if (dec(f, geom, d)) {
             dv.push_back(d);
+        }
     }
     if (dv.empty()) {
         guard.commit = true; // nothing in the list addresses this launch: dropped, as the oracle ignores them
@@ -632,14 +640,38 @@ bool decode_mm_mfma(const coast_fault &f, const void *gp, DevFault &d)
     return true;
 }
 
+// counters inside the sphere of replication: the item is the call (one matrix per lane group); sites i / j / k / sum
+bool decode_mm_indexed(const coast_fault &f, const void *gp, DevFault &d)
+{
+    const MmHostGeom &h = *(const MmHostGeom *)gp;
+    const uint64_t nn = (uint64_t)h.g.n * h.g.n;
+    if (f.item >= nn * h.batch || f.replica >= h.replicas)
+        return false;
+    if (f.site != COAST_SITE_MM_ACC && (f.site < COAST_SITE_MM_I || f.site > COAST_SITE_MM_K))
+        return false;
+    const uint64_t mat = f.item / nn;
+    const uint64_t ipw = 64u / (uint64_t)h.replicas;
+    d.block = (uint32_t)(mat / ipw);
+    d.local = (uint32_t)(mat % ipw);
+    d.step = f.step;
+    d.replica = f.replica;
+    d.site = f.site;
+    d.bit = f.bit;
+    d.index = f.index;
+    return true;
+}
+
 } // namespace
 
 extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t *d_s, uint32_t *d_r, int n,
                               size_t batch, const coast_cfg *cfg, uint8_t *d_detected)
 {
-    int rc = check_cfg(c, cfg);
+    int rc = check_cfg(c, cfg, true);
     if (rc)
         return rc;
+    if ((cfg->flags & (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC)) && cfg->sync_every)
+        return fail(c, COAST_EINVAL, "coast_mm_batch: sync_every belongs to the per-element schedule; with the loop counters inside "
+                                     "the sphere of replication every loop condition is a sync point already");
     if (batch == 0)
         return COAST_OK; // an empty batch is a no-op (armed faults stay armed for the next real launch)
     if (!d_f || !d_s || !d_r || n < 1 || n > 4096)
@@ -648,6 +680,36 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
         return fail(c, COAST_EINVAL, "coast_mm_batch: f, s, r must be %d-byte aligned for side %d (16-byte vector accesses "
                                      "when the side is a multiple of 4)", (n & 3) == 0 ? 16 : 4, n);
     HIP_TRY(c, hipSetDevice(c->device));
+    if (cfg->flags & (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC)) {
+        // the three loops as written, i / j / k / sum replica-private: one call per lane group (mm_indexed_kernel)
+        MmHostGeom hi;
+        hi.g.n = n;
+        hi.batch = batch;
+        hi.replicas = (int)cfg->replicas;
+        hi.tpb = 0;
+        const uint64_t ipw = 64u / cfg->replicas;
+        const uint64_t ntiles = ((uint64_t)batch + ipw - 1) / ipw;
+        if (ntiles > 0x7fffffffull)
+            return fail(c, COAST_EINVAL, "coast_mm_batch: %llu tiles exceed the grid limit", (unsigned long long)ntiles);
+        FaultTab fti;
+        int havei = 0;
+        rc = arm_faults(c, (uint32_t)ntiles, decode_mm_indexed, &hi, &fti, &havei);
+        if (rc)
+            return rc;
+        if (!havei)
+            fti.list = nullptr, fti.range = nullptr;
+        Counters ctri{c->dSlots, cfg->flags};
+        if (cfg->replicas == 3)
+            hipLaunchKernelGGL(mm_indexed_kernel<3>, dim3((uint32_t)ntiles), dim3(64), 0, c->stream, d_f, d_s, d_r, (uint32_t)n,
+                               (uint64_t)batch, ctri, fti, d_detected);
+        else if (cfg->replicas == 2)
+            hipLaunchKernelGGL(mm_indexed_kernel<2>, dim3((uint32_t)ntiles), dim3(64), 0, c->stream, d_f, d_s, d_r, (uint32_t)n,
+                               (uint64_t)batch, ctri, fti, d_detected);
+        else
+            hipLaunchKernelGGL(mm_indexed_kernel<1>, dim3((uint32_t)ntiles), dim3(64), 0, c->stream, d_f, d_s, d_r, (uint32_t)n,
+                               (uint64_t)batch, ctri, fti, d_detected);
+        return after_launch(c, havei, COAST_ENGINE_STEPWISE, ntiles, 0, 12.0 * (double)n * (double)n * (double)batch);
+    }
 
     MmHostGeom h;
     MmGeom &g = h.g;

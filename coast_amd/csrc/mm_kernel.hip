@@ -36,7 +36,7 @@ struct MmGeom {
     uint32_t nblocks;
 };
 
-enum { SITE_MM_ACC = 0, SITE_MM_OPA = 1, SITE_MM_OPB = 2 };
+enum { SITE_MM_ACC = 0, SITE_MM_OPA = 1, SITE_MM_OPB = 2, SITE_MM_I = 3, SITE_MM_J = 4, SITE_MM_K = 5 };
 
 constexpr int kMmMaxB = 4; // uint4 of the s panel a thread stages per chunk  (kt * npad/4 <= 256*kMmMaxB)
 constexpr int kMmMaxA = 4; // dwords of the f panel a thread stages per chunk (kt * rs     <= 256*kMmMaxA)
@@ -547,6 +547,113 @@ __global__ __launch_bounds__(256) void mm_general_kernel(const uint32_t *__restr
                 acc[e] ^= 1u << (df.bit & 31u);
     }
     mm_epilogue<NREP>(acc, L, g, R + L.mat * nn, tl, detected, L.mat * nn, sCnt, ctr);
+}
+
+
+// ------------------------------------------------------------------------------------------------ counters inside the sphere of replication
+// matrix_multiply with its three loops as written (mm_common_tmr.c:3-20), for COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC: the work
+// item is the CALL -- one matrix product per lane group -- and i, j, k and `sum` are replica-private registers of one sequential
+// walk, the registers the pass triplicates.  Sync points (frozen in oracle/coast_oracle.c:mm_call_indexed, statement by
+// statement): every evaluation of the three loop conditions -- (N+1)(N^2+N+1) of them, SURVEY.md section 3.2 --, the GEP
+// offsets of f[i][k], s[k][j] (loads) and r[i][j] (store), the data of that store.  f, s, r are memory: one copy; a load uses
+// the original instruction's address in every copy (cloning.cpp:2247-2255), i.e. the voted offset or replica 0's.  Opt-in and
+// slow by construction (one lane walks N^3 MACs): the sync-point-parity form of the kernel, not the throughput form.
+template <int NREP>
+__global__ __launch_bounds__(64) void mm_indexed_kernel(const uint32_t *__restrict__ F, const uint32_t *__restrict__ S,
+                                                        uint32_t *__restrict__ R, uint32_t n, uint64_t nmats, Counters ctr,
+                                                        FaultTab ft, uint8_t *__restrict__ detected)
+{
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    LaneMap<NREP> lm;
+    lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
+    const bool bs = (ctr.flags & kFlagBranchSync) != 0u, as = (ctr.flags & kFlagAddrSync) != 0u;
+    const bool ls = as && !(ctr.flags & kFlagNoLoadSync), ss = as && !(ctr.flags & kFlagNoStoreAddrSync);
+    const uint32_t tile = blockIdx.x;
+    const int slot = lm.q;
+    const uint64_t mat = (uint64_t)tile * IPW + (uint64_t)slot;
+    const bool live = lm.live && mat < nmats;
+    const bool cnt = live && lm.r == 0;
+    const bool writer = cnt; // the single memory copy is written by the original store (replica 0's lane)
+    const uint64_t nn = (uint64_t)n * n;
+    const uint32_t *f = F + (live ? mat : 0) * nn, *s = S + (live ? mat : 0) * nn;
+    uint32_t *r = R + (live ? mat : 0) * nn;
+    if (threadIdx.x < 4)
+        sCnt[threadIdx.x] = 0;
+    __syncthreads();
+    if (writer) // elements a derailed walk never stores stay 0
+        for (uint64_t e = 0; e < nn; ++e)
+            r[e] = 0u;
+    uint2 fr = make_uint2(0u, 0u);
+    if (ft.range)
+        fr = ft.range[tile];
+    const uint32_t N = live ? n : 0u;
+    const uint64_t cap = 4ull * ((uint64_t)n + 1ull) * (nn + n + 1ull) + 1024ull;
+    Tally tl;
+    uint32_t i = 0u, j = 0u, k = 0u, sum = 0u;
+    uint64_t tick = 0;
+    auto hook = [&]() __attribute__((always_inline)) {
+        for (uint32_t q = 0; q < fr.y; ++q) {
+            const DevFault df = ft.list[fr.x + q];
+            if ((uint64_t)df.step != tick || (int)df.local != slot || (int)df.replica != lm.r || !lm.live)
+                continue;
+            const uint32_t m = 1u << (df.bit & 31u);
+            if (df.site == SITE_MM_I)
+                i ^= m;
+            else if (df.site == SITE_MM_J)
+                j ^= m;
+            else if (df.site == SITE_MM_K)
+                k ^= m;
+            else if (df.site == SITE_MM_ACC)
+                sum ^= m;
+        }
+    };
+    auto cond = [&](uint32_t reg) __attribute__((always_inline)) { // one evaluated loop condition
+        ++tick;
+        return xmr_steer<NREP>(reg < N ? 1u : 0u, lm, bs, cnt, tl) != 0u;
+    };
+    // the lanes of one matrix always take the same (voted, or replica 0's) direction; different matrices have the same trip
+    // counts unless an upset derails one, so the wave stays together except around upsets
+    for (;;) {                                                           // for (i = 0; i < side; i++)              :10
+        hook();
+        if (tick >= cap || !cond(i))
+            break;
+        j = 0u;
+        for (;;) {                                                       // for (j = 0; j < side; j++)              :11
+            hook();
+            if (tick >= cap || !cond(j))
+                break;
+            sum = 0u;
+            k = 0u;
+            for (;;) {                                                   // for (k = 0; k < side; k++)              :13
+                hook();
+                if (tick >= cap || !cond(k))
+                    break;
+                const uint32_t fi = xmr_steer<NREP>(i, lm, ls, cnt, tl), fk = xmr_steer<NREP>(k, lm, ls, cnt, tl); // f[i][k]
+                const uint32_t sk = xmr_steer<NREP>(k, lm, ls, cnt, tl), sj = xmr_steer<NREP>(j, lm, ls, cnt, tl); // s[k][j]
+                const uint32_t a = (fi < N && fk < N) ? f[(uint64_t)fi * n + fk] : 0u;
+                const uint32_t b = (sk < N && sj < N) ? s[(uint64_t)sk * n + sj] : 0u;
+                sum += a * b;
+                k += 1u;
+            }
+            const uint32_t ri = xmr_steer<NREP>(i, lm, ss, cnt, tl), rj = xmr_steer<NREP>(j, lm, ss, cnt, tl);     // r[i][j] = sum
+            uint32_t v = xmr_store_sync<NREP>(sum, lm, cnt, tl);
+            if (NREP != 3 || !lm.storeSync)
+                v = xmr_rep0<NREP>(v, lm);
+            if (writer && ri < N && rj < N)
+                r[(uint64_t)ri * n + rj] = v;
+            j += 1u;
+        }
+        i += 1u;
+    }
+    uint32_t detItems = 0;
+    if (cnt && tl.det) { // unequal copies at a sync point of this call (DWC: detected, TMR: corrected)
+        if (NREP == 2)
+            detItems = 1;
+        if (detected)
+            detected[mat * nn] = 1; // the item is the call: its flag is the matrix's first byte
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, tile);
 }
 
 } // namespace coast

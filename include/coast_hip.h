@@ -19,8 +19,9 @@
 extern "C" {
 #endif
 
-#define COAST_HIP_ABI_VERSION 4 /* 2: coast_cfg.flags; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info, new flags/sites;
-                                 * 4: control-flow signatures (coast_cfcss_assign, coast_crazycf_*), additive */
+#define COAST_HIP_ABI_VERSION 5 /* 2: coast_cfg.flags; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info, new flags/sites;
+                                 * 4: control-flow signatures (coast_cfcss_assign, coast_crazycf_*), additive;
+                                 * 5: COAST_REPLICA_ALL, COAST_ETIMEOUT, coast_launch_info.hooked_blocks, additive */
 
 enum {
     COAST_OK = 0,
@@ -35,8 +36,14 @@ enum {
 /* Protection mode.  replicas = 3 is what `opt -TMR` selects (projects/TMR/TMR.cpp:33, DP.run(M,3)),
  * replicas = 2 is `opt -DWC` (projects/DWC/DWC.cpp:33), replicas = 1 runs the region unprotected.
  * The engine instantiates the reference's `-noMemReplication -countErrors -countSyncs` rule set
- * (dataflowProtection.cpp:14-18,37,46): one memory copy, every register value replicated across adjacent
- * lanes, store data and return values voted.  sync_every adds the reference's loop-condition sync points at a
+ * (dataflowProtection.cpp:14-18,37,46): one memory copy, store data and return values voted.  Where the replicas live:
+ * in the lane-replicated kernels (sha256, aes, crc16, cache_test, CHStone sha / aes, quicksort, the VALU mm kernels and the
+ * DWC / unprotected matrix-core mm kernel) replica r of work item q is lane replicas*q + r of a wavefront, so every vector
+ * register of the item is replicated; in the TMR matrix-core mm kernels (side 256, the default) the replicas of an output
+ * element are three accumulator blocks of ONE lane, each with its own B-operand registers and its own MFMAs, while the
+ * A-operand fragments (rows of f) and the s words on their way into the LDS slab are a single copy shared by the three --
+ * the analogue of a `__NO_xMR` value (tests/COAST.h:11): an upset there is common-mode (COAST_REPLICA_ALL below).
+ * Wave-uniform scalars (loop counters, lengths, base pointers) and LDS tables are outside the sphere of replication everywhere.  sync_every adds the reference's loop-condition sync points at a
  * chosen granularity (synchronization.cpp:146-155): mm = every V k-steps, crc16 = every V bytes,
  * aes = 1 -> after every round; 0 = mandatory sync points only. */
 typedef struct coast_cfg {
@@ -54,14 +61,17 @@ typedef struct coast_cfg {
  *   -noLoadSync, -noStoreAddrSync   by default addresses are built from wave-uniform scalars and lane indices, which are
  *                     outside the sphere of replication in this design (SURVEY.md section 8a', last table row): no replicated
  *                     address exists and the engine behaves as if both were given.  COAST_F_ADDR_SYNC (below) puts the
- *                     counters of sha256 / crc16 inside the SoR; there the two flags are real knobs.
+ *                     counters of mm / sha256 / crc16 inside the SoR; there the two flags are real knobs.
  *   -storeDataSync    the lane-replicated engine always votes store data (the default here); in the memory-replicated mode it
  *                     is what coast_sync_copies(..., scrub = 1) does at the region exit.
  *   -i / -s           instruction interleaving vs segmenting: replicas are lanes of one instruction, there is no order. */
 enum {
     COAST_F_NO_STORE_DATA_SYNC = 1u,
-    /* Loop / byte counters INSIDE the sphere of replication (sha256, crc16 -- the kernels whose reference source walks a
-     * data-dependent counter; the launch runs the stepwise kernel).  By default such counters are wave-uniform scalars outside
+    /* Loop / byte counters INSIDE the sphere of replication (mm, sha256, crc16; the launch runs a stepwise kernel).  mm: the
+     * work item becomes the CALL -- i, j, k and `sum` of matrix_multiply (mm_common_tmr.c:3-20) are replica-private registers of
+     * one sequential walk per matrix, the three loop conditions are voted at every evaluation ((N+1)(N^2+N+1) votes, SURVEY.md
+     * section 3.2) and so are the GEP offsets of f[i][k], s[k][j] (i, k, k, j: loads) and r[i][j] (i, j: store); fault sites
+     * COAST_SITE_MM_I / _J / _K / _ACC, d_detected[b * n * n] is matrix b's flag.  By default such counters are wave-uniform scalars outside
      * the SoR (see -noLoadSync above); with these flags they are replica-private lane registers with their own fault sites,
      * and the reference's rules for them apply:
      *   COAST_F_BRANCH_SYNC         every evaluation of a branch condition on them is a sync point (synchronization.cpp:146-155,
@@ -123,6 +133,10 @@ enum {
     COAST_SITE_MM_ACC = 0, /* accumulator before the MAC of k == step (step == n: after the loop) */
     COAST_SITE_MM_OPA = 1, /* loaded f[i][k], k == step */
     COAST_SITE_MM_OPB = 2, /* loaded s[k][j], k == step */
+    COAST_SITE_MM_I = 3,   /* COAST_F_BRANCH_SYNC / ADDR_SYNC (the item is the call: coast_fault.item / n^2 names the matrix): loop counter
+                            * i of a replica, flipped right before loop condition number `step` of the call is evaluated */
+    COAST_SITE_MM_J = 4,   /* ... j */
+    COAST_SITE_MM_K = 5,   /* ... k; COAST_SITE_MM_ACC is `sum` with the same timing in that mode */
     COAST_SITE_SHA_M = 8,  /* schedule word m[step%64] of compression step/64, right after it is produced */
     COAST_SITE_SHA_WV = 9, /* working variable index 0..7 (a..h) before round step%64 of compression step/64 */
     COAST_SITE_SHA_STATE = 10, /* ctx_state[index] before compression `step` (== ncompress: before the digest) */
@@ -157,11 +171,18 @@ enum {
 };
 
 /* One single-event upset: new = old XOR (1 << bit) on the 32-bit register holding the value
- * (FaultInjector.flipOneBit, injector.py:202-207).  Only replica-private state can be hit. */
+ * (FaultInjector.flipOneBit, injector.py:202-207).  replica = 0 .. replicas-1 hits that replica's private copy.
+ * replica = COAST_REPLICA_ALL is a COMMON-MODE upset: the same flip in every replica's copy of the value -- what an upset of
+ * state that the replicas of a lane group SHARE does (on the matrix-core mm engines: an MFMA A-operand fragment register, a raw
+ * or converted word of `s` on its way into the LDS slab; everywhere: an LDS table word, a wave-uniform scalar).  No voter can see
+ * it (all copies agree): expected outcome silent data corruption, as for a memory upset under -noMemReplication.  It is armed
+ * as one flip per replica, so coast_launch_info.armed_faults counts `replicas` flips for it.  tools/campaign.py samples such
+ * sites next to the replica-private ones, weighted by the register census of the kernel. */
+#define COAST_REPLICA_ALL 255
 typedef struct coast_fault {
     uint64_t item;   /* mm: b*n*n + i*n + j ; sha256: message ; aes: block ; crc16: block ; cache_test: array */
     uint32_t step;
-    uint8_t replica; /* 0 .. replicas-1 */
+    uint8_t replica; /* 0 .. replicas-1, or COAST_REPLICA_ALL */
     uint8_t site;    /* COAST_SITE_* */
     uint8_t bit;     /* 0..31 */
     uint8_t index;

@@ -166,6 +166,81 @@ static uint32_t mm_item(const uint32_t *f, const uint32_t *s, int n, int i, int 
     return acc[0];
 }
 
+static uint32_t gep_offset(sync_ctx *c, const uint32_t idx[3], int synced);
+static int branch_cond(sync_ctx *c, uint32_t c0, uint32_t c1, uint32_t c2, int synced);
+
+/* matrix_multiply with its three loops as written (tests/mm_common/mm_common_tmr.c:3-20), for ORC_F_BRANCH_SYNC /
+ * ORC_F_ADDR_SYNC: the work item is the CALL -- one matrix product -- and i, j, k and `sum` are replica-private registers of
+ * one sequential walk, exactly the registers the pass triplicates (cloning.cpp:2187-2209).  Sync points, the reference's rule
+ * set for -TMR -noMemReplication on the -O0 IR shape (the shape SURVEY.md section 3.2 derives the count from):
+ *   the three loop conditions, at every evaluation: (N+1) + N (N+1) + N^2 (N+1) = (N+1)(N^2+N+1)    synchronization.cpp:146-155
+ *   the GEP offsets: f[i][k] and s[k][j] are two GEPs each -- the row, then the element; syncGEP votes the LAST operand of a
+ *     GEP (:413-420) -- i, k, k, j per MAC (loads: off with -noLoadSync); r[i][j]: i, j per element (off with -noStoreAddrSync)
+ *   the data of the store r[i][j] = sum                                                             :197-224, 476-561
+ * A load keeps the ORIGINAL instruction's address in every copy under -noMemReplication (cloning.cpp:2247-2255): unvoted
+ * offsets are replica 0's.  Fault sites: ORC_SITE_MM_I / _J / _K / _ACC (= sum) of a replica, `step` = how many loop
+ * conditions the call has evaluated (the flip lands right before the next one).  A wild index reads 0 / stores nothing; a
+ * walk that a corrupted counter keeps alive is cut after 4 (N+1)(N^2+N+1) + 1024 conditions (the supervisor's timeout). */
+static int mm_call_indexed(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    const unsigned R = c->nrep;
+    const uint32_t N = (uint32_t)n;
+    const int bs = (c->flags & ORC_F_BRANCH_SYNC) != 0, as = (c->flags & ORC_F_ADDR_SYNC) != 0;
+    const int ls = as && !(c->flags & ORC_F_NO_LOAD_SYNC), ss = as && !(c->flags & ORC_F_NO_STORE_ADDR_SYNC);
+    const uint64_t cap = 4ull * (N + 1ull) * ((uint64_t)N * N + N + 1ull) + 1024ull;
+    uint32_t i[3] = {0, 0, 0}, j[3] = {0, 0, 0}, k[3] = {0, 0, 0}, sum[3] = {0, 0, 0};
+    uint64_t tick = 0;
+#define MM_HOOK()                                                                                              \
+    do {                                                                                                       \
+        for (size_t q_ = 0; q_ < nf; ++q_)                                                                     \
+            if ((uint64_t)fl[q_].step == tick && fl[q_].replica < R) {                                         \
+                uint32_t *t_ = fl[q_].site == ORC_SITE_MM_I ? i : fl[q_].site == ORC_SITE_MM_J ? j :           \
+                               fl[q_].site == ORC_SITE_MM_K ? k : fl[q_].site == ORC_SITE_MM_ACC ? sum : NULL; \
+                if (t_)                                                                                        \
+                    t_[fl[q_].replica] = flip(t_[fl[q_].replica], fl[q_].bit, 0xffffffffu);                    \
+            }                                                                                                  \
+    } while (0)
+#define MM_COND(reg) (tick++, branch_cond(c, reg[0] < N, reg[R > 1 ? 1 : 0] < N, reg[R > 2 ? 2 : 0] < N, bs))
+    for (;;) {                                                   /* for (i = 0; i < side; i++)                 :10 */
+        MM_HOOK();
+        if (tick >= cap || !MM_COND(i))
+            break;
+        j[0] = j[1] = j[2] = 0;
+        for (;;) {                                               /* for (j = 0; j < side; j++)                 :11 */
+            MM_HOOK();
+            if (tick >= cap || !MM_COND(j))
+                break;
+            sum[0] = sum[1] = sum[2] = 0;                        /* sum = 0                                    :12 */
+            k[0] = k[1] = k[2] = 0;
+            for (;;) {                                           /* for (k = 0; k < side; k++)                 :13 */
+                MM_HOOK();
+                if (tick >= cap || !MM_COND(k))
+                    break;
+                const uint32_t fi = gep_offset(c, i, ls), fk = gep_offset(c, k, ls);  /* f[i][k]                :14 */
+                const uint32_t sk = gep_offset(c, k, ls), sj = gep_offset(c, j, ls);  /* s[k][j]                    */
+                const uint32_t a = (fi < N && fk < N) ? f[(size_t)fi * N + fk] : 0u;
+                const uint32_t b = (sk < N && sj < N) ? s[(size_t)sk * N + sj] : 0u;
+                for (unsigned q = 0; q < 3; ++q) {
+                    sum[q] += a * b;
+                    k[q] += 1;
+                }
+            }
+            const uint32_t ri = gep_offset(c, i, ss), rj = gep_offset(c, j, ss);      /* r[i][j] = sum          :16 */
+            uint32_t v[3] = {sum[0], sum[1], sum[2]};
+            store_sync32(c, v);
+            if (ri < N && rj < N)
+                r[(size_t)ri * N + rj] = v[0];
+            for (unsigned q = 0; q < 3; ++q)
+                j[q] += 1;
+        }
+        for (unsigned q = 0; q < 3; ++q)
+            i[q] += 1;
+    }
+#undef MM_HOOK
+#undef MM_COND
+    return tick >= cap;
+}
+
 void orc_mm_xmr(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, size_t batch, const orc_cfg *cfg,
                 const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
 {
@@ -173,6 +248,26 @@ void orc_mm_xmr(const uint32_t *f, const uint32_t *s, uint32_t *r, int n, size_t
     sync_ctx c = {cfg->replicas, cfg->sync_every, st, 0, cfg->flags};
     const size_t nn = (size_t)n * n;
     size_t fp = 0;
+    if (cfg->flags & ORC_F_INDEXED) { /* the loop counters inside the sphere of replication: one work item per matrix */
+        for (size_t b = 0; b < batch; ++b) {
+            while (fp < nfaults && fs[fp].item < (uint64_t)b * nn)
+                ++fp;
+            size_t fe = fp;
+            while (fe < nfaults && fs[fe].item < (uint64_t)(b + 1) * nn)
+                ++fe;
+            memset(r + b * nn, 0, nn * sizeof(uint32_t)); /* elements a derailed walk never stores stay 0 */
+            c.detected = 0;
+            mm_call_indexed(f + b * nn, s + b * nn, r + b * nn, n, &c, fs + fp, fe - fp);
+            if (c.detected) {
+                st->dwc_detected += (cfg->replicas == 2);
+                if (detected)
+                    detected[b * nn] = 1; /* the item is the call: its flag is the matrix's first byte */
+            }
+            fp = fe;
+        }
+        free(fs);
+        return;
+    }
     for (size_t b = 0; b < batch; ++b)
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) {

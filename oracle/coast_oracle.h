@@ -41,6 +41,9 @@ enum {
     ORC_SITE_MM_ACC = 0,   /* accumulator, before the MAC of k == step (step == n: after the loop) */
     ORC_SITE_MM_OPA = 1,   /* loaded f[i][k] of k == step */
     ORC_SITE_MM_OPB = 2,   /* loaded s[k][j] of k == step */
+    ORC_SITE_MM_I = 3,     /* ORC_F_BRANCH_SYNC / ADDR_SYNC (the call is the item): loop counter i before loop condition number `step` */
+    ORC_SITE_MM_J = 4,     /* ... j */
+    ORC_SITE_MM_K = 5,     /* ... k (ORC_SITE_MM_ACC is `sum`, same timing, in that mode) */
 
     ORC_SITE_SHA_M = 8,    /* schedule word m[step%64] of compression step/64, right after it is produced */
     ORC_SITE_SHA_WV = 9,   /* working variable a..h (index 0..7) before round step%64 of compression step/64 */

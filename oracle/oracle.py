@@ -113,10 +113,23 @@ def ref_chsha_vectors():
     return np.frombuffer(bytes(arr), np.uint8).reshape(2, 8192).copy(), np.array(list(d), dtype=np.uint32)
 
 
+REPLICA_ALL = 255  # include/coast_hip.h COAST_REPLICA_ALL
+
+
 def _faults(faults):
+    """A common-mode upset (replica == REPLICA_ALL: state the replicas share) is the same flip in every replica's copy of the
+    value: stated here as one fault per replica -- the C model ignores replica numbers the run does not have."""
     if faults is None:
         return np.zeros(0, dtype=FAULT_DTYPE)
     f = np.ascontiguousarray(faults, dtype=FAULT_DTYPE)
+    common = f["replica"] == REPLICA_ALL
+    if common.any():
+        parts = [f[~common]]
+        for r in range(3):
+            c = f[common].copy()
+            c["replica"] = r
+            parts.append(c)
+        f = np.ascontiguousarray(np.concatenate(parts))
     return f
 
 

@@ -65,6 +65,50 @@ class MM(Bench):
         return (r * n * n + int(rng.integers(0, n * n)), int(rng.integers(0, nrep)), int(rng.integers(0, 3)),
                 int(rng.integers(0, n + 1)), int(rng.integers(0, 32)))
 
+    # Register census of one wave of mm_mfma_blk2_kernel<3> (the TMR default at side 256): 256 VGPRs x 64 lanes x 32 bits, named in
+    # the kernel source (tests/test_kernel_budget_cpu.py holds the total).  `getReg()` of the reference draws uniformly from the
+    # register class (simulation/platform/resources/injector.py:70-72, 237-260); here one draw = one bit of one lane of one VGPR.
+    # SGPRs are 32 bits per wave against 2048 per VGPR: < 1 % of the bits, filed under "other".
+    #   name      regs  what one flipped bit reaches
+    CENSUS_BLK2 = [
+        ("acc",     96, "private: limb sum C_t of one replica of one output element (2 row blocks x 3 replicas x 4 limbs x 4)"),
+        ("b_frag",  48, "private: 16 plane bytes of s[k..k+15][j] in ONE replica's B-operand registers: that replica of the wave's 32 rows"),
+        ("a_frag",  16, "COMMON: 4 plane bytes of f[i][k..k+3], the shared A operand: all three replicas of the tile's 16 columns"),
+        ("s_raw",   24, "COMMON: a raw / half-converted word of s[k][j] on its way into the LDS slab both waves of the pair and all "
+                        "three replicas read: the panel's 64 rows of column j"),
+        ("f_raw",    4, "COMMON: a raw word of f[i][k] of the next panel on its way into the LDS panel: all 256 columns of row i"),
+        ("tally",    8, "vote scratch and counters (teV, teVoted, teMiss, tl.*): the stored words are not reached"),
+        ("other",   60, "addresses, lane constants, compiler temporaries (+ the wave's SGPRs): not modelled"),
+    ]
+
+    def reg_event(self, r, nrep, rng):
+        """one physical register upset of run r (= matrix r) on the matrix-core TMR kernel -> (class, rows for the injector).
+        A limb-sum / plane-byte bit is mapped onto the model's 32-bit registers: limb t bit b = bit 8 t + b of the word (beyond
+        bit 31: no architectural effect); the operand sites take the bit of the operand value."""
+        n, nn = self.n, self.n * self.n
+        w = np.array([c[1] for c in self.CENSUS_BLK2], dtype=np.float64)
+        cls = self.CENSUS_BLK2[int(rng.choice(len(w), p=w / w.sum()))][0]
+        i, j, k = int(rng.integers(0, n)), int(rng.integers(0, n)), int(rng.integers(0, n))
+        limb, b = int(rng.integers(0, 4)), int(rng.integers(0, 32 if cls == "acc" else 8))
+        bit = 8 * limb + b
+        item = lambda ii, jj: r * nn + ii * n + jj
+        if cls in ("tally", "other"):
+            return cls, []
+        if cls == "acc":
+            if bit > 31:  # a bit of a limb sum that falls off the 32-bit word: no architectural effect
+                return cls, []
+            return cls, [(item(i, j), int(rng.integers(0, nrep)), ca.SITE_MM_ACC, int(rng.integers(0, n + 1)), bit)]
+        if cls == "b_frag":  # one replica's copy of s[k][j]: the 32 rows (two row blocks) the wave's accumulators stand for
+            rep, i0 = int(rng.integers(0, nrep)), (i // 32) * 32
+            return cls, [(item(ii, j), rep, ca.SITE_MM_OPB, k, bit) for ii in range(i0, i0 + 32)]
+        if cls == "a_frag":  # shared by the three replicas and by the 16 columns of the tile
+            j0 = (j // 16) * 16
+            return cls, [(item(i, jj), ca.REPLICA_ALL, ca.SITE_MM_OPA, k, bit) for jj in range(j0, j0 + 16)]
+        if cls == "s_raw":   # shared by the three replicas and the 64 rows of the panel
+            i0 = (i // 64) * 64
+            return cls, [(item(ii, j), ca.REPLICA_ALL, ca.SITE_MM_OPB, k, bit) for ii in range(i0, i0 + 64)]
+        return cls, [(item(i, jj), ca.REPLICA_ALL, ca.SITE_MM_OPA, k, bit) for jj in range(n)]  # f_raw
+
 
 class SHA256(Bench):
     def __init__(self, a, eng, g):
@@ -259,10 +303,23 @@ def run_campaign(a, eng=None):
     targets = []
     t0 = time.perf_counter()
     eng.reset_stats()
+    classes = None
     if a.section == "registers":
-        rows = [bench.reg_fault(r, nrep, rng) for r in range(runs)]
-        for r, row in enumerate(rows):
-            targets.append({"replica": row[1], "site": row[2], "step": row[3], "bit": row[4]})
+        physical = a.reg_model == "physical" and a.benchmark == "mm" and a.side == 256 and rep == ca.TMR
+        if a.reg_model == "physical" and not physical:
+            raise SystemExit("--reg-model physical: the register census is that of the TMR matrix-core kernel (-b mm --side 256 -m TMR)")
+        if physical:  # any register of the wave, weighted by the kernel's register census: shared state included
+            rows, classes = [], []
+            for r in range(runs):
+                cls, ev = bench.reg_event(r, nrep, rng)
+                classes.append(cls)
+                rows += ev
+                targets.append({"class": cls, "flips": len(ev), "site": ev[0][2] if ev else None, "step": ev[0][3] if ev else None,
+                                "bit": ev[0][4] if ev else None, "replica": ev[0][1] if ev else None})
+        else:
+            rows = [bench.reg_fault(r, nrep, rng) for r in range(runs)]
+            for r, row in enumerate(rows):
+                targets.append({"replica": row[1], "site": row[2], "step": row[3], "bit": row[4]})
         eng.inject_faults(ca.make_faults(rows))
         out = bench.run(inp, ca.XmrConfig(rep), det)
         engine = eng.last_launch()
@@ -328,10 +385,28 @@ def run_campaign(a, eng=None):
         "timeouts": counts["timeouts"], "invalids": counts["invalids"], "aborts": counts["aborts"],
         "coverage_pct": 100.0 * (runs - counts["errors"]) / runs,
         "TMR_ERROR_CNT": st["errors_corrected"], "__SYNC_COUNT": st["sync_count"], "dwc_detected": st["dwc_detected"],
-        "engine": engine["engine"], "stepwise_blocks": engine["general_blocks"], "wall_s": wall,
+        "engine": engine["engine"], "stepwise_blocks": engine["general_blocks"], "hooked_blocks": engine.get("hooked_blocks", 0),
+        "wall_s": wall,
         "seconds_per_injection": wall / runs,
         "fault_model": "one single-bit flip of a 32-bit word per run (FaultInjector.flipOneBit, injector.py:202-207)",
     }
+    if classes is not None:  # the physical register model: outcome per register class, and what the unmodelled share can change
+        by = {}
+        for r in range(runs):
+            d = by.setdefault(classes[r], {"runs": 0, "errors": 0, "corrected_or_masked": 0})
+            d["runs"] += 1
+            d["errors" if records[r]["class"] == "error" else "corrected_or_masked"] += 1
+        unmodelled = by.get("other", {"runs": 0})["runs"]
+        summary.update({
+            "reg_model": "physical: one bit of one lane of one of the wave's 256 VGPRs, weighted by the register census",
+            "census": [{"class": c[0], "vgprs": c[1], "reaches": c[2]} for c in MM.CENSUS_BLK2],
+            "by_class": by, "unmodelled_runs": unmodelled,
+            # `other` registers (addresses, lane constants, SGPRs) are not simulated: the two bounds file them under success / error
+            "coverage_pct_upper": 100.0 * (runs - counts["errors"]) / runs,
+            "coverage_pct_lower": 100.0 * (runs - counts["errors"] - unmodelled) / runs,
+        })
+    else:
+        summary["reg_model"] = "sites: replica-private injector sites only (what TMR corrects by construction)" if a.section == "registers" else None
     return records, summary
 
 
@@ -350,6 +425,13 @@ def format_summary(s):
              " (%3.6f seconds per injection)" % s["seconds_per_injection"]]
     if s["aborts"]:
         lines += ["Additional Data:", "Aborts:     %d (%3.2f%%)" % (s["aborts"], 100.0 * s["aborts"] / n)]
+    if s.get("by_class"):
+        lines += ["Register classes (physical model):"]
+        for c in s["census"]:
+            d = s["by_class"].get(c["class"], {"runs": 0, "errors": 0})
+            lines.append("  %-8s %3d VGPRs  runs %5d  errors %5d" % (c["class"], c["vgprs"], d["runs"], d["errors"]))
+        lines.append("Coverage:   %3.2f%% .. %3.2f%% (unmodelled registers counted as errors .. as successes)"
+                     % (s["coverage_pct_lower"], s["coverage_pct_upper"]))
     return "\n".join(lines)
 
 
@@ -377,6 +459,9 @@ def parse(argv=None):
     ap.add_argument("-t", "--runs", type=int, default=5000)
     ap.add_argument("-s", "--section", default="registers", choices=["registers", "memory"])
     ap.add_argument("--mem-mode", default="nomemrep", choices=["nomemrep", "default"])
+    ap.add_argument("--reg-model", default="sites", choices=["sites", "physical"],
+                    help="registers: `sites` = a replica-private injector site per run; `physical` (-b mm --side 256 -m TMR) = any "
+                         "register of the matrix-core kernel's wave, weighted by its register census, shared state included")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--side", type=int, default=9, help="mm: matrix side, one matrix per run (256 = the matrix-core engine)")
     ap.add_argument("--chaes-type", type=int, default=128128, help="chaes: key bits * 1000 + block bits (aes_key.c:83-134)")
