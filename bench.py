@@ -736,7 +736,9 @@ def extra_legs(a, eng, dist, dev, rank, world, coast_amd):
     legs = {}
     plan = [("crc16_256B", CRC16, {"block_len": 256}, 20, 5)]
     if world == 1:
-        plan += [("crc16_255B", CRC16, {"block_len": 255}, 20, 5), ("sha256", SHA256, {}, 20, 5), ("aes", AES, {}, 40, 8)]
+        plan += [("crc16_255B", CRC16, {"block_len": 255}, 20, 5), ("sha256", SHA256, {}, 20, 5), ("aes", AES, {}, 40, 8),
+                 # the BASELINE batch (1 Mi blocks) is a 50-80 us launch; the same kernels on 16 Mi blocks show what they sustain
+                 ("aes_16Mi_blocks", AES, {"batch": 1 << 24}, 12, 4)]
     for name, cls, over, steps, warm in plan:
         torch.cuda.synchronize()
         time.sleep(1.0)  # the matrix-core leg leaves the chip at its power limit: let the clocks settle before an HBM-bound leg

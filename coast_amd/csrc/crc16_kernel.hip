@@ -62,16 +62,18 @@ __device__ __forceinline__ uint32_t crc_perm_sel(uint32_t sh) { return 0x0001020
 __device__ __forceinline__ uint32_t crc_be32(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
 // crc16() byte by byte as written (crc16.c:25-29) with the injector hooks: a flip of the lane's crc register before byte `step`
-// (step == length: after the loop), of its temporary x right after `x ^= x >> 4`.  Used by both kernels for the tiles that own
-// an armed fault.
-__device__ __forceinline__ uint32_t crc16_bytes_hooked(const uint8_t *p, uint32_t blockLen, const FaultTab &ft, uint2 fr, int slot,
-                                                       int rep, bool laneLive)
+// (step == length: after the loop), of its temporary x right after `x ^= x >> 4`.  What the stream kernel runs for a tile that
+// owns an armed upset (and for the last tiles of an unaligned stream).  The lane's upsets are gathered from the table once (it sits
+// in HBM) and the row is fetched as the aligned dwords it covers, 8 at a time -- the walk costs about what the lookup walk of a
+// clean tile costs, so a persistent workgroup is not held up by it.  More than four upsets on one lane: crc16_bytes_hooked_any.
+__device__ __noinline__ uint32_t crc16_bytes_hooked_any(const uint8_t *p, uint32_t blockLen, const DevFault *list, uint2 fr, int slot,
+                                                        int rep, bool laneLive)
 {
     uint32_t crc = 0xFFFFu;
     for (uint32_t t = 0; t < blockLen; ++t) {
         uint32_t xm = 0u;
         for (uint32_t q = 0; q < fr.y; ++q) {
-            const DevFault df = ft.list[fr.x + q];
+            const DevFault df = list[fr.x + q];
             if (df.step != t || (int)df.local != slot || (int)df.replica != rep || !laneLive)
                 continue;
             if (df.site == SITE_CRC_CRC)
@@ -85,15 +87,82 @@ __device__ __forceinline__ uint32_t crc16_bytes_hooked(const uint8_t *p, uint32_
         crc = ((crc << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xffffu;
     }
     for (uint32_t q = 0; q < fr.y; ++q) {
-        const DevFault df = ft.list[fr.x + q];
+        const DevFault df = list[fr.x + q];
         if (df.step == blockLen && df.site == SITE_CRC_CRC && (int)df.local == slot && (int)df.replica == rep && laneLive)
             crc = flip_bit(crc, df.bit, 0xffffu);
     }
     return crc;
 }
 
-template <int NREP, int NT, bool ALIGNED>
-__global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
+__device__ __forceinline__ uint32_t crc16_bytes_hooked(const uint8_t *p, uint32_t blockLen, const FaultTab &ft, uint2 fr, int slot,
+                                                       int rep, bool laneLive)
+{
+    // this lane's upsets: step, and the XOR mask for crc (bits 0..15) or x (bits 16..23)
+    uint32_t fs0 = 0xffffffffu, fs1 = 0xffffffffu, fs2 = 0xffffffffu, fs3 = 0xffffffffu, fm0 = 0u, fm1 = 0u, fm2 = 0u, fm3 = 0u;
+    uint32_t nmine = 0u;
+    for (uint32_t q = 0; q < fr.y; ++q) {
+        const DevFault df = ft.list[fr.x + q];
+        if ((int)df.local != slot || (int)df.replica != rep || !laneLive || (df.site != SITE_CRC_CRC && df.site != SITE_CRC_X))
+            continue;
+        if (df.site == SITE_CRC_X && df.step >= blockLen)
+            continue; // x exists inside the loop only
+        const uint32_t bit = 1u << (df.bit & 31u);
+        const uint32_t m = df.site == SITE_CRC_CRC ? (bit & 0xffffu) : ((bit & 0xffu) << 16);
+        fs0 = nmine == 0u ? df.step : fs0, fm0 = nmine == 0u ? m : fm0;
+        fs1 = nmine == 1u ? df.step : fs1, fm1 = nmine == 1u ? m : fm1;
+        fs2 = nmine == 2u ? df.step : fs2, fm2 = nmine == 2u ? m : fm2;
+        fs3 = nmine == 3u ? df.step : fs3, fm3 = nmine == 3u ? m : fm3;
+        nmine += 1u;
+    }
+    // (the ballot keeps the lanes of the wave together: all of them take the rare generic path, or none)
+    if (__builtin_amdgcn_ballot_w64(nmine > 4u) != 0ull)
+        return crc16_bytes_hooked_any(p, blockLen, ft.list, fr, slot, rep, laneLive);
+    uint32_t crc = 0xFFFFu;
+    auto byteStep = [&](uint32_t t, uint32_t byte) __attribute__((always_inline)) {
+        const uint32_t m = (fs0 == t ? fm0 : 0u) ^ (fs1 == t ? fm1 : 0u) ^ (fs2 == t ? fm2 : 0u) ^ (fs3 == t ? fm3 : 0u);
+        crc ^= m & 0xffffu;
+        uint32_t x = ((crc >> 8) ^ byte) & 0xffu;
+        x ^= x >> 4;
+        x ^= m >> 16;
+        crc = ((crc << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xffffu;
+    };
+    uint32_t t = 0u;
+    const uint32_t head = min(blockLen, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u)) & 3u));
+    for (; t < head; ++t)
+        byteStep(t, (uint32_t)p[t]);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p + head);
+    const uint32_t ndw = (blockLen - head) >> 2;
+    uint32_t d = 0u;
+#pragma unroll 1
+    for (; d + 8u <= ndw; d += 8u) { // eight loads in flight, then their 32 byte steps
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v[i] = w[d + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                byteStep(t++, (v[i] >> (8 * b)) & 0xffu);
+    }
+    for (; d < ndw; ++d) {
+        const uint32_t v = w[d];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            byteStep(t++, (v >> (8 * b)) & 0xffu);
+    }
+    for (; t < blockLen; ++t)
+        byteStep(t, (uint32_t)p[t]);
+    const uint32_t mEnd = (fs0 == blockLen ? fm0 : 0u) ^ (fs1 == blockLen ? fm1 : 0u) ^ (fs2 == blockLen ? fm2 : 0u) ^
+                          (fs3 == blockLen ? fm3 : 0u);
+    return crc ^ (mEnd & 0xffffu);
+}
+
+// THREADS: workgroup size (one persistent workgroup per CU: the table fills its LDS).  Lookup chains in flight per CU =
+// THREADS / 64 x NT; registers per lane = 512 x 256 / THREADS.  1024 x NT 2 is the shipped shape for aligned rows; 768 x NT 4
+// (48 chains, 170 registers) is the experiment of round 3 (COAST_CRC_SHAPE, profiles/r03_crc16_shapes.txt).
+template <int NREP, int NT, bool ALIGNED, int THREADS = kCrcStreamThreads>
+__global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
     const uint8_t *__restrict__ data, uint32_t blockLen, uint64_t nblocksData, uint16_t *__restrict__ crcs,
     const uint16_t *__restrict__ t16g, uint64_t ntiles, uint64_t ntilesWalk, Counters ctr, FaultTab ft,
     uint8_t *__restrict__ detected)
@@ -108,16 +177,15 @@ __global__ __launch_bounds__(kCrcStreamThreads) void crc16_stream_kernel(
     { // 128 KiB table: 1024 threads x 8 x 16 B, L2-resident after the first workgroup
         const uint4 *src = reinterpret_cast<const uint4 *>(t16g);
         uint4 *dst = reinterpret_cast<uint4 *>(T);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            dst[tid + u * kCrcStreamThreads] = src[tid + u * kCrcStreamThreads];
+        for (int e = tid; e < kCrcTableBytes / 16; e += THREADS)
+            dst[e] = src[e];
     }
     if (tid < 4)
         sCnt[tid] = 0;
     __syncthreads();
 
-    const uint64_t wavesTotal = (uint64_t)gridDim.x * (kCrcStreamThreads / kWave);
-    const uint64_t wave0 = (uint64_t)blockIdx.x * (kCrcStreamThreads / kWave) + (tid >> 6);
+    const uint64_t wavesTotal = (uint64_t)gridDim.x * (THREADS / kWave);
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (THREADS / kWave) + (tid >> 6);
     Tally tl;
     uint32_t detItems = 0;
     // A block is walked as nd full dwords, then tb tail bytes.  Rows that do not start on a 16-byte boundary are read as the
