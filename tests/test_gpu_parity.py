@@ -503,7 +503,7 @@ def test_mm_256_common_mode_upsets_are_silent_data_corruption(eng, orc, tile, mo
     for jj in range(32, 48):  # an A-fragment register of matrix 0: row 70, k = 129, one bit, the 16 columns of a tile
         rows.append((0 * nn + 70 * 256 + jj, coast_amd.REPLICA_ALL, coast_amd.SITE_MM_OPA, 129, 13))
     for ii in range(64, 128):  # a raw s word of matrix 1: column 5, k = 3, the 64 rows of a panel
-        rows.append((1 * nn + ii * 256 + 5, coast_amd.REPLICA_ALL, coast_amd.SITE_MM_OPB, 3, 30))
+        rows.append((1 * nn + ii * 256 + 5, coast_amd.REPLICA_ALL, coast_amd.SITE_MM_OPB, 3, 0))  # bit 0: every nonzero f[i][3] shows it
     rows.append((2 * nn + 9 * 256 + 9, 1, coast_amd.SITE_MM_OPA, 77, 4))            # private: out-voted
     rows.append((2 * nn + 9 * 256 + 10, coast_amd.REPLICA_ALL, coast_amd.SITE_MM_ACC, 256, 0))  # all three accumulators: silent
     rows.append((0 * nn + 70 * 256 + 33, 2, coast_amd.SITE_MM_ACC, 10, 7))          # private upset on top of a common-mode one
