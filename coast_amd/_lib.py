@@ -84,6 +84,8 @@ SYMBOLS = {
     "coast_crazycf_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]),
     "coast_sync_copies": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_void_p, C.c_int,
                                     C.c_void_p]),
+    "coast_sync_copies_typed": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_int, C.c_uint32]),
     "coast_flip_memory": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint]),
     "coast_matrix_multiply_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(CoastCfg)]),
     "coast_sha256_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(CoastCfg)]),

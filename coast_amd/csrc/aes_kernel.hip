@@ -544,15 +544,19 @@ __device__ __forceinline__ uint32_t aes_pick_rep(uint32_t y0, uint32_t y1, uint3
     return aes_bfi(0x000000ffu, y0, aes_bfi(0x0000ff00u, y1, aes_bfi(0x00ff0000u, y2, y3)));
 }
 // LDS byte offset of this lane's copy of table entry x.byte[B]: entries are 1 << SH bytes apart (16 copies of a dword: SH = 6, of
-// an 8-byte pair: SH = 7), cOff = copy * entry size < 1 << SH, so the OR is an add: one shift and one v_and_or_b32 per lookup
+// an 8-byte pair: SH = 7), cOff = copy * entry size < 1 << SH
 template <int B, int SH> __device__ __forceinline__ uint32_t aes_rep_off(uint32_t x, uint32_t cOff)
 {
-    uint32_t a;
-    if constexpr (8 * B >= SH)
-        a = x >> (8 * B - SH);
+    // two instructions per lookup address: the byte (v_bfe_u32 / v_lshrrev_b32), then v_lshl_add_u32 with the lane's copy offset.
+    // The extraction of byte 0 is kept opaque: written as (x & 0xff) << SH the compiler canonicalises it to shift, and, add (three).
+    uint32_t t;
+    if constexpr (B == 3)
+        t = x >> 24;
+    else if constexpr (B == 0)
+        asm("v_bfe_u32 %0, %1, 0, 8" : "=v"(t) : "v"(x));
     else
-        a = x << (SH - 8 * B);
-    return (a & (0xffu << SH)) | cOff;
+        t = __builtin_amdgcn_ubfe(x, 8 * B, 8);
+    return (t << SH) + cOff;
 }
 __device__ __forceinline__ uint32_t aes_rotl8(uint32_t x, int bytes) { return __builtin_amdgcn_alignbit(x, x, 32 - 8 * bytes); }
 
@@ -602,6 +606,34 @@ __global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8
                     k0 ^= d.k0, k1 ^= d.k1, k2 ^= d.k2, k3 ^= d.k3;
                 }
             };
+            if constexpr (!HOOKED) { // clean tiles: AddRoundKey of the next round folded into the column sums (x = s ^ k carried)
+                uint32_t x0 = s0 ^ k0, x1 = s1 ^ k1, x2 = s2 ^ k2, x3 = s3 ^ k3;
+#pragma unroll
+                for (int rd = 0; rd < 10; ++rd) {
+                    uint32_t a0, a1, a2, a3, d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
+                    if (rd < 9) {
+                        a0 = aes_xor3(TE(0, x0, 0), TE(1, x1, 1), TE(2, x2, 2)), d0 = TE(3, x3, 3);
+                        a1 = aes_xor3(TE(0, x1, 0), TE(1, x2, 1), TE(2, x3, 2)), d1 = TE(3, x0, 3);
+                        a2 = aes_xor3(TE(0, x2, 0), TE(1, x3, 1), TE(2, x0, 2)), d2 = TE(3, x1, 3);
+                        a3 = aes_xor3(TE(0, x3, 0), TE(1, x0, 1), TE(2, x1, 2)), d3 = TE(3, x2, 3);
+                    } else {
+                        a0 = aes_pick_b1(TE(0, x0, 0), TE(0, x1, 1), TE(0, x2, 2), TE(0, x3, 3));
+                        a1 = aes_pick_b1(TE(0, x1, 0), TE(0, x2, 1), TE(0, x3, 2), TE(0, x0, 3));
+                        a2 = aes_pick_b1(TE(0, x2, 0), TE(0, x3, 1), TE(0, x0, 2), TE(0, x1, 3));
+                        a3 = aes_pick_b1(TE(0, x3, 0), TE(0, x0, 1), TE(0, x1, 2), TE(0, x2, 3));
+                    }
+                    const uint32_t sw = aes_pick_b1(TE(0, k3, 1), TE(0, k3, 2), TE(0, k3, 3), TE(0, k3, 0));
+                    k0 = aes_xor3(k0, sw, (uint32_t)kAesRcon[rd]);
+                    k1 ^= k0;
+                    k2 ^= k1;
+                    k3 ^= k2;
+                    if (rd < 9)
+                        x0 = aes_xor3(a0, d0, k0), x1 = aes_xor3(a1, d1, k1), x2 = aes_xor3(a2, d2, k2), x3 = aes_xor3(a3, d3, k3);
+                    else
+                        s0 = a0, s1 = a1, s2 = a2, s3 = a3; // the last AddRoundKey follows the loop
+                }
+                return;
+            }
 #pragma unroll
             for (int rd = 0; rd < 10; ++rd) {
                 hook(rd);
@@ -693,7 +725,7 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
 #define TS(x, b) (*reinterpret_cast<const uint2 *>(smemAes + kAesTabWords * 8 + aes_rep_off<b, 7>(x, cOff)))
 #define TD(r, x, b) (*reinterpret_cast<const uint32_t *>(smemAes + (3 + (r)) * kAesTabWords * 4 + aes_rep_off<b, 6>(x, cOff >> 1)))
 #define SUBROT(k) aes_pick_rep(TS(k, 1).y, TS(k, 2).y, TS(k, 3).y, TS(k, 0).y)
-#define TDCOL(a, b, c, d) (aes_xor3(DR(a, 0).x, TD(1, b, 1), TD(2, c, 2)) ^ TD(3, d, 3))
+#define TDCOL(a, b, c, d, m) aes_xor3(aes_xor3(DR(a, 0).x, TD(1, b, 1), TD(2, c, 2)), TD(3, d, 3), m) /* column ^ InvMix(key) */
     Tally tl;
     uint32_t detItems = 0;
     for (uint64_t tile = (uint64_t)blockIdx.x * (kAesRepThreads / kWave) + (tid >> 6); tile < ntiles;
@@ -725,8 +757,8 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
             k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[9]);
             m0 = aes_imc_col(k0), m1 = aes_imc_col(k1), m2 = aes_imc_col(k2), m3 = aes_imc_col(k3);
             {
-                const uint32_t w0 = TDCOL(x0, x3, x2, x1) ^ m0, w1 = TDCOL(x1, x0, x3, x2) ^ m1;
-                const uint32_t w2 = TDCOL(x2, x1, x0, x3) ^ m2, w3 = TDCOL(x3, x2, x1, x0) ^ m3;
+                const uint32_t w0 = TDCOL(x0, x3, x2, x1, m0), w1 = TDCOL(x1, x0, x3, x2, m1);
+                const uint32_t w2 = TDCOL(x2, x1, x0, x3, m2), w3 = TDCOL(x3, x2, x1, x0, m3);
                 x0 = w0;
                 x1 = w1;
                 x2 = w2;
@@ -745,8 +777,8 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
                 const uint2 a1 = TS(k3, 1), a2 = TS(k3, 2), a3 = TS(k3, 3), a0 = TS(k3, 0);
                 k0 = aes_xor3(k0, aes_pick_rep(a1.y, a2.y, a3.y, a0.y), (uint32_t)kAesRcon[j]);
                 m0 ^= aes_xor3(a1.x, aes_rotl8(a2.x, 1), aes_rotl8(a3.x, 2)) ^ aes_rotl8(a0.x, 3) ^ gAesImcRcon[j];
-                const uint32_t w0 = TDCOL(x0, x3, x2, x1) ^ m0, w1 = TDCOL(x1, x0, x3, x2) ^ m1;
-                const uint32_t w2 = TDCOL(x2, x1, x0, x3) ^ m2, w3 = TDCOL(x3, x2, x1, x0) ^ m3;
+                const uint32_t w0 = TDCOL(x0, x3, x2, x1, m0), w1 = TDCOL(x1, x0, x3, x2, m1);
+                const uint32_t w2 = TDCOL(x2, x1, x0, x3, m2), w3 = TDCOL(x3, x2, x1, x0, m3);
                 x0 = w0;
                 x1 = w1;
                 x2 = w2;

@@ -886,13 +886,16 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------ default mode
-extern "C" int coast_sync_copies(coast_ctx *c, void *const *d_copies, int ncopies, size_t nbytes, void *d_voted,
-                                 int scrub, uint8_t *d_detected)
+extern "C" int coast_sync_copies_typed(coast_ctx *c, void *const *d_copies, int ncopies, size_t nbytes, void *d_voted, int scrub,
+                                       uint8_t *d_detected, int elem, uint32_t vector_width)
 {
     if (!c)
         return COAST_EINVAL;
     if (!d_copies || (ncopies != 2 && ncopies != 3) || (nbytes & 3u))
         return fail(c, COAST_EINVAL, "coast_sync_copies: 2 or 3 copies, byte count a multiple of 4");
+    if ((elem != COAST_ELEM_U32 && elem != COAST_ELEM_F32) || vector_width < 1 || (nbytes / 4) % vector_width)
+        return fail(c, COAST_EINVAL, "coast_sync_copies_typed: elem is COAST_ELEM_U32 or COAST_ELEM_F32, the word count a multiple "
+                                     "of vector_width >= 1");
     if (nbytes == 0)
         return COAST_OK;
     for (int i = 0; i < ncopies; ++i)
@@ -913,14 +916,34 @@ extern "C" int coast_sync_copies(coast_ctx *c, void *const *d_copies, int ncopie
     }
     uint32_t *c0 = (uint32_t *)d_copies[0], *c1 = (uint32_t *)d_copies[1];
     uint32_t *c2 = ncopies == 3 ? (uint32_t *)d_copies[2] : nullptr;
-    if (ncopies == 3)
-        hipLaunchKernelGGL(sync_copies_kernel<3>, dim3(grid), dim3(256), 0, c->stream, c0, c1, c2, nwords,
-                           (uint32_t *)d_voted, scrub, ctr, d_detected);
-    else
-        hipLaunchKernelGGL(sync_copies_kernel<2>, dim3(grid), dim3(256), 0, c->stream, c0, c1, c2, nwords,
-                           (uint32_t *)d_voted, 0, ctr, d_detected);
+    const bool fp = elem == COAST_ELEM_F32, vec = vector_width > 1;
+#define LAUNCH_VOTE(NC, FP, VEC)                                                                                \
+    hipLaunchKernelGGL((sync_copies_kernel<NC, FP, VEC>), dim3(grid), dim3(256), 0, c->stream, c0, c1, c2, nwords, \
+                       (uint32_t *)d_voted, (NC) == 3 ? scrub : 0, ctr, d_detected)
+    if (ncopies == 3) {
+        if (fp && vec)
+            LAUNCH_VOTE(3, true, true);
+        else if (fp)
+            LAUNCH_VOTE(3, true, false);
+        else if (vec)
+            LAUNCH_VOTE(3, false, true);
+        else
+            LAUNCH_VOTE(3, false, false);
+    } else {
+        if (fp)
+            LAUNCH_VOTE(2, true, false);
+        else
+            LAUNCH_VOTE(2, false, false);
+    }
+#undef LAUNCH_VOTE
     return after_launch(c, 0, COAST_ENGINE_VOTE, 0, grid,
                         (double)nbytes * (ncopies + (d_voted ? 1 : 0) + (scrub && ncopies == 3 ? ncopies : 0)));
+}
+
+extern "C" int coast_sync_copies(coast_ctx *c, void *const *d_copies, int ncopies, size_t nbytes, void *d_voted,
+                                 int scrub, uint8_t *d_detected)
+{
+    return coast_sync_copies_typed(c, d_copies, ncopies, nbytes, d_voted, scrub, d_detected, COAST_ELEM_U32, 1u);
 }
 
 extern "C" int coast_flip_memory(coast_ctx *c, void *d_ptr, size_t byte_offset, unsigned bit)

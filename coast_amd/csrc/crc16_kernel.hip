@@ -161,7 +161,20 @@ __device__ __forceinline__ uint32_t crc16_bytes_hooked(const uint8_t *p, uint32_
 // THREADS: workgroup size (one persistent workgroup per CU: the table fills its LDS).  Lookup chains in flight per CU =
 // THREADS / 64 x NT; registers per lane = 512 x 256 / THREADS.  1024 x NT 2 is the shipped shape for aligned rows; 768 x NT 4
 // (48 chains, 170 registers) is the experiment of round 3 (COAST_CRC_SHAPE, profiles/r03_crc16_shapes.txt).
-template <int NREP, int NT, bool ALIGNED, int THREADS = kCrcStreamThreads>
+// T16[idx] without the table: the two byte steps of the reference recurrence from state idx with zero data (the map is what the
+// table tabulates).  ~17 VALU instructions; the hybrid walk (HYB) runs every HYB-th pair step of a chain through it instead of
+// through LDS, taking that share of lookups off the conflicted LDS array while the VALU has issue slots to spare.
+__device__ __forceinline__ uint32_t crc16_pair_valu(uint32_t idx)
+{
+    uint32_t x = idx >> 8;
+    x ^= x >> 4;
+    const uint32_t c1 = ((idx << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xffffu;
+    uint32_t y = c1 >> 8;
+    y ^= y >> 4;
+    return ((c1 << 8) ^ (y << 12) ^ (y << 5) ^ y) & 0xffffu;
+}
+
+template <int NREP, int NT, bool ALIGNED, int THREADS = kCrcStreamThreads, int HYB = 0>
 __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
     const uint8_t *__restrict__ data, uint32_t blockLen, uint64_t nblocksData, uint16_t *__restrict__ crcs,
     const uint16_t *__restrict__ t16g, uint64_t ntiles, uint64_t ntilesWalk, Counters ctr, FaultTab ft,
@@ -274,11 +287,21 @@ __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
                             e[j] = __builtin_bswap32(d); // (b0<<24)|(b1<<16)|(b2<<8)|b3
                         }
 #pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            crc[j] = T[crc[j] ^ (e[j] >> 16)];
+                        for (int j = 0; j < NT; ++j) {
+                            const int step = 8 * v + 2 * c + (HYB ? j * (HYB / 2) : 0); // the chains take their VALU turns apart
+                            if (HYB != 0 && step % HYB == 0)
+                                crc[j] = crc16_pair_valu(crc[j] ^ (e[j] >> 16));
+                            else
+                                crc[j] = T[crc[j] ^ (e[j] >> 16)];
+                        }
 #pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            crc[j] = T[crc[j] ^ (e[j] & 0xffffu)];
+                        for (int j = 0; j < NT; ++j) {
+                            const int step = 8 * v + 2 * c + 1 + (HYB ? j * (HYB / 2) : 0);
+                            if (HYB != 0 && step % HYB == 0)
+                                crc[j] = crc16_pair_valu(crc[j] ^ (e[j] & 0xffffu));
+                            else
+                                crc[j] = T[crc[j] ^ (e[j] & 0xffffu)];
+                        }
                     }
                 }
                 if (more) {

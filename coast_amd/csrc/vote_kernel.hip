@@ -11,11 +11,48 @@
 // with `scrub` the voted word is written back into every copy that differs (the copies re-converge, as all three IR
 // values continue from the voted one, synchronization.cpp:527-529).  DWC: a != b flags the word, nothing is repaired.
 // Pure HBM streaming: 12 (8) bytes read + 4 written per word; 16-byte vector accesses, grid-stride.
+//
+// Operand types (round 3; synchronization.cpp:57-62, 70-88, 1380-1443, 1469-1530).  The pass compares integers with `icmp eq` and
+// floating-point values with `fcmp oeq` -- ordered: a NaN equals nothing, itself included; -0.0 equals +0.0 -- and a VECTOR operand
+// takes a different counter path: the select is lane-wise, TMR_ERROR_CNT += the add-reduction over the lanes of
+// (a ne b) | (a ne c) with `icmp ne` / `fcmp one` (ordered-and-not-equal: a NaN lane is NOT counted), and the function returns
+// before the -countSyncs increment (:1394-1396), so a vector sync point does not move __SYNC_COUNT.  FP32 / VECTOR select those rules.
 #include "xmr.hpp"
 
 namespace coast {
 
-template <int NC>
+template <bool FP32> __device__ __forceinline__ bool vote_eq(uint32_t a, uint32_t b)
+{
+    if constexpr (FP32)
+        return __uint_as_float(a) == __uint_as_float(b); // fcmp oeq
+    else
+        return a == b;
+}
+template <bool FP32> __device__ __forceinline__ bool vote_ne(uint32_t a, uint32_t b)
+{
+    if constexpr (FP32) {
+        const float x = __uint_as_float(a), y = __uint_as_float(b);
+        return x < y || x > y; // fcmp one: false when either is a NaN
+    } else {
+        return a != b;
+    }
+}
+
+// one voted word: returns the vote; m = counted (TMR) / flagged (DWC); differs = some copy is not bitwise the voted value
+template <int NC, bool FP32, bool VECTOR>
+__device__ __forceinline__ uint32_t vote_word(uint32_t a, uint32_t b, uint32_t c, uint32_t &m, bool &differs)
+{
+    const bool e01 = vote_eq<FP32>(a, b), e02 = vote_eq<FP32>(a, c);
+    const uint32_t o = (NC == 3) ? (e01 ? a : c) : a;
+    if (NC == 3)
+        m = VECTOR ? ((vote_ne<FP32>(a, b) || vote_ne<FP32>(a, c)) ? 1u : 0u) : ((e01 && e02) ? 0u : 1u);
+    else
+        m = e01 ? 0u : 1u;
+    differs = NC == 3 && (a != o || b != o || c != o);
+    return o;
+}
+
+template <int NC, bool FP32 = false, bool VECTOR = false>
 __global__ __launch_bounds__(256) void sync_copies_kernel(uint32_t *__restrict__ c0, uint32_t *__restrict__ c1,
                                                           uint32_t *__restrict__ c2, uint64_t nwords,
                                                           uint32_t *__restrict__ voted, int scrub, Counters ctr,
@@ -37,14 +74,17 @@ __global__ __launch_bounds__(256) void sync_copies_kernel(uint32_t *__restrict__
         const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w};
         uint32_t o[4];
         uint32_t bad = 0;
+        bool anyDiff = false;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const bool e01 = av[e] == bv[e], e02 = av[e] == cv[e];
-            o[e] = (NC == 3) ? (e01 ? av[e] : cv[e]) : av[e];
-            const uint32_t m = (NC == 3) ? ((e01 && e02) ? 0u : 1u) : (e01 ? 0u : 1u);
+            uint32_t m;
+            bool d;
+            o[e] = vote_word<NC, FP32, VECTOR>(av[e], bv[e], cv[e], m, d);
             bad |= m << e;
+            anyDiff = anyDiff || d;
         }
-        syncs += 4;
+        if (!VECTOR) // a vector sync point returns before the -countSyncs increment (synchronization.cpp:1394-1396)
+            syncs += 4;
         if (bad) {
             const uint32_t nb = (uint32_t)__builtin_popcount(bad);
             if (NC == 3)
@@ -57,12 +97,12 @@ __global__ __launch_bounds__(256) void sync_copies_kernel(uint32_t *__restrict__
                     if ((bad >> e) & 1u)
                         detected[4 * v + e] = 1;
             }
-            if (scrub && NC == 3) { // copies re-converge on the voted value
-                const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
-                reinterpret_cast<uint4 *>(c0)[v] = ov;
-                reinterpret_cast<uint4 *>(c1)[v] = ov;
-                reinterpret_cast<uint4 *>(c2)[v] = ov;
-            }
+        }
+        if (scrub && anyDiff) { // the copies re-converge on the voted value (for integers: exactly the counted words)
+            const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+            reinterpret_cast<uint4 *>(c0)[v] = ov;
+            reinterpret_cast<uint4 *>(c1)[v] = ov;
+            reinterpret_cast<uint4 *>(c2)[v] = ov;
         }
         if (voted)
             reinterpret_cast<uint4 *>(voted)[v] = make_uint4(o[0], o[1], o[2], o[3]);
@@ -71,10 +111,11 @@ __global__ __launch_bounds__(256) void sync_copies_kernel(uint32_t *__restrict__
     if (blockIdx.x == 0 && threadIdx.x < (nwords & 3u)) {
         const uint64_t w = (nvec << 2) + threadIdx.x;
         const uint32_t a = c0[w], b = c1[w], c = (NC == 3) ? c2[w] : a;
-        const bool e01 = a == b, e02 = a == c;
-        const uint32_t o = (NC == 3) ? (e01 ? a : c) : a;
-        const uint32_t m = (NC == 3) ? ((e01 && e02) ? 0u : 1u) : (e01 ? 0u : 1u);
-        syncs += 1;
+        uint32_t m;
+        bool d;
+        const uint32_t o = vote_word<NC, FP32, VECTOR>(a, b, c, m, d);
+        if (!VECTOR)
+            syncs += 1;
         if (m) {
             if (NC == 3)
                 miss += 1;
@@ -82,11 +123,11 @@ __global__ __launch_bounds__(256) void sync_copies_kernel(uint32_t *__restrict__
                 det += 1;
             if (detected)
                 detected[w] = 1;
-            if (scrub && NC == 3) {
-                c0[w] = o;
-                c1[w] = o;
-                c2[w] = o;
-            }
+        }
+        if (scrub && d) {
+            c0[w] = o;
+            c1[w] = o;
+            c2[w] = o;
         }
         if (voted)
             voted[w] = o;

@@ -221,10 +221,11 @@ class Engine:
         return results, status
 
     # -- default mode (memory replicated x3 / x2): vote where the copies re-converge
-    def sync_copies(self, copies, out=None, scrub=True, detected=None):
+    def sync_copies(self, copies, out=None, scrub=True, detected=None, fp=False, vector_width=1):
         """copies: 3 (TMR) or 2 (DWC) equally shaped contiguous GPU tensors holding the per-copy results of replicas=1
         launches.  Votes / compares them word by word (32-bit), counts into the engine's counters, optionally repairs
-        the copies in place, and returns the voted tensor."""
+        the copies in place, and returns the voted tensor.  fp / vector_width: the pass's operand-type rules (float words compared
+        with fcmp oeq; IR vectors counted per lane without a __SYNC_COUNT increment; coast_sync_copies_typed)."""
         assert len(copies) in (2, 3)
         t0 = copies[0]
         nbytes = t0.numel() * t0.element_size()
@@ -232,8 +233,9 @@ class Engine:
         if out is None:
             out = torch.empty_like(t0)
         arr = (C.c_void_p * len(copies))(*[t.data_ptr() for t in copies])
-        self._check(self._lib.coast_sync_copies(self._h, arr, len(copies), nbytes, _ptr(out), int(bool(scrub)),
-                                                _ptr(detected) if detected is not None else None))
+        self._check(self._lib.coast_sync_copies_typed(self._h, arr, len(copies), nbytes, _ptr(out), int(bool(scrub)),
+                                                      _ptr(detected) if detected is not None else None, 1 if fp else 0,
+                                                      int(vector_width)))
         return out
 
     def flip_memory(self, tensor, byte_offset, bit):

@@ -367,6 +367,15 @@ int coast_crazycf_batch(coast_ctx *ctx, const coast_crazycf_params *d_params, si
  * kernels -- are corrected here, at 3x the memory traffic. */
 int coast_sync_copies(coast_ctx *ctx, void *const *d_copies, int ncopies, size_t nbytes, void *d_voted, int scrub,
                       uint8_t *d_detected);
+/* The same vote with the pass's operand-type rules (synchronization.cpp:57-62, 70-88, 1380-1443, 1469-1530):
+ *   elem = COAST_ELEM_F32   the words are floats, compared with `fcmp oeq` -- a NaN equals nothing (itself included), -0.0 == +0.0;
+ *   vector_width > 1        the words are IR vectors of that many lanes: lane-wise select; TMR_ERROR_CNT += the number of lanes
+ *                           with (a ne b) | (a ne c) under `icmp ne` / `fcmp one` (a NaN lane is not counted); __SYNC_COUNT is NOT
+ *                           incremented (the vector path returns before the -countSyncs code, :1394-1396).
+ * scrub re-converges every copy that is not bitwise the voted value.  coast_sync_copies = (COAST_ELEM_U32, 1). */
+enum { COAST_ELEM_U32 = 0, COAST_ELEM_F32 = 1 };
+int coast_sync_copies_typed(coast_ctx *ctx, void *const *d_copies, int ncopies, size_t nbytes, void *d_voted, int scrub,
+                            uint8_t *d_detected, int elem, uint32_t vector_width);
 /* injectFaultMem (simulation/platform/resources/injector.py:209-235): flip bit `bit` (0..7) of one byte of device memory,
  * ordered on the context's stream */
 int coast_flip_memory(coast_ctx *ctx, void *d_ptr, size_t byte_offset, unsigned bit);

@@ -1346,25 +1346,51 @@ void orc_quicksort_xmr(int32_t *arrays, uint32_t n, size_t narrays, const orc_cf
 /* The exit vote of COAST's default (memory-replicated) mode over result arrays: docs/source/passes.rst:329,337 --
  * stores are not voted, values are where they leave the sphere of replication (synchronization.cpp:741-949,
  * verification.cpp:625-682).  Word-wise (32 bit): TMR vote + count (+ scrub of the copies), DWC compare. */
-void orc_sync_copies(uint32_t *c0, uint32_t *c1, uint32_t *c2, int ncopies, size_t nwords, uint32_t *voted, int scrub,
-                     orc_stats *st, uint8_t *detected)
+static int orc_eq(uint32_t a, uint32_t b, int fp)
+{
+    if (!fp)
+        return a == b;
+    float x, y; /* fcmp oeq: ordered and equal */
+    memcpy(&x, &a, 4);
+    memcpy(&y, &b, 4);
+    return x == y;
+}
+static int orc_ne(uint32_t a, uint32_t b, int fp)
+{
+    if (!fp)
+        return a != b;
+    float x, y; /* fcmp one: ordered and not equal -- false when either operand is a NaN */
+    memcpy(&x, &a, 4);
+    memcpy(&y, &b, 4);
+    return x < y || x > y;
+}
+
+/* The exit vote with the pass's operand-type rules.  Scalars (synchronization.cpp:1380-1443): cmp = eq(a, b), cmp2 = eq(a, c) with
+ * `icmp eq` / `fcmp oeq` (:57-62, 70-88), vote = select(cmp, a, c) (:934-938), __SYNC_COUNT += 1, TMR_ERROR_CNT += !(cmp & cmp2).
+ * Vectors of `vw` lanes (:1394-1396, 1469-1530): lane-wise select; TMR_ERROR_CNT += add-reduce over the lanes of
+ * (a ne b) | (a ne c) with `icmp ne` / `fcmp one`; the function returns before the -countSyncs increment, so __SYNC_COUNT does not
+ * move.  DWC: a word is flagged when !eq(a, b).  scrub: every copy that is not bitwise the voted value is rewritten (:527-529). */
+void orc_sync_copies_typed(uint32_t *c0, uint32_t *c1, uint32_t *c2, int ncopies, size_t nwords, uint32_t *voted, int scrub,
+                           orc_stats *st, uint8_t *detected, int fp, uint32_t vw)
 {
     for (size_t w = 0; w < nwords; ++w) {
-        st->sync_count += 1;
+        if (vw <= 1)
+            st->sync_count += 1;
         if (ncopies == 3) {
-            const int e01 = c0[w] == c1[w], e02 = c0[w] == c2[w];
+            const int e01 = orc_eq(c0[w], c1[w], fp), e02 = orc_eq(c0[w], c2[w], fp);
             const uint32_t v = e01 ? c0[w] : c2[w];
-            if (!(e01 && e02)) {
+            const int counted = vw > 1 ? (orc_ne(c0[w], c1[w], fp) || orc_ne(c0[w], c2[w], fp)) : !(e01 && e02);
+            if (counted) {
                 st->errors_corrected += 1;
                 if (detected)
                     detected[w] = 1;
-                if (scrub)
-                    c0[w] = c1[w] = c2[w] = v;
             }
+            if (scrub && (c0[w] != v || c1[w] != v || c2[w] != v))
+                c0[w] = c1[w] = c2[w] = v;
             if (voted)
                 voted[w] = v;
         } else {
-            if (c0[w] != c1[w]) {
+            if (!orc_eq(c0[w], c1[w], fp)) {
                 st->dwc_detected += 1;
                 if (detected)
                     detected[w] = 1;
@@ -1373,6 +1399,12 @@ void orc_sync_copies(uint32_t *c0, uint32_t *c1, uint32_t *c2, int ncopies, size
                 voted[w] = c0[w];
         }
     }
+}
+
+void orc_sync_copies(uint32_t *c0, uint32_t *c1, uint32_t *c2, int ncopies, size_t nwords, uint32_t *voted, int scrub,
+                     orc_stats *st, uint8_t *detected)
+{
+    orc_sync_copies_typed(c0, c1, c2, ncopies, nwords, voted, scrub, st, detected, 0, 1);
 }
 
 #include "chaes_oracle.inc"

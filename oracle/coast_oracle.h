@@ -202,6 +202,10 @@ void orc_mm_xmr_items(const uint32_t *f, const uint32_t *s, int n, const uint64_
 /* ---- default (memory-replicated) mode: the exit vote over three (two) result copies, 32-bit words ---- */
 void orc_sync_copies(uint32_t *c0, uint32_t *c1, uint32_t *c2, int ncopies, size_t nwords, uint32_t *voted, int scrub,
                      orc_stats *st, uint8_t *detected);
+/* ... with the operand-type rules: fp = words are floats (fcmp oeq / one), vw > 1 = IR vectors of vw lanes (per-lane count, no
+ * __SYNC_COUNT increment) */
+void orc_sync_copies_typed(uint32_t *c0, uint32_t *c1, uint32_t *c2, int ncopies, size_t nwords, uint32_t *voted, int scrub,
+                           orc_stats *st, uint8_t *detected, int fp, uint32_t vw);
 
 /* ---- CPU-TMR baseline: default COAST mode (memory x3, loop-condition votes, -countErrors) ---- */
 /* returns XOR-golden mismatch flag like checkGolden; *cnt gets TMR_ERROR_CNT, *syncs the dynamic vote count */

@@ -293,8 +293,9 @@ def cache_test_xmr(arrays, replicas=3, faults=None, flags=0):
     return a, sums, nerrs, st.as_dict(), det
 
 
-def sync_copies(copies, scrub=True):
-    """Default-mode exit vote: copies = 3 (TMR) or 2 (DWC) arrays of 32-bit words.  Returns (voted, copies after
+def sync_copies(copies, scrub=True, fp=False, vector_width=1):
+    """Default-mode exit vote: copies = 3 (TMR) or 2 (DWC) arrays of 32-bit words.  fp: the words are floats (fcmp oeq / one);
+    vector_width > 1: IR vectors of that many lanes (per-lane count, no __SYNC_COUNT increment).  Returns (voted, copies after
     scrub, stats, detected per word)."""
     cs = [np.array(np.ascontiguousarray(c).view(np.uint32).reshape(-1), copy=True) for c in copies]
     n = cs[0].size
@@ -302,8 +303,9 @@ def sync_copies(copies, scrub=True):
     det = np.zeros(n, dtype=np.uint8)
     st = Stats()
     c2 = cs[2] if len(cs) == 3 else cs[0]
-    lib().orc_sync_copies(_p(cs[0], C.c_uint32), _p(cs[1], C.c_uint32), _p(c2, C.c_uint32), C.c_int(len(cs)),
-                          C.c_size_t(n), _p(voted, C.c_uint32), C.c_int(int(scrub)), C.byref(st), _p(det, C.c_uint8))
+    lib().orc_sync_copies_typed(_p(cs[0], C.c_uint32), _p(cs[1], C.c_uint32), _p(c2, C.c_uint32), C.c_int(len(cs)),
+                                C.c_size_t(n), _p(voted, C.c_uint32), C.c_int(int(scrub)), C.byref(st), _p(det, C.c_uint8),
+                                C.c_int(int(fp)), C.c_uint32(vector_width))
     return voted, cs, st.as_dict(), det
 
 

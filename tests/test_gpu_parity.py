@@ -1200,6 +1200,45 @@ def test_default_mode_exit_vote_vs_oracle(eng, orc, nwords, ncopies, scrub):
         assert (_host(d, np.uint32) == e).all()
 
 
+@pytest.mark.parametrize("fp,vw", [(True, 1), (True, 4), (False, 4), (True, 8), (False, 1)])
+@pytest.mark.parametrize("ncopies,scrub", [(3, True), (3, False), (2, False)])
+def test_exit_vote_operand_type_rules_vs_oracle(eng, orc, fp, vw, ncopies, scrub):
+    """VERDICT r2 missing 4: the pass's operand-type rules at a sync point (synchronization.cpp:57-62, 1380-1443, 1469-1530) --
+    floats compare with `fcmp oeq` (a NaN equals nothing, -0.0 == +0.0), vector operands select lane-wise, count the lanes with
+    (a ne b) | (a ne c) under `fcmp one` / `icmp ne` (a NaN lane is NOT counted) and do not move __SYNC_COUNT."""
+    import torch
+
+    rng = np.random.default_rng(17 + 2 * vw + ncopies + scrub + fp)
+    n = 64 * vw + (0 if vw > 1 else 3)
+    base = rng.standard_normal(n).astype(np.float32).view(np.uint32) if fp else rng.integers(0, 2**32, n, dtype=np.uint32)
+    copies = [base.copy() for _ in range(ncopies)]
+    nan, pz, nz = np.uint32(0x7FC00000), np.uint32(0), np.uint32(0x80000000)
+    special = [(nan, None, None), (None, nan, None), (None, None, nan), (nan, nan, nan), (pz, nz, pz), (nz, pz, nz), (pz, pz, nz),
+               (nan, nan, None), (np.uint32(0x7FC00001), nan, nan), (np.uint32(0x3F800000), np.uint32(0x3F800001), None)]
+    for q, vals in enumerate(special):  # NaNs in every position, signed zeros, one-ulp differences
+        for cpy in range(ncopies):
+            if vals[cpy] is not None:
+                copies[cpy][5 * q + 1] = vals[cpy]
+    for _ in range(30):  # plain single-bit upsets on top
+        w = int(rng.integers(0, n))
+        copies[int(rng.integers(0, ncopies))][w] ^= np.uint32(1 << int(rng.integers(0, 32)))
+    exp_v, exp_after, exp_st, exp_det = orc.sync_copies(copies, scrub=scrub, fp=fp, vector_width=vw)
+    dev = [torch.from_numpy(c.view(np.int32).copy()).cuda() for c in copies]
+    det = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    eng.reset_stats()
+    out = eng.sync_copies(dev, scrub=scrub, detected=det, fp=fp, vector_width=vw)
+    assert (_host(out, np.uint32) == exp_v).all()
+    assert _stats3(eng.stats()) == exp_st
+    assert (det.cpu().numpy() == exp_det).all()
+    for d, e in zip(dev, exp_after):
+        assert (_host(d, np.uint32) == e).all()
+    if ncopies == 3:
+        assert exp_st["sync_count"] == (0 if vw > 1 else n)  # a vector sync point does not count as a sync
+        if fp and vw > 1:  # lanes whose only disagreement is a NaN are selected around, but not counted
+            plain = orc.sync_copies(copies, scrub=False, fp=True, vector_width=1)[2]["errors_corrected"]
+            assert exp_st["errors_corrected"] < plain
+
+
 def test_default_mode_end_to_end_all_kernels(eng, orc):
     """COAST's default mode (memory x3, stores not voted, docs/source/passes.rst:329,337): three unprotected launches on
     three HBM copies, upsets in MEMORY (injectFaultMem, injector.py:209-235) and in one copy's registers, exit vote.
@@ -1589,8 +1628,12 @@ def test_mm_loop_counters_in_the_sor_vs_oracle(eng, orc, n, batch, replicas):
         got = _host(eng.mm_batch(_dev(f), _dev(s), cfg=ca.XmrConfig(replicas, 0, flags), detected=det), np.uint32)
         assert (got == want).all(), flags
         assert _stats3(eng.stats()) == want_st and (det.cpu().numpy() == want_det).all(), flags
-        if replicas == 3 and flags == (B | A):  # everything voted: every upset is out-voted
-            assert (got == clean).all() and want_st["errors_corrected"] > 0
+        if replicas == 3 and flags == (B | A):  # everything voted: a single upset per call is always out-voted (two upsets of one
+            one = ca.make_faults(rows[::3])      # counter in replicas 0 and 2 are not: select(a == b, a, c) then takes the wrong c)
+            eng.reset_stats()
+            eng.inject_faults(one)
+            got1 = _host(eng.mm_batch(_dev(f), _dev(s), cfg=ca.XmrConfig(3, 0, flags)), np.uint32)
+            assert (got1 == clean).all() and eng.stats()["errors_corrected"] > 0
     if n == 32 and replicas == 3:
         assert orc.mm_xmr(f[:1], s[:1], replicas=3, flags=B | ND)[1]["sync_count"] == 34881
 
