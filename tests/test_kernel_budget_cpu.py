@@ -119,7 +119,7 @@ def test_lds_table_kernels_keep_their_occupancy(compiled):
     # (the compiler may sink a few lookups of the last round below the join of the two instantiations)
     ne, nd, nd64 = len(re.findall(r"ds_read_b32", be)), len(re.findall(r"ds_read_b32", bd)), len(re.findall(r"ds_read_b64", bd))
     assert 2 * 203 - 8 <= ne <= 2 * 203 and not re.search(r"ds_read_b64", be), ne
-    assert 2 * 199 - 8 <= nd <= 2 * 199 + 16 and 2 * 32 - 4 <= nd64 <= 2 * 32, (nd, nd64)
+    assert 2 * 199 - 8 <= nd <= 2 * 199 + 16 and 2 * 24 <= nd64 <= 2 * 32, (nd, nd64)  # (pair reads whose Tis half is dead are narrowed to dwords)
     for name in ("void coast::crc16_stream_kernel<3, 2, true, 1024>", "void coast::crc16_stream_kernel<3, 1, false, 1024>"):
         u = _find(usage, name)  # 1024-thread persistent workgroups: 128 registers per lane
         assert u["VGPRs"] <= 128 and u["VGPRs Spill"] == 0, (name, u)
