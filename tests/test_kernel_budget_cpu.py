@@ -120,7 +120,7 @@ def test_lds_table_kernels_keep_their_occupancy(compiled):
     ne, nd, nd64 = len(re.findall(r"ds_read_b32", be)), len(re.findall(r"ds_read_b32", bd)), len(re.findall(r"ds_read_b64", bd))
     assert 2 * 203 - 8 <= ne <= 2 * 203 and not re.search(r"ds_read_b64", be), ne
     assert 2 * 199 - 8 <= nd <= 2 * 199 + 16 and 2 * 24 <= nd64 <= 2 * 32, (nd, nd64)  # (pair reads whose Tis half is dead are narrowed to dwords)
-    for name in ("void coast::crc16_stream_kernel<3, 2, true, 1024>", "void coast::crc16_stream_kernel<3, 1, false, 1024>"):
+    for name in ("void coast::crc16_stream_kernel<3, 2, true, 1024,", "void coast::crc16_stream_kernel<3, 1, false, 1024,"):
         u = _find(usage, name)  # 1024-thread persistent workgroups: 128 registers per lane
         assert u["VGPRs"] <= 128 and u["VGPRs Spill"] == 0, (name, u)
 
@@ -132,7 +132,7 @@ def test_injector_hooks_cost_the_lean_kernels_nothing(compiled):
     sha = _find(usage, "void coast::sha256_fast_kernel<3, true>")
     assert sha["VGPRs"] <= 64 and sha["Occupancy [waves/SIMD]"] == 8 and sha["ScratchSize [bytes/lane]"] == 0, sha
     for name in ("aes128_enc_fast_kernel<3>", "aes128_dec_fast_kernel<3>", "aes128_enc_rep_kernel<2>", "aes128_dec_rep_kernel<2>",
-                 "crc16_stream_kernel<3, 2, true, 1024>", "crc16_stream_kernel<3, 1, false, 1024>"):
+                 "crc16_stream_kernel<3, 2, true, 1024,", "crc16_stream_kernel<3, 1, false, 1024,"):
         u = _find(usage, "void coast::" + name)
         assert u["ScratchSize [bytes/lane]"] == 0 and u["VGPRs Spill"] == 0, (name, u)
     assert _find(usage, "void coast::aes128_enc_fast_kernel<3>")["VGPRs"] <= 64
