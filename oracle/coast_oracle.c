@@ -1374,8 +1374,8 @@ void orc_sync_copies_typed(uint32_t *c0, uint32_t *c1, uint32_t *c2, int ncopies
                            orc_stats *st, uint8_t *detected, int fp, uint32_t vw)
 {
     for (size_t w = 0; w < nwords; ++w) {
-        if (vw <= 1)
-            st->sync_count += 1;
+        if (vw <= 1 || ncopies == 2) /* (the pass counts syncs in its TMR path only, :1415; the engine's DWC count of compared */
+            st->sync_count += 1;      /*  words is its own and does not depend on the operand kind)                          */
         if (ncopies == 3) {
             const int e01 = orc_eq(c0[w], c1[w], fp), e02 = orc_eq(c0[w], c2[w], fp);
             const uint32_t v = e01 ? c0[w] : c2[w];
