@@ -774,13 +774,17 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     const dim3 block(256);
     uint32_t engine = COAST_ENGINE_VALU;
     uint64_t generalBlocks = 0, fastBlocks = g.nblocks;
+    uint32_t hookedBlocks = 0;
 #define LAUNCH_FAST(R, V, K)                                                                                    \
     do {                                                                                                        \
         if (lds > 64 * 1024)                                                                                    \
             HIP_TRY(c, hipFuncSetAttribute((const void *)mm_fast_kernel<R, V, K>,                               \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        FaultTab ftk = ft;                                                                                      \
+        if (!have)                                                                                              \
+            ftk.list = nullptr, ftk.range = nullptr;                                                            \
         hipLaunchKernelGGL((mm_fast_kernel<R, V, K>), dim3(g.nblocks), block, lds, c->stream, d_f, d_s, d_r, g, \
-                           ctr, have ? ft.range : (const uint2 *)nullptr, d_detected);                          \
+                           ctr, ftk, d_detected);                                                               \
     } while (0)
 #define LAUNCH_FAST_K(R, V)                                                                                     \
     do {                                                                                                        \
@@ -852,7 +856,12 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
             generalBlocks = g.nblocks;                                                                          \
             fastBlocks = 0;                                                                                     \
         } else {                                                                                                \
-            const bool sideGeneral = have && nFaultBlocks;                                                      \
+            /* side 256 on the VALU engine (COAST_MM_ENGINE=valu): the specialised kernel keeps its register budget, armed  */ \
+            /* workgroups go to the stepwise kernel on the side stream; every other side: mm_fast_kernel walks them itself  */ \
+            const bool fast256 = n == 256 && g.rs == Mm256<R>::RS && g.bpm == Mm256<R>::BPM;                    \
+            const bool sideGeneral = have && nFaultBlocks && fast256;                                           \
+            if (have && nFaultBlocks && !fast256)                                                               \
+                hookedBlocks = nFaultBlocks;                                                                    \
             if (sideGeneral) { /* faulted workgroups: stepwise kernel on the side stream, beside the fast one */ \
                 HIP_TRY(c, hipEventRecord(c->evMainReady, c->stream));                                          \
                 HIP_TRY(c, hipStreamWaitEvent(c->side, c->evMainReady, 0));                                     \
@@ -862,7 +871,7 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
                 generalBlocks = nFaultBlocks;                                                                   \
                 fastBlocks = g.nblocks - nFaultBlocks;                                                          \
             }                                                                                                   \
-            if (n == 256 && g.rs == Mm256<R>::RS && g.bpm == Mm256<R>::BPM)                                    \
+            if (fast256)                                                                                        \
                 hipLaunchKernelGGL(mm_fast256_kernel<R>, dim3(g.nblocks), block, Mm256<R>::LDS_BYTES, c->stream, \
                                    d_f, d_s, d_r, g, ctr, have ? ft.range : (const uint2 *)nullptr, d_detected); \
             else if ((n & 3) == 0)                                                                              \
@@ -882,6 +891,7 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
 #undef LAUNCH_FAST
 #undef LAUNCH_FAST_K
 #undef LAUNCH_MM
+    c->last.hooked_blocks = hookedBlocks;
     return after_launch(c, have, engine, generalBlocks, fastBlocks, 12.0 * (double)n * (double)n * (double)batch);
 }
 

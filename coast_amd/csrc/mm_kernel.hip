@@ -152,10 +152,15 @@ __device__ __forceinline__ void mac16_u64(unsigned long long (&acc)[16], const u
 // VEC: n % 4 == 0, every panel row is 16-byte aligned (the bench shape); !VEC handles ragged sides (9, 19, 30 ...).
 // KT: the k-chunk as a compile-time constant so the MAC loop is fully unrolled and the LDS reads of step kk+1 are
 // issued under the 16 MACs of step kk.
+// one workgroup, a k step at a time, with the injector hooks and the optional accumulator votes (defined below)
+template <int NREP>
+__device__ __forceinline__ void mm_stepwise_body(const uint32_t *__restrict__ F, const uint32_t *__restrict__ S,
+                                                 uint32_t *__restrict__ R, const MmGeom &g, uint32_t syncEvery, const Counters &ctr,
+                                                 const FaultTab &ft, uint32_t lb, uint8_t *__restrict__ detected);
+
 template <int NREP, bool VEC, int KT>
 __global__ __launch_bounds__(256) void mm_fast_kernel(const uint32_t *__restrict__ F, const uint32_t *__restrict__ S,
-                                                      uint32_t *__restrict__ R, MmGeom g, Counters ctr,
-                                                      const uint2 *__restrict__ faultRange,
+                                                      uint32_t *__restrict__ R, MmGeom g, Counters ctr, FaultTab ft,
                                                       uint8_t *__restrict__ detected)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -163,8 +168,12 @@ __global__ __launch_bounds__(256) void mm_fast_kernel(const uint32_t *__restrict
     uint32_t *sCnt = smem + 2 * panel;
 
     const uint32_t lb = xcd_logical_block(blockIdx.x, g.nblocks);
-    if (faultRange && faultRange[lb].y != 0u)
-        return; // an armed fault points into this workgroup: mm_general_kernel owns it
+    if (ft.range && ft.range[lb].y != 0u) {
+        // round 3: a workgroup that owns an armed upset walks its k steps with the injector hooks HERE (same LDS budget, same
+        // geometry, and the same mm_epilogue: voter, stores, counters) instead of leaving them to a twin launch on the side stream
+        mm_stepwise_body<NREP>(F, S, R, g, 0u, ctr, ft, lb, detected);
+        return;
+    }
     const MmLane<NREP> L(g, lb);
     const int tid = threadIdx.x;
     const int n = g.n;
@@ -419,18 +428,15 @@ __global__ __launch_bounds__(256) void mm_fast256_kernel(const uint32_t *__restr
 
 // ------------------------------------------------------------------------------------------------ general path
 template <int NREP>
-__global__ __launch_bounds__(256) void mm_general_kernel(const uint32_t *__restrict__ F, const uint32_t *__restrict__ S,
-                                                         uint32_t *__restrict__ R, MmGeom g, uint32_t syncEvery,
-                                                         Counters ctr, FaultTab ft,
-                                                         const uint32_t *__restrict__ blockList,
-                                                         uint8_t *__restrict__ detected)
+__device__ __forceinline__ void mm_stepwise_body(const uint32_t *__restrict__ F, const uint32_t *__restrict__ S,
+                                                 uint32_t *__restrict__ R, const MmGeom &g, uint32_t syncEvery, const Counters &ctr,
+                                                 const FaultTab &ft, uint32_t lb, uint8_t *__restrict__ detected)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *As = smem;                 // [kt][rs]   f panel, k-major
     uint32_t *Bs = smem + g.kt * g.rs;   // [kt][npad] s panel
     uint32_t *sCnt = smem + 2 * g.kt * (g.rs + g.npad);
 
-    const uint32_t lb = blockList ? blockList[blockIdx.x] : blockIdx.x;
     MmLane<NREP> L(g, lb);
     L.lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
     const LaneMap<NREP> &lm = L.lm;
@@ -549,6 +555,16 @@ __global__ __launch_bounds__(256) void mm_general_kernel(const uint32_t *__restr
     mm_epilogue<NREP>(acc, L, g, R + L.mat * nn, tl, detected, L.mat * nn, sCnt, ctr);
 }
 
+
+template <int NREP>
+__global__ __launch_bounds__(256) void mm_general_kernel(const uint32_t *__restrict__ F, const uint32_t *__restrict__ S,
+                                                         uint32_t *__restrict__ R, MmGeom g, uint32_t syncEvery,
+                                                         Counters ctr, FaultTab ft,
+                                                         const uint32_t *__restrict__ blockList,
+                                                         uint8_t *__restrict__ detected)
+{
+    mm_stepwise_body<NREP>(F, S, R, g, syncEvery, ctr, ft, blockList ? blockList[blockIdx.x] : blockIdx.x, detected);
+}
 
 // ------------------------------------------------------------------------------------------------ counters inside the sphere of replication
 // matrix_multiply with its three loops as written (mm_common_tmr.c:3-20), for COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC: the work

@@ -105,6 +105,9 @@ def test_mm_faults_vs_oracle(eng, orc, n, batch, replicas, sync_every):
     assert (got == exp_r).all()
     assert _stats3(eng.stats()) == exp_st
     assert (det.cpu().numpy() == exp_det).all()
+    if sync_every == 0 and k:  # round 3: the armed workgroups walk their k steps inside mm_fast_kernel, no side-stream twin
+        li = eng.last_launch()
+        assert li["engine"] == "valu" and li["general_blocks"] == 0 and li["hooked_blocks"] > 0, li
     # the table is consumed by exactly one launch: the next one is clean
     eng.reset_stats()
     got = _host(eng.mm_batch(_dev(f), _dev(s), cfg=coast_amd.XmrConfig(replicas, sync_every)), np.uint32)
