@@ -71,18 +71,14 @@ __global__ __launch_bounds__(256) void cache_test_kernel(uint32_t *__restrict__ 
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
     LaneMap<NREP> lm;
     lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
-    // main launch (tileList == nullptr): every tile except those an armed fault points into; side launch: exactly those,
-    // element by element with the injector hooks, next to the main one (disjoint arrays)
+    // one launch covers every tile (round 3): a tile an armed fault points into is walked element by element with the injector
+    // hooks by its own wave (wave-uniform branch below) -- rounds 1-2 ran those tiles as a second launch on the side stream
     const uint64_t widx = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint64_t tile = tileList ? (widx < nListed ? tileList[widx] : ntiles) : widx;
-    bool tileOk = tile < ntiles;
+    const bool tileOk = tile < ntiles;
     uint2 fr = make_uint2(0u, 0u);
     if (ft.range && tileOk)
         fr = ft.range[tile];
-    if (!tileList && fr.y != 0u) { // the side launch owns this tile
-        tileOk = false;
-        fr = make_uint2(0u, 0u);
-    }
     const int slot = lm.q;
     const uint64_t item = tile * IPW + (uint64_t)slot;
     const bool live = tileOk && lm.live && item < narrays;
