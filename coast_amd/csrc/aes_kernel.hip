@@ -233,7 +233,7 @@ __device__ __forceinline__ uint2 aes_tile_faults(const FaultTab &ft, uint64_t ti
 template <int NREP>
 __global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
                                                               uint64_t nblocksData, uint64_t ntiles, Counters ctr,
-                                                              FaultTab ft, uint8_t *__restrict__ detected)
+                                                              FaultTab ft, uint8_t *__restrict__ detected, size_t copyBytes = 0)
 {
     __shared__ uint32_t sTe[4][256];
     __shared__ uint8_t sSb[256];
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restric
     const bool live = !skip && lm.live && item < nblocksData;
     const bool cnt = live && lm.r == 0;
     const uint64_t it = live ? item : 0;
-    uint4 sv = reinterpret_cast<const uint4 *>(states)[it];
-    uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
+    uint4 sv = reinterpret_cast<const uint4 *>(states + (size_t)lm.r * copyBytes)[it];
+    uint4 kv = reinterpret_cast<const uint4 *>(keys + (size_t)lm.r * copyBytes)[it];
     uint32_t s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w; // column c = state[4c..4c+3], row r in bits 8r
     uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
 
@@ -325,9 +325,11 @@ __global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restric
     k2 = xmr_sync<NREP>(k2, lm, cnt, tl);
     k3 = xmr_sync<NREP>(k3, lm, cnt, tl);
     uint32_t detItems = 0;
+    if (cnt || (live && copyBytes != 0)) { // memory copies: every replica stores the voted state / key into its own copy
+        reinterpret_cast<uint4 *>(states + (size_t)lm.r * copyBytes)[item] = make_uint4(s0, s1, s2, s3);
+        reinterpret_cast<uint4 *>(keys + (size_t)lm.r * copyBytes)[item] = make_uint4(k0, k1, k2, k3);
+    }
     if (cnt) {
-        reinterpret_cast<uint4 *>(states)[item] = make_uint4(s0, s1, s2, s3);
-        reinterpret_cast<uint4 *>(keys)[item] = make_uint4(k0, k1, k2, k3);
         if (tl.det) { // unequal copies seen at a sync point of this block (DWC: detected, TMR: corrected)
             if (NREP == 2)
                 detItems = 1;
@@ -376,7 +378,7 @@ __device__ __forceinline__ uint32_t aes_imc_col(uint32_t x) // InvMixColumns of 
 template <int NREP>
 __global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
                                                               uint64_t nblocksData, uint64_t ntiles, Counters ctr,
-                                                              FaultTab ft, uint8_t *__restrict__ detected)
+                                                              FaultTab ft, uint8_t *__restrict__ detected, size_t copyBytes = 0)
 {
     __shared__ uint32_t sTd[4][256];
     __shared__ uint32_t sTis[4][256];
@@ -404,8 +406,8 @@ __global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restric
     const bool live = !skip && lm.live && item < nblocksData;
     const bool cnt = live && lm.r == 0;
     const uint64_t it = live ? item : 0;
-    const uint4 sv = reinterpret_cast<const uint4 *>(states)[it];
-    const uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
+    const uint4 sv = reinterpret_cast<const uint4 *>(states + (size_t)lm.r * copyBytes)[it];
+    const uint4 kv = reinterpret_cast<const uint4 *>(keys + (size_t)lm.r * copyBytes)[it];
     uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
     uint32_t x0, x1, x2, x3; // the state; after the loop: the plaintext columns
 
@@ -499,9 +501,11 @@ __global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restric
     k2 = xmr_sync<NREP>(k2, lm, cnt, tl);
     k3 = xmr_sync<NREP>(k3, lm, cnt, tl);
     uint32_t detItems = 0;
+    if (cnt || (live && copyBytes != 0)) { // memory copies: every replica stores the voted state / key into its own copy
+        reinterpret_cast<uint4 *>(states + (size_t)lm.r * copyBytes)[item] = make_uint4(s0, s1, s2, s3);
+        reinterpret_cast<uint4 *>(keys + (size_t)lm.r * copyBytes)[item] = make_uint4(k0, k1, k2, k3);
+    }
     if (cnt) {
-        reinterpret_cast<uint4 *>(states)[item] = make_uint4(s0, s1, s2, s3);
-        reinterpret_cast<uint4 *>(keys)[item] = make_uint4(k0, k1, k2, k3);
         if (tl.det) {
             if (NREP == 2)
                 detItems = 1;
@@ -563,7 +567,7 @@ __device__ __forceinline__ uint32_t aes_rotl8(uint32_t x, int bytes) { return __
 template <int NREP>
 __global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
                                                                         uint64_t nblocksData, uint64_t ntiles, Counters ctr,
-                                                                        FaultTab ft, uint8_t *__restrict__ detected)
+                                                                        FaultTab ft, uint8_t *__restrict__ detected, size_t copyBytes = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smemAes[];
     uint32_t *sT = reinterpret_cast<uint32_t *>(smemAes);
@@ -593,8 +597,8 @@ __global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8
         const bool live = lm.live && item < nblocksData;
         const bool cnt = live && lm.r == 0;
         const uint64_t it = live ? item : 0;
-        const uint4 sv = reinterpret_cast<const uint4 *>(states)[it];
-        const uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
+        const uint4 sv = reinterpret_cast<const uint4 *>(states + (size_t)lm.r * copyBytes)[it];
+        const uint4 kv = reinterpret_cast<const uint4 *>(keys + (size_t)lm.r * copyBytes)[it];
         uint32_t s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w;
         uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
         auto rounds = [&](auto hookTag) __attribute__((always_inline)) { // as aes128_enc_fast_kernel, HOOKED included
@@ -677,9 +681,11 @@ __global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8
         k3 = xmr_sync<NREP>(k3, lm, cnt, te);
         tl.miss = te.miss;
         tl.syncs = te.syncs;
+        if (cnt || (live && copyBytes != 0)) {
+            reinterpret_cast<uint4 *>(states + (size_t)lm.r * copyBytes)[item] = make_uint4(s0, s1, s2, s3);
+            reinterpret_cast<uint4 *>(keys + (size_t)lm.r * copyBytes)[item] = make_uint4(k0, k1, k2, k3);
+        }
         if (cnt) {
-            reinterpret_cast<uint4 *>(states)[item] = make_uint4(s0, s1, s2, s3);
-            reinterpret_cast<uint4 *>(keys)[item] = make_uint4(k0, k1, k2, k3);
             if (te.det) {
                 if (NREP == 2)
                     detItems += 1;
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8
 template <int NREP>
 __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
                                                                         uint64_t nblocksData, uint64_t ntiles, Counters ctr,
-                                                                        FaultTab ft, uint8_t *__restrict__ detected)
+                                                                        FaultTab ft, uint8_t *__restrict__ detected, size_t copyBytes = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smemAes[];
     uint2 *sDR = reinterpret_cast<uint2 *>(smemAes);                      // {Td_0[v], rsbox[v] x 4}
@@ -735,8 +741,8 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
         const bool live = lm.live && item < nblocksData;
         const bool cnt = live && lm.r == 0;
         const uint64_t it = live ? item : 0;
-        const uint4 sv = reinterpret_cast<const uint4 *>(states)[it];
-        const uint4 kv = reinterpret_cast<const uint4 *>(keys)[it];
+        const uint4 sv = reinterpret_cast<const uint4 *>(states + (size_t)lm.r * copyBytes)[it];
+        const uint4 kv = reinterpret_cast<const uint4 *>(keys + (size_t)lm.r * copyBytes)[it];
         uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
         uint32_t x0, x1, x2, x3;
         auto rounds = [&](auto hookTag) __attribute__((always_inline)) { // as aes128_dec_fast_kernel, HOOKED included
@@ -813,9 +819,11 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
         k3 = xmr_sync<NREP>(k3, lm, cnt, te);
         tl.miss = te.miss;
         tl.syncs = te.syncs;
+        if (cnt || (live && copyBytes != 0)) {
+            reinterpret_cast<uint4 *>(states + (size_t)lm.r * copyBytes)[item] = make_uint4(s0, s1, s2, s3);
+            reinterpret_cast<uint4 *>(keys + (size_t)lm.r * copyBytes)[item] = make_uint4(k0, k1, k2, k3);
+        }
         if (cnt) {
-            reinterpret_cast<uint4 *>(states)[item] = make_uint4(s0, s1, s2, s3);
-            reinterpret_cast<uint4 *>(keys)[item] = make_uint4(k0, k1, k2, k3);
             if (te.det) {
                 if (NREP == 2)
                     detItems += 1;

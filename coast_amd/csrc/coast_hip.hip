@@ -115,15 +115,23 @@ int fail(coast_ctx *ctx, int code, const char *fmt, ...)
 unsigned long long *totals_of(coast_ctx *c) { return c->dBound ? c->dBound : c->dTotals; }
 
 // `indexedOk`: this kernel implements the index-in-the-sphere-of-replication flags (mm, sha256, crc16)
-int check_cfg(coast_ctx *ctx, const coast_cfg *cfg, bool indexedOk = false)
+int check_cfg(coast_ctx *ctx, const coast_cfg *cfg, bool indexedOk = false, bool copiesOk = false)
 {
     if (!ctx)
         return COAST_EINVAL;
     if (!cfg || cfg->replicas < 1 || cfg->replicas > 3)
         return fail(ctx, COAST_EINVAL, "coast_cfg.replicas must be 1 (none), 2 (DWC) or 3 (TMR)");
     const uint32_t indexed = COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC | COAST_F_NO_LOAD_SYNC | COAST_F_NO_STORE_ADDR_SYNC;
-    if (cfg->flags & ~((uint32_t)COAST_F_NO_STORE_DATA_SYNC | indexed))
+    if (cfg->flags & ~((uint32_t)COAST_F_NO_STORE_DATA_SYNC | indexed | (uint32_t)COAST_F_MEMORY_COPIES))
         return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: unknown bits", cfg->flags);
+    if (cfg->flags & COAST_F_MEMORY_COPIES) {
+        if (!copiesOk)
+            return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: COAST_F_MEMORY_COPIES is implemented for sha256, aes128 and crc16",
+                        cfg->flags);
+        if (cfg->flags != COAST_F_MEMORY_COPIES || cfg->sync_every)
+            return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: COAST_F_MEMORY_COPIES runs on the lean kernels: no sync_every, no "
+                                           "other flag", cfg->flags);
+    }
     if ((cfg->flags & indexed) && !indexedOk)
         return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC are implemented for mm, sha256 "
                                        "and crc16 (quicksort votes its indices by default)", cfg->flags);

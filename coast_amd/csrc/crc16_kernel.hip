@@ -178,7 +178,7 @@ template <int NREP, int NT, bool ALIGNED, int THREADS = kCrcStreamThreads, int H
 __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
     const uint8_t *__restrict__ data, uint32_t blockLen, uint64_t nblocksData, uint16_t *__restrict__ crcs,
     const uint16_t *__restrict__ t16g, uint64_t ntiles, uint64_t ntilesWalk, Counters ctr, FaultTab ft,
-    uint8_t *__restrict__ detected)
+    uint8_t *__restrict__ detected, size_t copyIn = 0, size_t copyOut = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smemRaw[];
     uint16_t *T = reinterpret_cast<uint16_t *>(smemRaw);
@@ -246,7 +246,8 @@ __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
             liveT[j] = !skip && lm.live && itemT[j] < nblocksData;
             cntT[j] = liveT[j] && lm.r == 0;
             // the lookup walk of a lane that has no block of its own (or whose tile is walked byte by byte) reads row 0
-            const uint8_t *row = data + ((liveT[j] && !slowT[j]) ? itemT[j] : 0) * (uint64_t)blockLen;
+            // (copyIn != 0: COAST_F_MEMORY_COPIES -- NREP copies of the stream back to back, replica r walks copy r)
+            const uint8_t *row = data + (size_t)lm.r * copyIn + ((liveT[j] && !slowT[j]) ? itemT[j] : 0) * (uint64_t)blockLen;
             const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(row) & 3u);
             p[j] = row - sh;
             sel[j] = crc_perm_sel(sh);
@@ -409,16 +410,17 @@ __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
                     fr.x = __builtin_amdgcn_readfirstlane(rg.x);
                     fr.y = __builtin_amdgcn_readfirstlane(rg.y);
                 }
-                crc[j] = crc16_bytes_hooked(data + (liveT[j] ? itemT[j] : 0) * (uint64_t)blockLen, liveT[j] ? blockLen : 0u, ft,
-                                            fr, lm.q, lm.r, lm.live);
+                crc[j] = crc16_bytes_hooked(data + (size_t)lm.r * copyIn + (liveT[j] ? itemT[j] : 0) * (uint64_t)blockLen,
+                                            liveT[j] ? blockLen : 0u, ft, fr, lm.q, lm.r, lm.live);
             }
             Tally te = tl;
             te.det = 0;
             const uint32_t voted = xmr_sync<NREP>(crc[j], lm, cntT[j], te); // return-value sync
             tl.miss = te.miss;
             tl.syncs = te.syncs;
+            if (cntT[j] || (liveT[j] && copyOut != 0)) // memory copies: every replica stores the voted crc into its own result copy
+                crcs[(size_t)lm.r * copyOut + itemT[j]] = (uint16_t)(NREP == 3 ? voted : crc[j]);
             if (cntT[j]) {
-                crcs[itemT[j]] = (uint16_t)voted;
                 if (te.det) { // unequal copies at the sync point of this block (DWC: detected, TMR: corrected)
                     if (NREP == 2)
                         detItems += 1;

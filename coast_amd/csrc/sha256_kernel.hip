@@ -226,8 +226,11 @@ template <int NREP, bool VEC16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void sha256_fast_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
                                                           uint64_t nmsgs, uint8_t *__restrict__ digests,
                                                           uint64_t ntiles, Counters ctr, FaultTab ft,
-                                                          uint8_t *__restrict__ detected)
+                                                          uint8_t *__restrict__ detected, size_t copyIn = 0, size_t copyOut = 0)
 {
+    // copyIn / copyOut != 0: COAST_F_MEMORY_COPIES -- the message array and the digest array are NREP copies back to back (that many
+    // bytes apart); replica r loads from copy r and stores the voted digest into copy r (the reference's memory-replicated mode with
+    // -storeDataSync: dataflowProtection.cpp:14-18, synchronization.cpp:197-224).  0: one memory copy, replica 0 stores.
     __shared__ uint32_t sCnt[4];
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
     const LaneMap<NREP> lm;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint64_t item = tile * IPW + (uint64_t)lm.q;
     const bool live = !skip && lm.live && item < nmsgs;
     const bool cnt = live && lm.r == 0;
-    const uint8_t *msg = msgs + (live ? item : 0) * stride;
+    const uint8_t *msg = msgs + (size_t)lm.r * copyIn + (live ? item : 0) * stride;
 
     uint32_t st[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au,
                       0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u}; // :107-114
@@ -298,9 +301,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         dg[w] = bswap32(xmr_sync<NREP>(st[w], lm, cnt, tl)); // digest words voted before the store (:169-178)
 
     uint32_t detItems = 0;
-    if (cnt) {
-        uint8_t *out = digests + item * 32u;
-        if ((reinterpret_cast<uintptr_t>(digests) & 15u) == 0u) {
+    if (cnt || (live && copyOut != 0)) { // one memory copy: the original store (replica 0); memory copies: every replica into its own
+        uint8_t *out = digests + (size_t)lm.r * copyOut + item * 32u;
+        if ((reinterpret_cast<uintptr_t>(out) & 15u) == 0u) {
             reinterpret_cast<uint4 *>(out)[0] = make_uint4(dg[0], dg[1], dg[2], dg[3]);
             reinterpret_cast<uint4 *>(out)[1] = make_uint4(dg[4], dg[5], dg[6], dg[7]);
         } else {
@@ -310,12 +313,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 for (int b = 0; b < 4; ++b)
                     out[4 * w + b] = (uint8_t)(dg[w] >> (8 * b));
         }
-        if (tl.det) { // unequal copies seen at a sync point of this message (DWC: detected, TMR: corrected)
-            if (NREP == 2)
-                detItems = 1;
-            if (detected)
-                detected[item] = 1;
-        }
+    }
+    if (cnt && tl.det) { // unequal copies seen at a sync point of this message (DWC: detected, TMR: corrected)
+        if (NREP == 2)
+            detItems = 1;
+        if (detected)
+            detected[item] = 1;
     }
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
 }

@@ -16,7 +16,8 @@ from . import _lib
 
 TMR, DWC, UNPROTECTED = 3, 2, 1
 F_NO_STORE_DATA_SYNC = 1  # coast_cfg.flags: the reference's -noStoreDataSync (include/coast_hip.h)
-F_BRANCH_SYNC, F_ADDR_SYNC, F_NO_LOAD_SYNC, F_NO_STORE_ADDR_SYNC = 2, 4, 8, 16  # counters inside the SoR (sha256, crc16)
+F_BRANCH_SYNC, F_ADDR_SYNC, F_NO_LOAD_SYNC, F_NO_STORE_ADDR_SYNC = 2, 4, 8, 16  # counters inside the SoR (mm, sha256, crc16)
+F_MEMORY_COPIES = 32  # sha256 / aes128 / crc16: arrays hold `replicas` copies back to back; loads per copy, voted stores into every copy
 
 
 @dataclass(frozen=True)
@@ -129,31 +130,39 @@ class Engine:
         return out
 
     def sha256_batch(self, msgs, length, out=None, cfg: XmrConfig = XmrConfig(), detected=None):
-        """msgs: (n_msgs, stride) uint8 on the GPU; message m = first `length` bytes of row m."""
-        assert msgs.is_cuda and msgs.dtype == torch.uint8 and msgs.dim() == 2 and msgs.is_contiguous()
-        n, stride = msgs.shape
+        """msgs: (n_msgs, stride) uint8 on the GPU; message m = first `length` bytes of row m.  With F_MEMORY_COPIES in cfg.flags:
+        (replicas, n_msgs, stride) -- replica r hashes copy r, the voted digests come back as (replicas, n_msgs, 32)."""
+        copies = bool(cfg.flags & F_MEMORY_COPIES)
+        assert msgs.is_cuda and msgs.dtype == torch.uint8 and msgs.dim() == (3 if copies else 2) and msgs.is_contiguous()
+        assert not copies or msgs.shape[0] == cfg.replicas
+        n, stride = msgs.shape[-2:]
         if out is None:
-            out = torch.empty((n, 32), dtype=torch.uint8, device=msgs.device)
+            out = torch.empty((cfg.replicas, n, 32) if copies else (n, 32), dtype=torch.uint8, device=msgs.device)
         cc = cfg.c()
         self._check(self._lib.coast_sha256_batch(self._h, _ptr(msgs), stride, length, n, _ptr(out), C.byref(cc),
                                                  _ptr(detected) if detected is not None else None))
         return out
 
     def aes128_batch(self, states, keys, direction, cfg: XmrConfig = XmrConfig(DWC), detected=None):
-        """states, keys: (n, 16) uint8 on the GPU, both updated IN PLACE (reference contract)."""
+        """states, keys: (n, 16) uint8 on the GPU, both updated IN PLACE (reference contract); with F_MEMORY_COPIES in cfg.flags
+        both are (replicas, n, 16): replica r works on copy r, the voted state / key is stored into every copy."""
         assert states.is_cuda and keys.is_cuda and states.dtype == torch.uint8 and keys.dtype == torch.uint8
-        assert states.shape == keys.shape and states.shape[1] == 16 and states.is_contiguous() and keys.is_contiguous()
+        assert states.shape == keys.shape and states.shape[-1] == 16 and states.is_contiguous() and keys.is_contiguous()
+        assert states.dim() == (3 if cfg.flags & F_MEMORY_COPIES else 2)
         cc = cfg.c()
-        self._check(self._lib.coast_aes128_batch(self._h, _ptr(states), _ptr(keys), states.shape[0], int(direction),
+        self._check(self._lib.coast_aes128_batch(self._h, _ptr(states), _ptr(keys), states.shape[-2], int(direction),
                                                  C.byref(cc), _ptr(detected) if detected is not None else None))
         return states, keys
 
     def crc16_batch(self, data, block_len, out=None, cfg: XmrConfig = XmrConfig(), detected=None):
-        """data: uint8 tensor holding n_blocks * block_len bytes.  Returns (n_blocks,) crcs as int16 bit patterns."""
+        """data: uint8 tensor holding n_blocks * block_len bytes.  Returns (n_blocks,) crcs as int16 bit patterns.  With
+        F_MEMORY_COPIES in cfg.flags: (replicas, n_blocks * block_len) -- replica r walks copy r -- and (replicas, n_blocks) crcs."""
         assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
-        nb = data.numel() // block_len if block_len else data.shape[0]
+        copies = bool(cfg.flags & F_MEMORY_COPIES)
+        total = data.numel() // (cfg.replicas if copies else 1)
+        nb = total // block_len if block_len else data.shape[0]
         if out is None:
-            out = torch.empty(nb, dtype=torch.int16, device=data.device)
+            out = torch.empty((cfg.replicas, nb) if copies else nb, dtype=torch.int16, device=data.device)
         cc = cfg.c()
         self._check(self._lib.coast_crc16_batch(self._h, _ptr(data), block_len, nb, _ptr(out), C.byref(cc),
                                                 _ptr(detected) if detected is not None else None))

@@ -335,10 +335,11 @@ static inline uint32_t rotr(uint32_t x, unsigned n) { return (x >> n) | (x << (3
 
 /* sha256_transform (sha256_common_tmr.c:27-98) on nrep register copies; `blk` is the single memory copy of the
  * 64-byte block.  `cidx` numbers the compressions of this message for the fault steps. */
-static void sha_compress(uint32_t st[3][8], const uint8_t *blk, unsigned nrep, uint32_t cidx, const orc_fault *fl,
-                         size_t nf)
+static void sha_compress3(uint32_t st[3][8], const uint8_t *const blk3[3], unsigned nrep, uint32_t cidx, const orc_fault *fl,
+                          size_t nf)
 {
     for (unsigned r = 0; r < nrep; ++r) {
+        const uint8_t *blk = blk3[r]; /* memory-copies mode: replica r loads from its own copy */
         uint32_t m[64], v[8];
         for (unsigned t = 0; t < 64; ++t) {
             if (t < 16) {
@@ -381,6 +382,12 @@ static void sha_compress(uint32_t st[3][8], const uint8_t *blk, unsigned nrep, u
     }
 }
 
+static void sha_compress(uint32_t st[3][8], const uint8_t *blk, unsigned nrep, uint32_t cidx, const orc_fault *fl, size_t nf)
+{
+    const uint8_t *const b3[3] = {blk, blk, blk};
+    sha_compress3(st, b3, nrep, cidx, fl, nf);
+}
+
 static void sha_state_faults(uint32_t st[3][8], unsigned nrep, uint32_t cidx, const orc_fault *fl, size_t nf)
 {
     for (size_t q = 0; q < nf; ++q)
@@ -401,11 +408,16 @@ static void sha_sync_state(sync_ctx *c, uint32_t st[3][8])
 
 /* sha256_hash (sha256_common_tmr.c:100-179): one-shot hash of `len` bytes incl. padding; the bit length is
  * kept as two u32 exactly like DBL_INT_ADD (:2-5). */
-static void sha_item(const uint8_t *data, uint32_t len, uint8_t hash[32], sync_ctx *c, const orc_fault *fl,
-                     size_t nf)
+/* data3[r] / hash3[r]: replica r's memory copy of the message / of the digest (all three the same pointer in the single-copy
+ * mode).  COAST_F_MEMORY_COPIES -- the reference's memory-replicated mode with -storeDataSync (dataflowProtection.cpp:14-18,
+ * synchronization.cpp:197-224): every clone loads from its own copy, the data of every store is voted, and every clone stores the
+ * voted value into its own copy. */
+static void sha_item3(const uint8_t *const data3[3], uint32_t len, uint8_t *const hash3[3], sync_ctx *c, const orc_fault *fl,
+                      size_t nf)
 {
     uint32_t st[3][8];
-    uint8_t buf[64];
+    uint8_t buf[3][64];
+    const uint8_t *const b3[3] = {buf[0], buf[1], buf[2]};
     uint32_t bitlen[2] = {0, 0};
     uint32_t datalen = 0, cidx = 0;
     const unsigned R = c->nrep;
@@ -414,10 +426,12 @@ static void sha_item(const uint8_t *data, uint32_t len, uint8_t hash[32], sync_c
             st[r][w] = SHA_IV[w];
 
     for (uint32_t i = 0; i < len; ++i) {
-        buf[datalen++] = data[i];
+        for (unsigned r = 0; r < 3; ++r)
+            buf[r][datalen] = data3[r][i];
+        ++datalen;
         if (datalen == 64) {
             sha_state_faults(st, R, cidx, fl, nf);
-            sha_compress(st, buf, R, cidx, fl, nf);
+            sha_compress3(st, b3, R, cidx, fl, nf);
             sha_sync_state(c, st);
             ++cidx;
             if (bitlen[0] > 0xffffffffu - 512u)
@@ -427,37 +441,49 @@ static void sha_item(const uint8_t *data, uint32_t len, uint8_t hash[32], sync_c
         }
     }
     uint32_t i = datalen;
+    for (unsigned r = 0; r < 3; ++r)
+        buf[r][i] = 0x80;
+    ++i;
     if (datalen < 56) {
-        buf[i++] = 0x80;
-        while (i < 56)
-            buf[i++] = 0;
+        for (unsigned r = 0; r < 3; ++r)
+            memset(buf[r] + i, 0, 56 - i);
     } else {
-        buf[i++] = 0x80;
-        while (i < 64)
-            buf[i++] = 0;
+        for (unsigned r = 0; r < 3; ++r)
+            memset(buf[r] + i, 0, 64 - i);
         sha_state_faults(st, R, cidx, fl, nf);
-        sha_compress(st, buf, R, cidx, fl, nf);
+        sha_compress3(st, b3, R, cidx, fl, nf);
         sha_sync_state(c, st);
         ++cidx;
-        memset(buf, 0, 56);
+        for (unsigned r = 0; r < 3; ++r)
+            memset(buf[r], 0, 56);
     }
     if (bitlen[0] > 0xffffffffu - datalen * 8u)
         ++bitlen[1];
     bitlen[0] += datalen * 8u;
-    for (unsigned b = 0; b < 4; ++b) {
-        buf[63 - b] = (uint8_t)(bitlen[0] >> (8 * b));
-        buf[59 - b] = (uint8_t)(bitlen[1] >> (8 * b));
-    }
+    for (unsigned r = 0; r < 3; ++r)
+        for (unsigned b = 0; b < 4; ++b) {
+            buf[r][63 - b] = (uint8_t)(bitlen[0] >> (8 * b));
+            buf[r][59 - b] = (uint8_t)(bitlen[1] >> (8 * b));
+        }
     sha_state_faults(st, R, cidx, fl, nf);
-    sha_compress(st, buf, R, cidx, fl, nf);
+    sha_compress3(st, b3, R, cidx, fl, nf);
     sha_sync_state(c, st);
     ++cidx;
 
     sha_state_faults(st, R, cidx, fl, nf); /* step == ncompress: between the last compression and the digest */
     sha_sync_state(c, st);                 /* digest words voted before the store, :169-178 */
-    for (unsigned w = 0; w < 8; ++w)
-        for (unsigned b = 0; b < 4; ++b)
-            hash[4 * w + b] = (uint8_t)(st[0][w] >> (24 - 8 * b));
+    for (unsigned r = 0; r < 3; ++r)
+        if (r == 0 || (r < R && hash3[r] != hash3[0]))
+            for (unsigned w = 0; w < 8; ++w)
+                for (unsigned b = 0; b < 4; ++b)
+                    hash3[r][4 * w + b] = (uint8_t)(st[r][w] >> (24 - 8 * b));
+}
+
+static void sha_item(const uint8_t *data, uint32_t len, uint8_t hash[32], sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    const uint8_t *const d3[3] = {data, data, data};
+    uint8_t *const h3[3] = {hash, hash, hash};
+    sha_item3(d3, len, h3, c, fl, nf);
 }
 
 /* A sync point on a GEP offset (syncGEP, synchronization.cpp:413-474): the voted value replaces the offset operand of the
@@ -586,10 +612,17 @@ void orc_sha256_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nms
         while (fe < nfaults && fs[fe].item == m)
             ++fe;
         c.detected = 0;
-        if (cfg->flags & ORC_F_INDEXED)
+        if (cfg->flags & ORC_F_INDEXED) {
             sha_item_indexed(msgs + m * stride, len, digests + 32 * m, &c, fs + fp, fe - fp);
-        else
+        } else if (cfg->flags & ORC_F_MEMORY_COPIES) { /* the arrays are `replicas` copies back to back */
+            const size_t cin = nmsgs * stride, cout = nmsgs * 32;
+            const unsigned R = cfg->replicas;
+            const uint8_t *const d3[3] = {msgs + m * stride, msgs + (R > 1 ? cin : 0) + m * stride, msgs + (R > 2 ? 2 * cin : 0) + m * stride};
+            uint8_t *const h3[3] = {digests + 32 * m, digests + (R > 1 ? cout : 0) + 32 * m, digests + (R > 2 ? 2 * cout : 0) + 32 * m};
+            sha_item3(d3, len, h3, &c, fs + fp, fe - fp);
+        } else {
             sha_item(msgs + m * stride, len, digests + 32 * m, &c, fs + fp, fe - fp);
+        }
         if (c.detected) {
             st->dwc_detected += (cfg->replicas == 2);
             if (detected)
@@ -764,14 +797,16 @@ static void aes_sync(sync_ctx *c, uint8_t s[3][16], uint8_t k[3][16])
         }
 }
 
-static void aes_item(uint8_t state[16], uint8_t key[16], int dir, sync_ctx *c, const orc_fault *fl, size_t nf)
+/* state3[r] / key3[r]: replica r's memory copy (all three the same pointer in the single-copy mode; ORC_F_MEMORY_COPIES: see
+ * sha_item3) */
+static void aes_item3(uint8_t *const state3[3], uint8_t *const key3[3], int dir, sync_ctx *c, const orc_fault *fl, size_t nf)
 {
     uint8_t s[3][16], k[3][16];
     const unsigned R = c->nrep;
     aes_tables();
     for (unsigned r = 0; r < 3; ++r) {
-        memcpy(s[r], state, 16);
-        memcpy(k[r], key, 16);
+        memcpy(s[r], state3[r], 16);
+        memcpy(k[r], key3[r], 16);
     }
     if (dir)
         for (unsigned r = 0; r < R; ++r) { /* :110-128 last encryption key, first AddRoundKey */
@@ -793,8 +828,17 @@ static void aes_item(uint8_t state[16], uint8_t key[16], int dir, sync_ctx *c, c
             for (int i = 0; i < 16; ++i)
                 s[r][i] ^= k[r][i];
     aes_sync(c, s, k);
-    memcpy(state, s[0], 16);
-    memcpy(key, k[0], 16);
+    for (unsigned r = 0; r < 3; ++r)
+        if (r == 0 || (r < R && state3[r] != state3[0])) {
+            memcpy(state3[r], s[r], 16);
+            memcpy(key3[r], k[r], 16);
+        }
+}
+
+static void aes_item(uint8_t state[16], uint8_t key[16], int dir, sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    uint8_t *const s3[3] = {state, state, state}, *const k3[3] = {key, key, key};
+    aes_item3(s3, k3, dir, c, fl, nf);
 }
 
 void orc_aes128_plain(uint8_t state[16], uint8_t key[16], uint8_t dir)
@@ -817,7 +861,15 @@ void orc_aes128_xmr(uint8_t *states, uint8_t *keys, size_t nblocks, int dir, con
         while (fe < nfaults && fs[fe].item == b)
             ++fe;
         c.detected = 0;
-        aes_item(states + 16 * b, keys + 16 * b, dir ? 1 : 0, &c, fs + fp, fe - fp);
+        if (cfg->flags & ORC_F_MEMORY_COPIES) { /* `replicas` copies of both arrays back to back */
+            const size_t cs = nblocks * 16;
+            const unsigned R = cfg->replicas;
+            uint8_t *const s3[3] = {states + 16 * b, states + (R > 1 ? cs : 0) + 16 * b, states + (R > 2 ? 2 * cs : 0) + 16 * b};
+            uint8_t *const k3[3] = {keys + 16 * b, keys + (R > 1 ? cs : 0) + 16 * b, keys + (R > 2 ? 2 * cs : 0) + 16 * b};
+            aes_item3(s3, k3, dir ? 1 : 0, &c, fs + fp, fe - fp);
+        } else {
+            aes_item(states + 16 * b, keys + 16 * b, dir ? 1 : 0, &c, fs + fp, fe - fp);
+        }
         if (c.detected) {
             st->dwc_detected += (cfg->replicas == 2);
             if (detected)
@@ -894,18 +946,22 @@ static uint16_t crc_item_branch(const uint8_t *data, uint32_t len, sync_ctx *c, 
     return (uint16_t)crc[0];
 }
 
-static uint16_t crc_item(const uint8_t *data, uint32_t len, sync_ctx *c, const orc_fault *fl, size_t nf)
+/* data3[r]: replica r's memory copy of the block (all three the same pointer in the single-copy mode; ORC_F_MEMORY_COPIES: see
+ * sha_item3).  The return value is the function's one sync point either way. */
+static uint16_t crc_item3(const uint8_t *const data3[3], uint32_t len, sync_ctx *c, const orc_fault *fl, size_t nf, uint32_t out[3])
 {
     uint32_t crc[3] = {0xFFFF, 0xFFFF, 0xFFFF};
     const unsigned R = c->nrep;
-    if (c->flags & ORC_F_BRANCH_SYNC)
-        return crc_item_branch(data, len, c, fl, nf);
+    if (c->flags & ORC_F_BRANCH_SYNC) {
+        out[0] = out[1] = out[2] = crc_item_branch(data3[0], len, c, fl, nf);
+        return (uint16_t)out[0];
+    }
     for (uint32_t t = 0; t < len; ++t) {
         for (unsigned r = 0; r < R; ++r) {
             for (size_t q = 0; q < nf; ++q)
                 if (fl[q].site == ORC_SITE_CRC_CRC && fl[q].step == t && fl[q].replica == r)
                     crc[r] = flip(crc[r], fl[q].bit, 0xffffu);
-            uint8_t x = (uint8_t)((crc[r] >> 8) ^ data[t]);
+            uint8_t x = (uint8_t)((crc[r] >> 8) ^ data3[r][t]);
             x ^= (uint8_t)(x >> 4);
             for (size_t q = 0; q < nf; ++q)
                 if (fl[q].site == ORC_SITE_CRC_X && fl[q].step == t && fl[q].replica == r)
@@ -920,7 +976,15 @@ static uint16_t crc_item(const uint8_t *data, uint32_t len, sync_ctx *c, const o
         if (fl[q].site == ORC_SITE_CRC_CRC && fl[q].step == len && fl[q].replica < R)
             crc[fl[q].replica] = flip(crc[fl[q].replica], fl[q].bit, 0xffffu);
     sync32(c, crc); /* return-value sync, synchronization.cpp:741-949 (ReturnInst) */
+    out[0] = crc[0], out[1] = crc[1], out[2] = crc[2];
     return (uint16_t)crc[0];
+}
+
+static uint16_t crc_item(const uint8_t *data, uint32_t len, sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    const uint8_t *const d3[3] = {data, data, data};
+    uint32_t out[3];
+    return crc_item3(d3, len, c, fl, nf, out);
 }
 
 void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint16_t *crcs, const orc_cfg *cfg,
@@ -936,7 +1000,18 @@ void orc_crc16_xmr(const uint8_t *data, uint32_t block_len, size_t nblocks, uint
         while (fe < nfaults && fs[fe].item == b)
             ++fe;
         c.detected = 0;
-        crcs[b] = crc_item(data + (size_t)b * block_len, block_len, &c, fs + fp, fe - fp);
+        if (cfg->flags & ORC_F_MEMORY_COPIES) { /* `replicas` copies of the stream (and of the result array) back to back */
+            const size_t cs = nblocks * (size_t)block_len;
+            const unsigned R = cfg->replicas;
+            const uint8_t *const d3[3] = {data + (size_t)b * block_len, data + (R > 1 ? cs : 0) + (size_t)b * block_len,
+                                          data + (R > 2 ? 2 * cs : 0) + (size_t)b * block_len};
+            uint32_t out[3];
+            crc_item3(d3, block_len, &c, fs + fp, fe - fp, out);
+            for (unsigned r = 0; r < R; ++r)
+                crcs[r * nblocks + b] = (uint16_t)out[r];
+        } else {
+            crcs[b] = crc_item(data + (size_t)b * block_len, block_len, &c, fs + fp, fe - fp);
+        }
         if (c.detected) {
             st->dwc_detected += (cfg->replicas == 2);
             if (detected)

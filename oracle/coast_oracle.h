@@ -111,7 +111,10 @@ enum {
     ORC_F_BRANCH_SYNC = 2u,        /* their branch conditions are voted (synchronization.cpp:146-155, 741-949) */
     ORC_F_ADDR_SYNC = 4u,          /* GEP offsets built from them are voted (:226-235, 333-372, 413-474) ... */
     ORC_F_NO_LOAD_SYNC = 8u,       /* ... except load addresses (-noLoadSync, :341-352) */
-    ORC_F_NO_STORE_ADDR_SYNC = 16u /* ... except store addresses (-noStoreAddrSync, :354-367) */
+    ORC_F_NO_STORE_ADDR_SYNC = 16u, /* ... except store addresses (-noStoreAddrSync, :354-367) */
+    /* the reference's memory-replicated mode with -storeDataSync (sha256 / aes / crc16): every array is `replicas` copies back
+     * to back, replica r loads from copy r, the data of every store is voted, every replica stores the voted value to its copy */
+    ORC_F_MEMORY_COPIES = 32u
 };
 #define ORC_F_INDEXED (ORC_F_BRANCH_SYNC | ORC_F_ADDR_SYNC)
 

@@ -114,6 +114,7 @@ def ref_chsha_vectors():
 
 
 REPLICA_ALL = 255  # include/coast_hip.h COAST_REPLICA_ALL
+F_MEMORY_COPIES = 32  # ORC_F_MEMORY_COPIES: arrays are (replicas, n, ...) -- replica r works on copy r, stores are voted into every copy
 
 
 def _faults(faults):
@@ -215,8 +216,11 @@ def mm_xmr_items(f, s, items, replicas=3, sync_every=0, faults=None, flags=0):
 def sha256_xmr(msgs, length, replicas=3, faults=None, flags=0):
     """msgs: (nmsgs, stride) uint8, each message = first `length` bytes of its row."""
     msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
-    nm, stride = msgs.shape
-    dig = np.empty((nm, 32), dtype=np.uint8)
+    copies = bool(flags & F_MEMORY_COPIES)  # msgs: (replicas, nmsgs, stride); the digests come back as (replicas, nmsgs, 32)
+    if copies:
+        assert msgs.ndim == 3 and msgs.shape[0] == replicas
+    nm, stride = msgs.shape[-2:]
+    dig = np.empty((replicas, nm, 32) if copies else (nm, 32), dtype=np.uint8)
     fl = _faults(faults)
     st = Stats()
     det = np.zeros(nm, dtype=np.uint8)
@@ -232,7 +236,9 @@ def aes128_xmr(states, keys, direction, replicas=2, sync_every=0, faults=None, f
     """states, keys: (n, 16) uint8; returns new (states, keys, stats, detected) -- inputs untouched."""
     s = np.array(states, dtype=np.uint8, copy=True, order="C")
     k = np.array(keys, dtype=np.uint8, copy=True, order="C")
-    n = s.shape[0]
+    if flags & F_MEMORY_COPIES:  # (replicas, n, 16) each
+        assert s.ndim == 3 and s.shape[0] == replicas and k.shape == s.shape
+    n = s.shape[-2]
     fl = _faults(faults)
     st = Stats()
     det = np.zeros(n, dtype=np.uint8)
@@ -244,10 +250,15 @@ def aes128_xmr(states, keys, direction, replicas=2, sync_every=0, faults=None, f
 
 def crc16_xmr(data, block_len, replicas=3, sync_every=0, faults=None, flags=0):
     """data: (nblocks, block_len) uint8."""
-    data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, max(block_len, 1))[:, :block_len]
-    data = np.ascontiguousarray(data)
-    nb = data.shape[0]
-    crcs = np.empty(nb, dtype=np.uint16)
+    copies = bool(flags & F_MEMORY_COPIES)  # data: (replicas, nblocks, block_len); crcs come back as (replicas, nblocks)
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    if copies:
+        assert data.ndim == 3 and data.shape[0] == replicas and data.shape[2] == block_len
+        nb = data.shape[1]
+    else:
+        data = np.ascontiguousarray(data.reshape(-1, max(block_len, 1))[:, :block_len])
+        nb = data.shape[0]
+    crcs = np.empty((replicas, nb) if copies else nb, dtype=np.uint16)
     fl = _faults(faults)
     st = Stats()
     det = np.zeros(nb, dtype=np.uint8)

@@ -35,13 +35,13 @@ template __global__ void mm_mfma_blk2_kernel<3, true>(MMARGS);
 template __global__ void mm_mfma_blk2_kernel<3, false>(MMARGS);
 template __global__ void mm_mfma_blk_kernel<3, true>(MMARGS);
 template __global__ void mm_mfma_blk_kernel<3, false>(MMARGS);
-#define AESARGS uint8_t *, uint8_t *, uint64_t, uint64_t, Counters, FaultTab, uint8_t *
+#define AESARGS uint8_t *, uint8_t *, uint64_t, uint64_t, Counters, FaultTab, uint8_t *, size_t
 template __global__ void aes128_enc_rep_kernel<2>(AESARGS);
 template __global__ void aes128_dec_rep_kernel<2>(AESARGS);
 template __global__ void aes128_enc_fast_kernel<3>(AESARGS);
 template __global__ void aes128_dec_fast_kernel<3>(AESARGS);
-template __global__ void sha256_fast_kernel<3, true>(const uint8_t *, size_t, uint32_t, uint64_t, uint8_t *, uint64_t, Counters, FaultTab, uint8_t *);
-#define CRCARGS const uint8_t *, uint32_t, uint64_t, uint16_t *, const uint16_t *, uint64_t, uint64_t, Counters, FaultTab, uint8_t *
+template __global__ void sha256_fast_kernel<3, true>(const uint8_t *, size_t, uint32_t, uint64_t, uint8_t *, uint64_t, Counters, FaultTab, uint8_t *, size_t, size_t);
+#define CRCARGS const uint8_t *, uint32_t, uint64_t, uint16_t *, const uint16_t *, uint64_t, uint64_t, Counters, FaultTab, uint8_t *, size_t, size_t
 template __global__ void crc16_stream_kernel<3, 2, true>(CRCARGS);
 template __global__ void crc16_stream_kernel<3, 1, false>(CRCARGS);
 }

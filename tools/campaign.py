@@ -15,6 +15,8 @@ lines in a .log, and the jsonParser summary table.
                           every replica (reference: 86.3 % coverage ~ unmitigated, docs/images/msp430/fault_injection_results.png)
     --mem-mode default    COAST's default mode: one unprotected launch per memory copy + the exit vote (coast_sync_copies);
                           the upset sits in one copy and is out-voted (reference: 98.8 %)
+    --mem-mode storesync  memory replicated + -storeDataSync: one launch of the lane-replicated kernel on `replicas` memory
+                          copies (COAST_F_MEMORY_COPIES: sha256, aes, crc16); the upset is out-voted at the next store
 
 Classification per run, exactly jsonParser.summarizeRuns (:162-186): errors > 0 -> error; else faults > 0 -> fault (counted
 with the successes in "Successes"); a DWC compare failure is FAULT_DETECTED_DWC() -> abort(), which the reference's
@@ -328,6 +330,28 @@ def run_campaign(a, eng=None):
             targets.append(flip_memory(eng, inp, r, rng))
         out = bench.run(inp, ca.XmrConfig(rep), det)
         engine = eng.last_launch()
+    elif a.mem_mode == "storesync":
+        # the memory-replicated mode with -storeDataSync (dataflowProtection.cpp:14-18): ONE launch of the lane-replicated lean
+        # kernel on `replicas` memory copies (COAST_F_MEMORY_COPIES) -- replica r loads from copy r, stores are voted into every copy
+        if a.benchmark not in ("sha256", "aes", "crc16"):
+            raise SystemExit("--mem-mode storesync: sha256, aes, crc16 (the kernels that implement COAST_F_MEMORY_COPIES)")
+        stacked = [torch.stack([t] * nrep).contiguous() for t in inp]
+        for r in range(runs):
+            k = int(rng.integers(0, nrep))
+            tgt = flip_memory(eng, [t[k] for t in stacked], r, rng)
+            tgt["copy"] = k
+            targets.append(tgt)
+        cfgc = ca.XmrConfig(rep, 0, ca.F_MEMORY_COPIES)
+        if a.benchmark == "sha256":
+            o = eng.sha256_batch(stacked[0], bench.len, cfg=cfgc, detected=det)
+        elif a.benchmark == "aes":
+            st, key = stacked[0].clone(), stacked[1].clone()
+            eng.aes128_batch(st, key, 0, cfg=cfgc, detected=det)
+            o = torch.cat([st, key], dim=2)
+        else:
+            o = eng.crc16_batch(stacked[0][:, :, : bench.bl].contiguous().reshape(nrep, -1), bench.bl, cfg=cfgc, detected=det).reshape(nrep, runs, 1)
+        out = o[0].reshape(runs, -1)  # (under TMR every copy holds the voted result)
+        engine = eng.last_launch()
     else:
         # default mode (docs/source/passes.rst:329,337): memory replicated, the clones run on their own copies, the values that
         # leave the region are voted.  The upset sits in ONE copy.
@@ -458,7 +482,7 @@ def parse(argv=None):
     ap.add_argument("-m", "--mode", default="TMR", choices=list(MODES))
     ap.add_argument("-t", "--runs", type=int, default=5000)
     ap.add_argument("-s", "--section", default="registers", choices=["registers", "memory"])
-    ap.add_argument("--mem-mode", default="nomemrep", choices=["nomemrep", "default"])
+    ap.add_argument("--mem-mode", default="nomemrep", choices=["nomemrep", "default", "storesync"])
     ap.add_argument("--reg-model", default="sites", choices=["sites", "physical"],
                     help="registers: `sites` = a replica-private injector site per run; `physical` (-b mm --side 256 -m TMR) = any "
                          "register of the matrix-core kernel's wave, weighted by its register census, shared state included")
