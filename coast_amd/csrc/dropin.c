@@ -25,8 +25,9 @@
  *       -noMemReplication              the lane-replicated engine; WITHOUT it (the reference's default) every clone runs on its
  *                                      own memory copy and the copies are voted at the region exit (COAST_F_HOST_MEMORY_REPLICATED)
  *       -noStoreDataSync               COAST_F_NO_STORE_DATA_SYNC (only meaningful next to -noMemReplication, as in the reference)
- *       -countErrors -countSyncs -storeDataSync -i -s   accepted; always on / no effect here (include/coast_hip.h says why)
- *       -noLoadSync -noStoreAddrSync   accepted; real knobs for crc16 / sha256_hash once COAST_COUNTERS_IN_SOR=1 puts their loop
+ *       -countErrors -countSyncs -storeDataSync -i -s   accepted; always on / no effect here (include/coast_hip.h says why; the
+ *                                      batch ABI has the memory-replicated -storeDataSync form as COAST_F_MEMORY_COPIES)
+ *       -noLoadSync -noStoreAddrSync   accepted; real knobs for matrix_multiply / crc16 / sha256_hash once COAST_COUNTERS_IN_SOR=1 puts their loop
  *                                      counters inside the sphere of replication (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC, the
  *                                      reference's -noMemReplication rule set for them); otherwise no replicated address exists
  *   or, shorter, COAST_MODE = TMR (default) | DWC | NONE  (lane-replicated engine);
@@ -83,7 +84,7 @@ static coast_cfg dropin_cfg(void)
     return c;
 }
 
-/* crc16 / sha256_hash: the kernels whose loop counters can be put inside the sphere of replication */
+/* matrix_multiply / crc16 / sha256_hash: the kernels whose loop counters can be put inside the sphere of replication */
 static coast_cfg dropin_cfg_counters(void)
 {
     coast_cfg c = dropin_cfg();
@@ -238,7 +239,9 @@ void sha256_hash(unsigned char ctx_data[], uint32_t ctx_bitlen[], uint32_t ctx_s
 
 void coast_dropin_matrix_multiply(const void *f, const void *s, void *r, int side)
 {
-    const coast_cfg cfg = dropin_cfg();
+    coast_cfg cfg = dropin_cfg_counters(); /* COAST_COUNTERS_IN_SOR=1: i, j, k, sum replica-private, loop conditions + GEP offsets voted */
+    if (cfg.flags & (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC))
+        cfg.sync_every = 0u; /* every loop condition is a sync point already */
     dropin_maybe_inject();
     const int rc = coast_matrix_multiply_host((const uint32_t *)f, (const uint32_t *)s, (uint32_t *)r, side, &cfg);
     if (rc)

@@ -1764,7 +1764,7 @@ def test_indexed_flags_are_rejected_where_not_implemented(eng):
 
 
 def test_dropin_counters_in_sor_env():
-    """COAST_COUNTERS_IN_SOR=1: the unmodified C program's crc16() / sha256_hash() run with their loop counters replicated and
+    """COAST_COUNTERS_IN_SOR=1: the unmodified C program's matrix_multiply() / crc16() / sha256_hash() run with their loop counters replicated and
     the reference's -noMemReplication votes on them; -noLoadSync / -noStoreAddrSync of COAST_OPT_PASSES then change __SYNC_COUNT."""
     import os
     import re
@@ -1785,9 +1785,10 @@ def test_dropin_counters_in_sor_env():
     full = syncs("-TMR -noMemReplication", True)
     nl = syncs("-TMR -noMemReplication -noLoadSync", True)
     ns = syncs("-TMR -noMemReplication -noStoreAddrSync", True)
-    # crc16("Automated TMR", 13): + 14 loop conditions; sha256_hash("abc", 3): + (3+1) + 3 + 3 + 3 + 1 + 1 + 1
-    assert full == base + 14 + 16
-    assert nl == full - 3 and ns == full - 4
+    # crc16("Automated TMR", 13): + 14 loop conditions; sha256_hash("abc", 3): + (3+1) + 3 + 3 + 3 + 1 + 1 + 1;
+    # matrix_multiply at side 4 (round 3): + (N+1)(N^2+N+1) = 105 loop conditions, 4 N^3 = 256 load offsets, 2 N^2 = 32 store offsets
+    assert full == base + 14 + 16 + 105 + 256 + 32
+    assert nl == full - 3 - 256 and ns == full - 4 - 32
 
 
 # ------------------------------------------------------------------------------------------------ campaign front-end
