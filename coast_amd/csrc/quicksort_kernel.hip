@@ -72,12 +72,7 @@ __global__ __launch_bounds__(64) void quicksort_kernel(int32_t *__restrict__ arr
 
     Tally tl;
     uint32_t base = 0u, len = live ? n : 0u, sp = 0u, tick = 0u, st = kQsOk;
-    // the watchdog (the supervisor's timeout) guards sorts an armed upset can derail; a clean sort always terminates, and a
-    // legitimate bad-pivot order may take ~n^2 conditions, so an array without an armed upset runs without it
-    bool armedItem = false;
-    for (uint32_t q = 0; q < fr.y; ++q)
-        armedItem = armedItem || (int)ft.list[fr.x + q].local == slot;
-    const uint32_t cap = armedItem ? 64u * n + 1024u : 0xffffffffu;
+    const uint32_t cap = 64u * n + 1024u; // the watchdog (the supervisor's timeout): a sort is cut after this many branch conditions
     uint32_t i = 0u, j = 0u, pv = 0u, vi = 0u, vj = 0u;
     auto hook = [&]() __attribute__((always_inline)) {
         for (uint32_t q = 0; q < fr.y; ++q) {
@@ -99,6 +94,12 @@ __global__ __launch_bounds__(64) void quicksort_kernel(int32_t *__restrict__ arr
     };
     auto cond = [&](bool c) __attribute__((always_inline)) { // one evaluated branch condition: always a sync point
         ++tick;
+        // The idle lane of a TMR wave (lane 63: 64 = 3 x 21 + 1) has no item: its "replica group" wraps around to lanes 0 and 1,
+        // so a voted condition would make it shadow item 0's control flow on garbage until the watchdog cut it -- every TMR tile
+        // then ran for the full 64 n + 1024 conditions (found in round 3, when lifting the watchdog for clean arrays hung the
+        // kernel).  It follows its own condition: len = 0 < 2, it leaves at once.
+        if (!lm.live)
+            return c;
         return xmr_steer<NREP>(c ? 1u : 0u, lm, true, cnt, tl) != 0u;
     };
     auto load = [&](uint32_t off) __attribute__((always_inline)) { return off < n ? (uint32_t)A[off] : pv; };

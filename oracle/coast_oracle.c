@@ -1277,8 +1277,8 @@ void orc_quicksort_plain(int32_t *array, uint32_t n) { qs_plain(array, (int)n); 
  * `temp = A[i]` and the A[j] of `A[i] = A[j]` reuse the values the two scans loaded last (what -O3 leaves of them).
  * The replicas of an array always take the same direction (voted, or replica 0's under DWC), so control flow -- and with it the
  * condition counter that addresses the fault steps -- is one per array.  A corrupted index can leave the array: such loads
- * return the replica's pivot (both scans stop), such stores are dropped; a sort with an armed upset that does not end within
- * 64 n + 1024 conditions, or nests deeper than ORC_QS_MAXDEPTH pending right parts, is cut (status WATCHDOG / STACK -- the reference's
+ * return the replica's pivot (both scans stop), such stores are dropped; a sort that does not end within 64 n + 1024
+ * conditions, or nests deeper than ORC_QS_MAXDEPTH pending right parts, is cut (status WATCHDOG / STACK -- the reference's
  * supervisor files those runs under timeout / stack overflow, jsonParser.py:162-186). */
 static int qs_item(int32_t *A, uint32_t n, sync_ctx *c, const orc_fault *fl, size_t nf)
 {
@@ -1287,12 +1287,7 @@ static int qs_item(int32_t *A, uint32_t n, sync_ctx *c, const orc_fault *fl, siz
     uint32_t base[3] = {0, 0, 0}, len[3] = {n, n, n};
     uint32_t stk[3][ORC_QS_MAXDEPTH][2];
     uint32_t sp = 0, tick = 0;
-    /* the watchdog guards sorts an armed upset can derail; an array without one runs without it (a clean sort terminates,
-     * and a bad-pivot order may legitimately take ~n^2 conditions) */
-    size_t narmed = 0;
-    for (size_t q_ = 0; q_ < nf; ++q_)
-        narmed += fl[q_].replica < R && fl[q_].site >= ORC_SITE_QS_I && fl[q_].site <= ORC_SITE_QS_VJ;
-    const uint32_t cap = narmed ? 64u * n + 1024u : 0xffffffffu;
+    const uint32_t cap = 64u * n + 1024u;
     uint32_t i[3] = {0, 0, 0}, j[3] = {0, 0, 0}, pv[3] = {0, 0, 0}, vi[3] = {0, 0, 0}, vj[3] = {0, 0, 0};
 #define QS_HOOK()                                                                                              \
     do {                                                                                                       \
