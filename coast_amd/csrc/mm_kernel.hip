@@ -626,6 +626,8 @@ __global__ __launch_bounds__(64) void mm_indexed_kernel(const uint32_t *__restri
     };
     auto cond = [&](uint32_t reg) __attribute__((always_inline)) { // one evaluated loop condition
         ++tick;
+        if (!lm.live) // the idle lane of a TMR wave has no call of its own (its replica group would wrap to lanes 0, 1): N = 0, it leaves
+            return reg < N;
         return xmr_steer<NREP>(reg < N ? 1u : 0u, lm, bs, cnt, tl) != 0u;
     };
     // the lanes of one matrix always take the same (voted, or replica 0's) direction; different matrices have the same trip
