@@ -56,6 +56,26 @@ __global__ void crc16_table_kernel(uint16_t *__restrict__ t16)
 constexpr int kCrcStreamThreads = 1024;
 constexpr int kCrcTableBytes = 65536 * 2;
 
+// Slicing by four bytes (round 3).  The two-byte step M16 = T16 is linear over GF(2) (shifts and xors, T16[0] = 0), so one dword
+// b0 b1 b2 b3 takes the state s to  M32(s ^ b0b1) ^ M16(b2b3)  and each term splits into its bytes:
+//     s' = U3[s_hi ^ b0] ^ U2[s_lo ^ b1] ^ U1[b2] ^ U0[b3],   U3[e] = T16[T16[e << 8]], U2[e] = T16[T16[e]], U1[e] = T16[e << 8], U0[e] = T16[e].
+// Only the first two lookups depend on the running crc: the dependent chain is ONE table level per dword instead of two, and the
+// four 256-entry tables can be laid out conflict-free (entry e of lane l in bank l: dword e * 64 + l), where the 64 Ki-entry pair
+// table loses half its LDS cycles to bank conflicts.  Two packed arrays of 64 KB: PA[e] = U3'[e] | U1'[e] << 16, PB[e] = U2'[e] |
+// U0'[e] << 16 -- the halves are chosen so that the chain's two values meet in the low halves and the data's two in the high ones.
+// The primes: every value is stored byte-swapped, because the walk keeps the state byte-swapped (sigma = s_lo << 8 | s_hi): then
+// sigma ^ (little-endian data dword) carries s_hi ^ b0 and s_lo ^ b1 in its bytes 0 and 1 with no byte-order swap at all.
+constexpr int kCrcSliceWords = 512; // PA[256], PB[256] behind the pair table in the context's table buffer
+__global__ void crc16_slice_table_kernel(const uint16_t *__restrict__ t16, uint32_t *__restrict__ pab)
+{
+    const uint32_t e = threadIdx.x; // 256 threads
+    auto sw = [](uint32_t v) { return ((v & 0xffu) << 8) | ((v >> 8) & 0xffu); };
+    const uint32_t u1 = t16[e << 8], u0 = t16[e];
+    const uint32_t u3 = t16[u1], u2 = t16[u0];
+    pab[e] = sw(u3) | (sw(u1) << 16);
+    pab[256 + e] = sw(u2) | (sw(u0) << 16);
+}
+
 // big-endian dword (b0<<24)|(b1<<16)|(b2<<8)|b3 of the four bytes that start `sh` bytes into the little-endian dword pair
 // {hi, lo}: v_perm_b32 picks byte k of the result from byte sel[k] of the pair (0..3 = lo, 4..7 = hi).  sh = 0 is bswap(lo).
 __device__ __forceinline__ uint32_t crc_perm_sel(uint32_t sh) { return 0x00010203u + 0x01010101u * sh; }
@@ -187,12 +207,34 @@ __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
     const LaneMap<NREP> lm;
     const int tid = threadIdx.x;
 
-    { // 128 KiB table: 1024 threads x 8 x 16 B, L2-resident after the first workgroup
+    static_assert(HYB >= 0 || ALIGNED, "slicing walk: aligned rows");
+    constexpr bool SLICE4 = HYB < 0; // the walk: slicing by four over bank-replicated byte tables instead of the pair table
+    if constexpr (SLICE4) { // t16g points at PA[256], PB[256]: every entry is written 64 times, once per bank (= lane)
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(t16g);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(smemRaw);
+        for (int e = tid; e < kCrcTableBytes / 4; e += THREADS)
+            dst[e] = src[e >> 6];
+    } else { // 128 KiB table: 1024 threads x 8 x 16 B, L2-resident after the first workgroup
         const uint4 *src = reinterpret_cast<const uint4 *>(t16g);
         uint4 *dst = reinterpret_cast<uint4 *>(T);
         for (int e = tid; e < kCrcTableBytes / 16; e += THREADS)
             dst[e] = src[e];
     }
+    if constexpr (SLICE4) {
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smemRaw != 0u)
+            __builtin_trap(); // the slicing walk addresses the tables from LDS offset 0
+    }
+    // slicing walk: byte 0 = the lane's bank (4 * lane), byte 1 = 1 (the 64 KB step from PA to PB)
+    const uint32_t laneSel = ((uint32_t)(tid & 63) << 2) | 0x100u;
+    auto slice4 = [&](uint32_t sigma, uint32_t d) __attribute__((always_inline)) {
+        const uint32_t y = sigma ^ d; // bytes 0, 1: s_hi ^ b0, s_lo ^ b1 (the upper half of sigma is never clean, nor read)
+        const uint32_t a0 = __builtin_amdgcn_perm(y, laneSel, 0x0c0c0400u), a1 = __builtin_amdgcn_perm(y, laneSel, 0x0c010500u);
+        const uint32_t a2 = __builtin_amdgcn_perm(d, laneSel, 0x0c0c0600u), a3 = __builtin_amdgcn_perm(d, laneSel, 0x0c010700u);
+        // the permuted bytes ARE the LDS address (the dynamic segment starts at 0, checked above): no base add per lookup
+        typedef const __attribute__((address_space(3))) uint32_t *lds_u32p;
+        const uint32_t r0 = *(lds_u32p)(a0), r1 = *(lds_u32p)(a1), r2 = *(lds_u32p)(a2), r3 = *(lds_u32p)(a3);
+        return r0 ^ r1 ^ ((r2 ^ r3) >> 16);
+    };
     if (tid < 4)
         sCnt[tid] = 0;
     __syncthreads();
@@ -281,6 +323,14 @@ __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
                 for (int v = 0; v < 4; ++v) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
+                        if constexpr (SLICE4) {
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) {
+                                const uint32_t d = (c == 0) ? c4[j][v].x : (c == 1) ? c4[j][v].y : (c == 2) ? c4[j][v].z : c4[j][v].w;
+                                crc[j] = slice4(crc[j], d);
+                            }
+                            continue;
+                        }
                         uint32_t e[NT];
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
@@ -289,16 +339,16 @@ __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
                         }
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
-                            const int step = 8 * v + 2 * c + (HYB ? j * (HYB / 2) : 0); // the chains take their VALU turns apart
-                            if (HYB != 0 && step % HYB == 0)
+                            const int step = 8 * v + 2 * c + (HYB > 0 ? j * (HYB / 2) : 0); // the chains take their VALU turns apart
+                            if (HYB > 0 && step % HYB == 0)
                                 crc[j] = crc16_pair_valu(crc[j] ^ (e[j] >> 16));
                             else
                                 crc[j] = T[crc[j] ^ (e[j] >> 16)];
                         }
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
-                            const int step = 8 * v + 2 * c + 1 + (HYB ? j * (HYB / 2) : 0);
-                            if (HYB != 0 && step % HYB == 0)
+                            const int step = 8 * v + 2 * c + 1 + (HYB > 0 ? j * (HYB / 2) : 0);
+                            if (HYB > 0 && step % HYB == 0)
                                 crc[j] = crc16_pair_valu(crc[j] ^ (e[j] & 0xffffu));
                             else
                                 crc[j] = T[crc[j] ^ (e[j] & 0xffffu)];
@@ -316,6 +366,10 @@ __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
             for (uint32_t t = 0; t < rem; t += 4u) { // a block of 16, 32 or 48 bytes past the last batch
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
+                    if constexpr (SLICE4) {
+                        crc[j] = slice4(crc[j], *reinterpret_cast<const uint32_t *>(p[j] + (size_t)nbatch * 64 + t));
+                        continue;
+                    }
                     const uint32_t e = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(p[j] + (size_t)nbatch * 64 + t));
                     crc[j] = T[crc[j] ^ (e >> 16)];
                     crc[j] = T[crc[j] ^ (e & 0xffffu)];
@@ -394,6 +448,11 @@ __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
                 }
             }
         }
+        }
+        if constexpr (SLICE4) { // sigma (byte-swapped, upper half dirty) -> crc
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                crc[j] = ((crc[j] & 0xffu) << 8) | ((crc[j] >> 8) & 0xffu);
         }
         } // anyWalk
 #undef CRC_NEXT

@@ -30,7 +30,8 @@ def main():
         out = torch.empty(nb, dtype=torch.int16, device="cuda")
         for rep in (3, 2):
             for nt in os.environ.get("CRC_NTS", "1,2").split(","):
-                os.environ["COAST_CRC_NT"] = nt
+                os.environ["COAST_CRC_NT"] = nt.rstrip("s")
+                os.environ["COAST_CRC_WALK"] = "slice4" if nt.endswith("s") else "pair"
                 cfg = coast_amd.XmrConfig(rep)
                 out.zero_()
                 mn, av = timeit(lambda: eng.crc16_batch(data[: nb * bl], bl, out=out, cfg=cfg), reps=5, warm=2)
