@@ -498,8 +498,9 @@ class AES(Workload):
     # LDS lookups of one block per replica lane (tools/instr_mix.py on the compiled kernels).  One-copy tables: encryption 147
     # ds_read_b32 (four T-tables x 4 columns x 9 rounds + last round) + 56 ds_read_u8 (S-box: key schedule, last round);
     # decryption 179 + 84.  Bank-replicated tables (what 1 Mi DWC blocks run): encryption 203 ds_read_b32 (the S-box bytes come
-    # out of Te_0 entries), decryption 199 ds_read_b32 + 32 ds_read_b64 ({Tis_0, S} pairs: one lookup per key-schedule byte)
-    LOOKUPS = {0: 203, 1: 199 + 32}
+    # out of Te_0 entries), decryption 208 ds_read_b32 (144 Td, 48 S-box, 16 rsbox) + 32 ds_read_b64 ({Tis_0, S} pairs: one lookup per
+    # key-schedule byte of the main rounds)
+    LOOKUPS = {0: 203, 1: 208 + 32}
 
     def __init__(self, a, eng, dev, rank, coast_amd):
         self.n = a.batch or (1 << 20)

@@ -203,11 +203,11 @@ __device__ __forceinline__ uint32_t aes_xor3(uint32_t a, uint32_t b, uint32_t c)
 struct AesDue { // XOR masks for the four state columns and the four key columns
     uint32_t s0 = 0u, s1 = 0u, s2 = 0u, s3 = 0u, k0 = 0u, k1 = 0u, k2 = 0u, k3 = 0u;
 };
-__device__ __forceinline__ AesDue aes_due_masks(const FaultTab &ft, uint2 fr, uint32_t rd, int slot, int rep, bool laneLive)
+__device__ __forceinline__ AesDue aes_due_scan(const DevFault *list, uint2 fr, uint32_t rd, int slot, int rep, bool laneLive)
 {
     AesDue d;
     for (uint32_t q = 0; q < fr.y; ++q) {
-        const DevFault *fp = ft.list + fr.x + q;
+        const DevFault *fp = list + fr.x + q;
         const uint32_t packed = *reinterpret_cast<const uint32_t *>(&fp->replica); // replica, site, bit, index
         if (fp->step != rd || (int)fp->local != slot || (int)(packed & 0xffu) != rep || !laneLive)
             continue;
@@ -215,6 +215,69 @@ __device__ __forceinline__ AesDue aes_due_masks(const FaultTab &ft, uint2 fr, ui
         const uint32_t ms = site == (uint32_t)SITE_AES_STATE ? m : 0u, mk = site == (uint32_t)SITE_AES_KEY ? m : 0u;
         d.s0 ^= c == 0u ? ms : 0u, d.s1 ^= c == 1u ? ms : 0u, d.s2 ^= c == 2u ? ms : 0u, d.s3 ^= c == 3u ? ms : 0u;
         d.k0 ^= c == 0u ? mk : 0u, d.k1 ^= c == 1u ? mk : 0u, d.k2 ^= c == 2u ? mk : 0u, d.k3 ^= c == 3u ? mk : 0u;
+    }
+    return d;
+}
+// This lane's upsets, read from the table (HBM) ONCE per tile: up to four of them as 16-bit records {round : 4, column code : 3,
+// bit : 5} in the lane's own 8-byte LDS slot -- a table scan per round (11 dependent trips to L2 per tile) made an armed tile cost
+// several clean ones, and a persistent workgroup waits for its slowest wave; registers would cost the encryption kernels their
+// 64-register budget.  More than four on one lane (wave-uniform through the ballot): the scan, as before.
+typedef uint32_t aes_rec2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) aes_rec2 *aes_lds_rec_p; // a 32-bit LDS pointer: one register
+struct AesLaneFaults {
+    aes_lds_rec_p slot = nullptr; // this thread's LDS slot (written and read by this lane only: program order is enough)
+    bool over = false;
+};
+__device__ __forceinline__ AesLaneFaults aes_gather_faults(aes_lds_rec_p slotLds, const FaultTab &ft, uint2 fr, int slot, int rep,
+                                                           bool laneLive)
+{
+    AesLaneFaults lf;
+    lf.slot = slotLds;
+    uint32_t n = 0u, p01 = 0xffffffffu, p23 = 0xffffffffu; // round nibble 15 = empty
+    for (uint32_t q = 0; q < fr.y; ++q) {
+        const DevFault *fp = ft.list + fr.x + q;
+        const uint32_t packed = *reinterpret_cast<const uint32_t *>(&fp->replica); // replica, site, bit, index
+        const uint32_t site = (packed >> 8) & 0xffu;
+        if ((int)fp->local != slot || (int)(packed & 0xffu) != rep || !laneLive || fp->step > 10u ||
+            (site != (uint32_t)SITE_AES_STATE && site != (uint32_t)SITE_AES_KEY))
+            continue;
+        const uint32_t code = ((packed >> 24) & 3u) | (site == (uint32_t)SITE_AES_KEY ? 4u : 0u);
+        const uint32_t rec = fp->step | (code << 4) | (((packed >> 16) & 31u) << 7);
+        if (n == 0u)
+            p01 = (p01 & 0xffff0000u) | rec;
+        else if (n == 1u)
+            p01 = (p01 & 0x0000ffffu) | (rec << 16);
+        else if (n == 2u)
+            p23 = (p23 & 0xffff0000u) | rec;
+        else if (n == 3u)
+            p23 = (p23 & 0x0000ffffu) | (rec << 16);
+        n += 1u;
+    }
+    *slotLds = aes_rec2{p01, p23};
+    lf.over = __builtin_amdgcn_ballot_w64(n > 4u) != 0ull;
+    return lf;
+}
+__device__ __forceinline__ AesDue aes_due_masks(const AesLaneFaults &lf, const FaultTab &ft, uint2 fr, uint32_t rd, int slot, int rep,
+                                                bool laneLive)
+{
+    if (lf.over)
+        return aes_due_scan(ft.list, fr, rd, slot, rep, laneLive);
+    AesDue d;
+    aes_rec2 p = *lf.slot;
+    // opaque per round: otherwise the eleven decodes of the unrolled rounds are merged and computed up front (their masks then live
+    // through the whole block: 30 spilled registers in the 64-register encryption kernel)
+    asm volatile("" : "+v"(p.x), "+v"(p.y));
+    const bool hit = (p.x & 15u) == rd || ((p.x >> 16) & 15u) == rd || (p.y & 15u) == rd || ((p.y >> 16) & 15u) == rd;
+    if (__builtin_amdgcn_ballot_w64(hit) != 0ull) { // wave-uniform: almost every round of an armed tile passes by
+        auto one = [&](uint32_t rec) __attribute__((always_inline)) {
+            const uint32_t mm = (rec & 15u) == rd ? 1u << ((rec >> 7) & 31u) : 0u, code = (rec >> 4) & 7u;
+            d.s0 ^= code == 0u ? mm : 0u, d.s1 ^= code == 1u ? mm : 0u, d.s2 ^= code == 2u ? mm : 0u, d.s3 ^= code == 3u ? mm : 0u;
+            d.k0 ^= code == 4u ? mm : 0u, d.k1 ^= code == 5u ? mm : 0u, d.k2 ^= code == 6u ? mm : 0u, d.k3 ^= code == 7u ? mm : 0u;
+        };
+        one(p.x & 0xffffu);
+        one(p.x >> 16);
+        one(p.y & 0xffffu);
+        one(p.y >> 16);
     }
     return d;
 }
@@ -238,6 +301,7 @@ __global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restric
     __shared__ uint32_t sTe[4][256];
     __shared__ uint8_t sSb[256];
     __shared__ uint32_t sCnt[4];
+    __shared__ uint2 sLf[256]; // the lanes' armed upsets (aes_gather_faults)
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
     const LaneMap<NREP> lm;
     const int tid = threadIdx.x;
@@ -270,9 +334,12 @@ __global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restric
     // sync points, the counters, the stores -- is the code every other tile runs.
     auto rounds = [&](auto hookTag) __attribute__((always_inline)) {
         constexpr bool HOOKED = decltype(hookTag)::value;
+            AesLaneFaults lf; // this lane's armed upsets (read once)
+            if constexpr (HOOKED)
+                lf = aes_gather_faults((aes_lds_rec_p)(sLf + tid), ft, fr, lm.q, lm.r, lm.live);
         auto hook = [&](int rd) __attribute__((always_inline)) {
             if constexpr (HOOKED) {
-                const AesDue d = aes_due_masks(ft, fr, (uint32_t)rd, lm.q, lm.r, lm.live);
+                const AesDue d = aes_due_masks(lf, ft, fr, (uint32_t)rd, lm.q, lm.r, lm.live);
                 s0 ^= d.s0, s1 ^= d.s1, s2 ^= d.s2, s3 ^= d.s3;
                 k0 ^= d.k0, k1 ^= d.k1, k2 ^= d.k2, k3 ^= d.k3;
             }
@@ -364,7 +431,7 @@ __device__ __forceinline__ uint32_t aes_imc_col(uint32_t x) // InvMixColumns of 
 #define AES_DEC_HOOK(rd, mixedState, haveM)                                                                       \
     do {                                                                                                          \
         if constexpr (HOOKED) {                                                                                   \
-            const AesDue d_ = aes_due_masks(ft, fr, (uint32_t)(rd), lm.q, lm.r, lm.live);                         \
+            const AesDue d_ = aes_due_masks(lf, ft, fr, (uint32_t)(rd), lm.q, lm.r, lm.live);                         \
             if (mixedState)                                                                                       \
                 x0 ^= aes_imc_col(d_.s0), x1 ^= aes_imc_col(d_.s1), x2 ^= aes_imc_col(d_.s2), x3 ^= aes_imc_col(d_.s3); \
             else                                                                                                  \
@@ -385,6 +452,7 @@ __global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restric
     __shared__ uint8_t sSb[256];
     __shared__ uint8_t sRsb[256];
     __shared__ uint32_t sCnt[4];
+    __shared__ uint2 sLf[256]; // the lanes' armed upsets (aes_gather_faults)
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
     const LaneMap<NREP> lm;
     const int tid = threadIdx.x;
@@ -419,6 +487,9 @@ __global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restric
     // instantiated twice, as in aes128_enc_fast_kernel: HOOKED = a tile that owns armed upsets
     auto rounds = [&](auto hookTag) __attribute__((always_inline)) {
         constexpr bool HOOKED = decltype(hookTag)::value;
+            AesLaneFaults lf; // this lane's armed upsets (read once)
+            if constexpr (HOOKED)
+                lf = aes_gather_faults((aes_lds_rec_p)(sLf + tid), ft, fr, lm.q, lm.r, lm.live);
         uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
         // the last encryption key first (:110-123)
 #pragma unroll
@@ -530,11 +601,27 @@ __global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restric
 //   decryption  Td_0 and Tis_0 are stored as 8-byte pairs {Td_0[v], rsbox[v] * 0x01010101} / {Tis_0[v], S[v] * 0x01010101}
 //               and read with ds_read_b64 (same 2 LDS cycles as a dword read): the key-schedule word and its InvMixColumns
 //               image come out of ONE lookup per byte (Tis_r = Tis_0 rotated by r bytes), the last round reads the .y halves.
+// Round 3, the lookup address in ONE instruction: every table entry value v owns a 256-byte row of the table block -- four slots
+// of 16 copies x 4 bytes -- so the LDS address of "slot r, entry x.byte[B], this lane's copy" is the byte string
+// {copy * 4, x.byte[B], block, 0}: one v_perm_b32 of x and a per-lane constant, with r * 64 in the instruction's offset field
+// (rounds 1-2 needed v_bfe_u32 + v_lshl_add_u32 per lookup; the kernels are VALU-bound).  Encryption: one 64 KiB
+// block {Te_0, Te_1, Te_2, Te_3}.  Decryption: block 0 = {Td_0, Td_1, Td_2, Td_3}, block 1 = {Tis_0 | S pairs (two slots),
+// rsbox, -}.  A copy still sits in bank 16 r + copy (dwords) / 2 copy + {0, 1} (pairs): the 16 distinct blocks of a 32-lane
+// group never meet on a bank.
 constexpr int kAesCopies = 16;
 constexpr int kAesRepThreads = 1024;
-constexpr int kAesTabWords = 256 * kAesCopies; // one replicated dword table: 16 KiB
-constexpr size_t kAesEncRepLds = (size_t)4 * kAesTabWords * 4 + 16;
-constexpr size_t kAesDecRepLds = (size_t)(3 + 2 + 2) * kAesTabWords * 4 + 16;
+constexpr int kAesRowBytes = 256;                      // one entry value: 4 slots x 16 copies x 4 bytes
+constexpr int kAesBlockBytes = 256 * kAesRowBytes;     // 64 KiB
+constexpr size_t kAesEncRepLds = (size_t)kAesBlockBytes + 16 + kAesRepThreads * 8; // tables, counters, the lanes' upset records
+constexpr size_t kAesDecRepLds = (size_t)2 * kAesBlockBytes + 16 + kAesRepThreads * 8;
+typedef const __attribute__((address_space(3))) uint32_t *aes_lds_u32p;
+typedef uint32_t aes_u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) aes_u32x2 *aes_lds_u64p;
+// LDS address of entry x.byte[B] in table block BLK for the lane whose selector word is laneSel = copy offset | 0x100
+template <int B, int BLK> __device__ __forceinline__ uint32_t aes_rep_addr(uint32_t x, uint32_t laneSel)
+{
+    return __builtin_amdgcn_perm(x, laneSel, (BLK ? 0x0c010000u : 0x0c0c0000u) + ((4u + B) << 8));
+}
 
 __device__ __forceinline__ uint32_t aes_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32
 // bytes 0..3 = byte 1 of t0..t3
@@ -547,65 +634,57 @@ __device__ __forceinline__ uint32_t aes_pick_rep(uint32_t y0, uint32_t y1, uint3
 {
     return aes_bfi(0x000000ffu, y0, aes_bfi(0x0000ff00u, y1, aes_bfi(0x00ff0000u, y2, y3)));
 }
-// LDS byte offset of this lane's copy of table entry x.byte[B]: entries are 1 << SH bytes apart (16 copies of a dword: SH = 6, of
-// an 8-byte pair: SH = 7), cOff = copy * entry size < 1 << SH
-template <int B, int SH> __device__ __forceinline__ uint32_t aes_rep_off(uint32_t x, uint32_t cOff)
-{
-    // two instructions per lookup address: the byte (v_bfe_u32 / v_lshrrev_b32), then v_lshl_add_u32 with the lane's copy offset.
-    // The extraction of byte 0 is kept opaque: written as (x & 0xff) << SH the compiler canonicalises it to shift, and, add (three).
-    uint32_t t;
-    if constexpr (B == 3)
-        t = x >> 24;
-    else if constexpr (B == 0)
-        asm("v_bfe_u32 %0, %1, 0, 8" : "=v"(t) : "v"(x));
-    else
-        t = __builtin_amdgcn_ubfe(x, 8 * B, 8);
-    return (t << SH) + cOff;
-}
 __device__ __forceinline__ uint32_t aes_rotl8(uint32_t x, int bytes) { return __builtin_amdgcn_alignbit(x, x, 32 - 8 * bytes); }
 
 template <int NREP>
-__global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
+__global__ __launch_bounds__(kAesRepThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void aes128_enc_rep_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
                                                                         uint64_t nblocksData, uint64_t ntiles, Counters ctr,
                                                                         FaultTab ft, uint8_t *__restrict__ detected, size_t copyBytes = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smemAes[];
-    uint32_t *sT = reinterpret_cast<uint32_t *>(smemAes);
-    uint32_t *sCnt = sT + 4 * kAesTabWords;
+    uint32_t *sCnt = reinterpret_cast<uint32_t *>(smemAes + kAesBlockBytes);
+    uint2 *sLf = reinterpret_cast<uint2 *>(smemAes + kAesBlockBytes + 16);
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
     const LaneMap<NREP> lm;
     const int tid = threadIdx.x;
-    { // thread (copy c, entry row v0): 64 entries per pass; lanes 0..15 / 16..31 of a group write entries v / v + 1 -> 32 banks
-        const int c = tid & (kAesCopies - 1), v0 = tid >> 4;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smemAes != 0u)
+        __builtin_trap(); // the permuted bytes are the LDS address: the dynamic segment starts at 0
+    { // a wave writes whole rows: lane = (slot r, copy c) -- 64 consecutive dwords, two lanes per bank (free for ds_write_b32)
+        const int c = tid & (kAesCopies - 1), r = (tid >> 4) & 3, v0 = (tid >> 6) * 16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                sT[r * kAesTabWords + (v0 + 64 * i) * kAesCopies + c] = gAesTe[r][v0 + 64 * i];
+        for (int i = 0; i < 16; ++i)
+            *reinterpret_cast<uint32_t *>(smemAes + (v0 + i) * kAesRowBytes + r * 64 + c * 4) = gAesTe[r][v0 + i];
     }
     if (tid < 4)
         sCnt[tid] = 0;
     __syncthreads();
-    const uint32_t cOff = (uint32_t)((NREP == 1 ? lm.lane : lm.q) & (kAesCopies - 1)) * 4u; // this lane's copy
-#define TE(r, x, b) (*reinterpret_cast<const uint32_t *>(smemAes + (r) * kAesTabWords * 4 + aes_rep_off<b, 6>(x, cOff)))
+    const uint32_t laneSel = (uint32_t)((NREP == 1 ? lm.lane : lm.q) & (kAesCopies - 1)) * 4u | 0x100u; // this lane's copy
+#define TE(r, x, b) (*(aes_lds_u32p)(uintptr_t)(aes_rep_addr<b, 0>(x, laneSel) + (r) * 64))
     Tally tl;
     uint32_t detItems = 0;
     for (uint64_t tile = (uint64_t)blockIdx.x * (kAesRepThreads / kWave) + (tid >> 6); tile < ntiles;
          tile += (uint64_t)gridDim.x * (kAesRepThreads / kWave)) {
         const uint2 fr = aes_tile_faults(ft, tile); // this tile's armed upsets (wave-uniform)
-        const uint64_t item = tile * IPW + (uint64_t)lm.q;
-        const bool live = lm.live && item < nblocksData;
-        const bool cnt = live && lm.r == 0;
+        // (the tile's lane map from a fresh lane id as well: the per-lane array bases of the memory-copies mode are loop invariants
+        // the register allocator would otherwise carry -- spilled -- through every tile)
+        const LaneMap<NREP> lmT(xmr_fresh_lane());
+        const uint64_t item = tile * IPW + (uint64_t)lmT.q;
+        const bool live = lmT.live && item < nblocksData;
         const uint64_t it = live ? item : 0;
-        const uint4 sv = reinterpret_cast<const uint4 *>(states + (size_t)lm.r * copyBytes)[it];
-        const uint4 kv = reinterpret_cast<const uint4 *>(keys + (size_t)lm.r * copyBytes)[it];
+        const uint8_t *stBase = states, *kyBase = keys; // (kept in SGPRs up to here: their VGPR copies were hoisted and spilled)
+        asm volatile("" : "+s"(stBase), "+s"(kyBase));
+        const uint4 sv = reinterpret_cast<const uint4 *>(stBase + (size_t)lmT.r * copyBytes)[it];
+        const uint4 kv = reinterpret_cast<const uint4 *>(kyBase + (size_t)lmT.r * copyBytes)[it];
         uint32_t s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w;
         uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
         auto rounds = [&](auto hookTag) __attribute__((always_inline)) { // as aes128_enc_fast_kernel, HOOKED included
             constexpr bool HOOKED = decltype(hookTag)::value;
+            AesLaneFaults lf; // this lane's armed upsets (read once)
+            if constexpr (HOOKED)
+                lf = aes_gather_faults((aes_lds_rec_p)(sLf + tid), ft, fr, lmT.q, lmT.r, lmT.live);
             auto hook = [&](int rd) __attribute__((always_inline)) {
                 if constexpr (HOOKED) {
-                    const AesDue d = aes_due_masks(ft, fr, (uint32_t)rd, lm.q, lm.r, lm.live);
+                    const AesDue d = aes_due_masks(lf, ft, fr, (uint32_t)rd, lmT.q, lmT.r, lmT.live);
                     s0 ^= d.s0, s1 ^= d.s1, s2 ^= d.s2, s3 ^= d.s3;
                     k0 ^= d.k0, k1 ^= d.k1, k2 ^= d.k2, k3 ^= d.k3;
                 }
@@ -669,28 +748,33 @@ __global__ __launch_bounds__(kAesRepThreads, 2) void aes128_enc_rep_kernel(uint8
         s1 ^= k1;
         s2 ^= k2;
         s3 ^= k3;
+        // the epilogue's lane map, item and gates from a fresh lane id: the kernel has 64 registers per lane (two workgroups per
+        // CU), and what the votes and stores need must not stay alive across the ten rounds (it was being spilled to scratch)
+        const LaneMap<NREP> lmE(xmr_fresh_lane());
+        const uint64_t itemE = tile * IPW + (uint64_t)lmE.q;
+        const bool liveE = lmE.live && itemE < nblocksData, cntE = liveE && lmE.r == 0;
         Tally te = tl;
         te.det = 0;
-        s0 = xmr_sync<NREP>(s0, lm, cnt, te);
-        s1 = xmr_sync<NREP>(s1, lm, cnt, te);
-        s2 = xmr_sync<NREP>(s2, lm, cnt, te);
-        s3 = xmr_sync<NREP>(s3, lm, cnt, te);
-        k0 = xmr_sync<NREP>(k0, lm, cnt, te);
-        k1 = xmr_sync<NREP>(k1, lm, cnt, te);
-        k2 = xmr_sync<NREP>(k2, lm, cnt, te);
-        k3 = xmr_sync<NREP>(k3, lm, cnt, te);
+        s0 = xmr_sync<NREP>(s0, lmE, cntE, te);
+        s1 = xmr_sync<NREP>(s1, lmE, cntE, te);
+        s2 = xmr_sync<NREP>(s2, lmE, cntE, te);
+        s3 = xmr_sync<NREP>(s3, lmE, cntE, te);
+        k0 = xmr_sync<NREP>(k0, lmE, cntE, te);
+        k1 = xmr_sync<NREP>(k1, lmE, cntE, te);
+        k2 = xmr_sync<NREP>(k2, lmE, cntE, te);
+        k3 = xmr_sync<NREP>(k3, lmE, cntE, te);
         tl.miss = te.miss;
         tl.syncs = te.syncs;
-        if (cnt || (live && copyBytes != 0)) {
-            reinterpret_cast<uint4 *>(states + (size_t)lm.r * copyBytes)[item] = make_uint4(s0, s1, s2, s3);
-            reinterpret_cast<uint4 *>(keys + (size_t)lm.r * copyBytes)[item] = make_uint4(k0, k1, k2, k3);
+        if (cntE || (liveE && copyBytes != 0)) {
+            reinterpret_cast<uint4 *>(states + (size_t)lmE.r * copyBytes)[itemE] = make_uint4(s0, s1, s2, s3);
+            reinterpret_cast<uint4 *>(keys + (size_t)lmE.r * copyBytes)[itemE] = make_uint4(k0, k1, k2, k3);
         }
-        if (cnt) {
+        if (cntE) {
             if (te.det) {
                 if (NREP == 2)
                     detItems += 1;
                 if (detected)
-                    detected[item] = 1;
+                    detected[itemE] = 1;
             }
         }
     }
@@ -704,34 +788,38 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
                                                                         FaultTab ft, uint8_t *__restrict__ detected, size_t copyBytes = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smemAes[];
-    uint2 *sDR = reinterpret_cast<uint2 *>(smemAes);                      // {Td_0[v], rsbox[v] x 4}
-    uint2 *sTS = sDR + kAesTabWords;                                      // {Tis_0[v], S[v] x 4}
-    uint32_t *sTd = reinterpret_cast<uint32_t *>(sTS + kAesTabWords);     // Td_1..3
-    uint32_t *sCnt = sTd + 3 * kAesTabWords;
+    uint32_t *sCnt = reinterpret_cast<uint32_t *>(smemAes + 2 * kAesBlockBytes);
+    uint2 *sLf = reinterpret_cast<uint2 *>(smemAes + 2 * kAesBlockBytes + 16);
     constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
     const LaneMap<NREP> lm;
     const int tid = threadIdx.x;
-    {
-        const int c = tid & (kAesCopies - 1), v0 = tid >> 4;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smemAes != 0u)
+        __builtin_trap(); // the permuted bytes are the LDS address: the dynamic segment starts at 0
+    { // block 0: Td_0..3; block 1: {Tis_0[v], S[v] x 4} pairs in slots 0-1, rsbox[v] x 4 in slot 2.  A wave writes whole rows:
+      // lane = (slot r, copy c); in block 1 slot group 0 writes the pairs, group 1 the rsbox dwords
+        const int c = tid & (kAesCopies - 1), r = (tid >> 4) & 3, v0 = (tid >> 6) * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = v0 + 64 * i;
-            sDR[v * kAesCopies + c] = make_uint2(gAesTd[0][v], (uint32_t)gAesRsbox[v] * 0x01010101u);
-            sTS[v * kAesCopies + c] = make_uint2(gAesTis[0][v], (uint32_t)gAesSbox[v] * 0x01010101u);
-#pragma unroll
-            for (int r = 1; r < 4; ++r)
-                sTd[(r - 1) * kAesTabWords + v * kAesCopies + c] = gAesTd[r][v];
+        for (int i = 0; i < 16; ++i) {
+            const int v = v0 + i;
+            uint8_t *row0 = smemAes + v * kAesRowBytes, *row1 = row0 + kAesBlockBytes;
+            *reinterpret_cast<uint32_t *>(row0 + r * 64 + c * 4) = gAesTd[r][v];
+            if (r == 0)
+                *reinterpret_cast<uint2 *>(row1 + c * 8) = make_uint2(gAesTis[0][v], (uint32_t)gAesSbox[v] * 0x01010101u);
+            else if (r == 1)
+                *reinterpret_cast<uint32_t *>(row1 + 128 + c * 4) = (uint32_t)gAesRsbox[v] * 0x01010101u;
         }
     }
     if (tid < 4)
         sCnt[tid] = 0;
     __syncthreads();
-    const uint32_t cOff = (uint32_t)((NREP == 1 ? lm.lane : lm.q) & (kAesCopies - 1)) * 8u; // this lane's copy (8-byte pairs)
-#define DR(x, b) (*reinterpret_cast<const uint2 *>(smemAes + aes_rep_off<b, 7>(x, cOff)))
-#define TS(x, b) (*reinterpret_cast<const uint2 *>(smemAes + kAesTabWords * 8 + aes_rep_off<b, 7>(x, cOff)))
-#define TD(r, x, b) (*reinterpret_cast<const uint32_t *>(smemAes + (3 + (r)) * kAesTabWords * 4 + aes_rep_off<b, 6>(x, cOff >> 1)))
-#define SUBROT(k) aes_pick_rep(TS(k, 1).y, TS(k, 2).y, TS(k, 3).y, TS(k, 0).y)
-#define TDCOL(a, b, c, d, m) aes_xor3(aes_xor3(DR(a, 0).x, TD(1, b, 1), TD(2, c, 2)), TD(3, d, 3), m) /* column ^ InvMix(key) */
+    const uint32_t copy = (uint32_t)((NREP == 1 ? lm.lane : lm.q) & (kAesCopies - 1));
+    const uint32_t laneSel = copy * 4u | 0x100u, laneSelP = copy * 8u | 0x100u; // dword slots / 8-byte pair slots
+#define TD(r, x, b) (*(aes_lds_u32p)(uintptr_t)(aes_rep_addr<b, 0>(x, laneSel) + (r) * 64))
+#define TS(x, b) (*(aes_lds_u64p)(uintptr_t)(aes_rep_addr<b, 1>(x, laneSelP)))
+#define TSY(x, b) (*(aes_lds_u32p)(uintptr_t)(aes_rep_addr<b, 1>(x, laneSelP) + 4))  /* the S-box half of a pair alone */
+#define RSB(x, b) (*(aes_lds_u32p)(uintptr_t)(aes_rep_addr<b, 1>(x, laneSel) + 128))
+#define SUBROT(k) aes_pick_rep(TSY(k, 1), TSY(k, 2), TSY(k, 3), TSY(k, 0))
+#define TDCOL(a, b, c, d, m) aes_xor3(aes_xor3(TD(0, a, 0), TD(1, b, 1), TD(2, c, 2)), TD(3, d, 3), m) /* column ^ InvMix(key) */
     Tally tl;
     uint32_t detItems = 0;
     for (uint64_t tile = (uint64_t)blockIdx.x * (kAesRepThreads / kWave) + (tid >> 6); tile < ntiles;
@@ -747,6 +835,9 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
         uint32_t x0, x1, x2, x3;
         auto rounds = [&](auto hookTag) __attribute__((always_inline)) { // as aes128_dec_fast_kernel, HOOKED included
             constexpr bool HOOKED = decltype(hookTag)::value;
+            AesLaneFaults lf; // this lane's armed upsets (read once)
+            if constexpr (HOOKED)
+                lf = aes_gather_faults((aes_lds_rec_p)(sLf + tid), ft, fr, lm.q, lm.r, lm.live);
             uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
 #pragma unroll
             for (int rd = 0; rd < 10; ++rd) { // the last encryption key first (:110-123)
@@ -780,7 +871,7 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
                 m2 ^= m1;
                 m1 ^= m0;
                 // one 8-byte lookup per byte of k3: the S-box byte for the key word, Tis_0 for its InvMixColumns image
-                const uint2 a1 = TS(k3, 1), a2 = TS(k3, 2), a3 = TS(k3, 3), a0 = TS(k3, 0);
+                const aes_u32x2 a1 = TS(k3, 1), a2 = TS(k3, 2), a3 = TS(k3, 3), a0 = TS(k3, 0);
                 k0 = aes_xor3(k0, aes_pick_rep(a1.y, a2.y, a3.y, a0.y), (uint32_t)kAesRcon[j]);
                 m0 ^= aes_xor3(a1.x, aes_rotl8(a2.x, 1), aes_rotl8(a3.x, 2)) ^ aes_rotl8(a0.x, 3) ^ gAesImcRcon[j];
                 const uint32_t w0 = TDCOL(x0, x3, x2, x1, m0), w1 = TDCOL(x1, x0, x3, x2, m1);
@@ -795,10 +886,10 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
             k2 ^= k1;
             k1 ^= k0;
             k0 = aes_xor3(k0, SUBROT(k3), (uint32_t)kAesRcon[0]);
-            const uint32_t p0 = aes_pick_rep(DR(x0, 0).y, DR(x3, 1).y, DR(x2, 2).y, DR(x1, 3).y) ^ k0;
-            const uint32_t p1 = aes_pick_rep(DR(x1, 0).y, DR(x0, 1).y, DR(x3, 2).y, DR(x2, 3).y) ^ k1;
-            const uint32_t p2 = aes_pick_rep(DR(x2, 0).y, DR(x1, 1).y, DR(x0, 2).y, DR(x3, 3).y) ^ k2;
-            const uint32_t p3 = aes_pick_rep(DR(x3, 0).y, DR(x2, 1).y, DR(x1, 2).y, DR(x0, 3).y) ^ k3;
+            const uint32_t p0 = aes_pick_rep(RSB(x0, 0), RSB(x3, 1), RSB(x2, 2), RSB(x1, 3)) ^ k0;
+            const uint32_t p1 = aes_pick_rep(RSB(x1, 0), RSB(x0, 1), RSB(x3, 2), RSB(x2, 3)) ^ k1;
+            const uint32_t p2 = aes_pick_rep(RSB(x2, 0), RSB(x1, 1), RSB(x0, 2), RSB(x3, 3)) ^ k2;
+            const uint32_t p3 = aes_pick_rep(RSB(x3, 0), RSB(x2, 1), RSB(x1, 2), RSB(x0, 3)) ^ k3;
             x0 = p0, x1 = p1, x2 = p2, x3 = p3;
             AES_DEC_HOOK(10, false, false);
         };
@@ -832,7 +923,8 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
             }
         }
     }
-#undef DR
+#undef RSB
+#undef TSY
 #undef TS
 #undef TD
 #undef SUBROT

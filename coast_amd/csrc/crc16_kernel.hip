@@ -232,7 +232,7 @@ __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
         const uint32_t a2 = __builtin_amdgcn_perm(d, laneSel, 0x0c0c0600u), a3 = __builtin_amdgcn_perm(d, laneSel, 0x0c010700u);
         // the permuted bytes ARE the LDS address (the dynamic segment starts at 0, checked above): no base add per lookup
         typedef const __attribute__((address_space(3))) uint32_t *lds_u32p;
-        const uint32_t r0 = *(lds_u32p)(a0), r1 = *(lds_u32p)(a1), r2 = *(lds_u32p)(a2), r3 = *(lds_u32p)(a3);
+        const uint32_t r0 = *(lds_u32p)(uintptr_t)(a0), r1 = *(lds_u32p)(uintptr_t)(a1), r2 = *(lds_u32p)(uintptr_t)(a2), r3 = *(lds_u32p)(uintptr_t)(a3);
         return r0 ^ r1 ^ ((r2 ^ r3) >> 16);
     };
     if (tid < 4)

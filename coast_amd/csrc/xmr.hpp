@@ -46,15 +46,25 @@ template <int NREP> struct LaneMap {
     bool live; // false for the idle lane(s) when 64 % NREP != 0
     int base4; // byte address (lane*4) of replica 0 of this item, for ds_bpermute
     bool storeSync = true; // false under -noStoreDataSync (general kernels only): xmr_store_sync passes values through
-    __device__ __forceinline__ LaneMap()
+    __device__ __forceinline__ LaneMap() : LaneMap((int)(threadIdx.x & (kWave - 1))) {}
+    // from an explicit lane id -- xmr_fresh_lane(): a map for a kernel's epilogue that keeps no register alive across its main loop
+    __device__ __forceinline__ explicit LaneMap(int laneId)
     {
-        lane = threadIdx.x & (kWave - 1);
+        lane = laneId;
         q = lane / NREP;
         r = lane - q * NREP;
         live = q < kItemsPerWave;
         base4 = (lane - r) * 4;
     }
 };
+
+// the lane id, recomputed where it is used (v_mbcnt inside an asm volatile: nothing is hoisted or kept from an earlier copy)
+__device__ __forceinline__ int xmr_fresh_lane()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 
 // Running tallies of one lane; only replica 0 of a live item tallies, so every sync point counts once.
 struct Tally {

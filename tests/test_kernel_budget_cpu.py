@@ -113,13 +113,14 @@ def test_lds_table_kernels_keep_their_occupancy(compiled):
     # encryption: two 1024-thread workgroups per CU (64 KiB of tables each) need <= 64 registers per lane
     assert enc["VGPRs"] <= 64 and enc["VGPRs Spill"] == 0 and enc["Occupancy [waves/SIMD]"] == 8
     assert dec["VGPRs"] <= 128 and dec["VGPRs Spill"] == 0
-    # lookups per block: encryption 203 dword reads; decryption 199 dword + 32 eight-byte pair reads (bench.py AES.LOOKUPS).  The
+    # lookups per block: encryption 203 dword reads; decryption 208 dword + 32 eight-byte pair reads (bench.py AES.LOOKUPS).  The
     # rounds are instantiated twice -- clean tiles, and tiles that own an armed upset (injector hooks between the same rounds)
     be, bd = _find(bodies, "void coast::aes128_enc_rep_kernel<2>"), _find(bodies, "void coast::aes128_dec_rep_kernel<2>")
     # (the compiler may sink a few lookups of the last round below the join of the two instantiations)
     ne, nd, nd64 = len(re.findall(r"ds_read_b32", be)), len(re.findall(r"ds_read_b32", bd)), len(re.findall(r"ds_read_b64", bd))
-    assert 2 * 203 - 8 <= ne <= 2 * 203 and not re.search(r"ds_read_b64", be), ne
-    assert 2 * 199 - 8 <= nd <= 2 * 199 + 16 and 2 * 24 <= nd64 <= 2 * 32, (nd, nd64)  # (pair reads whose Tis half is dead are narrowed to dwords)
+    # (eight-byte reads of the encryption kernel: the armed tiles' per-round look at the lane's upset records, 11 hook points)
+    assert 2 * 203 - 8 <= ne <= 2 * 203 and len(re.findall(r"ds_read_b64", be)) <= 11, ne
+    assert 2 * 208 - 8 <= nd <= 2 * 208 and 2 * 24 <= nd64 <= 2 * 32 + 11, (nd, nd64)  # (pair reads whose Tis half is dead are narrowed to dwords)
     for name in ("void coast::crc16_stream_kernel<3, 2, true, 1024,", "void coast::crc16_stream_kernel<3, 1, false, 1024,"):
         u = _find(usage, name)  # 1024-thread persistent workgroups: 128 registers per lane
         assert u["VGPRs"] <= 128 and u["VGPRs Spill"] == 0, (name, u)
@@ -144,7 +145,7 @@ def test_bench_lookup_counts_match_the_compiled_kernels():
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    assert b.AES.LOOKUPS == {0: 203, 1: 199 + 32}
+    assert b.AES.LOOKUPS == {0: 203, 1: 208 + 32}
 
 
 def test_evidence_pointers_resolve():

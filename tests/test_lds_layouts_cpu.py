@@ -73,10 +73,10 @@ def test_mm_conversion_stores_stay_within_two_way():
 
 @pytest.mark.parametrize("nrep", [1, 2, 3])
 def test_aes_replicated_tables_never_conflict(nrep):
-    """aes_kernel.hip aes_rep_off: copy c of entry v at (16 v + c) x entry size, lanes of block slot q read copy q % 16 (lane % 16
-    unprotected).  Random table indices per block -- the replicas of a block look up the same entry -- for dword tables
-    (ds_read_b32) and the 8-byte pair tables of the decryption kernel (ds_read_b64).  DWC and TMR: conflict-free whatever the
-    indices; unprotected: 32 blocks share 16 copies, at most two-way."""
+    """aes_kernel.hip aes_rep_addr (round 3): entry value v owns a 256-byte row of a 64 KiB table block -- four slots of 16 copies x 4
+    bytes (decryption block 1: 16 copies x 8-byte pairs in slots 0-1, rsbox dwords in slot 2) -- and the lanes of block slot q read
+    copy q % 16 (lane % 16 unprotected).  Random table indices per block -- the replicas of a block look up the same entry.  DWC and
+    TMR: conflict-free whatever the indices; unprotected: 32 blocks share 16 copies, two-way."""
     rng = np.random.default_rng(nrep)
     q = LANE // nrep if nrep > 1 else LANE
     copy = q & 15
@@ -84,23 +84,45 @@ def test_aes_replicated_tables_never_conflict(nrep):
     for _ in range(2000):
         v_block = rng.integers(0, 256, 64)
         v = v_block[q]  # every replica lane of a block holds the same byte when nothing is upset
-        assert worst_multiplicity((v * 16 + copy) * 4, 4, G32, 32) <= bound
-        assert worst_multiplicity((v * 16 + copy) * 8, 8, G32, 64) <= bound
-        assert worst_multiplicity((v * 16 + copy) * 8 + 4, 4, G32, 32) <= bound  # the .y half alone (S-box byte lookups)
-    # adversarial: all blocks on entries of one parity (every copy then owns exactly one bank)
+        for r in range(4):
+            assert worst_multiplicity(v * 256 + r * 64 + copy * 4, 4, G32, 32) <= bound
+        assert worst_multiplicity(65536 + v * 256 + copy * 8, 8, G32, 64) <= bound
+        assert worst_multiplicity(65536 + v * 256 + copy * 8 + 4, 4, G32, 32) <= bound  # the S-box half of a pair alone
+        assert worst_multiplicity(65536 + v * 256 + 128 + copy * 4, 4, G32, 32) <= bound  # rsbox
     for v0 in (0, 1, 254, 255):
         v = np.full(64, v0)
-        assert worst_multiplicity((v * 16 + copy) * 4, 4, G32, 32) <= bound
+        assert worst_multiplicity(v * 256 + copy * 4, 4, G32, 32) <= bound
+
+
+def test_aes_lookup_address_is_one_byte_permute():
+    """the address of a lookup = the byte string {copy offset, x.byte[B], block, 0}: what v_perm_b32(x, laneSel, selector) returns for
+    the selectors of aes_rep_addr (bytes 0..3 of the result picked from {laneSel bytes 0..3, x bytes 0..3} = indices 0..7, 0x0c = 0)"""
+    def perm(a, b, sel):
+        src = [(b >> (8 * i)) & 0xff for i in range(4)] + [(a >> (8 * i)) & 0xff for i in range(4)]
+        out = 0
+        for k in range(4):
+            idx = (sel >> (8 * k)) & 0xff
+            out |= (0 if idx == 0x0c else src[idx]) << (8 * k)
+        return out
+
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        x, copy = int(rng.integers(0, 1 << 32)), int(rng.integers(0, 16))
+        for B in range(4):
+            byte = (x >> (8 * B)) & 0xff
+            for blk, lane_sel in ((0, copy * 4 | 0x100), (1, copy * 4 | 0x100), (1, copy * 8 | 0x100)):
+                sel = (0x0c010000 if blk else 0x0c0c0000) + ((4 + B) << 8)
+                assert perm(x, lane_sel, sel) == blk * 65536 + byte * 256 + (lane_sel & 0xff)
 
 
 def test_aes_table_fill_is_conflict_free():
-    """the fill loops of aes128_enc_rep_kernel / aes128_dec_rep_kernel: thread (copy = tid % 16, entry = tid / 16 + 64 i)"""
-    for wave in range(16):
-        tid = wave * 64 + LANE
-        c, v0 = tid & 15, tid >> 4
-        for i in range(4):
-            assert worst_multiplicity(((v0 + 64 * i) * 16 + c) * 4, 4, G32, 32) == 1
-            assert worst_multiplicity(((v0 + 64 * i) * 16 + c) * 8, 8, G32, 64) == 1
+    """the fill loops of aes128_enc_rep_kernel / aes128_dec_rep_kernel: a wave writes whole rows, lane = (slot r, copy c): at most two
+    lanes per bank (free for ds_write_b32); the pair stores of decryption block 1 come from 16 lanes"""
+    c, r = LANE & 15, (LANE >> 4) & 3
+    for v in (0, 7, 255):
+        assert worst_multiplicity(v * 256 + r * 64 + c * 4, 4, G32, 32) <= 2
+    pair = (65536 + 3 * 256 + (LANE & 15) * 8)[:16]
+    assert len(set((pair // 4) % 64)) == 16
 
 
 def test_aes_table_identities():
