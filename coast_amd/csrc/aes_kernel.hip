@@ -257,9 +257,12 @@ __device__ __forceinline__ AesLaneFaults aes_gather_faults(aes_lds_rec_p slotLds
     lf.over = __builtin_amdgcn_ballot_w64(n > 4u) != 0ull;
     return lf;
 }
+// `any` (wave-uniform): some lane of the wave has an upset due this round -- the callers skip their mask arithmetic otherwise (the
+// decryption hooks run InvMixColumns over the eight masks: done blindly at every hook it made an armed tile cost two clean ones)
 __device__ __forceinline__ AesDue aes_due_masks(const AesLaneFaults &lf, const FaultTab &ft, uint2 fr, uint32_t rd, int slot, int rep,
-                                                bool laneLive)
+                                                bool laneLive, bool &any)
 {
+    any = true;
     if (lf.over)
         return aes_due_scan(ft.list, fr, rd, slot, rep, laneLive);
     AesDue d;
@@ -268,7 +271,8 @@ __device__ __forceinline__ AesDue aes_due_masks(const AesLaneFaults &lf, const F
     // through the whole block: 30 spilled registers in the 64-register encryption kernel)
     asm volatile("" : "+v"(p.x), "+v"(p.y));
     const bool hit = (p.x & 15u) == rd || ((p.x >> 16) & 15u) == rd || (p.y & 15u) == rd || ((p.y >> 16) & 15u) == rd;
-    if (__builtin_amdgcn_ballot_w64(hit) != 0ull) { // wave-uniform: almost every round of an armed tile passes by
+    any = __builtin_amdgcn_ballot_w64(hit) != 0ull;
+    if (any) { // wave-uniform: almost every round of an armed tile passes by
         auto one = [&](uint32_t rec) __attribute__((always_inline)) {
             const uint32_t mm = (rec & 15u) == rd ? 1u << ((rec >> 7) & 31u) : 0u, code = (rec >> 4) & 7u;
             d.s0 ^= code == 0u ? mm : 0u, d.s1 ^= code == 1u ? mm : 0u, d.s2 ^= code == 2u ? mm : 0u, d.s3 ^= code == 3u ? mm : 0u;
@@ -339,9 +343,12 @@ __global__ __launch_bounds__(256) void aes128_enc_fast_kernel(uint8_t *__restric
                 lf = aes_gather_faults((aes_lds_rec_p)(sLf + tid), ft, fr, lm.q, lm.r, lm.live);
         auto hook = [&](int rd) __attribute__((always_inline)) {
             if constexpr (HOOKED) {
-                const AesDue d = aes_due_masks(lf, ft, fr, (uint32_t)rd, lm.q, lm.r, lm.live);
-                s0 ^= d.s0, s1 ^= d.s1, s2 ^= d.s2, s3 ^= d.s3;
-                k0 ^= d.k0, k1 ^= d.k1, k2 ^= d.k2, k3 ^= d.k3;
+                bool any;
+                const AesDue d = aes_due_masks(lf, ft, fr, (uint32_t)rd, lm.q, lm.r, lm.live, any);
+                if (any) {
+                    s0 ^= d.s0, s1 ^= d.s1, s2 ^= d.s2, s3 ^= d.s3;
+                    k0 ^= d.k0, k1 ^= d.k1, k2 ^= d.k2, k3 ^= d.k3;
+                }
             }
         };
 #pragma unroll
@@ -431,14 +438,17 @@ __device__ __forceinline__ uint32_t aes_imc_col(uint32_t x) // InvMixColumns of 
 #define AES_DEC_HOOK(rd, mixedState, haveM)                                                                       \
     do {                                                                                                          \
         if constexpr (HOOKED) {                                                                                   \
-            const AesDue d_ = aes_due_masks(lf, ft, fr, (uint32_t)(rd), lm.q, lm.r, lm.live);                         \
-            if (mixedState)                                                                                       \
-                x0 ^= aes_imc_col(d_.s0), x1 ^= aes_imc_col(d_.s1), x2 ^= aes_imc_col(d_.s2), x3 ^= aes_imc_col(d_.s3); \
-            else                                                                                                  \
-                x0 ^= d_.s0, x1 ^= d_.s1, x2 ^= d_.s2, x3 ^= d_.s3;                                               \
-            k0 ^= d_.k0, k1 ^= d_.k1, k2 ^= d_.k2, k3 ^= d_.k3;                                                   \
-            if (haveM)                                                                                            \
-                m0 ^= aes_imc_col(d_.k0), m1 ^= aes_imc_col(d_.k1), m2 ^= aes_imc_col(d_.k2), m3 ^= aes_imc_col(d_.k3); \
+            bool any_;                                                                                            \
+            const AesDue d_ = aes_due_masks(lf, ft, fr, (uint32_t)(rd), lm.q, lm.r, lm.live, any_);               \
+            if (any_) {                                                                                           \
+                if (mixedState)                                                                                   \
+                    x0 ^= aes_imc_col(d_.s0), x1 ^= aes_imc_col(d_.s1), x2 ^= aes_imc_col(d_.s2), x3 ^= aes_imc_col(d_.s3); \
+                else                                                                                              \
+                    x0 ^= d_.s0, x1 ^= d_.s1, x2 ^= d_.s2, x3 ^= d_.s3;                                           \
+                k0 ^= d_.k0, k1 ^= d_.k1, k2 ^= d_.k2, k3 ^= d_.k3;                                               \
+                if (haveM)                                                                                        \
+                    m0 ^= aes_imc_col(d_.k0), m1 ^= aes_imc_col(d_.k1), m2 ^= aes_imc_col(d_.k2), m3 ^= aes_imc_col(d_.k3); \
+            }                                                                                                     \
         }                                                                                                         \
     } while (0)
 
@@ -684,9 +694,12 @@ __global__ __launch_bounds__(kAesRepThreads) __attribute__((amdgpu_waves_per_eu(
                 lf = aes_gather_faults((aes_lds_rec_p)(sLf + tid), ft, fr, lmT.q, lmT.r, lmT.live);
             auto hook = [&](int rd) __attribute__((always_inline)) {
                 if constexpr (HOOKED) {
-                    const AesDue d = aes_due_masks(lf, ft, fr, (uint32_t)rd, lmT.q, lmT.r, lmT.live);
-                    s0 ^= d.s0, s1 ^= d.s1, s2 ^= d.s2, s3 ^= d.s3;
-                    k0 ^= d.k0, k1 ^= d.k1, k2 ^= d.k2, k3 ^= d.k3;
+                    bool any;
+                    const AesDue d = aes_due_masks(lf, ft, fr, (uint32_t)rd, lmT.q, lmT.r, lmT.live, any);
+                    if (any) {
+                        s0 ^= d.s0, s1 ^= d.s1, s2 ^= d.s2, s3 ^= d.s3;
+                        k0 ^= d.k0, k1 ^= d.k1, k2 ^= d.k2, k3 ^= d.k3;
+                    }
                 }
             };
             if constexpr (!HOOKED) { // clean tiles: AddRoundKey of the next round folded into the column sums (x = s ^ k carried)
