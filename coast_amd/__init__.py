@@ -17,7 +17,7 @@ SITE_MM_I, SITE_MM_J, SITE_MM_K = 3, 4, 5  # COAST_F_BRANCH_SYNC / COAST_F_ADDR_
 SITE_SHA_M, SITE_SHA_WV, SITE_SHA_STATE, SITE_SHA_DATALEN, SITE_SHA_I = 8, 9, 10, 11, 12
 SITE_AES_STATE, SITE_AES_KEY = 16, 17
 SITE_CRC_CRC, SITE_CRC_X, SITE_CRC_LEN = 24, 25, 26
-SITE_CT_SUM, SITE_CT_VAL, SITE_CT_NERR = 32, 33, 34
+SITE_CT_SUM, SITE_CT_VAL, SITE_CT_NERR, SITE_CT_I = 32, 33, 34, 35
 SITE_CHSHA_W, SITE_CHSHA_WV, SITE_CHSHA_DIGEST = 40, 41, 42
 SITE_QS_I, SITE_QS_J, SITE_QS_PIVOT, SITE_QS_VI, SITE_QS_VJ = 48, 49, 50, 51, 52
 SITE_CFC_PC, SITE_CFC_RTS, SITE_CFC_RTSA = 56, 57, 58

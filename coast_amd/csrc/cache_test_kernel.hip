@@ -22,7 +22,7 @@
 
 namespace coast {
 
-enum { SITE_CT_SUM = 32, SITE_CT_VAL = 33, SITE_CT_NERR = 34 };
+enum { SITE_CT_SUM = 32, SITE_CT_VAL = 33, SITE_CT_NERR = 34, SITE_CT_I = 35 };
 
 // vote a mask of up to 32 branch conditions (bit k = condition k of the group, `gmask` = the bits in use)
 template <int NREP>
@@ -216,6 +216,109 @@ __global__ __launch_bounds__(256) void cache_test_kernel(uint32_t *__restrict__ 
         }
     }
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+// calc_sum with its loop as written (cacheTest.c:107-131), for COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC: the loop counter i is a
+// replica-private lane register beside sum and numberOfErrors -- one lane per (array, replica), one sequential walk.  Sync points, the
+// reference's rule set for -TMR -noMemReplication on the source as written:
+//   `i < data_array_elements` at every evaluation (n + 1 per clean array)                                     synchronization.cpp:146-155
+//   the GEP offsets: array[i] of `sum += array[i]` and of `array[i] != i` (two loads: off with -noLoadSync), array[i] of the
+//     scrub `array[i] = i` (a store: off with -noStoreAddrSync)                                               :333-372, 413-474
+//   `array[i] != i` (the data-dependent condition every schedule votes), the data of `array[i] = i` -- the counter itself now
+//     (off with -noStoreDataSync), the returned sum, the stored error count
+// The printf block of the error branch is I/O outside the batch model, as in the default schedule.  The array is memory: one copy,
+// a load uses the original instruction's address in every copy (the voted offset, or replica 0's); the original store (replica
+// 0's lane) writes it.  Fault sites: SITE_CT_I / _SUM / _NERR of a replica with `step` = how many loop conditions the call has
+// evaluated (the flip lands right before the next one); SITE_CT_VAL = the element loaded in the iteration that condition `step`
+// entered.  A wild index reads 0 / stores nothing; a walk that a corrupted counter keeps alive is cut after 4 (n + 1) + 1024
+// conditions.  The sync-point-parity form of the kernel, not the throughput form.
+template <int NREP>
+__global__ __launch_bounds__(64) void cache_test_indexed_kernel(uint32_t *__restrict__ arrays, uint32_t n, uint64_t narrays,
+                                                                int32_t *__restrict__ sums, uint32_t *__restrict__ nerrs,
+                                                                Counters ctr, FaultTab ft, uint8_t *__restrict__ detected)
+{
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    LaneMap<NREP> lm;
+    lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
+    const bool bs = (ctr.flags & kFlagBranchSync) != 0u, as = (ctr.flags & kFlagAddrSync) != 0u;
+    const bool ls = as && !(ctr.flags & kFlagNoLoadSync), ss = as && !(ctr.flags & kFlagNoStoreAddrSync);
+    const uint32_t tile = blockIdx.x;
+    const int slot = lm.q;
+    const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
+    const bool live = lm.live && item < narrays;
+    const bool cnt = live && lm.r == 0;
+    const bool writer = cnt; // the single memory copy is written by the original store (replica 0's lane)
+    uint32_t *a = arrays + (live ? item : 0) * (uint64_t)n;
+    if (threadIdx.x < 4)
+        sCnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint2 fr = make_uint2(0u, 0u);
+    if (ft.range)
+        fr = ft.range[tile];
+    const uint32_t N = live ? n : 0u;
+    const uint64_t cap = 4ull * ((uint64_t)n + 1ull) + 1024ull;
+    Tally tl;
+    uint32_t i = 0u, sum = 0u, nerr = 0u;
+    uint64_t tick = 0;
+    auto hook = [&](uint64_t step, bool loaded, uint32_t &v) __attribute__((always_inline)) {
+        for (uint32_t q = 0; q < fr.y; ++q) {
+            const DevFault df = ft.list[fr.x + q];
+            if ((uint64_t)df.step != step || (int)df.local != slot || (int)df.replica != lm.r || !lm.live)
+                continue;
+            const uint32_t m = 1u << (df.bit & 31u);
+            if (loaded) {
+                if (df.site == SITE_CT_VAL)
+                    v ^= m;
+            } else if (df.site == SITE_CT_I)
+                i ^= m;
+            else if (df.site == SITE_CT_SUM)
+                sum ^= m;
+            else if (df.site == SITE_CT_NERR)
+                nerr ^= m;
+        }
+    };
+    uint32_t none = 0u;
+    for (;;) {                                                       // for (i = 0; i < data_array_elements; i++)   :107
+        hook(tick, false, none);
+        if (tick >= cap)
+            break;
+        const uint64_t t = tick++;
+        // (the idle lane of a TMR wave has no array of its own -- its replica group would wrap to lanes 0, 1: N = 0, it leaves)
+        const bool go = lm.live ? xmr_steer<NREP>(i < N ? 1u : 0u, lm, bs, cnt, tl) != 0u : i < N;
+        if (!go)
+            break;
+        const uint32_t o1 = xmr_steer<NREP>(i, lm, ls, cnt, tl);     // sum += array[i]                             :108
+        uint32_t v = o1 < N ? a[o1] : 0u;
+        hook(t, true, v);
+        sum += v;
+        (void)xmr_steer<NREP>(i, lm, ls, cnt, tl);                   // if (array[i] != i): the same offset, voted again :110
+        const bool taken = xmr_steer<NREP>(v != i ? 1u : 0u, lm, true, cnt, tl) != 0u; // (the element as loaded above)
+        if (taken) {
+            nerr += 1u;                                              // numberOfErrors++                            :111
+            const uint32_t os = xmr_steer<NREP>(i, lm, ss, cnt, tl); // array[i] = i                                :127
+            uint32_t d = xmr_store_sync<NREP>(i, lm, cnt, tl);
+            if (NREP != 3 || !lm.storeSync)
+                d = xmr_rep0<NREP>(d, lm);
+            if (writer && os < N)
+                a[os] = d;
+        }
+        i += 1u;
+    }
+    sum = xmr_sync<NREP>(sum, lm, cnt, tl);          // return sum
+    nerr = xmr_store_sync<NREP>(nerr, lm, cnt, tl);  // stored to the caller's error count
+    uint32_t detItems = 0;
+    if (cnt) {
+        sums[item] = (int32_t)sum;
+        nerrs[item] = nerr;
+        if (tl.det) { // unequal copies at a sync point of this array (DWC: detected, TMR: corrected)
+            if (NREP == 2)
+                detItems = 1;
+            if (detected)
+                detected[item] = 1;
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, tile);
 }
 
 } // namespace coast

@@ -67,7 +67,7 @@ typedef struct coast_cfg {
  *   -i / -s           instruction interleaving vs segmenting: replicas are lanes of one instruction, there is no order. */
 enum {
     COAST_F_NO_STORE_DATA_SYNC = 1u,
-    /* Loop / byte counters INSIDE the sphere of replication (mm, sha256, crc16; the launch runs a stepwise kernel).  mm: the
+    /* Loop / byte counters INSIDE the sphere of replication (mm, sha256, crc16, cache_test; the launch runs a stepwise kernel).  mm: the
      * work item becomes the CALL -- i, j, k and `sum` of matrix_multiply (mm_common_tmr.c:3-20) are replica-private registers of
      * one sequential walk per matrix, the three loop conditions are voted at every evaluation ((N+1)(N^2+N+1) votes, SURVEY.md
      * section 3.2) and so are the GEP offsets of f[i][k], s[k][j] (i, k, k, j: loads) and r[i][j] (i, j: store); fault sites
@@ -76,12 +76,15 @@ enum {
      * and the reference's rules for them apply:
      *   COAST_F_BRANCH_SYNC         every evaluation of a branch condition on them is a sync point (synchronization.cpp:146-155,
      *                               741-949): sha256 `i < len`, `ctx_datalen == 64` per byte and `ctx_datalen < 56`
-     *                               (sha256_common_tmr.c:119,122,132); crc16 `length--` per byte (crc16.c:25).  Not set, the
+     *                               (sha256_common_tmr.c:119,122,132); crc16 `length--` per byte (crc16.c:25); cache_test
+     *                               `i < data_array_elements` (cacheTest.c:107).  Not set, the
      *                               branch follows the original instruction's operand = replica 0's copy.
      *   COAST_F_ADDR_SYNC           GEP offsets built from them are sync points (:226-235, 333-372, 413-474), the reference's
      *                               default under -noMemReplication: sha256 data[i] (a load address) and ctx_data[ctx_datalen]
      *                               (a store address), sha256_common_tmr.c:120.  crc16's `*data_p++` has a constant offset:
-     *                               nothing to vote.  Not set, the access uses replica 0's offset.
+     *                               nothing to vote.  cache_test: array[i] of both loads and of the scrub store
+     *                               (cacheTest.c:108,110,127), whose data is the counter itself.  Not set, the access uses
+     *                               replica 0's offset.
      *   COAST_F_NO_LOAD_SYNC        -noLoadSync: with ADDR_SYNC, load addresses are not voted (:341-352)
      *   COAST_F_NO_STORE_ADDR_SYNC  -noStoreAddrSync: with ADDR_SYNC, store addresses are not voted (:354-367)
      * The reference's `-TMR -noMemReplication` is BRANCH_SYNC | ADDR_SYNC. */
@@ -158,6 +161,8 @@ enum {
     COAST_SITE_CT_SUM = 32,    /* cache_test: running sum before element `step` is added (step == n: after the loop) */
     COAST_SITE_CT_VAL = 33,    /* the loaded array[step], right after the load */
     COAST_SITE_CT_NERR = 34,   /* numberOfErrors before element `step` (step == n: after the loop) */
+    COAST_SITE_CT_I = 35,      /* COAST_F_BRANCH_SYNC / ADDR_SYNC: calc_sum's loop counter i; `step` of all four cache_test sites then counts
+                                * the loop conditions the call has evaluated (_CT_VAL: the element loaded in the iteration it entered) */
     COAST_SITE_CHSHA_W = 40,      /* CHStone sha: schedule word W[step%80] of transform step/80, right after it is produced */
     COAST_SITE_CHSHA_WV = 41,     /* working variable index 0..4 (A..E) before round step%80 of transform step/80 */
     COAST_SITE_CHSHA_DIGEST = 42, /* sha_info_digest[index] before transform `step` */

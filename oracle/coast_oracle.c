@@ -1211,6 +1211,70 @@ static void ct_item(int32_t *a, uint32_t n, int32_t *sum_out, uint32_t *nerr_out
     *nerr_out = nerr[0];
 }
 
+/* calc_sum with its loop as written (cacheTest.c:107-131), for ORC_F_BRANCH_SYNC / ORC_F_ADDR_SYNC: the loop counter i is a
+ * replica-private register beside sum and numberOfErrors.  Sync points, the reference's rule set for -TMR -noMemReplication on
+ * the source as written:
+ *   `i < data_array_elements` at every evaluation                                                   synchronization.cpp:146-155
+ *   the GEP offsets: array[i] of `sum += array[i]` and of `array[i] != i` (loads: off with -noLoadSync), array[i] of the scrub
+ *     `array[i] = i` (a store: off with -noStoreAddrSync)                                           :333-372, 413-474
+ *   `array[i] != i` (voted in every schedule), the data of `array[i] = i` -- the counter itself (off with -noStoreDataSync),
+ *   the returned sum, the stored error count
+ * The printf block of the error branch is I/O outside the batch model, as in the default schedule.  A load keeps the ORIGINAL
+ * instruction's address in every copy (cloning.cpp:2247-2255): unvoted offsets are replica 0's.  Fault sites: ORC_SITE_CT_I /
+ * _SUM / _NERR of a replica, `step` = how many loop conditions the call has evaluated (the flip lands right before the next
+ * one); ORC_SITE_CT_VAL = the element loaded in the iteration that condition `step` entered.  A wild index reads 0 / stores
+ * nothing; a walk that a corrupted counter keeps alive is cut after 4 (n + 1) + 1024 conditions. */
+static void ct_item_indexed(int32_t *a, uint32_t n, int32_t *sum_out, uint32_t *nerr_out, sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    const unsigned R = c->nrep;
+    const int bs = (c->flags & ORC_F_BRANCH_SYNC) != 0, as = (c->flags & ORC_F_ADDR_SYNC) != 0;
+    const int ls = as && !(c->flags & ORC_F_NO_LOAD_SYNC), ss = as && !(c->flags & ORC_F_NO_STORE_ADDR_SYNC);
+    const uint64_t cap = 4ull * ((uint64_t)n + 1ull) + 1024ull;
+    uint32_t i[3] = {0, 0, 0}, sum[3] = {0, 0, 0}, nerr[3] = {0, 0, 0};
+    uint64_t tick = 0;
+    for (;;) {
+        for (size_t q = 0; q < nf; ++q)
+            if ((uint64_t)fl[q].step == tick && fl[q].replica < R) {
+                uint32_t *t = fl[q].site == ORC_SITE_CT_I ? i : fl[q].site == ORC_SITE_CT_SUM ? sum : fl[q].site == ORC_SITE_CT_NERR ? nerr : NULL;
+                if (t)
+                    t[fl[q].replica] = flip(t[fl[q].replica], fl[q].bit, 0xffffffffu);
+            }
+        if (tick >= cap)
+            break;
+        const uint64_t t0 = tick++;
+        if (!branch_cond(c, i[0] < n, i[R > 1 ? 1 : 0] < n, i[R > 2 ? 2 : 0] < n, bs))
+            break;
+        const uint32_t o1 = gep_offset(c, i, ls);                 /* sum += array[i]        :108 */
+        uint32_t v[3], cond[3] = {0, 0, 0};
+        for (unsigned r = 0; r < 3; ++r) {
+            v[r] = o1 < n ? (uint32_t)a[o1] : 0u;
+            for (size_t q = 0; q < nf; ++q)
+                if (fl[q].site == ORC_SITE_CT_VAL && (uint64_t)fl[q].step == t0 && fl[q].replica == r && r < R)
+                    v[r] = flip(v[r], fl[q].bit, 0xffffffffu);
+            sum[r] += v[r];
+        }
+        (void)gep_offset(c, i, ls);                               /* if (array[i] != i)     :110 */
+        for (unsigned r = 0; r < 3; ++r)
+            cond[r] = (v[r < R ? r : 0] != i[r < R ? r : 0]) ? 1u : 0u;
+        if (branch_cond(c, cond[0], cond[1], cond[2], 1)) {
+            for (unsigned r = 0; r < 3; ++r)
+                nerr[r] += 1;                                     /* numberOfErrors++       :111 */
+            const uint32_t os = gep_offset(c, i, ss);             /* array[i] = i           :127 */
+            uint32_t d[3] = {i[0], i[R > 1 ? 1 : 0], i[R > 2 ? 2 : 0]};
+            store_sync32(c, d);
+            if (os < n)
+                a[os] = (int32_t)d[0];
+        }
+        for (unsigned r = 0; r < 3; ++r)
+            i[r] += 1;
+    }
+    uint32_t vs[3] = {sum[0], sum[R > 1 ? 1 : 0], sum[R > 2 ? 2 : 0]}, vn[3] = {nerr[0], nerr[R > 1 ? 1 : 0], nerr[R > 2 ? 2 : 0]};
+    sync32(c, vs);        /* return value */
+    store_sync32(c, vn);  /* stored to the caller's error count */
+    *sum_out = (int32_t)vs[0];
+    *nerr_out = vn[0];
+}
+
 void orc_cache_test_xmr(int32_t *arrays, uint32_t n, size_t narrays, int32_t *sums, uint32_t *nerrs, const orc_cfg *cfg,
                         const orc_fault *faults, size_t nfaults, orc_stats *st, uint8_t *detected)
 {
@@ -1224,7 +1288,10 @@ void orc_cache_test_xmr(int32_t *arrays, uint32_t n, size_t narrays, int32_t *su
         while (fe < nfaults && fs[fe].item == b)
             ++fe;
         c.detected = 0;
-        ct_item(arrays + (size_t)b * n, n, &sums[b], &nerrs[b], &c, fs + fp, fe - fp);
+        if (cfg->flags & ORC_F_INDEXED)
+            ct_item_indexed(arrays + (size_t)b * n, n, &sums[b], &nerrs[b], &c, fs + fp, fe - fp);
+        else
+            ct_item(arrays + (size_t)b * n, n, &sums[b], &nerrs[b], &c, fs + fp, fe - fp);
         if (c.detected) {
             st->dwc_detected += (cfg->replicas == 2);
             if (detected)

@@ -61,6 +61,7 @@ enum {
     ORC_SITE_CT_SUM = 32,  /* cache_test: running sum before element `step` is added (step == n: after the loop) */
     ORC_SITE_CT_VAL = 33,  /* the loaded array[step], right after the load */
     ORC_SITE_CT_NERR = 34, /* numberOfErrors before element `step` (step == n: after the loop) */
+    ORC_SITE_CT_I = 35,    /* ORC_F_BRANCH_SYNC / ADDR_SYNC: the loop counter; `step` then counts evaluated loop conditions */
 
     ORC_SITE_CHSHA_W = 40,     /* CHStone sha: schedule word W[step%80] of transform step/80, right after it is produced */
     ORC_SITE_CHSHA_WV = 41,    /* working variable index 0..4 (A..E) before round step%80 of transform step/80 */

@@ -402,3 +402,26 @@ def test_chaes_oracle_votes_out_single_upsets(orc):
         _, st2, det2 = orc.chaes_xmr(fx["st%d" % t], fx["key%d" % t], t, 0, replicas=2,
                                      faults=make_faults([(r[0], r[1] % 2) + r[2:] for r in rows]))
         assert st2["dwc_detected"] == det2.sum() >= 10
+
+
+def test_cache_test_loop_counter_in_the_sor_schedule(orc):
+    """ORC_F_BRANCH_SYNC / ORC_F_ADDR_SYNC for calc_sum (cacheTest.c:107-131): i beside sum / numberOfErrors inside the sphere of
+    replication.  Clean arrays of n elements: n + 1 loop conditions, 2 n load offsets, n element compares, the returned sum and the
+    stored error count = 4 n + 3 votes per array; every corrupt element adds its scrub's store offset and data.  Results equal the
+    default schedule's; a single upset of i is out-voted under TMR, detected under DWC."""
+    n, na = 600, 7
+    a = np.tile(np.arange(n, dtype=np.int32), (na, 1))
+    B, A = 2, 4
+    w_a, w_s, w_e, st, det = orc.cache_test_xmr(a, replicas=3, flags=B | A)
+    assert st["sync_count"] == na * (4 * n + 3) and st["errors_corrected"] == 0 and not det.any()
+    assert (w_s == 179700).all() and not w_e.any()                      # generateGolden(), cacheTest.c:86
+    a[3, 17] = 99
+    w_a, w_s, w_e, st, det = orc.cache_test_xmr(a, replicas=3, flags=B | A)
+    assert st["sync_count"] == na * (4 * n + 3) + 2 and w_e[3] == 1 and w_a[3, 17] == 17
+    ref = orc.cache_test_xmr(a, replicas=3)
+    assert (w_a == ref[0]).all() and (w_s == ref[1]).all() and (w_e == ref[2]).all()
+    fl = orc.make_faults([(5, 1, 35, 100, 3)])                          # replica 1's i before condition 100
+    t = orc.cache_test_xmr(a, replicas=3, flags=B | A, faults=fl)
+    assert (t[0] == ref[0]).all() and (t[1] == ref[1]).all() and t[3]["errors_corrected"] > 0 and t[4][5] == 1
+    dw = orc.cache_test_xmr(a, replicas=2, flags=B | A, faults=fl)
+    assert dw[3]["dwc_detected"] == 1 and dw[4][5] == 1
