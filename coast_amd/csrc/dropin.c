@@ -27,7 +27,7 @@
  *       -noStoreDataSync               COAST_F_NO_STORE_DATA_SYNC (only meaningful next to -noMemReplication, as in the reference)
  *       -countErrors -countSyncs -storeDataSync -i -s   accepted; always on / no effect here (include/coast_hip.h says why; the
  *                                      batch ABI has the memory-replicated -storeDataSync form as COAST_F_MEMORY_COPIES)
- *       -noLoadSync -noStoreAddrSync   accepted; real knobs for matrix_multiply / crc16 / sha256_hash once COAST_COUNTERS_IN_SOR=1 puts their loop
+ *       -noLoadSync -noStoreAddrSync   accepted; real knobs for matrix_multiply / crc16 / sha256_hash / calc_sum once COAST_COUNTERS_IN_SOR=1 puts their loop
  *                                      counters inside the sphere of replication (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC, the
  *                                      reference's -noMemReplication rule set for them); otherwise no replicated address exists
  *   or, shorter, COAST_MODE = TMR (default) | DWC | NONE  (lane-replicated engine);
@@ -84,7 +84,7 @@ static coast_cfg dropin_cfg(void)
     return c;
 }
 
-/* matrix_multiply / crc16 / sha256_hash: the kernels whose loop counters can be put inside the sphere of replication */
+/* matrix_multiply / crc16 / sha256_hash / calc_sum: the kernels whose loop counters can be put inside the sphere of replication */
 static coast_cfg dropin_cfg_counters(void)
 {
     coast_cfg c = dropin_cfg();
@@ -261,7 +261,7 @@ extern int golden __attribute__((weak));
 
 int coast_dropin_calc_sum(int *array, int n)
 {
-    const coast_cfg cfg = dropin_cfg();
+    const coast_cfg cfg = dropin_cfg_counters(); /* COAST_COUNTERS_IN_SOR=1: the loop counter i replica-private, its condition and GEP offsets voted */
     dropin_maybe_inject();
     int *found = (int *)malloc((size_t)n * sizeof(int));
     if (!found)

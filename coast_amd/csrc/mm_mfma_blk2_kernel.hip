@@ -25,6 +25,17 @@
 
 #include "xmr.hpp"
 
+// Cache policy of the streams that are touched once (profiles/r03_mm_nt.txt): the aux field of the buffer instructions, bit 1 = nt
+// (non-temporal).  r is written once and f is read once per panel workgroup; s is the operand the four panel workgroups of a matrix
+// share through their XCD's L2 -- 4 MB for the eight matrices an XCD has in flight, which f + s + r (6 MB) did not fit: about half of s
+// was filled twice (15.3 GB of HBM traffic per launch against 12.9 algorithmic).  With r and f non-temporal: 13.6 GB = 1.05 x.
+#ifndef COAST_MM_AUX_R
+#define COAST_MM_AUX_R 2
+#endif
+#ifndef COAST_MM_AUX_F
+#define COAST_MM_AUX_F 2
+#endif
+
 namespace coast {
 
 template <int NREP> struct MmBlk2 {
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
         u32x4_t pa[G::A_PER_THR];
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u)
-            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffFof(), soffFw + (pnl * G::BM + u * 8) * G::N * 4, 0);
+            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffFof(), soffFw + (pnl * G::BM + u * 8) * G::N * 4, COAST_MM_AUX_F);
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u) {
             const uint32_t y[4] = {mm_digits(pa[u][0]), mm_digits(pa[u][1]), mm_digits(pa[u][2]), mm_digits(pa[u][3])};
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
     }
     // background piece of step g (a step in which this wave is not converting s): piece (g % 16) / 2 of the next item's panel
     auto bgLoad = [&](int g) __attribute__((always_inline)) {
-        return __builtin_amdgcn_raw_buffer_load_b128(rsFof((g >> 4) + 1), voffFof(), soffFw + (pnl * G::BM + 8 * ((g & 15) >> 1)) * G::N * 4, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(rsFof((g >> 4) + 1), voffFof(), soffFw + (pnl * G::BM + 8 * ((g & 15) >> 1)) * G::N * 4, COAST_MM_AUX_F);
     };
 
     auto tileCol0 = [&](int g) __attribute__((always_inline)) { return (wave + G::NLANE * ((g >> 2) & 3)) * G::CT; };
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
                     detItems += teMiss;
             } else {
                 const int erow = pnl * G::BM + (2 * H + rb) * 16 + i;
-                __builtin_amdgcn_raw_buffer_store_b32(teVoted, rb == 0 ? rsR : rsRp, voffR, (erow * G::N + tileCol0(g)) * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(teVoted, rb == 0 ? rsR : rsRp, voffR, (erow * G::N + tileCol0(g)) * 4, COAST_MM_AUX_R);
                 if constexpr (FLAGS)
                     __builtin_amdgcn_raw_buffer_store_b8((uint8_t)1, rb == 0 ? rsD : rsDp, teMiss ? (voffR >> 2) : 0x40000000, erow * G::N + tileCol0(g), 0);
             }

@@ -31,6 +31,16 @@
 
 #include "xmr.hpp"
 
+// cache policy of the streams touched once (r stores, f panel loads): the aux field of the buffer instructions, bit 1 = nt -- see
+// mm_mfma_blk2_kernel.hip and profiles/r03_mm_nt.txt
+#ifndef COAST_MM_AUX_R
+#define COAST_MM_AUX_R 2
+#endif
+#ifndef COAST_MM_AUX_F
+#define COAST_MM_AUX_F 2
+#endif
+
+
 #ifndef COAST_BLK_KNOCK
 #define COAST_BLK_KNOCK 0 // development timing knock-outs (results wrong): 1 no tile end, 2 no background panel, 4 no s conversion
 #endif
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
         u32x4_t pa[G::A_PER_THR];
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u)
-            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffF, (pnl * G::BM + u * 4) * G::N * 4, 0);
+            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffF, (pnl * G::BM + u * 4) * G::N * 4, COAST_MM_AUX_F);
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u) {
             const uint32_t y[4] = {mm_digits(pa[u][0]), mm_digits(pa[u][1]), mm_digits(pa[u][2]), mm_digits(pa[u][3])};
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
     // background pieces in flight: piece g % 16 of the NEXT item's panel is loaded during step g - 2 and converted during step g
     // (g = step number in the workgroup's life: item g / 16, tile (g / 4) % 4, slab g % 4)
     auto bgLoad = [&](int g) __attribute__((always_inline)) {
-        return __builtin_amdgcn_raw_buffer_load_b128(rsFof((g >> 4) + 1), voffF, (pnl * G::BM + 4 * (g & 15)) * G::N * 4, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(rsFof((g >> 4) + 1), voffF, (pnl * G::BM + 4 * (g & 15)) * G::N * 4, COAST_MM_AUX_F);
     };
     u32x4_t bgRaw[2] = {bgLoad(0), bgLoad(1)}; // two pieces in flight: piece g lives in set g & 1, reloaded with piece g + 2
 
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
         } else {
             // one per-lane offset for the whole kernel; the element's row / the tile's column are a scalar offset
             const int erow = pnl * G::BM + rb * 16 + i;
-            __builtin_amdgcn_raw_buffer_store_b32(teVoted, rsR, voffR, (erow * G::N + tileCol0(g)) * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(teVoted, rsR, voffR, (erow * G::N + tileCol0(g)) * 4, COAST_MM_AUX_R);
             if constexpr (FLAGS)
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)1, rsD, teMiss ? (voffR >> 2) : 0x40000000, erow * G::N + tileCol0(g), 0);
         }
@@ -505,7 +515,7 @@ __global__ __launch_bounds__(MmBlk<NREP>::NTHR, 1) void mm_mfma_blk_kernel(const
                     constexpr int k = decltype(kTag)::value;
                     x ^= (uint32_t)acc[k / (NREP * 4)][(k / 4) % NREP][k % 4][0];
                 });
-                __builtin_amdgcn_raw_buffer_store_b32(x, rsR, voffR, (pnl * G::BM * G::N + tileCol0(g0)) * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(x, rsR, voffR, (pnl * G::BM * G::N + tileCol0(g0)) * 4, COAST_MM_AUX_R);
             }
         }
     }

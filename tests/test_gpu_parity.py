@@ -1872,7 +1872,7 @@ def test_indexed_flags_are_rejected_where_not_implemented(eng):
     import coast_amd as ca
 
     st = torch.zeros((4, 16), dtype=torch.uint8, device="cuda")
-    with pytest.raises(RuntimeError, match="mm, sha256 and crc16"):
+    with pytest.raises(RuntimeError, match="are implemented for mm, sha256"):
         eng.aes128_batch(st, st.clone(), 0, cfg=ca.XmrConfig(2, 0, ca.F_BRANCH_SYNC))
     f = torch.zeros((1, 16, 16), dtype=torch.int32, device="cuda")
     with pytest.raises(RuntimeError, match="sync_every belongs to the per-element schedule"):
