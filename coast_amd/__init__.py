@@ -15,7 +15,7 @@ REPLICA_ALL = 255  # COAST_REPLICA_ALL: a common-mode upset (state the replicas 
 SITE_MM_ACC, SITE_MM_OPA, SITE_MM_OPB = 0, 1, 2
 SITE_MM_I, SITE_MM_J, SITE_MM_K = 3, 4, 5  # COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC: the loop counters, one item per call
 SITE_SHA_M, SITE_SHA_WV, SITE_SHA_STATE, SITE_SHA_DATALEN, SITE_SHA_I = 8, 9, 10, 11, 12
-SITE_AES_STATE, SITE_AES_KEY = 16, 17
+SITE_AES_STATE, SITE_AES_KEY, SITE_AES_ROUND, SITE_AES_I = 16, 17, 18, 19
 SITE_CRC_CRC, SITE_CRC_X, SITE_CRC_LEN = 24, 25, 26
 SITE_CT_SUM, SITE_CT_VAL, SITE_CT_NERR, SITE_CT_I = 32, 33, 34, 35
 SITE_CHSHA_W, SITE_CHSHA_WV, SITE_CHSHA_DIGEST = 40, 41, 42

@@ -24,7 +24,7 @@
 
 namespace coast {
 
-enum { SITE_AES_STATE = 16, SITE_AES_KEY = 17 };
+enum { SITE_AES_STATE = 16, SITE_AES_KEY = 17, SITE_AES_ROUND = 18, SITE_AES_I = 19 };
 
 __constant__ uint8_t kAesRcon[10] = {0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80, 0x1b, 0x36}; // :83
 
@@ -1051,6 +1051,231 @@ __global__ __launch_bounds__(256, 5) void aes128_xmr_kernel(uint8_t *__restrict_
         }
     }
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, lb);
+}
+
+// aes_enc_dec with its loops as written (TI_aes_128.c:107-235), for COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC: the two loop counters
+// `round` and `i` (unsigned char) are replica-private lane registers -- one lane per (block, replica), one sequential walk.  Sync
+// points added to the frozen schedule, the reference's rule set for -TMR -noMemReplication on the source as written:
+//   every evaluated branch condition: the loop conditions `round < 10`, `i < 16`, `i > 3`, `i < 4`, the tests of `dir`, the operands of
+//     `(round > 0 && dir) || (round < 9 && !dir)` in short-circuit order                                    synchronization.cpp:146-155
+//   every GEP with a variable index: state[i], key[i], key[i-4], state[buf4 + c], Rcon[round], Rcon[9-round], and the table lookups
+//     sbox[..] / rsbox[..], whose index is DATA (loads: off with -noLoadSync; the state[] / key[] stores: off with -noStoreAddrSync);
+//     constant indices (key[13], the ShiftRows moves) have nothing to vote (syncGEP returns early, :428-431)
+// state[] and key[] stay what they are in the frozen schedule: replica-private (the lane's own 16 + 16 bytes of LDS here, because they
+// are indexed at run time) until the function's exit, where their 8 dwords are voted as stored data; a voted (or, unvoted, replica
+// 0's) offset selects the element every copy accesses.  Fault sites: SITE_AES_ROUND / _I of a replica (8 bits live), `step` = how
+// many LOOP conditions the call has evaluated; SITE_AES_STATE / _KEY keep their meaning (start of main-loop iteration `step`, 10: after
+// the loop).  A wild index reads 0 / stores nothing; a walk that a corrupted counter keeps alive is cut after 4096 loop conditions
+// (a clean call evaluates 373 / 514).  Oracle: aes_item_indexed.  The sync-point-parity form of the kernel, not the throughput form.
+template <int NREP>
+__global__ __launch_bounds__(64) void aes128_indexed_kernel(uint8_t *__restrict__ states, uint8_t *__restrict__ keys,
+                                                            uint64_t nblocksData, int dirFlag, Counters ctr, FaultTab ft,
+                                                            uint8_t *__restrict__ detected)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sSb[256];
+    __shared__ __attribute__((aligned(16))) uint8_t sRsb[256];
+    __shared__ __attribute__((aligned(16))) uint8_t sSt[64 * 16];
+    __shared__ __attribute__((aligned(16))) uint8_t sKy[64 * 16];
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    LaneMap<NREP> lm;
+    lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
+    const bool bs = (ctr.flags & kFlagBranchSync) != 0u, as = (ctr.flags & kFlagAddrSync) != 0u;
+    const bool ls = as && !(ctr.flags & kFlagNoLoadSync), ss = as && !(ctr.flags & kFlagNoStoreAddrSync);
+    const uint32_t tile = blockIdx.x;
+    const int slot = lm.q;
+    const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
+    const bool live = lm.live && item < nblocksData;
+    const bool cnt = live && lm.r == 0;
+    const bool d = dirFlag != 0;
+    reinterpret_cast<uint32_t *>(sSb)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gAesSbox)[threadIdx.x];
+    reinterpret_cast<uint32_t *>(sRsb)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gAesRsbox)[threadIdx.x];
+    if (threadIdx.x < 4)
+        sCnt[threadIdx.x] = 0;
+    uint8_t *S = sSt + lm.lane * 16, *K = sKy + lm.lane * 16; // this lane's copy of state[] and key[]
+    {
+        const uint64_t it = live ? item : 0;
+        *reinterpret_cast<uint4 *>(S) = reinterpret_cast<const uint4 *>(states)[it];
+        *reinterpret_cast<uint4 *>(K) = reinterpret_cast<const uint4 *>(keys)[it];
+    }
+    __syncthreads();
+    uint2 fr = make_uint2(0u, 0u);
+    if (ft.range)
+        fr = ft.range[tile];
+    Tally tl;
+    uint32_t round = 0u, i = 0u, tick = 0u;
+    if (lm.live) { // (the idle lane of a TMR wave has no block of its own: its replica group would wrap to lanes 0, 1)
+        auto loopc = [&](uint32_t &reg, uint32_t limit, bool gt) __attribute__((always_inline)) { // one evaluated loop condition
+            for (uint32_t q = 0; q < fr.y; ++q) { // the counters' upsets land right before the condition reads them
+                const DevFault df = ft.list[fr.x + q];
+                if (df.step != tick || (int)df.local != slot || (int)df.replica != lm.r)
+                    continue;
+                const uint32_t m = (1u << (df.bit & 31u)) & 0xffu;
+                if (df.site == SITE_AES_ROUND)
+                    round ^= m;
+                else if (df.site == SITE_AES_I)
+                    i ^= m;
+            }
+            if (tick >= 4096u)
+                return false;
+            ++tick;
+            return xmr_steer<NREP>((gt ? reg > limit : reg < limit) ? 1u : 0u, lm, bs, cnt, tl) != 0u;
+        };
+        auto ifc = [&](bool c) __attribute__((always_inline)) { return xmr_steer<NREP>(c ? 1u : 0u, lm, bs, cnt, tl) != 0u; };
+        auto ld = [&](const uint8_t *arr, int32_t idx) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t o = xmr_steer<NREP>((uint32_t)idx, lm, ls, cnt, tl);
+            return o < 16u ? (uint32_t)arr[o] : 0u;
+        };
+        auto st = [&](uint8_t *arr, int32_t idx, uint32_t v) __attribute__((always_inline)) {
+            const uint32_t o = xmr_steer<NREP>((uint32_t)idx, lm, ss, cnt, tl);
+            if (o < 16u)
+                arr[o] = (uint8_t)v;
+        };
+        auto tab = [&](const uint8_t *t, uint32_t size, uint32_t x) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t o = xmr_steer<NREP>(x, lm, ls, cnt, tl);
+            return o < size ? (uint32_t)t[o] : 0u;
+        };
+        auto rcon = [&](uint32_t x) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t o = xmr_steer<NREP>(x, lm, ls, cnt, tl);
+            return o < 10u ? (uint32_t)kAesRcon[o] : 0u;
+        };
+        auto keyCore = [&](uint32_t rc) __attribute__((always_inline)) { // key[0..3] ^= sbox[key[13, 14, 15, 12]] (^ Rcon[rc])
+            const uint32_t s0 = tab(sSb, 256u, K[13]) ^ rcon(rc);
+            K[0] ^= (uint8_t)s0;
+            K[1] ^= (uint8_t)tab(sSb, 256u, K[14]);
+            K[2] ^= (uint8_t)tab(sSb, 256u, K[15]);
+            K[3] ^= (uint8_t)tab(sSb, 256u, K[12]);
+        };
+        auto keyXor = [&]() __attribute__((always_inline)) { // key[i] = key[i] ^ key[i-4]
+            const uint32_t a = ld(K, (int32_t)i), b = ld(K, (int32_t)i - 4);
+            st(K, (int32_t)i, a ^ b);
+        };
+        auto dataHook = [&](uint32_t step) __attribute__((always_inline)) { // SITE_AES_STATE / _KEY: dword `index`, as in aes128_xmr_kernel
+            for (uint32_t q = 0; q < fr.y; ++q) {
+                const DevFault df = ft.list[fr.x + q];
+                if (df.step != step || (int)df.local != slot || (int)df.replica != lm.r)
+                    continue;
+                const int byteIdx = 4 * (df.index & 3) + (int)((df.bit & 31u) >> 3);
+                const uint8_t bm = (uint8_t)(1u << (df.bit & 7u));
+                if (df.site == SITE_AES_STATE)
+                    S[byteIdx] ^= bm;
+                else if (df.site == SITE_AES_KEY)
+                    K[byteIdx] ^= bm;
+            }
+        };
+        if (ifc(d)) {                                                        // if (dir)                                  :111
+            for (round = 0u; loopc(round, 10u, false); round = (round + 1u) & 0xffu) { // for (round = 0; round < 10; round++) :113
+                keyCore(round);
+                for (i = 4u; loopc(i, 16u, false); i = (i + 1u) & 0xffu)     //   for (i = 4; i < 16; i++)                :119
+                    keyXor();
+            }
+            for (i = 0u; loopc(i, 16u, false); i = (i + 1u) & 0xffu) {       // first AddRoundKey                         :125
+                const uint32_t a = ld(S, (int32_t)i), b = ld(K, (int32_t)i);
+                st(S, (int32_t)i, a ^ b);
+            }
+        }
+        uint32_t iter = 0u;
+        for (round = 0u; loopc(round, 10u, false); round = (round + 1u) & 0xffu) { // main loop                           :131
+            dataHook(iter < 10u ? iter : 0xffffffffu);
+            ++iter;
+            if (ifc(d)) {                                                    //   if (dir): inverse key schedule          :132-141
+                for (i = 15u; loopc(i, 3u, true); i = (i - 1u) & 0xffu)
+                    keyXor();
+                keyCore((uint32_t)(9 - (int32_t)round));
+            } else {
+                for (i = 0u; loopc(i, 16u, false); i = (i + 1u) & 0xffu) {   //   state[i] = sbox[state[i] ^ key[i]]      :143-146
+                    const uint32_t a = ld(S, (int32_t)i), b = ld(K, (int32_t)i);
+                    const uint32_t v = tab(sSb, 256u, a ^ b);
+                    st(S, (int32_t)i, v);
+                }
+                uint8_t t;                                                   //   shift rows: constant indices            :148-166
+                t = S[1], S[1] = S[5], S[5] = S[9], S[9] = S[13], S[13] = t;
+                t = S[2], S[2] = S[10], S[10] = t;
+                t = S[6], S[6] = S[14], S[14] = t;
+                t = S[15], S[15] = S[11], S[11] = S[7], S[7] = S[3], S[3] = t;
+            }
+            bool mix = false;                                                //   if ((round > 0 && dir) || (round < 9 && !dir)) :168
+            if (ifc(round > 0u))
+                mix = ifc(d);
+            if (!mix && ifc(round < 9u))
+                mix = ifc(!d);
+            if (mix) {
+                for (i = 0u; loopc(i, 4u, false); i = (i + 1u) & 0xffu) {    //   for (i = 0; i < 4; i++)                 :169
+                    const int32_t b4 = (int32_t)((i << 2) & 0xffu);          //     buf4 = (i << 2), an unsigned char
+                    uint32_t buf1, buf2, buf3;
+                    if (ifc(d)) {                                            //     if (dir): precompute                  :171-175
+                        const uint32_t a0 = ld(S, b4), a2 = ld(S, b4 + 2);
+                        buf1 = xtime(xtime(a0 ^ a2));
+                        const uint32_t a1 = ld(S, b4 + 1), a3 = ld(S, b4 + 3);
+                        buf2 = xtime(xtime(a1 ^ a3));
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                            const uint32_t a = ld(S, b4 + cc);
+                            st(S, b4 + cc, a ^ ((cc & 1) ? buf2 : buf1));
+                        }
+                    }
+                    {
+                        const uint32_t a = ld(S, b4), b = ld(S, b4 + 1), cv = ld(S, b4 + 2), dv = ld(S, b4 + 3);
+                        buf1 = a ^ b ^ cv ^ dv;                              //     the column's xor                      :177
+                    }
+                    buf2 = ld(S, b4);                                        //     buf2 = state[buf4]                    :178
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {                         //     the four rows                         :179-182
+                        const uint32_t a = ld(S, b4 + cc);
+                        const uint32_t b = cc < 3 ? ld(S, b4 + cc + 1) : buf2;
+                        buf3 = xtime(a ^ b);
+                        const uint32_t a2 = ld(S, b4 + cc);
+                        st(S, b4 + cc, a2 ^ buf3 ^ buf1);
+                    }
+                }
+            }
+            if (ifc(d)) {                                                    //   if (dir): inverse shift rows, rsbox     :187-211
+                uint8_t t;
+                t = S[13], S[13] = S[9], S[9] = S[5], S[5] = S[1], S[1] = t;
+                t = S[10], S[10] = S[2], S[2] = t;
+                t = S[14], S[14] = S[6], S[6] = t;
+                t = S[3], S[3] = S[7], S[7] = S[11], S[11] = S[15], S[15] = t;
+                for (i = 0u; loopc(i, 16u, false); i = (i + 1u) & 0xffu) {   //   state[i] = rsbox[state[i]] ^ key[i]     :208-211
+                    const uint32_t a = ld(S, (int32_t)i);
+                    const uint32_t x = tab(sRsb, 256u, a);
+                    const uint32_t b = ld(K, (int32_t)i);
+                    st(S, (int32_t)i, x ^ b);
+                }
+            } else {                                                         //   key schedule                            :213-226
+                keyCore(round);
+                for (i = 4u; loopc(i, 16u, false); i = (i + 1u) & 0xffu)
+                    keyXor();
+            }
+        }
+        dataHook(10u);
+        if (ifc(!d))                                                         // if (!dir): last AddRoundKey               :228-233
+            for (i = 0u; loopc(i, 16u, false); i = (i + 1u) & 0xffu) {
+                const uint32_t a = ld(S, (int32_t)i), b = ld(K, (int32_t)i);
+                st(S, (int32_t)i, a ^ b);
+            }
+        // the function's exit: state[] and key[] as stored data, 8 dwords (the frozen schedule's sync points)
+        uint4 sv = *reinterpret_cast<const uint4 *>(S), kv = *reinterpret_cast<const uint4 *>(K);
+        sv.x = xmr_store_sync<NREP>(sv.x, lm, cnt, tl);
+        sv.y = xmr_store_sync<NREP>(sv.y, lm, cnt, tl);
+        sv.z = xmr_store_sync<NREP>(sv.z, lm, cnt, tl);
+        sv.w = xmr_store_sync<NREP>(sv.w, lm, cnt, tl);
+        kv.x = xmr_store_sync<NREP>(kv.x, lm, cnt, tl);
+        kv.y = xmr_store_sync<NREP>(kv.y, lm, cnt, tl);
+        kv.z = xmr_store_sync<NREP>(kv.z, lm, cnt, tl);
+        kv.w = xmr_store_sync<NREP>(kv.w, lm, cnt, tl);
+        if (cnt) {
+            reinterpret_cast<uint4 *>(states)[item] = sv;
+            reinterpret_cast<uint4 *>(keys)[item] = kv;
+        }
+    }
+    uint32_t detItems = 0;
+    if (cnt && tl.det) { // unequal copies seen at a sync point of this block (DWC: detected, TMR: corrected)
+        if (NREP == 2)
+            detItems = 1;
+        if (detected)
+            detected[item] = 1;
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, tile);
 }
 
 } // namespace coast

@@ -67,7 +67,7 @@ typedef struct coast_cfg {
  *   -i / -s           instruction interleaving vs segmenting: replicas are lanes of one instruction, there is no order. */
 enum {
     COAST_F_NO_STORE_DATA_SYNC = 1u,
-    /* Loop / byte counters INSIDE the sphere of replication (mm, sha256, crc16, cache_test; the launch runs a stepwise kernel).  mm: the
+    /* Loop / byte counters INSIDE the sphere of replication (mm, sha256, aes128, crc16, cache_test; the launch runs a stepwise kernel).  mm: the
      * work item becomes the CALL -- i, j, k and `sum` of matrix_multiply (mm_common_tmr.c:3-20) are replica-private registers of
      * one sequential walk per matrix, the three loop conditions are voted at every evaluation ((N+1)(N^2+N+1) votes, SURVEY.md
      * section 3.2) and so are the GEP offsets of f[i][k], s[k][j] (i, k, k, j: loads) and r[i][j] (i, j: store); fault sites
@@ -77,13 +77,15 @@ enum {
      *   COAST_F_BRANCH_SYNC         every evaluation of a branch condition on them is a sync point (synchronization.cpp:146-155,
      *                               741-949): sha256 `i < len`, `ctx_datalen == 64` per byte and `ctx_datalen < 56`
      *                               (sha256_common_tmr.c:119,122,132); crc16 `length--` per byte (crc16.c:25); cache_test
-     *                               `i < data_array_elements` (cacheTest.c:107).  Not set, the
+     *                               `i < data_array_elements` (cacheTest.c:107); aes128 every loop condition on `round` / `i`,
+     *                               the tests of `dir` and the operands of the MixColumns condition (TI_aes_128.c:111-228).  Not set, the
      *                               branch follows the original instruction's operand = replica 0's copy.
      *   COAST_F_ADDR_SYNC           GEP offsets built from them are sync points (:226-235, 333-372, 413-474), the reference's
      *                               default under -noMemReplication: sha256 data[i] (a load address) and ctx_data[ctx_datalen]
      *                               (a store address), sha256_common_tmr.c:120.  crc16's `*data_p++` has a constant offset:
      *                               nothing to vote.  cache_test: array[i] of both loads and of the scrub store
-     *                               (cacheTest.c:108,110,127), whose data is the counter itself.  Not set, the access uses
+     *                               (cacheTest.c:108,110,127), whose data is the counter itself.  aes128: state[i], key[i], key[i-4],
+     *                               state[buf4 + c], Rcon[round] and the table lookups sbox[..] / rsbox[..] (data indices).  Not set, the access uses
      *                               replica 0's offset.
      *   COAST_F_NO_LOAD_SYNC        -noLoadSync: with ADDR_SYNC, load addresses are not voted (:341-352)
      *   COAST_F_NO_STORE_ADDR_SYNC  -noStoreAddrSync: with ADDR_SYNC, store addresses are not voted (:354-367)
@@ -155,6 +157,9 @@ enum {
     COAST_SITE_SHA_I = 12,       /* the byte loop's counter i, same timing */
     COAST_SITE_AES_STATE = 16, /* state dword `index` at the start of main-loop round `step` (10: after the loop) */
     COAST_SITE_AES_KEY = 17,   /* running round-key dword `index`, same timing */
+    COAST_SITE_AES_ROUND = 18, /* COAST_F_BRANCH_SYNC / ADDR_SYNC: aes_enc_dec's loop counter `round` (8 bits live) before loop condition
+                                * `step` of the call (all loops of the function count) */
+    COAST_SITE_AES_I = 19,     /* ... its loop counter `i`, same timing */
     COAST_SITE_CRC_CRC = 24,   /* crc register before byte `step` (== length: after the loop) */
     COAST_SITE_CRC_X = 25,     /* temporary x of byte `step` after x ^= x>>4 */
     COAST_SITE_CRC_LEN = 26,   /* COAST_F_BRANCH_SYNC: the `length` register (8 bits live) before the loop condition of iteration `step` */

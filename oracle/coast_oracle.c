@@ -841,6 +841,274 @@ static void aes_item(uint8_t state[16], uint8_t key[16], int dir, sync_ctx *c, c
     aes_item3(s3, k3, dir, c, fl, nf);
 }
 
+/* aes_enc_dec with its loops as written (TI_aes_128.c:107-235), for ORC_F_BRANCH_SYNC / ORC_F_ADDR_SYNC: the two loop counters
+ * `round` and `i` (unsigned char) are replica-private registers.  Sync points added to the frozen schedule, the reference's rule set
+ * for -TMR -noMemReplication on the source as written:
+ *   every evaluated branch condition: the loop conditions `round < 10`, `i < 16`, `i > 3`, `i < 4`, the tests of `dir`, and the
+ *     operands of `(round > 0 && dir) || (round < 9 && !dir)` in short-circuit order                 synchronization.cpp:146-155
+ *   every GEP with a variable index: state[i], key[i], key[i-4], state[buf4 + c] (buf4 = i << 2), Rcon[round], Rcon[9-round], and the
+ *     table lookups sbox[..] / rsbox[..], whose index is DATA (loads: off with -noLoadSync; the state[] / key[] stores: off with
+ *     -noStoreAddrSync); constant indices (key[13], the ShiftRows moves) have nothing to vote (syncGEP returns early, :428-431)
+ * state[] and key[] stay what they are in the frozen schedule: replica-private until the function's exit, where their 8 dwords are
+ * voted as stored data; a voted (or, unvoted, replica 0's) offset selects the element every copy accesses.  Fault sites:
+ * ORC_SITE_AES_ROUND / _I of a replica (8 bits live), `step` = how many LOOP conditions the call has evaluated (the flip lands right
+ * before the next one); ORC_SITE_AES_STATE / _KEY keep their meaning (start of main-loop iteration `step`, 10: after the loop).  A wild
+ * index reads 0 / stores nothing; a walk that a corrupted counter keeps alive is cut after 4096 loop conditions (a clean call
+ * evaluates at most 551). */
+typedef struct {
+    sync_ctx *c;
+    const orc_fault *fl;
+    size_t nf;
+    unsigned R;
+    int bs, ls, ss, wd;
+    uint8_t s[3][16], k[3][16];
+    uint32_t round[3], i[3];
+    uint64_t tick;
+} aesx;
+
+static int aesx_loop(aesx *m, int c0, int c1, int c2, const uint32_t cur[3], uint32_t limit, int gt)
+{
+    /* the counter's upsets land right before the condition reads it: re-evaluate after the hook */
+    (void)c0, (void)c1, (void)c2;
+    for (size_t q = 0; q < m->nf; ++q)
+        if ((uint64_t)m->fl[q].step == m->tick && m->fl[q].replica < m->R) {
+            uint32_t *t = m->fl[q].site == ORC_SITE_AES_ROUND ? m->round : m->fl[q].site == ORC_SITE_AES_I ? m->i : NULL;
+            if (t)
+                t[m->fl[q].replica] = flip(t[m->fl[q].replica], m->fl[q].bit, 0xffu);
+        }
+    if (m->tick >= 4096u) {
+        m->wd = 1;
+        return 0;
+    }
+    m->tick++;
+    return gt ? branch_cond(m->c, cur[0] > limit, cur[1] > limit, cur[2] > limit, m->bs)
+              : branch_cond(m->c, cur[0] < limit, cur[1] < limit, cur[2] < limit, m->bs);
+}
+static void aesx_set(uint32_t reg[3], uint32_t v) { reg[0] = reg[1] = reg[2] = v; }
+static void aesx_add(uint32_t reg[3], uint32_t d) /* unsigned char arithmetic */
+{
+    for (int r = 0; r < 3; ++r)
+        reg[r] = (reg[r] + d) & 0xffu;
+}
+static int aesx_if(aesx *m, int c0, int c1, int c2) { return branch_cond(m->c, (uint32_t)c0, (uint32_t)c1, (uint32_t)c2, m->bs); }
+static uint32_t aesx_off(aesx *m, const int32_t idx[3], int store)
+{
+    const uint32_t v[3] = {(uint32_t)idx[0], (uint32_t)idx[1], (uint32_t)idx[2]};
+    return gep_offset(m->c, v, store ? m->ss : m->ls);
+}
+static void aesx_ld(aesx *m, uint8_t (*arr)[16], const int32_t idx[3], uint32_t out[3])
+{
+    const uint32_t o = aesx_off(m, idx, 0);
+    for (int r = 0; r < 3; ++r)
+        out[r] = o < 16u ? arr[r][o] : 0u;
+}
+static void aesx_st(aesx *m, uint8_t (*arr)[16], const int32_t idx[3], const uint32_t v[3])
+{
+    const uint32_t o = aesx_off(m, idx, 1);
+    if (o < 16u)
+        for (int r = 0; r < 3; ++r)
+            arr[r][o] = (uint8_t)v[r];
+}
+static void aesx_tab(aesx *m, const uint8_t *tab, uint32_t size, const uint32_t x[3], uint32_t out[3])
+{
+    const int32_t idx[3] = {(int32_t)x[0], (int32_t)x[1], (int32_t)x[2]};
+    const uint32_t o = aesx_off(m, idx, 0);
+    for (int r = 0; r < 3; ++r)
+        out[r] = o < size ? tab[o] : 0u;
+}
+#define AX3(dst, expr)                                                                                         \
+    do {                                                                                                       \
+        for (int r_ = 0; r_ < 3; ++r_) {                                                                       \
+            const int r = r_;                                                                                  \
+            (dst)[r] = (expr);                                                                                 \
+        }                                                                                                      \
+    } while (0)
+/* key[0..3] ^= sbox[key[13, 14, 15, 12]] (^ Rcon[rc] on byte 0): the key[] indices are constants, the table indices are data */
+static void aesx_key_core(aesx *m, const uint32_t rc[3])
+{
+    static const int src[4] = {13, 14, 15, 12};
+    for (int b = 0; b < 4; ++b) {
+        uint32_t x[3], sb[3];
+        AX3(x, m->k[r][src[b]]);
+        aesx_tab(m, AES_S, 256u, x, sb);
+        if (b == 0) {
+            uint32_t rcv[3];
+            aesx_tab(m, AES_RCON, 10u, rc, rcv);
+            AX3(sb, sb[r] ^ rcv[r]);
+        }
+        for (int r = 0; r < 3; ++r)
+            m->k[r][b] ^= (uint8_t)sb[r];
+    }
+}
+static void aesx_key_xor(aesx *m) /* key[i] = key[i] ^ key[i-4] with the replicas' own i */
+{
+    int32_t ii[3], im4[3];
+    uint32_t a[3], b[3], v[3];
+    AX3(ii, (int32_t)m->i[r]);
+    AX3(im4, (int32_t)m->i[r] - 4);
+    aesx_ld(m, m->k, ii, a);
+    aesx_ld(m, m->k, im4, b);
+    AX3(v, a[r] ^ b[r]);
+    aesx_st(m, m->k, ii, v);
+}
+
+static int aes_item_indexed(uint8_t *state, uint8_t *key, int dir, sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    aesx mm, *m = &mm;
+    memset(m, 0, sizeof *m);
+    m->c = c, m->fl = fl, m->nf = nf, m->R = c->nrep;
+    m->bs = (c->flags & ORC_F_BRANCH_SYNC) != 0;
+    const int as = (c->flags & ORC_F_ADDR_SYNC) != 0;
+    m->ls = as && !(c->flags & ORC_F_NO_LOAD_SYNC);
+    m->ss = as && !(c->flags & ORC_F_NO_STORE_ADDR_SYNC);
+    aes_tables();
+    for (int r = 0; r < 3; ++r) {
+        memcpy(m->s[r], state, 16);
+        memcpy(m->k[r], key, 16);
+    }
+    const int d = dir ? 1 : 0;
+#define LOOP_LT(reg, lim) aesx_loop(m, 0, 0, 0, m->reg, (lim), 0)
+#define LOOP_GT(reg, lim) aesx_loop(m, 0, 0, 0, m->reg, (lim), 1)
+#define INC(reg) aesx_add(m->reg, 1u)
+#define SET(reg, v) aesx_set(m->reg, (uint32_t)(v))
+    if (aesx_if(m, d, d, d)) {                                              /* if (dir)                                  :111 */
+        for (SET(round, 0); LOOP_LT(round, 10u); INC(round)) {              /*   for (round = 0; round < 10; round++)    :113 */
+            aesx_key_core(m, m->round);                                     /*     key[0..3] ^= sbox[..] (^ Rcon[round]) :115-118 */
+            for (SET(i, 4); LOOP_LT(i, 16u); INC(i))                        /*     for (i = 4; i < 16; i++)              :119 */
+                aesx_key_xor(m);
+        }
+        for (SET(i, 0); LOOP_LT(i, 16u); INC(i)) {                          /*   first AddRoundKey                       :125 */
+            int32_t ii[3];
+            uint32_t a[3], b[3], v[3];
+            AX3(ii, (int32_t)m->i[r]);
+            aesx_ld(m, m->s, ii, a);
+            aesx_ld(m, m->k, ii, b);
+            AX3(v, a[r] ^ b[r]);
+            aesx_st(m, m->s, ii, v);
+        }
+    }
+    uint32_t iter = 0;
+    for (SET(round, 0); LOOP_LT(round, 10u); INC(round)) {                  /* main loop                                 :131 */
+        aes_faults(m->s, m->k, m->R, iter < 10u ? iter : 0xffffffffu, fl, nf);
+        ++iter;
+        if (aesx_if(m, d, d, d)) {                                          /*   if (dir): inverse key schedule          :132-141 */
+            for (SET(i, 15); LOOP_GT(i, 3u); aesx_add(m->i, 0xffu))
+                aesx_key_xor(m);
+            uint32_t rc[3];
+            AX3(rc, (uint32_t)(9 - (int32_t)m->round[r]));
+            aesx_key_core(m, rc);
+        } else {
+            for (SET(i, 0); LOOP_LT(i, 16u); INC(i)) {                      /*   state[i] = sbox[state[i] ^ key[i]]      :143-146 */
+                int32_t ii[3];
+                uint32_t a[3], b[3], x[3], v[3];
+                AX3(ii, (int32_t)m->i[r]);
+                aesx_ld(m, m->s, ii, a);
+                aesx_ld(m, m->k, ii, b);
+                AX3(x, a[r] ^ b[r]);
+                aesx_tab(m, AES_S, 256u, x, v);
+                aesx_st(m, m->s, ii, v);
+            }
+            for (int r = 0; r < 3; ++r) {                                   /*   shift rows: constant indices            :148-166 */
+                uint8_t *st = m->s[r], t;
+                t = st[1], st[1] = st[5], st[5] = st[9], st[9] = st[13], st[13] = t;
+                t = st[2], st[2] = st[10], st[10] = t;
+                t = st[6], st[6] = st[14], st[14] = t;
+                t = st[15], st[15] = st[11], st[11] = st[7], st[7] = st[3], st[3] = t;
+            }
+        }
+        /* if ((round > 0 && dir) || (round < 9 && !dir))                                                           :168 */
+        int mix = 0;
+        if (aesx_if(m, m->round[0] > 0u, m->round[1] > 0u, m->round[2] > 0u))
+            mix = aesx_if(m, d, d, d);
+        if (!mix && aesx_if(m, m->round[0] < 9u, m->round[1] < 9u, m->round[2] < 9u))
+            mix = aesx_if(m, !d, !d, !d);
+        if (mix) {
+            for (SET(i, 0); LOOP_LT(i, 4u); INC(i)) {                       /*   for (i = 0; i < 4; i++)                 :169 */
+                int32_t b4[3][4];
+                for (int r = 0; r < 3; ++r)
+                    for (int cc = 0; cc < 4; ++cc)
+                        b4[r][cc] = (int32_t)(((m->i[r] << 2) & 0xffu) + (uint32_t)cc); /* buf4 = (i << 2), an unsigned char */
+#define IDX(cc) ((const int32_t[3]){b4[0][cc], b4[1][cc], b4[2][cc]})
+                uint32_t a[3], b[3], cv[3], dv[3], buf1[3], buf2[3], buf3[3], v[3];
+                if (aesx_if(m, d, d, d)) {                                  /*     if (dir): precompute                  :171-175 */
+                    aesx_ld(m, m->s, IDX(0), a);
+                    aesx_ld(m, m->s, IDX(2), b);
+                    AX3(buf1, xtime(xtime((uint8_t)(a[r] ^ b[r]))));
+                    aesx_ld(m, m->s, IDX(1), a);
+                    aesx_ld(m, m->s, IDX(3), b);
+                    AX3(buf2, xtime(xtime((uint8_t)(a[r] ^ b[r]))));
+                    for (int cc = 0; cc < 4; ++cc) {                        /*     state[buf4 + cc] ^= buf1 / buf2                */
+                        aesx_ld(m, m->s, IDX(cc), a);
+                        AX3(v, a[r] ^ ((cc & 1) ? buf2[r] : buf1[r]));
+                        aesx_st(m, m->s, IDX(cc), v);
+                    }
+                }
+                aesx_ld(m, m->s, IDX(0), a);                                /*     buf1 = the column's xor               :177 */
+                aesx_ld(m, m->s, IDX(1), b);
+                aesx_ld(m, m->s, IDX(2), cv);
+                aesx_ld(m, m->s, IDX(3), dv);
+                AX3(buf1, a[r] ^ b[r] ^ cv[r] ^ dv[r]);
+                aesx_ld(m, m->s, IDX(0), buf2);                             /*     buf2 = state[buf4]                    :178 */
+                for (int cc = 0; cc < 4; ++cc) {                            /*     the four rows                         :179-182 */
+                    aesx_ld(m, m->s, IDX(cc), a);
+                    if (cc < 3)
+                        aesx_ld(m, m->s, IDX(cc + 1), b);
+                    else
+                        AX3(b, buf2[r]);
+                    AX3(buf3, xtime((uint8_t)(a[r] ^ b[r])));
+                    aesx_ld(m, m->s, IDX(cc), a);
+                    AX3(v, a[r] ^ buf3[r] ^ buf1[r]);
+                    aesx_st(m, m->s, IDX(cc), v);
+                }
+#undef IDX
+            }
+        }
+        if (aesx_if(m, d, d, d)) {                                          /*   if (dir): inverse shift rows, rsbox     :187-211 */
+            for (int r = 0; r < 3; ++r) {
+                uint8_t *st = m->s[r], t;
+                t = st[13], st[13] = st[9], st[9] = st[5], st[5] = st[1], st[1] = t;
+                t = st[10], st[10] = st[2], st[2] = t;
+                t = st[14], st[14] = st[6], st[6] = t;
+                t = st[3], st[3] = st[7], st[7] = st[11], st[11] = st[15], st[15] = t;
+            }
+            for (SET(i, 0); LOOP_LT(i, 16u); INC(i)) {                      /*   state[i] = rsbox[state[i]] ^ key[i]     :208-211 */
+                int32_t ii[3];
+                uint32_t a[3], b[3], x[3], v[3];
+                AX3(ii, (int32_t)m->i[r]);
+                aesx_ld(m, m->s, ii, a);
+                aesx_tab(m, AES_RS, 256u, a, x);
+                aesx_ld(m, m->k, ii, b);
+                AX3(v, x[r] ^ b[r]);
+                aesx_st(m, m->s, ii, v);
+            }
+        } else {                                                            /*   key schedule                            :213-226 */
+            aesx_key_core(m, m->round);
+            for (SET(i, 4); LOOP_LT(i, 16u); INC(i))
+                aesx_key_xor(m);
+        }
+    }
+    aes_faults(m->s, m->k, m->R, 10u, fl, nf);
+    if (aesx_if(m, !d, !d, !d))                                             /* if (!dir): last AddRoundKey               :228-233 */
+        for (SET(i, 0); LOOP_LT(i, 16u); INC(i)) {
+            int32_t ii[3];
+            uint32_t a[3], b[3], v[3];
+            AX3(ii, (int32_t)m->i[r]);
+            aesx_ld(m, m->s, ii, a);
+            aesx_ld(m, m->k, ii, b);
+            AX3(v, a[r] ^ b[r]);
+            aesx_st(m, m->s, ii, v);
+        }
+#undef LOOP_LT
+#undef LOOP_GT
+#undef INC
+#undef SET
+    aes_sync(c, m->s, m->k);
+    memcpy(state, m->s[0], 16);
+    memcpy(key, m->k[0], 16);
+    return m->wd;
+}
+#undef AX3
+
 void orc_aes128_plain(uint8_t state[16], uint8_t key[16], uint8_t dir)
 {
     orc_stats st = {0, 0, 0, 0};
@@ -867,6 +1135,8 @@ void orc_aes128_xmr(uint8_t *states, uint8_t *keys, size_t nblocks, int dir, con
             uint8_t *const s3[3] = {states + 16 * b, states + (R > 1 ? cs : 0) + 16 * b, states + (R > 2 ? 2 * cs : 0) + 16 * b};
             uint8_t *const k3[3] = {keys + 16 * b, keys + (R > 1 ? cs : 0) + 16 * b, keys + (R > 2 ? 2 * cs : 0) + 16 * b};
             aes_item3(s3, k3, dir ? 1 : 0, &c, fs + fp, fe - fp);
+        } else if (cfg->flags & ORC_F_INDEXED) { /* the loop counters inside the sphere of replication */
+            aes_item_indexed(states + 16 * b, keys + 16 * b, dir ? 1 : 0, &c, fs + fp, fe - fp);
         } else {
             aes_item(states + 16 * b, keys + 16 * b, dir ? 1 : 0, &c, fs + fp, fe - fp);
         }

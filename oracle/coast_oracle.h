@@ -53,6 +53,8 @@ enum {
 
     ORC_SITE_AES_STATE = 16, /* dword `index` (0..3) of the state at the start of main-loop round `step` (10: after loop) */
     ORC_SITE_AES_KEY = 17,   /* dword `index` (0..3) of the running round key, same timing */
+    ORC_SITE_AES_ROUND = 18, /* ORC_F_BRANCH_SYNC / ADDR_SYNC: the loop counter `round` (8 bits) before loop condition `step` of the call */
+    ORC_SITE_AES_I = 19,     /* the loop counter `i`, same timing */
 
     ORC_SITE_CRC_CRC = 24, /* crc register before byte `step` (step == length: after the loop) */
     ORC_SITE_CRC_X = 25,   /* temporary x of byte `step`, after x ^= x>>4 */

@@ -1866,14 +1866,70 @@ def test_mm_address_votes_are_what_stops_a_replica0_counter_upset(eng, orc):
     assert (out["voted"] == clean).all() and not (out["noLoadSync"] == clean).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+@pytest.mark.parametrize("direction", [0, 1])
+def test_aes_loop_counters_in_the_sor_vs_oracle(eng, orc, direction, replicas):
+    """COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC for aes_enc_dec -- `round` and `i` replica-private,
+    every loop condition / `dir` test / MixColumns-condition operand voted, every variable-index GEP voted (state[i], key[i], key[i-4],
+    state[buf4 + c], Rcon[..], and the data-indexed sbox / rsbox lookups), -noLoadSync / -noStoreAddrSync / -noStoreDataSync as knobs.
+    Results equal the frozen schedule's (and with it the NIST vectors), counters and flags equal the oracle's, clean and under upsets
+    of round / i / state / key."""
+    import torch
+
+    import coast_amd as ca
+
+    rng = np.random.default_rng(1700 + 10 * direction + replicas)
+    nb = 21 * 3 + 5
+    st = rng.integers(0, 256, (nb, 16), dtype=np.uint8)
+    ky = rng.integers(0, 256, (nb, 16), dtype=np.uint8)
+    ref_s, ref_k, _, _ = orc.aes128_xmr(st, ky, direction, replicas=1)
+    B, A, NL, NS, ND = ca.F_BRANCH_SYNC, ca.F_ADDR_SYNC, ca.F_NO_LOAD_SYNC, ca.F_NO_STORE_ADDR_SYNC, ca.F_NO_STORE_DATA_SYNC
+    nloop = 514 if direction else 373  # loop conditions of a clean call
+    for flags in (B, B | A, B | A | NL, B | A | NS, A, B | A | NL | NS | ND):
+        ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky.copy()).cuda()
+        eng.reset_stats()
+        eng.aes128_batch(ds, dk, direction, cfg=ca.XmrConfig(replicas, 0, flags))
+        w_s, w_k, w_st, _ = orc.aes128_xmr(st, ky, direction, replicas=replicas, flags=flags)
+        assert (ds.cpu().numpy() == w_s).all() and (dk.cpu().numpy() == w_k).all() and (w_s == ref_s).all() and (w_k == ref_k).all(), flags
+        assert _stats3(eng.stats()) == w_st and eng.last_launch()["engine"] == "stepwise", flags
+        if replicas == 1:
+            continue
+        rows = []
+        for b in range(nb):
+            rows.append((b, int(rng.integers(0, replicas)), int(rng.choice([18, 19, 19])), int(rng.integers(0, nloop)), int(rng.integers(0, 8))))
+            if b % 3 == 0:
+                rows.append((b, int(rng.integers(0, replicas)), int(rng.choice([16, 17])), int(rng.integers(0, 11)), int(rng.integers(0, 32)),
+                             int(rng.integers(0, 4))))
+        fl = ca.make_faults(rows)
+        w_s, w_k, w_st, w_det = orc.aes128_xmr(st, ky, direction, replicas=replicas, flags=flags, faults=fl)
+        ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky.copy()).cuda()
+        det = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        eng.aes128_batch(ds, dk, direction, cfg=ca.XmrConfig(replicas, 0, flags), detected=det)
+        assert (ds.cpu().numpy() == w_s).all() and (dk.cpu().numpy() == w_k).all(), flags
+        assert _stats3(eng.stats()) == w_st and (det.cpu().numpy() == w_det).all(), flags
+        if replicas == 3 and flags == (B | A):  # everything voted: one counter upset per block is always out-voted
+            one = ca.make_faults([r for r in rows if r[2] in (18, 19)])
+            ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky.copy()).cuda()
+            eng.reset_stats()
+            eng.inject_faults(one)
+            eng.aes128_batch(ds, dk, direction, cfg=ca.XmrConfig(3, 0, flags))
+            assert (ds.cpu().numpy() == ref_s).all() and (dk.cpu().numpy() == ref_k).all() and eng.stats()["errors_corrected"] > 0
+
+
 def test_indexed_flags_are_rejected_where_not_implemented(eng):
     import torch
 
     import coast_amd as ca
 
-    st = torch.zeros((4, 16), dtype=torch.uint8, device="cuda")
+    msgs = torch.zeros((4, 64), dtype=torch.uint8, device="cuda")
     with pytest.raises(RuntimeError, match="are implemented for mm, sha256"):
-        eng.aes128_batch(st, st.clone(), 0, cfg=ca.XmrConfig(2, 0, ca.F_BRANCH_SYNC))
+        eng.chsha_batch(msgs, 64, cfg=ca.XmrConfig(2, 0, ca.F_BRANCH_SYNC))
+    st = torch.zeros((4, 16), dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError, match="sync_every and the counter flags do not combine"):
+        eng.aes128_batch(st, st.clone(), 0, cfg=ca.XmrConfig(3, 2, ca.F_BRANCH_SYNC))
     f = torch.zeros((1, 16, 16), dtype=torch.int32, device="cuda")
     with pytest.raises(RuntimeError, match="sync_every belongs to the per-element schedule"):
         eng.mm_batch(f, f, cfg=ca.XmrConfig(3, 4, ca.F_BRANCH_SYNC))

@@ -425,3 +425,35 @@ def test_cache_test_loop_counter_in_the_sor_schedule(orc):
     assert (t[0] == ref[0]).all() and (t[1] == ref[1]).all() and t[3]["errors_corrected"] > 0 and t[4][5] == 1
     dw = orc.cache_test_xmr(a, replicas=2, flags=B | A, faults=fl)
     assert dw[3]["dwc_detected"] == 1 and dw[4][5] == 1
+
+
+def test_aes_loop_counters_in_the_sor_schedule(orc, golden):
+    """ORC_F_BRANCH_SYNC / ORC_F_ADDR_SYNC for aes_enc_dec (TI_aes_128.c:107-235): `round` and `i` inside the sphere of replication.
+    The counts follow from the source as written.  Encryption: branch conditions 1 (`if (dir)`) + 11 (`round < 10`) + per round
+    1 (`if (dir)`) + 17 (`i < 16`) + 1 (`if (dir)`) + 13 (`i < 16` from 4) = 320, the MixColumns condition 3 + 8 x 4 + 3 = 38 operands,
+    9 x (5 + 4) in its loop, 1 + 17 after the loop = 469; loop conditions alone 11 + 10 x 30 + 9 x 5 + 17 = 373.  Decryption: 593 / 514.
+    Results are the frozen schedule's -- the NIST vectors included."""
+    B, A = 2, 4
+    rng = np.random.default_rng(5)
+    st = rng.integers(0, 256, (9, 16), dtype=np.uint8)
+    ky = rng.integers(0, 256, (9, 16), dtype=np.uint8)
+    for d, nbr, ngep in ((0, 469, 1818), (1, 593, 2660)):
+        ref = orc.aes128_xmr(st, ky, d, replicas=3)
+        b = orc.aes128_xmr(st, ky, d, replicas=3, flags=B)
+        ba = orc.aes128_xmr(st, ky, d, replicas=3, flags=B | A)
+        assert (b[0] == ref[0]).all() and (ba[0] == ref[0]).all() and (ba[1] == ref[1]).all()
+        assert b[2]["sync_count"] == 9 * (8 + nbr) and ba[2]["sync_count"] == 9 * (8 + nbr + ngep)
+        assert ba[2]["errors_corrected"] == 0
+        # a single upset of a counter: out-voted under TMR with everything voted, flagged under DWC
+        fl = orc.make_faults([(4, 1, 19, 100, 2), (7, 2, 18, 200, 0)])
+        t = orc.aes128_xmr(st, ky, d, replicas=3, flags=B | A, faults=fl)
+        assert (t[0] == ref[0]).all() and (t[1] == ref[1]).all() and t[2]["errors_corrected"] > 0 and t[3][4] == 1 and t[3][7] == 1
+        dw = orc.aes128_xmr(st, ky, d, replicas=2, flags=B | A, faults=orc.make_faults([(4, 1, 19, 100, 2)]))
+        assert dw[2]["dwc_detected"] == 1 and dw[3][4] == 1
+    # the known-answer vectors through the counters-in-the-SoR walk
+    kat = np.asarray(golden["aes_kat"], dtype=np.uint8)  # rows: key, key2, ciphertext, plaintext, input (tests/aes/aes.c:91-99)
+    key, key2, ct, pt = (np.ascontiguousarray(kat[:, 16 * q:16 * q + 16]) for q in range(4))
+    enc = orc.aes128_xmr(pt, key, 0, replicas=3, flags=B | A)
+    assert (enc[0] == ct).all()
+    dec = orc.aes128_xmr(ct, key2, 1, replicas=2, flags=B | A)
+    assert (dec[0] == pt).all() and (dec[1] == key2).all()
