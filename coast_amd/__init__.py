@@ -18,7 +18,7 @@ SITE_SHA_M, SITE_SHA_WV, SITE_SHA_STATE, SITE_SHA_DATALEN, SITE_SHA_I = 8, 9, 10
 SITE_AES_STATE, SITE_AES_KEY, SITE_AES_ROUND, SITE_AES_I = 16, 17, 18, 19
 SITE_CRC_CRC, SITE_CRC_X, SITE_CRC_LEN = 24, 25, 26
 SITE_CT_SUM, SITE_CT_VAL, SITE_CT_NERR, SITE_CT_I = 32, 33, 34, 35
-SITE_CHSHA_W, SITE_CHSHA_WV, SITE_CHSHA_DIGEST = 40, 41, 42
+SITE_CHSHA_W, SITE_CHSHA_WV, SITE_CHSHA_DIGEST, SITE_CHSHA_I, SITE_CHSHA_COUNT = 40, 41, 42, 43, 44
 SITE_QS_I, SITE_QS_J, SITE_QS_PIVOT, SITE_QS_VI, SITE_QS_VJ = 48, 49, 50, 51, 52
 SITE_CFC_PC, SITE_CFC_RTS, SITE_CFC_RTSA = 56, 57, 58
 SITE_CHAES_STATE, SITE_CHAES_WORD = 64, 65

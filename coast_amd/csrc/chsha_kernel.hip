@@ -17,7 +17,7 @@
 
 namespace coast {
 
-enum { SITE_CHSHA_W = 40, SITE_CHSHA_WV = 41, SITE_CHSHA_DIGEST = 42 };
+enum { SITE_CHSHA_W = 40, SITE_CHSHA_WV = 41, SITE_CHSHA_DIGEST = 42, SITE_CHSHA_I = 43, SITE_CHSHA_COUNT = 44 };
 
 __device__ __forceinline__ uint32_t chsha_rotl(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
 
@@ -203,6 +203,154 @@ __global__ __launch_bounds__(256) void chsha_kernel(const uint8_t *__restrict__ 
         }
     }
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+// CHStone sha with its loops as written (sha.c:84-172), for COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC: sha_transform's loop counter `i`
+// (an int) and sha_update's `count` are replica-private lane registers -- one lane per (message, replica), one sequential walk.
+// memcpy / memset are library names (functions.config:12): calls outside the sphere of replication.  Sync points added to the frozen
+// schedule, the reference's rule set for -TMR -noMemReplication on the source as written:
+//   every evaluated branch condition: `count >= SHA_BLOCKSIZE` (:141), the carry test of sha_update (:136), `count > 56` of sha_final
+//     (:162), the six loop conditions of sha_transform (17 + 65 + 4 x 21 = 166 per transform)                synchronization.cpp:146-155
+//   every GEP with a variable index: sha_info_data[i] (load) and W[i] (store) of the copy loop; W[i-3], W[i-8], W[i-14], W[i-16]
+//     (loads) and W[i] (store) of the expansion; W[i] (load) of the 80 rounds = 432 per transform (loads: off with -noLoadSync,
+//     stores: off with -noStoreAddrSync)
+// W[] stays replica-private as in the frozen schedule (the lane's own 320 bytes of LDS, since it is indexed at run time); a voted
+// (or, unvoted, replica 0's) offset selects the element every copy accesses.  Fault sites: SITE_CHSHA_I / _COUNT of a replica, `step`
+// = how many LOOP conditions the call has evaluated; SITE_CHSHA_DIGEST keeps its meaning.  A wild index reads 0 / stores nothing;
+// blocks past the message read as 0; a walk that a corrupted counter keeps alive is cut after 4 x the clean count + 1024 loop
+// conditions.  Oracle: chsha_item_indexed.  The sync-point-parity form of the kernel, not the throughput form.
+template <int NREP>
+__global__ __launch_bounds__(64) void chsha_indexed_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
+                                                           uint64_t nmsgs, uint32_t *__restrict__ digests, Counters ctr,
+                                                           FaultTab ft, uint8_t *__restrict__ detected)
+{
+    __shared__ uint32_t sW[80 * 64]; // W[t] of lane l at t * 64 + l
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    LaneMap<NREP> lm;
+    lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
+    const bool bs = (ctr.flags & kFlagBranchSync) != 0u, as = (ctr.flags & kFlagAddrSync) != 0u;
+    const bool ls = as && !(ctr.flags & kFlagNoLoadSync), ss = as && !(ctr.flags & kFlagNoStoreAddrSync);
+    const uint32_t tile = blockIdx.x;
+    const int slot = lm.q;
+    const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
+    const bool live = lm.live && item < nmsgs;
+    const bool cnt = live && lm.r == 0;
+    const uint8_t *msg = msgs + (live ? item : 0) * stride;
+    if (threadIdx.x < 4)
+        sCnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint2 fr = make_uint2(0u, 0u);
+    if (ft.range)
+        fr = ft.range[tile];
+    uint32_t *W = sW + lm.lane;
+    const uint32_t nblk = len / 64u;
+    const uint32_t cap = 4u * ((nblk + 1u) * 167u + 1u) + 1024u;
+    Tally tl;
+    uint32_t dg[5] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u, 0xc3d2e1f0u};
+    uint32_t i = 0u, count = len, tick = 0u;
+    if (lm.live) { // (the idle lane of a TMR wave has no message of its own: its replica group would wrap to lanes 0, 1)
+        auto loopc = [&](int32_t limit, bool ge, bool isCount) __attribute__((always_inline)) { // one evaluated loop condition
+            for (uint32_t q = 0; q < fr.y; ++q) { // the counters' upsets land right before the condition reads them
+                const DevFault df = ft.list[fr.x + q];
+                if (df.step != tick || (int)df.local != slot || (int)df.replica != lm.r)
+                    continue;
+                const uint32_t m = 1u << (df.bit & 31u);
+                if (df.site == SITE_CHSHA_I)
+                    i ^= m;
+                else if (df.site == SITE_CHSHA_COUNT)
+                    count ^= m;
+            }
+            if (tick >= cap)
+                return false;
+            ++tick;
+            const int32_t v = (int32_t)(isCount ? count : i); // (read after the hook: it may just have flipped it)
+            return xmr_steer<NREP>((ge ? v >= limit : v < limit) ? 1u : 0u, lm, bs, cnt, tl) != 0u;
+        };
+        auto off = [&](int32_t delta, bool store) __attribute__((always_inline)) {
+            return xmr_steer<NREP>(i + (uint32_t)delta, lm, store ? ss : ls, cnt, tl);
+        };
+        auto digestHook = [&](uint32_t cidx) __attribute__((always_inline)) {
+            for (uint32_t q = 0; q < fr.y; ++q) {
+                const DevFault df = ft.list[fr.x + q];
+                if (df.site != SITE_CHSHA_DIGEST || df.step != cidx || (int)df.local != slot || (int)df.replica != lm.r)
+                    continue;
+                const uint32_t m = 1u << (df.bit & 31u), w = df.index % 5u;
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    if ((uint32_t)k == w)
+                        dg[k] ^= m;
+            }
+        };
+        // sha_transform on block `blk` of the message (blocks past the message read as 0), or on sha_final's padding block
+        auto transform = [&](uint32_t blk, bool pad) __attribute__((always_inline)) {
+            auto inWord = [&](uint32_t o) __attribute__((always_inline)) -> uint32_t {
+                if (o >= 16u)
+                    return 0u;
+                if (pad)
+                    return o == 0u ? 0x80u : o == 14u ? (len >> 29) : o == 15u ? (len << 3) : 0u;
+                if (blk < nblk) {
+                    const uint8_t *p = msg + (size_t)blk * 64u + 4u * o;
+                    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+                }
+                return 0u;
+            };
+            for (int t = 0; t < 80; ++t)
+                W[t * 64] = 0u;
+            for (i = 0u; loopc(16, false, false); i += 1u) {                 // W[i] = sha_info_data[i]          :88-90
+                const uint32_t ol = off(0, false), os = off(0, true);
+                if (os < 80u)
+                    W[os * 64u] = inWord(ol);
+            }
+            for (i = 16u; loopc(80, false, false); i += 1u) {                // the expansion                     :91-93
+                const uint32_t o3 = off(-3, false), o8 = off(-8, false), o14 = off(-14, false), o16 = off(-16, false);
+                const uint32_t os = off(0, true);
+                const uint32_t x = (o3 < 80u ? W[o3 * 64u] : 0u) ^ (o8 < 80u ? W[o8 * 64u] : 0u) ^ (o14 < 80u ? W[o14 * 64u] : 0u) ^
+                                   (o16 < 80u ? W[o16 * 64u] : 0u);
+                if (os < 80u)
+                    W[os * 64u] = x;
+            }
+            uint32_t A = dg[0], B = dg[1], C = dg[2], D = dg[3], E = dg[4];
+#pragma unroll 1
+            for (int seg = 0; seg < 4; ++seg)                                   // FUNC(1..4, i)                     :100-111
+                for (i = 20u * (uint32_t)seg; loopc(20 * (seg + 1), false, false); i += 1u) {
+                    const uint32_t o = off(0, false);
+                    const uint32_t f = seg == 0 ? ((B & C) | (~B & D)) : seg == 2 ? ((B & C) | (B & D) | (C & D)) : (B ^ C ^ D);
+                    const uint32_t k = seg == 0 ? 0x5a827999u : seg == 1 ? 0x6ed9eba1u : seg == 2 ? 0x8f1bbcdcu : 0xca62c1d6u;
+                    const uint32_t temp = chsha_rotl(A, 5) + f + E + (o < 80u ? W[o * 64u] : 0u) + k;
+                    E = D, D = C, C = chsha_rotl(B, 30), B = A, A = temp;
+                }
+            dg[0] += A, dg[1] += B, dg[2] += C, dg[3] += D, dg[4] += E;
+#pragma unroll
+            for (int w = 0; w < 5; ++w)                                         // sha_info_digest[w] += ...: stored  :113-117
+                dg[w] = xmr_store_sync<NREP>(dg[w], lm, cnt, tl);
+        };
+        (void)xmr_steer<NREP>(0u, lm, bs, cnt, tl);                             // the carry test of sha_update      :136
+        uint32_t cidx = 0u;
+        for (;; count -= 64u) {                                                 // while (count >= SHA_BLOCKSIZE)     :141
+            if (!loopc(64, true, true))
+                break;
+            digestHook(cidx);
+            transform(cidx, false);
+            ++cidx;
+        }
+        (void)xmr_steer<NREP>(0u, lm, bs, cnt, tl);                             // sha_final: if (count > 56)        :162
+        digestHook(cidx);
+        transform(0u, true); // the padding block -- a derailed walk pads all the same (sha_final does)
+    }
+    uint32_t detItems = 0;
+    if (cnt) {
+#pragma unroll
+        for (int w = 0; w < 5; ++w)
+            digests[item * 5 + w] = dg[w];
+        if (tl.det) {
+            if (NREP == 2)
+                detItems = 1;
+            if (detected)
+                detected[item] = 1;
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, tile);
 }
 
 } // namespace coast

@@ -67,7 +67,7 @@ typedef struct coast_cfg {
  *   -i / -s           instruction interleaving vs segmenting: replicas are lanes of one instruction, there is no order. */
 enum {
     COAST_F_NO_STORE_DATA_SYNC = 1u,
-    /* Loop / byte counters INSIDE the sphere of replication (mm, sha256, aes128, crc16, cache_test; the launch runs a stepwise kernel).  mm: the
+    /* Loop / byte counters INSIDE the sphere of replication (mm, sha256, aes128, crc16, cache_test, CHStone sha; the launch runs a stepwise kernel).  mm: the
      * work item becomes the CALL -- i, j, k and `sum` of matrix_multiply (mm_common_tmr.c:3-20) are replica-private registers of
      * one sequential walk per matrix, the three loop conditions are voted at every evaluation ((N+1)(N^2+N+1) votes, SURVEY.md
      * section 3.2) and so are the GEP offsets of f[i][k], s[k][j] (i, k, k, j: loads) and r[i][j] (i, j: store); fault sites
@@ -171,6 +171,9 @@ enum {
     COAST_SITE_CHSHA_W = 40,      /* CHStone sha: schedule word W[step%80] of transform step/80, right after it is produced */
     COAST_SITE_CHSHA_WV = 41,     /* working variable index 0..4 (A..E) before round step%80 of transform step/80 */
     COAST_SITE_CHSHA_DIGEST = 42, /* sha_info_digest[index] before transform `step` */
+    COAST_SITE_CHSHA_I = 43,      /* COAST_F_BRANCH_SYNC / ADDR_SYNC: sha_transform's loop counter i before loop condition `step` of the call
+                                   * (the W / A..E sites are those of the default schedule only) */
+    COAST_SITE_CHSHA_COUNT = 44,  /* ... sha_update's `count`, same timing */
     /* quicksort: `step` counts the branch conditions the sort of this array has evaluated; the flip lands right before
      * condition number `step` is evaluated (after the load that feeds it) */
     COAST_SITE_QS_I = 48,     /* the left scan index i */

@@ -1387,6 +1387,148 @@ static void chsha_item(const uint8_t *data, uint32_t len, uint32_t out[5], sync_
         out[w] = dg[0][w];
 }
 
+/* CHStone sha with its loops as written (sha.c:84-172), for ORC_F_BRANCH_SYNC / ORC_F_ADDR_SYNC: sha_transform's loop counter `i`
+ * (an int) and sha_update's `count` are replica-private registers.  memcpy / memset are library names (functions.config:12): calls
+ * outside the sphere of replication, as in sha256.  Sync points added to the frozen schedule, the reference's rule set for -TMR
+ * -noMemReplication on the source as written:
+ *   every evaluated branch condition: `count >= SHA_BLOCKSIZE` (:141), the carry test of sha_update (:136), `count > 56` of sha_final
+ *     (:162), and the six loop conditions of sha_transform (17 + 65 + 4 x 21 = 166 per transform)            synchronization.cpp:146-155
+ *   every GEP with a variable index: sha_info_data[i] (load) and W[i] (store) of the copy loop (:88-90); W[i-3], W[i-8], W[i-14],
+ *     W[i-16] (loads) and W[i] (store) of the expansion (:91-93); W[i] (load) of the 80 rounds (:100-111) = 432 per transform
+ *     (loads: off with -noLoadSync; stores: off with -noStoreAddrSync); the digest words have constant indices
+ * W[] stays replica-private as in the frozen schedule; a voted (or, unvoted, replica 0's) offset selects the element every copy
+ * accesses.  Fault sites: ORC_SITE_CHSHA_I / _COUNT of a replica, `step` = how many LOOP conditions the call has evaluated;
+ * ORC_SITE_CHSHA_DIGEST keeps its meaning (before transform `step`).  A wild index reads 0 / stores nothing; blocks past the message
+ * read as 0; a walk that a corrupted counter keeps alive is cut after 4 x the clean count + 1024 loop conditions. */
+typedef struct {
+    sync_ctx *c;
+    const orc_fault *fl;
+    size_t nf;
+    unsigned R;
+    int bs, ls, ss;
+    uint32_t i[3], count[3];
+    uint64_t tick, cap;
+} chx;
+
+static int chx_loop(chx *m, const uint32_t reg[3], int32_t limit, int ge)
+{
+    for (size_t q = 0; q < m->nf; ++q)
+        if ((uint64_t)m->fl[q].step == m->tick && m->fl[q].replica < m->R) {
+            uint32_t *t = m->fl[q].site == ORC_SITE_CHSHA_I ? m->i : m->fl[q].site == ORC_SITE_CHSHA_COUNT ? m->count : NULL;
+            if (t)
+                t[m->fl[q].replica] = flip(t[m->fl[q].replica], m->fl[q].bit, 0xffffffffu);
+        }
+    if (m->tick >= m->cap)
+        return 0;
+    m->tick++;
+    const int32_t a = (int32_t)reg[0], b = (int32_t)reg[1], d = (int32_t)reg[2]; /* the counters are ints */
+    return ge ? branch_cond(m->c, a >= limit, b >= limit, d >= limit, m->bs) : branch_cond(m->c, a < limit, b < limit, d < limit, m->bs);
+}
+static uint32_t chx_off(chx *m, int32_t delta, int store)
+{
+    const uint32_t v[3] = {m->i[0] + (uint32_t)delta, m->i[1] + (uint32_t)delta, m->i[2] + (uint32_t)delta};
+    return gep_offset(m->c, v, store ? m->ss : m->ls);
+}
+static void chx_set(uint32_t reg[3], uint32_t v) { reg[0] = reg[1] = reg[2] = v; }
+static void chx_add(uint32_t reg[3], uint32_t d)
+{
+    for (int r = 0; r < 3; ++r)
+        reg[r] += d;
+}
+
+static void chx_transform(chx *m, uint32_t dg[3][5], const uint32_t in[16])
+{
+    uint32_t W[3][80], v[3][5];
+    memset(W, 0, sizeof W);
+    for (chx_set(m->i, 0); chx_loop(m, m->i, 16, 0); chx_add(m->i, 1)) {      /* W[i] = sha_info_data[i]          :88-90 */
+        const uint32_t ol = chx_off(m, 0, 0), os = chx_off(m, 0, 1);
+        if (os < 80u)
+            for (int r = 0; r < 3; ++r)
+                W[r][os] = ol < 16u ? in[ol] : 0u;
+    }
+    for (chx_set(m->i, 16); chx_loop(m, m->i, 80, 0); chx_add(m->i, 1)) {     /* the expansion                     :91-93 */
+        const uint32_t o3 = chx_off(m, -3, 0), o8 = chx_off(m, -8, 0), o14 = chx_off(m, -14, 0), o16 = chx_off(m, -16, 0);
+        const uint32_t os = chx_off(m, 0, 1);
+        for (int r = 0; r < 3; ++r) {
+            const uint32_t x = (o3 < 80u ? W[r][o3] : 0u) ^ (o8 < 80u ? W[r][o8] : 0u) ^ (o14 < 80u ? W[r][o14] : 0u) ^
+                               (o16 < 80u ? W[r][o16] : 0u);
+            if (os < 80u)
+                W[r][os] = x;
+        }
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int w = 0; w < 5; ++w)
+            v[r][w] = dg[r][w];
+    for (int seg = 0; seg < 4; ++seg)                                         /* FUNC(1..4, i)                     :100-111 */
+        for (chx_set(m->i, 20u * (uint32_t)seg); chx_loop(m, m->i, 20 * (seg + 1), 0); chx_add(m->i, 1)) {
+            const uint32_t o = chx_off(m, 0, 0);
+            for (int r = 0; r < 3; ++r) {
+                const uint32_t A = v[r][0], B = v[r][1], C = v[r][2], D = v[r][3], E = v[r][4];
+                const uint32_t f = seg == 0 ? ((B & C) | (~B & D)) : seg == 2 ? ((B & C) | (B & D) | (C & D)) : (B ^ C ^ D);
+                const uint32_t k = seg == 0 ? 0x5a827999u : seg == 1 ? 0x6ed9eba1u : seg == 2 ? 0x8f1bbcdcu : 0xca62c1d6u;
+                const uint32_t temp = rotl(A, 5) + f + E + (o < 80u ? W[r][o] : 0u) + k;
+                v[r][4] = D, v[r][3] = C, v[r][2] = rotl(B, 30), v[r][1] = A, v[r][0] = temp;
+            }
+        }
+    for (int r = 0; r < 3; ++r)
+        for (int w = 0; w < 5; ++w)
+            dg[r][w] += v[r][w];
+    for (unsigned w = 0; w < 5; ++w) {                                        /* sha_info_digest[w] += ...: stored  :113-117 */
+        uint32_t x[3] = {dg[0][w], dg[1][w], dg[2][w]};
+        store_sync32(m->c, x);
+        dg[0][w] = x[0], dg[1][w] = x[1], dg[2][w] = x[2];
+    }
+}
+
+static void chsha_item_indexed(const uint8_t *data, uint32_t len, uint32_t out[5], sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    static const uint32_t IV[5] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u, 0xc3d2e1f0u};
+    chx mm, *m = &mm;
+    memset(m, 0, sizeof *m);
+    m->c = c, m->fl = fl, m->nf = nf, m->R = c->nrep;
+    m->bs = (c->flags & ORC_F_BRANCH_SYNC) != 0;
+    const int as = (c->flags & ORC_F_ADDR_SYNC) != 0;
+    m->ls = as && !(c->flags & ORC_F_NO_LOAD_SYNC);
+    m->ss = as && !(c->flags & ORC_F_NO_STORE_ADDR_SYNC);
+    const uint32_t nblk = len / 64;
+    m->cap = 4ull * ((uint64_t)(nblk + 1u) * 167ull + 1ull) + 1024ull;
+    uint32_t dg[3][5];
+    for (unsigned r = 0; r < 3; ++r)
+        for (unsigned w = 0; w < 5; ++w)
+            dg[r][w] = IV[w];
+    chx_set(m->count, len);
+    /* if ((sha_info_count_lo + ((LONG) count << 3)) < sha_info_count_lo): count_lo is 0 on entry                  :136 */
+    (void)branch_cond(c, 0u, 0u, 0u, m->bs); /* (0 + x < 0 is false whatever a replica's count holds) */
+    uint32_t cidx = 0;
+    for (;; chx_add(m->count, (uint32_t)-64)) {                               /* while (count >= SHA_BLOCKSIZE)     :141 */
+        if (!chx_loop(m, m->count, 64, 1))
+            break;
+        uint32_t in[16];
+        for (unsigned t = 0; t < 16; ++t) {
+            const uint8_t *p = data + (size_t)cidx * 64 + 4 * t;
+            in[t] = cidx < nblk ? ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)) : 0u;
+        }
+        for (size_t q = 0; q < nf; ++q)
+            if (fl[q].site == ORC_SITE_CHSHA_DIGEST && fl[q].step == cidx && fl[q].replica < m->R)
+                dg[fl[q].replica][fl[q].index % 5] = flip(dg[fl[q].replica][fl[q].index % 5], fl[q].bit, 0xffffffffu);
+        chx_transform(m, dg, in);
+        ++cidx;
+    }
+    /* sha_final: count = (lo_bit_count >> 3) & 0x3f = 0; sha_info_data[count++] = 0x80; if (count > 56)           :159-162 */
+    (void)branch_cond(c, 0u, 0u, 0u, m->bs);
+    uint32_t in[16];
+    memset(in, 0, sizeof in);
+    in[0] = 0x80u;
+    in[14] = len >> 29;
+    in[15] = len << 3;
+    for (size_t q = 0; q < nf; ++q)
+        if (fl[q].site == ORC_SITE_CHSHA_DIGEST && fl[q].step == cidx && fl[q].replica < m->R)
+            dg[fl[q].replica][fl[q].index % 5] = flip(dg[fl[q].replica][fl[q].index % 5], fl[q].bit, 0xffffffffu);
+    chx_transform(m, dg, in);
+    for (unsigned w = 0; w < 5; ++w)
+        out[w] = dg[0][w];
+}
+
 void orc_chsha_plain(const uint8_t *data, uint32_t len, uint32_t digest[5])
 {
     orc_stats st = {0, 0, 0, 0};
@@ -1407,7 +1549,10 @@ void orc_chsha_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nmsg
         while (fe < nfaults && fs[fe].item == m)
             ++fe;
         c.detected = 0;
-        chsha_item(msgs + m * stride, len, digests + 5 * m, &c, fs + fp, fe - fp);
+        if (cfg->flags & ORC_F_INDEXED)
+            chsha_item_indexed(msgs + m * stride, len, digests + 5 * m, &c, fs + fp, fe - fp);
+        else
+            chsha_item(msgs + m * stride, len, digests + 5 * m, &c, fs + fp, fe - fp);
         if (c.detected) {
             st->dwc_detected += (cfg->replicas == 2);
             if (detected)

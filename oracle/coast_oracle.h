@@ -68,6 +68,8 @@ enum {
     ORC_SITE_CHSHA_W = 40,     /* CHStone sha: schedule word W[step%80] of transform step/80, right after it is produced */
     ORC_SITE_CHSHA_WV = 41,    /* working variable index 0..4 (A..E) before round step%80 of transform step/80 */
     ORC_SITE_CHSHA_DIGEST = 42, /* sha_info_digest[index] before transform `step` */
+    ORC_SITE_CHSHA_I = 43,     /* ORC_F_BRANCH_SYNC / ADDR_SYNC: sha_transform's loop counter i before loop condition `step` of the call */
+    ORC_SITE_CHSHA_COUNT = 44, /* sha_update's `count`, same timing */
     /* quicksort: `step` counts the branch conditions the sort has evaluated so far; the flip lands right before condition
      * number `step` is evaluated (after the load that feeds it) */
     ORC_SITE_QS_I = 48,     /* the left scan index i */

@@ -457,3 +457,24 @@ def test_aes_loop_counters_in_the_sor_schedule(orc, golden):
     assert (enc[0] == ct).all()
     dec = orc.aes128_xmr(ct, key2, 1, replicas=2, flags=B | A)
     assert (dec[0] == pt).all() and (dec[1] == key2).all()
+
+
+def test_chsha_loop_counters_in_the_sor_schedule(orc, golden):
+    """ORC_F_BRANCH_SYNC / ORC_F_ADDR_SYNC for CHStone sha (sha.c:84-172): sha_transform's i and sha_update's count inside the sphere
+    of replication.  Per transform 17 + 65 + 4 x 21 = 166 loop conditions and 16 x 2 + 64 x 5 + 80 = 432 variable-index GEPs; per call
+    the `while (count >= 64)` conditions (one per block + 1), the carry test and sha_final's `count > 56`.  Digests are the default
+    schedule's -- the benchmark's own golden digest (2 x 8192 bytes, sha.h:59-60) included."""
+    B, A = 2, 4
+    fx = golden["chsha"]
+    data = np.ascontiguousarray(fx["indata"].reshape(1, -1))
+    ln = data.shape[1]
+    nt = ln // 64 + 1
+    ref = orc.chsha_xmr(data, ln, replicas=3)
+    got = orc.chsha_xmr(data, ln, replicas=3, flags=B | A)
+    assert (got[0] == ref[0]).all() and got[0][0].tolist() == fx["outData"].tolist()
+    assert got[1]["sync_count"] == 5 * nt + (nt * 166 + nt + 2) + nt * 432 and got[1]["errors_corrected"] == 0
+    fl = orc.make_faults([(0, 2, 43, 5000, 9), (0, 1, 44, 100, 30)])
+    t = orc.chsha_xmr(data, ln, replicas=3, flags=B | A, faults=fl)
+    assert (t[0] == ref[0]).all() and t[1]["errors_corrected"] > 0 and t[2][0] == 1
+    dw = orc.chsha_xmr(data, ln, replicas=2, flags=B | A, faults=orc.make_faults([(0, 1, 43, 5000, 9)]))
+    assert dw[1]["dwc_detected"] == 1
