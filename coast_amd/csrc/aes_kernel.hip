@@ -9,15 +9,16 @@
 // Sync points (frozen in oracle/coast_oracle.c): the 4 state dwords and 4 key dwords at the end (they are stored back),
 // and with sync_every != 0 also after every main-loop round.
 //
-// Two kernels, one wave per tile of IPW blocks:
-//   aes128_enc_fast_kernel  encryption, tiles without an armed fault, mandatory sync points only: state and key as four
+// The kernels, one wave per tile of IPW blocks (the persistent bank-replicated forms of the two lean ones: further down):
+//   aes128_enc_fast_kernel  encryption, mandatory sync points only (a tile that owns an armed upset applies it itself): state and key as four
 //                           little-endian column dwords; SubBytes + ShiftRows + MixColumns of one round are 16 lookups in
 //                           four 1-KiB LDS tables (Te_r[v] = MixColumns column r scaled by S[v]) folded with v_bitop3
 //                           xors -- the same bytes as TI_aes_128.c:142-185 computes one at a time.
 //   aes128_dec_fast_kernel  decryption likewise: InvMixColumns is linear, so the state chain is 16 Td lookups per round
 //                           and InvMix(round key) follows the inverse key schedule through a second table set.
 //   aes128_xmr_kernel       byte-at-a-time exactly as written in the reference, both directions, injector hooks and
-//                           per-round sync points; runs faulted tiles (side stream) and sync_every != 0.
+//                           per-round sync points; runs sync_every != 0 and -noStoreDataSync (round 3: armed tiles stay in the
+//                           lean kernels).  aes128_indexed_kernel: the same walk with `round` / `i` inside the sphere of replication.
 #include <type_traits>
 
 #include "xmr.hpp"
