@@ -478,3 +478,30 @@ def test_chsha_loop_counters_in_the_sor_schedule(orc, golden):
     assert (t[0] == ref[0]).all() and t[1]["errors_corrected"] > 0 and t[2][0] == 1
     dw = orc.chsha_xmr(data, ln, replicas=2, flags=B | A, faults=orc.make_faults([(0, 1, 43, 5000, 9)]))
     assert dw[1]["dwc_detected"] == 1
+
+
+def test_counter_votes_are_what_stops_a_replica0_upset_aes_and_chsha(orc):
+    """Unvoted uses follow the ORIGINAL instruction's operand = replica 0's copy (cloning.cpp:2247-2255): with the offset votes on, an
+    upset of replica 0's loop counter is out-voted at the next GEP and the results stay right; under -noLoadSync -noStoreAddrSync the
+    branch vote still corrects the direction, but the accesses of that iteration go where replica 0 points -- silent data corruption.
+    (The GPU flag sweeps of tests/test_gpu_parity.py hold the kernels to the same outcomes.)"""
+    B, A, NL, NS = 2, 4, 8, 16
+    rng = np.random.default_rng(3)
+    st = rng.integers(0, 256, (4, 16), dtype=np.uint8)
+    ky = rng.integers(0, 256, (4, 16), dtype=np.uint8)
+    ref = orc.aes128_xmr(st, ky, 0, replicas=3)
+    for tick in (15, 30, 40):  # inside round 0's `state[i] = sbox[state[i] ^ key[i]]` loop
+        fl = orc.make_faults([(1, 0, 19, tick, 1)])
+        voted = orc.aes128_xmr(st, ky, 0, replicas=3, flags=B | A, faults=fl)
+        loose = orc.aes128_xmr(st, ky, 0, replicas=3, flags=B | A | NL | NS, faults=fl)
+        assert (voted[0] == ref[0]).all() and (voted[1] == ref[1]).all() and voted[2]["errors_corrected"] > 1
+        assert not (loose[0][1] == ref[0][1]).all() and (loose[0][[0, 2, 3]] == ref[0][[0, 2, 3]]).all()
+        assert loose[2]["errors_corrected"] == 1  # only the loop condition saw the disagreement
+    msgs = rng.integers(0, 256, (3, 128), dtype=np.uint8)
+    r2 = orc.chsha_xmr(msgs, 128, replicas=3)
+    for tick in (5, 30, 120):
+        fl = orc.make_faults([(1, 0, 43, tick, 2)])
+        voted = orc.chsha_xmr(msgs, 128, replicas=3, flags=B | A, faults=fl)
+        loose = orc.chsha_xmr(msgs, 128, replicas=3, flags=B | A | NL | NS, faults=fl)
+        assert (voted[0] == r2[0]).all() and voted[1]["errors_corrected"] > 1
+        assert not (loose[0][1] == r2[0][1]).all() and (loose[0][[0, 2]] == r2[0][[0, 2]]).all() and loose[1]["errors_corrected"] == 1
