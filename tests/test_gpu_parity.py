@@ -2037,6 +2037,22 @@ def _campaign(argv, eng):
     return mod, a, records, summary
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("bench", ["aes", "cache_test", "chsha"])
+def test_campaign_aimed_at_the_loop_counters(eng, bench):
+    """tools/campaign.py --counters-in-sor (profiles/r03_campaign_counters.txt): every upset hits a loop counter that COAST_F_BRANCH_SYNC |
+    COAST_F_ADDR_SYNC put inside the sphere of replication -- unprotected runs mostly go wrong, TMR corrects all of them, DWC stops all
+    that had an effect."""
+    res = {}
+    for mode in ("TMR", "DWC", "NONE"):
+        _, _, _, s = _campaign(["-b", bench, "-m", mode, "-t", "300", "--counters-in-sor", "-n"], eng)
+        assert s["engine"] == "stepwise" and s["counters_in_sor"]
+        res[mode] = s
+    assert res["TMR"]["errors"] == 0 and res["TMR"]["TMR_ERROR_CNT"] > 0 and res["TMR"]["faults"] > 0.7 * 300
+    assert res["DWC"]["errors"] == 0 and res["DWC"]["aborts"] == res["TMR"]["faults"]
+    assert res["NONE"]["errors"] > 0.7 * 300 and res["NONE"]["TMR_ERROR_CNT"] == 0
+
+
 def test_campaign_registers_mm256_on_the_matrix_core_engine(eng, tmp_path, monkeypatch):
     """tools/campaign.py, register section (supervisor.py -s registers): 300 runs = 300 side-256 products, one upset each,
     voted by the matrix-core kernel itself.  TMR: no run ends in an error; unprotected: the same upsets corrupt outputs."""

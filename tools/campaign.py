@@ -67,6 +67,11 @@ class MM(Bench):
         return (r * n * n + int(rng.integers(0, n * n)), int(rng.integers(0, nrep)), int(rng.integers(0, 3)),
                 int(rng.integers(0, n + 1)), int(rng.integers(0, 32)))
 
+    def counter_fault(self, r, nrep, rng):  # --counters-in-sor: i / j / k / sum of the call, before loop condition `step`
+        n = self.n
+        return (r * n * n, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_MM_I, ca.SITE_MM_J, ca.SITE_MM_K, ca.SITE_MM_ACC])),
+                int(rng.integers(0, (n + 1) * (n * n + n + 1))), int(rng.integers(0, 32)))
+
     # Register census of one wave of mm_mfma_blk2_kernel<3> (the TMR default at side 256): 256 VGPRs x 64 lanes x 32 bits, named in
     # the kernel source (tests/test_kernel_budget_cpu.py holds the total).  `getReg()` of the reference draws uniformly from the
     # register class (simulation/platform/resources/injector.py:70-72, 237-260); here one draw = one bit of one lane of one VGPR.
@@ -127,6 +132,10 @@ class SHA256(Bench):
         step = int(rng.integers(0, 3)) if site == ca.SITE_SHA_STATE else int(rng.integers(0, 128))
         return (r, int(rng.integers(0, nrep)), site, step, int(rng.integers(0, 32)), int(rng.integers(0, 8)))
 
+    def counter_fault(self, r, nrep, rng):  # the byte loop's i / ctx_datalen before byte-loop iteration `step`
+        return (r, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_SHA_I, ca.SITE_SHA_DATALEN])), int(rng.integers(0, self.len + 1)),
+                int(rng.integers(0, 32)))
+
 
 class AES(Bench):
     def __init__(self, a, eng, g):
@@ -144,6 +153,10 @@ class AES(Bench):
         return (r, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_AES_STATE, ca.SITE_AES_KEY])),
                 int(rng.integers(0, 11)), int(rng.integers(0, 32)), int(rng.integers(0, 4)))
 
+    def counter_fault(self, r, nrep, rng):  # round / i (8 bits live) before loop condition `step` of the encryption walk (373 of them)
+        return (r, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_AES_ROUND, ca.SITE_AES_I])), int(rng.integers(0, 373)),
+                int(rng.integers(0, 8)))
+
 
 class CRC16(Bench):
     def __init__(self, a, eng, g):
@@ -159,6 +172,9 @@ class CRC16(Bench):
     def reg_fault(self, r, nrep, rng):
         return (r, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_CRC_CRC, ca.SITE_CRC_X])),
                 int(rng.integers(0, self.bl + 1)), int(rng.integers(0, 32)))
+
+    def counter_fault(self, r, nrep, rng):  # `length` (8 bits live) before the loop condition of iteration `step`
+        return (r, int(rng.integers(0, nrep)), ca.SITE_CRC_LEN, int(rng.integers(0, self.bl + 1)), int(rng.integers(0, 8)))
 
 
 class ChSha(Bench):
@@ -176,6 +192,10 @@ class ChSha(Bench):
         step = int(rng.integers(0, 4)) if site == ca.SITE_CHSHA_DIGEST else int(rng.integers(0, 4 * 80))
         return (r, int(rng.integers(0, nrep)), site, step, int(rng.integers(0, 32)), int(rng.integers(0, 5)))
 
+    def counter_fault(self, r, nrep, rng):  # sha_transform's i / sha_update's count before loop condition `step` (4 transforms x 167)
+        return (r, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_CHSHA_I, ca.SITE_CHSHA_I, ca.SITE_CHSHA_COUNT])),
+                int(rng.integers(0, 4 * 167)), int(rng.integers(0, 32)))
+
 
 class CacheTest(Bench):
     def __init__(self, a, eng, g):
@@ -192,6 +212,9 @@ class CacheTest(Bench):
     def reg_fault(self, r, nrep, rng):
         return (r, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_CT_SUM, ca.SITE_CT_VAL, ca.SITE_CT_NERR])),
                 int(rng.integers(0, self.n + 1)), int(rng.integers(0, 32)))
+
+    def counter_fault(self, r, nrep, rng):  # calc_sum's i before loop condition `step`
+        return (r, int(rng.integers(0, nrep)), ca.SITE_CT_I, int(rng.integers(0, self.n + 1)), int(rng.integers(0, 32)))
 
 
 class QuickSort(Bench):
@@ -319,11 +342,17 @@ def run_campaign(a, eng=None):
                 targets.append({"class": cls, "flips": len(ev), "site": ev[0][2] if ev else None, "step": ev[0][3] if ev else None,
                                 "bit": ev[0][4] if ev else None, "replica": ev[0][1] if ev else None})
         else:
-            rows = [bench.reg_fault(r, nrep, rng) for r in range(runs)]
+            if a.counters_in_sor:  # the loop counters are members of the sphere of replication and the campaign aims at THEM
+                if not hasattr(bench, "counter_fault") or (a.benchmark == "mm" and a.side > 32):
+                    raise SystemExit("--counters-in-sor: mm (--side <= 32), sha256, aes, crc16, chsha, cache_test")
+                rows = [bench.counter_fault(r, nrep, rng) for r in range(runs)]
+            else:
+                rows = [bench.reg_fault(r, nrep, rng) for r in range(runs)]
             for r, row in enumerate(rows):
                 targets.append({"replica": row[1], "site": row[2], "step": row[3], "bit": row[4]})
         eng.inject_faults(ca.make_faults(rows))
-        out = bench.run(inp, ca.XmrConfig(rep), det)
+        flags = (ca.F_BRANCH_SYNC if a.benchmark == "crc16" else ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC) if a.counters_in_sor else 0
+        out = bench.run(inp, ca.XmrConfig(rep, 0, flags), det)
         engine = eng.last_launch()
     elif a.mem_mode == "nomemrep" or rep == ca.UNPROTECTED:
         for r in range(runs):  # the single memory copy is hit: every replica loads the same corrupted word
@@ -413,6 +442,7 @@ def run_campaign(a, eng=None):
         "wall_s": wall,
         "seconds_per_injection": wall / runs,
         "fault_model": "one single-bit flip of a 32-bit word per run (FaultInjector.flipOneBit, injector.py:202-207)",
+        "counters_in_sor": bool(getattr(a, "counters_in_sor", False)),
     }
     if classes is not None:  # the physical register model: outcome per register class, and what the unmodelled share can change
         by = {}
@@ -486,6 +516,9 @@ def parse(argv=None):
     ap.add_argument("--reg-model", default="sites", choices=["sites", "physical"],
                     help="registers: `sites` = a replica-private injector site per run; `physical` (-b mm --side 256 -m TMR) = any "
                          "register of the matrix-core kernel's wave, weighted by its register census, shared state included")
+    ap.add_argument("--counters-in-sor", action="store_true",
+                    help="registers: run with COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC (the loop counters replica-private, their branch conditions "
+                         "and GEP offsets voted) and aim every upset at a loop counter")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--side", type=int, default=9, help="mm: matrix side, one matrix per run (256 = the matrix-core engine)")
     ap.add_argument("--chaes-type", type=int, default=128128, help="chaes: key bits * 1000 + block bits (aes_key.c:83-134)")
