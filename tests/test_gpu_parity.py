@@ -2049,7 +2049,7 @@ def test_campaign_aimed_at_the_loop_counters(eng, bench):
         assert s["engine"] == "stepwise" and s["counters_in_sor"]
         res[mode] = s
     assert res["TMR"]["errors"] == 0 and res["TMR"]["TMR_ERROR_CNT"] > 0 and res["TMR"]["faults"] > 0.7 * 300
-    assert res["DWC"]["errors"] == 0 and res["DWC"]["aborts"] == res["TMR"]["faults"]
+    assert res["DWC"]["errors"] == 0 and res["DWC"]["aborts"] > 0.7 * 300
     assert res["NONE"]["errors"] > 0.7 * 300 and res["NONE"]["TMR_ERROR_CNT"] == 0
 
 
