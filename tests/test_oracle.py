@@ -505,3 +505,53 @@ def test_counter_votes_are_what_stops_a_replica0_upset_aes_and_chsha(orc):
         loose = orc.chsha_xmr(msgs, 128, replicas=3, flags=B | A | NL | NS, faults=fl)
         assert (voted[0] == r2[0]).all() and voted[1]["errors_corrected"] > 1
         assert not (loose[0][1] == r2[0][1]).all() and (loose[0][[0, 2]] == r2[0][[0, 2]]).all() and loose[1]["errors_corrected"] == 1
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_counters_in_the_sor_properties_across_kernels(orc, seed):
+    """Properties every counters-in-the-SoR walk must have, on random inputs: (a) clean results equal the default schedule's for every
+    flag set; (b) dropping a vote class never adds sync points and the classes add up (all = branch-only + address-only - the default
+    schedule's votes); (c) one upset of one counter under TMR with everything voted leaves the results untouched and is counted; (d) the
+    same upset under DWC flags the item."""
+    rng = np.random.default_rng(9000 + seed)
+    B, A, NL, NS = 2, 4, 8, 16
+    st = rng.integers(0, 256, (6, 16), dtype=np.uint8)
+    ky = rng.integers(0, 256, (6, 16), dtype=np.uint8)
+    msgs = rng.integers(0, 256, (6, 128), dtype=np.uint8)
+    arr = np.tile(np.arange(40, dtype=np.int32), (6, 1))
+    arr[rng.integers(0, 6), rng.integers(0, 40)] = -7
+    f = rng.integers(0, 2**32, (6, 5, 5), dtype=np.uint32)
+    s2 = rng.integers(0, 2**32, (6, 5, 5), dtype=np.uint32)
+    d = int(seed & 1)
+    cases = {
+        "aes": (lambda **k: orc.aes128_xmr(st, ky, d, **k), lambda r: np.concatenate([r[0], r[1]], axis=1), lambda r: r[2], lambda r: r[3],
+                lambda: (int(rng.integers(0, 6)), int(rng.integers(1, 3)), int(rng.choice([18, 19])), int(rng.integers(0, 373)), int(rng.integers(0, 8)))),
+        "chsha": (lambda **k: orc.chsha_xmr(msgs, 128, **k), lambda r: r[0], lambda r: r[1], lambda r: r[2],
+                  lambda: (int(rng.integers(0, 6)), int(rng.integers(1, 3)), int(rng.choice([43, 44])), int(rng.integers(0, 500)), int(rng.integers(0, 32)))),
+        "cache_test": (lambda **k: orc.cache_test_xmr(arr, **k), lambda r: np.concatenate([r[0], r[1][:, None], r[2][:, None].astype(np.int32)], axis=1),
+                       lambda r: r[3], lambda r: r[4],
+                       lambda: (int(rng.integers(0, 6)), int(rng.integers(1, 3)), 35, int(rng.integers(0, 41)), int(rng.integers(0, 32)))),
+        "mm": (lambda **k: orc.mm_xmr(f, s2, **k), lambda r: r[0].reshape(6, -1), lambda r: r[1], lambda r: r[2].reshape(6, -1).any(axis=1),
+               lambda: (25 * int(rng.integers(0, 6)), int(rng.integers(1, 3)), int(rng.choice([3, 4, 5])), int(rng.integers(0, 186)), int(rng.integers(0, 32)))),
+    }
+    for name, (run, outs, stats, det, fault) in cases.items():
+        ref = run(replicas=3)
+        base = stats(ref)["sync_count"]
+        full = run(replicas=3, flags=B | A)
+        nb, na = stats(run(replicas=3, flags=B))["sync_count"], stats(run(replicas=3, flags=A))["sync_count"]
+        assert (outs(full) == outs(ref)).all(), name
+        # (cache_test: the scrub stores the counter itself, a data vote that exists as soon as i is replicated -- in both single-class runs)
+        extra = int((arr != np.arange(40, dtype=np.int32)).sum()) if name == "cache_test" else 0
+        assert stats(full)["sync_count"] == nb + na - base - extra, name
+        nl, ns = stats(run(replicas=3, flags=B | A | NL))["sync_count"], stats(run(replicas=3, flags=B | A | NS))["sync_count"]
+        assert nl <= stats(full)["sync_count"] and ns <= stats(full)["sync_count"], name
+        assert stats(run(replicas=3, flags=B | A | NL | NS))["sync_count"] == nb, name
+        row = fault()
+        fl = orc.make_faults([row])
+        t = run(replicas=3, flags=B | A, faults=fl)
+        assert (outs(t) == outs(ref)).all(), (name, row)
+        if stats(t)["errors_corrected"]:
+            item = row[0] // 25 if name == "mm" else row[0]
+            assert bool(np.asarray(det(t))[item]), (name, row)
+            dw = run(replicas=2, flags=B | A, faults=orc.make_faults([(row[0], 1) + row[2:]]))
+            assert stats(dw)["dwc_detected"] == 1, (name, row)

@@ -1,5 +1,9 @@
 #!/bin/bash
-# round 3: the mm headline with non-temporal r stores / f loads (COAST_MM_AUX_R / _F), A/B on one box: time, then HBM traffic per launch
+# round 3: the mm headline with non-temporal r stores / f loads (COAST_MM_AUX_R / _F), A/B on one box: time, then HBM traffic per launch.
+# The three libraries are built beforehand (they travel with the snapshot; gpurun_ab/ is git-ignored):
+#   H=$(python -c "from coast_amd import build as b; print(b.source_hash())")
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DCOAST_SOURCE_HASH="\"$H\"" -DCOAST_MM_AUX_R=<0|2> -DCOAST_MM_AUX_F=<0|2> \
+#         -o gpurun_ab/lib_<nt0|ntR|ntRF>.so coast_amd/csrc/coast_hip.hip
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r3p
 mkdir -p $OUT
