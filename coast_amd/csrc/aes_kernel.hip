@@ -1210,9 +1210,11 @@ __global__ __launch_bounds__(64) void aes128_indexed_kernel(uint8_t *__restrict_
                         const uint32_t a1 = ld(S, b4 + 1), a3 = ld(S, b4 + 3);
                         buf2 = xtime(xtime(a1 ^ a3));
 #pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) {
-                            const uint32_t a = ld(S, b4 + cc);
-                            st(S, b4 + cc, a ^ ((cc & 1) ? buf2 : buf1));
+                        for (int cc = 0; cc < 4; ++cc) { // state[buf4 + cc] ^= buf: ONE GEP serves the load and the store of a compound
+                            // assignment, and its first user is the load (user_back(), synchronization.cpp:341-351): load class
+                            const uint32_t o = xmr_steer<NREP>((uint32_t)(b4 + cc), lm, ls, cnt, tl);
+                            if (o < 16u)
+                                S[o] ^= (uint8_t)((cc & 1) ? buf2 : buf1);
                         }
                     }
                     {

@@ -260,6 +260,8 @@ __global__ __launch_bounds__(64) void cache_test_indexed_kernel(uint32_t *__rest
     const uint64_t cap = 4ull * ((uint64_t)n + 1ull) + 1024ull;
     Tally tl;
     uint32_t i = 0u, sum = 0u, nerr = 0u;
+    bool firstError = false, inBlock = false; // the report block's state: equal in every copy (no fault site)
+    uint32_t localErrors = 0u;
     uint64_t tick = 0;
     auto hook = [&](uint64_t step, bool loaded, uint32_t &v) __attribute__((always_inline)) {
         for (uint32_t q = 0; q < fr.y; ++q) {
@@ -296,6 +298,15 @@ __global__ __launch_bounds__(64) void cache_test_indexed_kernel(uint32_t *__rest
         const bool taken = xmr_steer<NREP>(v != i ? 1u : 0u, lm, true, cnt, tl) != 0u; // (the element as loaded above)
         if (taken) {
             nerr += 1u;                                              // numberOfErrors++                            :111
+            // the report block (:114-131), its printing aside: `if (!first_error)`, for the first bad element `if (!in_block && ..)`
+            // (in_block and local_errors are the program's globals: 0 when the call starts, in this batch model), and the
+            // `array[i]` argument of the printf -- one more load offset
+            if (xmr_steer<NREP>(!firstError ? 1u : 0u, lm, bs, cnt, tl) != 0u) {
+                (void)xmr_steer<NREP>(!inBlock ? 1u : 0u, lm, bs, cnt, tl);
+                firstError = true, inBlock = true;
+            }
+            (void)xmr_steer<NREP>(i, lm, ls, cnt, tl);
+            localErrors += 1u;
             const uint32_t os = xmr_steer<NREP>(i, lm, ss, cnt, tl); // array[i] = i                                :127
             uint32_t d = xmr_store_sync<NREP>(i, lm, cnt, tl);
             if (NREP != 3 || !lm.storeSync)
@@ -304,6 +315,15 @@ __global__ __launch_bounds__(64) void cache_test_indexed_kernel(uint32_t *__rest
                 a[os] = d;
         }
         i += 1u;
+    }
+    // after the loop: `if (first_error && robust_printing)` (:139) and `if (sum != golden)` (:157), golden = n (n - 1) / 2; a wrong sum
+    // looks at `local_errors == 0` (:161) and, with no element error behind it, at `!in_block` (:165)
+    if (lm.live) {
+        (void)xmr_steer<NREP>(firstError ? 1u : 0u, lm, bs, cnt, tl);
+        const uint32_t golden = (uint32_t)(((uint64_t)N * (uint64_t)(N - 1u)) / 2u);
+        if (xmr_steer<NREP>(sum != golden ? 1u : 0u, lm, bs, cnt, tl) != 0u)
+            if (xmr_steer<NREP>(localErrors == 0u ? 1u : 0u, lm, bs, cnt, tl) != 0u)
+                (void)xmr_steer<NREP>(!inBlock ? 1u : 0u, lm, bs, cnt, tl);
     }
     sum = xmr_sync<NREP>(sum, lm, cnt, tl);          // return sum
     nerr = xmr_store_sync<NREP>(nerr, lm, cnt, tl);  // stored to the caller's error count

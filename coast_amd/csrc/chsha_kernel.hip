@@ -334,6 +334,8 @@ __global__ __launch_bounds__(64) void chsha_indexed_kernel(const uint8_t *__rest
             transform(cidx, false);
             ++cidx;
         }
+        (void)xmr_steer<NREP>(0u, lm, ss, cnt, tl);                             // sha_final: sha_info_data[count++] = 0x80 -- a store
+                                                                                //   through a variable index (count = 0 here)  :161
         (void)xmr_steer<NREP>(0u, lm, bs, cnt, tl);                             // sha_final: if (count > 56)        :162
         digestHook(cidx);
         transform(0u, true); // the padding block -- a derailed walk pads all the same (sha_final does)

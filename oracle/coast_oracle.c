@@ -1037,10 +1037,11 @@ static int aes_item_indexed(uint8_t *state, uint8_t *key, int dir, sync_ctx *c, 
                     aesx_ld(m, m->s, IDX(1), a);
                     aesx_ld(m, m->s, IDX(3), b);
                     AX3(buf2, xtime(xtime((uint8_t)(a[r] ^ b[r]))));
-                    for (int cc = 0; cc < 4; ++cc) {                        /*     state[buf4 + cc] ^= buf1 / buf2                */
-                        aesx_ld(m, m->s, IDX(cc), a);
-                        AX3(v, a[r] ^ ((cc & 1) ? buf2[r] : buf1[r]));
-                        aesx_st(m, m->s, IDX(cc), v);
+                    for (int cc = 0; cc < 4; ++cc) {                        /*     state[buf4 + cc] ^= buf1 / buf2: ONE GEP serves the   */
+                        const uint32_t o = aesx_off(m, IDX(cc), 0);          /*     load and the store of a compound assignment; its first */
+                        if (o < 16u)                                        /*     user is the load (user_back(), :341-351): load class    */
+                            for (int r = 0; r < 3; ++r)
+                                m->s[r][o] ^= (uint8_t)((cc & 1) ? buf2[r] : buf1[r]);
                     }
                 }
                 aesx_ld(m, m->s, IDX(0), a);                                /*     buf1 = the column's xor               :177 */
@@ -1515,6 +1516,10 @@ static void chsha_item_indexed(const uint8_t *data, uint32_t len, uint32_t out[5
         ++cidx;
     }
     /* sha_final: count = (lo_bit_count >> 3) & 0x3f = 0; sha_info_data[count++] = 0x80; if (count > 56)           :159-162 */
+    {
+        const uint32_t zero[3] = {0u, 0u, 0u};
+        (void)gep_offset(c, zero, m->ss); /* sha_info_data[count++] = 0x80: a store through a variable index (count = 0 here)   :161 */
+    }
     (void)branch_cond(c, 0u, 0u, 0u, m->bs);
     uint32_t in[16];
     memset(in, 0, sizeof in);
@@ -1646,6 +1651,7 @@ static void ct_item_indexed(int32_t *a, uint32_t n, int32_t *sum_out, uint32_t *
     const int ls = as && !(c->flags & ORC_F_NO_LOAD_SYNC), ss = as && !(c->flags & ORC_F_NO_STORE_ADDR_SYNC);
     const uint64_t cap = 4ull * ((uint64_t)n + 1ull) + 1024ull;
     uint32_t i[3] = {0, 0, 0}, sum[3] = {0, 0, 0}, nerr[3] = {0, 0, 0};
+    uint32_t first_error = 0, in_block = 0, local_errors = 0; /* the report block's state: equal in every copy (no fault site) */
     uint64_t tick = 0;
     for (;;) {
         for (size_t q = 0; q < nf; ++q)
@@ -1674,6 +1680,15 @@ static void ct_item_indexed(int32_t *a, uint32_t n, int32_t *sum_out, uint32_t *
         if (branch_cond(c, cond[0], cond[1], cond[2], 1)) {
             for (unsigned r = 0; r < 3; ++r)
                 nerr[r] += 1;                                     /* numberOfErrors++       :111 */
+            /* the report block (:114-131), its printing aside: `if (!first_error)`, for the first bad element `if (!in_block && ..)`
+             * (in_block and local_errors are the program's globals: 0 when the call starts, in this batch model), and the
+             * `array[i]` argument of the printf -- one more load offset */
+            if (branch_cond(c, !first_error, !first_error, !first_error, bs)) {
+                (void)branch_cond(c, !in_block, !in_block, !in_block, bs);
+                first_error = 1, in_block = 1;
+            }
+            (void)gep_offset(c, i, ls);
+            local_errors += 1;
             const uint32_t os = gep_offset(c, i, ss);             /* array[i] = i           :127 */
             uint32_t d[3] = {i[0], i[R > 1 ? 1 : 0], i[R > 2 ? 2 : 0]};
             store_sync32(c, d);
@@ -1682,6 +1697,15 @@ static void ct_item_indexed(int32_t *a, uint32_t n, int32_t *sum_out, uint32_t *
         }
         for (unsigned r = 0; r < 3; ++r)
             i[r] += 1;
+    }
+    /* after the loop: `if (first_error && robust_printing)` (:139) and `if (sum != golden)` (:157) with golden = n (n - 1) / 2; a
+     * wrong sum looks at `local_errors == 0` (:161) and, with no element error behind it, at `!in_block` (:165) */
+    (void)branch_cond(c, first_error, first_error, first_error, bs);
+    {
+        const uint32_t golden = (uint32_t)(((uint64_t)n * (n - 1u)) / 2u);
+        if (branch_cond(c, sum[0] != golden, sum[R > 1 ? 1 : 0] != golden, sum[R > 2 ? 2 : 0] != golden, bs))
+            if (branch_cond(c, local_errors == 0u, local_errors == 0u, local_errors == 0u, bs))
+                (void)branch_cond(c, !in_block, !in_block, !in_block, bs);
     }
     uint32_t vs[3] = {sum[0], sum[R > 1 ? 1 : 0], sum[R > 2 ? 2 : 0]}, vn[3] = {nerr[0], nerr[R > 1 ? 1 : 0], nerr[R > 2 ? 2 : 0]};
     sync32(c, vs);        /* return value */

@@ -960,10 +960,16 @@ def test_cache_test_loop_counter_in_the_sor_vs_oracle(eng, orc, n, na, replicas)
         assert (d.cpu().numpy() == w_a).all() and (w_a == c_a).all(), flags
         assert (sums.cpu().numpy() == w_s).all() and (nerrs.cpu().numpy().view(np.uint32) == w_e).all() and (w_s == c_s).all(), flags
         assert _stats3(eng.stats()) == w_st and eng.last_launch()["engine"] == "stepwise", flags
-        if replicas > 1:  # the schedule: loop conditions, two load offsets per element, the element compare, per scrub: offset + data
-            votes = na * ((n + 1 if flags & B else 0) + n + 2) + (0 if flags & ND else nbad) - (na if flags & ND else 0)
+        if replicas > 1:  # the schedule (= the reference's -O0 IR, tools/ir_sync_counts.py): loop conditions + the two `if`s behind the
+            # loop, two load offsets per element, the element compare; per scrub: offset + data, `!first_error`, the printf's offset;
+            # per array with a scrub: `!in_block`; behind a wrong sum: `local_errors == 0` (and `!in_block` with no scrub before it)
+            bad_k = (a != np.arange(n, dtype=np.int32)).sum(axis=1)
+            wrong_k = (a.astype(np.int64).sum(axis=1) & 0xFFFFFFFF) != ((n * (n - 1) // 2) & 0xFFFFFFFF)
+            votes = na * (n + 2) + (0 if flags & ND else nbad) - (na if flags & ND else 0)
+            if flags & B:
+                votes += na * (n + 1 + 2) + nbad + int((bad_k > 0).sum()) + int(wrong_k.sum()) + int((wrong_k & (bad_k == 0)).sum())
             if flags & A:
-                votes += (0 if flags & NL else 2 * n * na) + (0 if flags & NS else nbad)
+                votes += (0 if flags & NL else 2 * n * na + nbad) + (0 if flags & NS else nbad)
             assert w_st["sync_count"] == votes, (flags, w_st, votes)
         if replicas == 1:
             continue
@@ -1946,7 +1952,7 @@ def test_chsha_loop_counters_in_the_sor_vs_oracle(eng, orc, length, replicas):
         if replicas > 1:
             votes = (0 if flags & ND else 5 * nt) + (nt * 166 + nt + 2 if flags & B else 0)
             if flags & A:
-                votes += (0 if flags & NL else nt * (16 + 4 * 64 + 80)) + (0 if flags & NS else nt * (16 + 64))
+                votes += (0 if flags & NL else nt * (16 + 4 * 64 + 80)) + (0 if flags & NS else nt * (16 + 64) + 1)
             assert want_st["sync_count"] == nm * votes, (flags, want_st)
         if replicas == 1:
             continue

@@ -1,0 +1,86 @@
+"""The counters-in-the-SoR schedules of the oracle against the reference's own LLVM IR (container-side pin, like oracle/_ref).
+
+tools/ir_sync_counts.py compiles the reference's C file where it lies with `clang -O0 -emit-llvm` (the reference's flow compiles at -O0
+before opt), puts a counting call in front of every conditional branch and every getelementptr with a variable last index of the
+function under test, RUNS it on the benchmark's kind of input and reports how many of each were executed, the GEPs split by the class
+the pass's -noLoadSync / -noStoreAddrSync rules give them (first user of the address, through a GEP that feeds a GEP:
+synchronization.cpp:341-367).  With COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC every one of them is a sync point
+(syncTerminator :146-155, syncGEP :413-474), so the oracle's `sync_count` must grow by exactly these numbers.  Needs /root/reference and
+clang: skipped elsewhere (the GPU box)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.skipif(not (os.path.isdir("/root/reference/tests") and os.path.exists("/opt/rocm/lib/llvm/bin/clang")),
+                                reason="needs the reference checkout and clang (container-side pin)")
+B, A, NL, NS = 2, 4, 8, 16
+
+
+def _classes(sync):
+    """(branch votes, load-offset votes, store-offset votes) that the flags add: sync(flags) -> sync_count"""
+    b = sync(B)
+    return b, sync(B | A | NS) - b, sync(B | A | NL) - b
+
+
+def test_mm_counts_equal_the_references_ir(orc):
+    import ir_sync_counts as ir
+
+    got = ir.mm(9)["mm"]  # tests/mm_common/mm.c: side 9
+    n = 9
+    rng = np.random.default_rng(0)
+    f = rng.integers(0, 2**32, (1, n, n), dtype=np.uint32)
+    s = rng.integers(0, 2**32, (1, n, n), dtype=np.uint32)
+    nd = 1  # -noStoreDataSync: leaves the loop / offset votes alone
+    br, ld, st = _classes(lambda fl: orc.mm_xmr(f, s, replicas=3, flags=fl | nd)[1]["sync_count"])
+    assert (br, ld, st) == (got["branches"], got["gep_loads"], got["gep_stores"]) == ((n + 1) * (n * n + n + 1), 4 * n**3, 2 * n * n)
+    assert got["gep_other"] == 0
+
+
+def test_aes_counts_equal_the_references_ir(orc):
+    import ir_sync_counts as ir
+
+    got = ir.aes()
+    st = np.array([[(17 * i + 3) & 255 for i in range(16)]], dtype=np.uint8)
+    ky = np.array([[(29 * i + 7) & 255 for i in range(16)]], dtype=np.uint8)
+    enc = orc.aes128_xmr(st, ky, 0, replicas=3)
+    for d, tag, s_, k_ in ((0, "aes_enc", st, ky), (1, "aes_dec", enc[0], enc[1])):
+        base = orc.aes128_xmr(s_, k_, d, replicas=3)[2]["sync_count"]  # the frozen schedule's 8 exit votes
+        br, ld, sto = _classes(lambda fl: orc.aes128_xmr(s_, k_, d, replicas=3, flags=fl)[2]["sync_count"])
+        assert (br - base, ld, sto) == (got[tag]["branches"], got[tag]["gep_loads"], got[tag]["gep_stores"]), tag
+        assert got[tag]["gep_other"] == 0
+    assert (got["aes_enc"]["branches"], got["aes_dec"]["branches"]) == (469, 593)
+
+
+@pytest.mark.parametrize("bad", [(), (40,), (40, 41), (40, 100, 599), (0,), (599,)])
+def test_cache_test_counts_equal_the_references_ir(orc, bad):
+    import ir_sync_counts as ir
+
+    n = 600
+    got = ir.cache_test(n, bad)["calc_sum"]
+    a = np.arange(n, dtype=np.int32).reshape(1, n).copy()
+    for k in bad:
+        a[0, k] = -5
+    # the IR's conditional branches include the n element compares, which the default schedule votes as well
+    base = orc.cache_test_xmr(a, replicas=3)[3]["sync_count"] - n
+    nd = 1
+    br, ld, sto = _classes(lambda fl: orc.cache_test_xmr(a, replicas=3, flags=fl | nd)[3]["sync_count"])
+    base_nd = orc.cache_test_xmr(a, replicas=3, flags=nd)[3]["sync_count"] - n
+    assert (br - base_nd, ld, sto) == (got["branches"], got["gep_loads"], got["gep_stores"]), (bad, base)
+    assert got["gep_other"] == 0
+
+
+@pytest.mark.parametrize("nbytes", [0, 64, 128, 1024])
+def test_chsha_counts_equal_the_references_ir(orc, nbytes):
+    import ir_sync_counts as ir
+
+    got = ir.chsha(nbytes)["chsha"]
+    m = np.array([[(i * 31 + 5) & 255 for i in range(max(nbytes, 64))]], dtype=np.uint8)
+    base = orc.chsha_xmr(m, nbytes, replicas=3)[1]["sync_count"]
+    br, ld, sto = _classes(lambda fl: orc.chsha_xmr(m, nbytes, replicas=3, flags=fl)[1]["sync_count"])
+    assert (br - base, ld, sto) == (got["branches"], got["gep_loads"], got["gep_stores"]), nbytes
+    assert got["gep_other"] == 0

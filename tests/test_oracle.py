@@ -406,18 +406,21 @@ def test_chaes_oracle_votes_out_single_upsets(orc):
 
 def test_cache_test_loop_counter_in_the_sor_schedule(orc):
     """ORC_F_BRANCH_SYNC / ORC_F_ADDR_SYNC for calc_sum (cacheTest.c:107-131): i beside sum / numberOfErrors inside the sphere of
-    replication.  Clean arrays of n elements: n + 1 loop conditions, 2 n load offsets, n element compares, the returned sum and the
-    stored error count = 4 n + 3 votes per array; every corrupt element adds its scrub's store offset and data.  Results equal the
+    replication.  Clean arrays of n elements: n + 1 loop conditions, 2 n load offsets, n element compares, the two `if`s behind the loop,
+    the returned sum and the stored error count = 4 n + 5 votes per array; a corrupt element adds its scrub's store offset and data and
+    the report block's branches.  Results equal the
     default schedule's; a single upset of i is out-voted under TMR, detected under DWC."""
     n, na = 600, 7
     a = np.tile(np.arange(n, dtype=np.int32), (na, 1))
     B, A = 2, 4
     w_a, w_s, w_e, st, det = orc.cache_test_xmr(a, replicas=3, flags=B | A)
-    assert st["sync_count"] == na * (4 * n + 3) and st["errors_corrected"] == 0 and not det.any()
+    assert st["sync_count"] == na * (4 * n + 5) and st["errors_corrected"] == 0 and not det.any()
     assert (w_s == 179700).all() and not w_e.any()                      # generateGolden(), cacheTest.c:86
     a[3, 17] = 99
     w_a, w_s, w_e, st, det = orc.cache_test_xmr(a, replicas=3, flags=B | A)
-    assert st["sync_count"] == na * (4 * n + 3) + 2 and w_e[3] == 1 and w_a[3, 17] == 17
+    # one corrupt element: its scrub's offset + data, the report block's `!first_error` / `!in_block`, the printf's array[i] offset,
+    # and `local_errors == 0` behind the now wrong sum
+    assert st["sync_count"] == na * (4 * n + 5) + 2 + 4 and w_e[3] == 1 and w_a[3, 17] == 17
     ref = orc.cache_test_xmr(a, replicas=3)
     assert (w_a == ref[0]).all() and (w_s == ref[1]).all() and (w_e == ref[2]).all()
     fl = orc.make_faults([(5, 1, 35, 100, 3)])                          # replica 1's i before condition 100
@@ -432,12 +435,13 @@ def test_aes_loop_counters_in_the_sor_schedule(orc, golden):
     The counts follow from the source as written.  Encryption: branch conditions 1 (`if (dir)`) + 11 (`round < 10`) + per round
     1 (`if (dir)`) + 17 (`i < 16`) + 1 (`if (dir)`) + 13 (`i < 16` from 4) = 320, the MixColumns condition 3 + 8 x 4 + 3 = 38 operands,
     9 x (5 + 4) in its loop, 1 + 17 after the loop = 469; loop conditions alone 11 + 10 x 30 + 9 x 5 + 17 = 373.  Decryption: 593 / 514.
+    The same numbers come out of the reference's own -O0 IR (tools/ir_sync_counts.py, tests/test_ir_counts_cpu.py).
     Results are the frozen schedule's -- the NIST vectors included."""
     B, A = 2, 4
     rng = np.random.default_rng(5)
     st = rng.integers(0, 256, (9, 16), dtype=np.uint8)
     ky = rng.integers(0, 256, (9, 16), dtype=np.uint8)
-    for d, nbr, ngep in ((0, 469, 1818), (1, 593, 2660)):
+    for d, nbr, ngep in ((0, 469, 1818), (1, 593, 2516)):
         ref = orc.aes128_xmr(st, ky, d, replicas=3)
         b = orc.aes128_xmr(st, ky, d, replicas=3, flags=B)
         ba = orc.aes128_xmr(st, ky, d, replicas=3, flags=B | A)
@@ -472,7 +476,7 @@ def test_chsha_loop_counters_in_the_sor_schedule(orc, golden):
     ref = orc.chsha_xmr(data, ln, replicas=3)
     got = orc.chsha_xmr(data, ln, replicas=3, flags=B | A)
     assert (got[0] == ref[0]).all() and got[0][0].tolist() == fx["outData"].tolist()
-    assert got[1]["sync_count"] == 5 * nt + (nt * 166 + nt + 2) + nt * 432 and got[1]["errors_corrected"] == 0
+    assert got[1]["sync_count"] == 5 * nt + (nt * 166 + nt + 2) + nt * 432 + 1 and got[1]["errors_corrected"] == 0  # (+1: sha_info_data[count++])
     fl = orc.make_faults([(0, 2, 43, 5000, 9), (0, 1, 44, 100, 30)])
     t = orc.chsha_xmr(data, ln, replicas=3, flags=B | A, faults=fl)
     assert (t[0] == ref[0]).all() and t[1]["errors_corrected"] > 0 and t[2][0] == 1

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Count, on the reference's own -O0 LLVM IR, the sync points that COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC add to a function: every
+EXECUTED conditional branch (`br i1`: syncTerminator, synchronization.cpp:146-155, 741-949) and every executed getelementptr whose last
+index is not a constant (syncGEP votes the last operand, :413-474; constant offsets return early, :428-431), split by what the address
+feeds (a load: -noLoadSync drops it; a store: -noStoreAddrSync).  The IR is what `clang -O0 -emit-llvm` makes of the C file where it lies
+under /root/reference (the reference's flow compiles at -O0 before opt, tests/makefiles/Makefile.common); the instrumentation is a call
+in front of each such instruction of the chosen functions, the counts come from RUNNING the instrumented code on the benchmark's own kind
+of input.  tests/test_ir_counts_cpu.py compares them with the oracle's schedules (coast_oracle.c: mm_call_indexed, aes_item_indexed,
+ct_item_indexed, chsha_item_indexed).  Needs the reference checkout: a container-side pin, like oracle/_ref."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+REF = "/root/reference/tests"
+
+
+def instrument(ll, funcs):
+    """returns the IR text with `call void @__coast_cnt(i32 k)` in front of the counted instructions of `funcs`
+    (k = 0 conditional branch, 1 variable GEP feeding a load, 2 feeding a store, 3 feeding something else)"""
+    out, cur, body = [], None, []
+    lines = ll.split("\n")
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        m = re.match(r"define .*@([\w.]+)\(", ln)
+        if m:
+            cur = m.group(1) if m.group(1) in funcs else None
+        if cur and ln.startswith("}"):
+            cur = None
+        if cur:
+            if re.match(r"\s+br i1 ", ln):
+                out.append("  call void @__coast_cnt(i32 0)")
+            g = re.match(r"\s+(%[\w.]+) = getelementptr .*, \w+ (\S+)$", ln)
+            if g and g.group(2).startswith("%"):
+                res, kind = g.group(1), 3
+                for nxt in lines[i + 1:i + 60]:  # the class of the address: its first user, through a GEP that feeds a GEP (:343-351)
+                    if nxt.startswith("}"):
+                        break
+                    if re.search(r"= load .*ptr %s(,|$)" % re.escape(res), nxt):
+                        kind = 1
+                        break
+                    if re.search(r"store .*, ptr %s(,|$)" % re.escape(res), nxt):
+                        kind = 2
+                        break
+                    g2 = re.match(r"\s+(%%[\w.]+) = getelementptr .*ptr %s," % re.escape(res), nxt)
+                    if g2:
+                        res = g2.group(1)
+                        continue
+                    if re.search(r"%s\b" % re.escape(res), nxt):
+                        break
+                out.append(ln)
+                out.append("  call void @__coast_cnt(i32 %d)" % kind)
+                i += 1
+                continue
+        out.append(ln)
+        i += 1
+    return "\n".join(out) + "\ndeclare void @__coast_cnt(i32)\n"
+
+
+DRIVER_HEAD = r'''
+#include <stdio.h>
+#include <string.h>
+static unsigned long cnt[4];
+void __coast_cnt(int k) { cnt[k]++; }
+static void report(const char *tag) { fprintf(stderr, "%s %lu %lu %lu %lu\n", tag, cnt[0], cnt[1], cnt[2], cnt[3]); cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; }
+'''
+
+
+def run_case(src, funcs, driver, cflags=(), rename=None):
+    with tempfile.TemporaryDirectory() as td:
+        ll = os.path.join(td, "ref.ll")
+        subprocess.check_call([CLANG, "-O0", "-S", "-emit-llvm", "-w", *cflags, src, "-o", ll])
+        text = open(ll).read()
+        for a, b in (rename or {}).items():
+            text = re.sub(r"@%s\b" % re.escape(a), "@" + b, text)
+        open(ll, "w").write(instrument(text, funcs))
+        drv = os.path.join(td, "drv.c")
+        open(drv, "w").write(DRIVER_HEAD + driver)
+        exe = os.path.join(td, "run")
+        subprocess.check_call([CLANG, "-O0", "-w", ll, drv, "-o", exe])
+        res = {}
+        for line in subprocess.run([exe], text=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True).stderr.strip().split("\n"):
+            tag, *v = line.split()
+            res[tag] = {"branches": int(v[0]), "gep_loads": int(v[1]), "gep_stores": int(v[2]), "gep_other": int(v[3])}
+        return res
+
+
+def aes():
+    drv = r'''
+void aes_enc_dec(unsigned char *state, unsigned char *key, unsigned char dir);
+int main(void) {
+    unsigned char st[16], ky[16];
+    for (int i = 0; i < 16; i++) st[i] = (unsigned char)(17 * i + 3), ky[i] = (unsigned char)(29 * i + 7);
+    aes_enc_dec(st, ky, 0); report("aes_enc");
+    aes_enc_dec(st, ky, 1); report("aes_dec");
+    return 0; }
+'''
+    return run_case(os.path.join(REF, "aes", "TI_aes_128.c"), {"aes_enc_dec"}, drv, cflags=["-I" + os.path.join(REF, "aes")])
+
+
+def mm(n=9):
+    """tests/mm_common/mm.c (the side-9 program; it includes mm_common.c): matrix_multiply on its own matrices"""
+    drv = r'''
+extern void mm_run_test(void);
+extern unsigned int first_matrix[9][9], second_matrix[9][9], results_matrix[9][9];
+extern void matrix_multiply(unsigned int f[][9], unsigned int s[][9], unsigned int r[][9]);
+int main(void) { matrix_multiply(first_matrix, second_matrix, results_matrix); report("mm"); return 0; }
+'''
+    assert n == 9
+    return run_case(os.path.join(REF, "mm_common", "mm.c"), {"matrix_multiply"}, drv,
+                    cflags=["-I" + os.path.join(REF, "mm_common"), "-I/root/reference/tests"], rename={"main": "ref_main"})
+
+
+def cache_test(n=600, corrupt=()):
+    drv = r'''
+extern int calc_sum(int *array);
+extern void generateGolden(void);
+static int arr[%d];
+int main(void) { generateGolden(); for (int i = 0; i < %d; i++) arr[i] = i; %s
+    calc_sum(arr); report("calc_sum"); return 0; }
+''' % (n, n, " ".join("arr[%d] = -5;" % k for k in corrupt))
+    return run_case(os.path.join(REF, "cache_test", "cacheTest.c"), {"calc_sum"}, drv, rename={"main": "ref_main"})
+
+
+def chsha(nbytes=128):
+    drv = r'''
+typedef unsigned char BYTE;
+extern void sha_init(void); extern void sha_update(const BYTE *, int); extern void sha_final(void);
+static BYTE buf[%d];
+int in_i[2]; BYTE indata[2][8192]; /* sha_stream's inputs (sha.h): unused here, the driver calls sha_update itself */
+int main(void) { for (int i = 0; i < %d; i++) buf[i] = (BYTE)(i * 31 + 5);
+    sha_init(); sha_update(buf, %d); sha_final(); report("chsha"); return 0; }
+''' % (max(nbytes, 1), nbytes, nbytes)
+    return run_case(os.path.join(REF, "chstone", "sha", "sha.c"),
+                    {"sha_transform", "sha_update", "sha_final"}, drv, cflags=["-I" + os.path.join(REF, "chstone", "sha")],
+                    rename={"main": "ref_main", "memcpy": "ch_memcpy", "memset": "ch_memset"})  # (sha.c defines its own, :50-80)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["aes", "mm", "cache_test", "chsha"]
+    for w in which:
+        print(w, globals()[w]())
