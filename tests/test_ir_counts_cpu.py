@@ -84,3 +84,18 @@ def test_chsha_counts_equal_the_references_ir(orc, nbytes):
     br, ld, sto = _classes(lambda fl: orc.chsha_xmr(m, nbytes, replicas=3, flags=fl)[1]["sync_count"])
     assert (br - base, ld, sto) == (got["branches"], got["gep_loads"], got["gep_stores"]), nbytes
     assert got["gep_other"] == 0
+
+
+def test_crc16_counts_equal_the_references_ir(orc):
+    """`while (length--)` (crc16.c:25): one conditional branch per evaluation, and `*data_p++` is a constant-offset GEP -- nothing for
+    COAST_F_ADDR_SYNC to vote (what the round-2 model of crc16 says)"""
+    import ir_sync_counts as ir
+
+    got = ir.crc16((0, 13, 255))
+    for n in (0, 13, 255):
+        g = got["crc16_%d" % n]
+        assert (g["branches"], g["gep_loads"], g["gep_stores"], g["gep_other"]) == (n + 1, 0, 0, 0)
+        if n:
+            data = np.array([[(i * 7 + 1) & 255 for i in range(n)]], dtype=np.uint8)
+            base = orc.crc16_xmr(data, n, replicas=3)[1]["sync_count"]
+            assert orc.crc16_xmr(data, n, replicas=3, flags=B)[1]["sync_count"] - base == n + 1

@@ -139,7 +139,16 @@ int main(void) { for (int i = 0; i < %d; i++) buf[i] = (BYTE)(i * 31 + 5);
                     rename={"main": "ref_main", "memcpy": "ch_memcpy", "memset": "ch_memset"})  # (sha.c defines its own, :50-80)
 
 
+def crc16(lengths=(0, 13, 255)):
+    drv = r'''
+unsigned short crc16(const unsigned char *data_p, unsigned char length);
+int main(void) { unsigned char d[255]; for (int i = 0; i < 255; i++) d[i] = (unsigned char)(i * 7 + 1);
+%s return 0; }
+''' % " ".join('crc16(d, %d); report("crc16_%d");' % (n, n) for n in lengths)
+    return run_case(os.path.join(REF, "crc16", "crc16.c"), {"crc16"}, drv, cflags=["-I" + REF], rename={"main": "ref_main"})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["aes", "mm", "cache_test", "chsha"]
+    which = sys.argv[1:] or ["aes", "mm", "cache_test", "chsha", "crc16"]
     for w in which:
         print(w, globals()[w]())
