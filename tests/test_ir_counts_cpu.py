@@ -39,6 +39,11 @@ def test_mm_counts_equal_the_references_ir(orc):
     br, ld, st = _classes(lambda fl: orc.mm_xmr(f, s, replicas=3, flags=fl | nd)[1]["sync_count"])
     assert (br, ld, st) == (got["branches"], got["gep_loads"], got["gep_stores"]) == ((n + 1) * (n * n + n + 1), 4 * n**3, 2 * n * n)
     assert got["gep_other"] == 0
+    # store-data votes: r[i][j] = sum is the only store that leaves the function (N^2; the schedule's store votes).  The -O0 IR also
+    # stores i, j, k and sum into their allocas, which -noMemReplication leaves single-copy and therefore votes; this design keeps
+    # the function's locals in registers (the mem2reg view), where those stores do not exist -- reported, not modelled
+    data_votes = orc.mm_xmr(f, s, replicas=3, flags=B | A)[1]["sync_count"] - orc.mm_xmr(f, s, replicas=3, flags=B | A | nd)[1]["sync_count"]
+    assert data_votes == got["stores_to_memory"] == n * n and got["stores_to_local_allocas"] > 0
 
 
 def test_aes_counts_equal_the_references_ir(orc):

@@ -17,9 +17,25 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang"
 REF = "/root/reference/tests"
 
 
+def _is_alloca(lines, func, store_line):
+    """is the pointer operand of this store one of the function's allocas (a local variable at -O0)?"""
+    ptr = re.search(r", ptr (%[\w.]+)", store_line).group(1)
+    inside = False
+    for ln in lines:
+        m = re.match(r"define .*@([\w.]+)\(", ln)
+        if m:
+            inside = m.group(1) == func
+        elif inside and ln.startswith("}"):
+            return False
+        elif inside and re.match(r"\s+%s = alloca " % re.escape(ptr), ln):
+            return True
+    return False
+
+
 def instrument(ll, funcs):
     """returns the IR text with `call void @__coast_cnt(i32 k)` in front of the counted instructions of `funcs`
-    (k = 0 conditional branch, 1 variable GEP feeding a load, 2 feeding a store, 3 feeding something else)"""
+    (k = 0 conditional branch, 1 variable GEP feeding a load, 2 feeding a store, 3 feeding something else, 4 store of a computed value
+    to memory the function does not own, 5 the same into one of its own allocas)"""
     out, cur, body = [], None, []
     lines = ll.split("\n")
     i = 0
@@ -33,6 +49,10 @@ def instrument(ll, funcs):
         if cur:
             if re.match(r"\s+br i1 ", ln):
                 out.append("  call void @__coast_cnt(i32 0)")
+            # a store of a computed, non-pointer value: a store-data sync point under -noMemReplication (:197-224) -- at -O0 that includes
+            # the stores into the allocas of the function's own locals (reported apart: this design keeps locals in registers)
+            if re.match(r"\s+store (?!ptr )\S+ %[\w.]+, ptr ", ln):
+                out.append("  call void @__coast_cnt(i32 %d)" % (5 if re.match(r"\s+store \S+ %[\w.]+, ptr %\d+,", ln) and _is_alloca(lines, cur, ln) else 4))
             g = re.match(r"\s+(%[\w.]+) = getelementptr .*, \w+ (\S+)$", ln)
             if g and g.group(2).startswith("%"):
                 res, kind = g.group(1), 3
@@ -63,9 +83,9 @@ def instrument(ll, funcs):
 DRIVER_HEAD = r'''
 #include <stdio.h>
 #include <string.h>
-static unsigned long cnt[4];
+static unsigned long cnt[6];
 void __coast_cnt(int k) { cnt[k]++; }
-static void report(const char *tag) { fprintf(stderr, "%s %lu %lu %lu %lu\n", tag, cnt[0], cnt[1], cnt[2], cnt[3]); cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; }
+static void report(const char *tag) { fprintf(stderr, "%s %lu %lu %lu %lu %lu %lu\n", tag, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5]); for (int i = 0; i < 6; i++) cnt[i] = 0; }
 '''
 
 
@@ -84,7 +104,8 @@ def run_case(src, funcs, driver, cflags=(), rename=None):
         res = {}
         for line in subprocess.run([exe], text=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True).stderr.strip().split("\n"):
             tag, *v = line.split()
-            res[tag] = {"branches": int(v[0]), "gep_loads": int(v[1]), "gep_stores": int(v[2]), "gep_other": int(v[3])}
+            res[tag] = {"branches": int(v[0]), "gep_loads": int(v[1]), "gep_stores": int(v[2]), "gep_other": int(v[3]),
+                        "stores_to_memory": int(v[4]), "stores_to_local_allocas": int(v[5])}
         return res
 
 
