@@ -169,7 +169,22 @@ int main(void) { unsigned char d[255]; for (int i = 0; i < 255; i++) d[i] = (uns
     return run_case(os.path.join(REF, "crc16", "crc16.c"), {"crc16"}, drv, cflags=["-I" + REF], rename={"main": "ref_main"})
 
 
+def sha256(lengths=(0, 3, 64)):
+    """tests/sha256_common (OPT_FLAGS empty: the -O0 shape; the hifive1 build of the same source runs -O3 in front of the pass)"""
+    drv = r'''
+void sha256_hash(unsigned char ctx_data[], unsigned ctx_bitlen[], unsigned ctx_state[], unsigned char data[], unsigned len, unsigned char hash[]);
+int main(void) { unsigned char h[32], cd[64], m[192]; unsigned bl[2], st[8]; for (int i = 0; i < 192; i++) m[i] = (unsigned char)(i * 3 + 1);
+%s return 0; }
+''' % " ".join('sha256_hash(cd, bl, st, m, %d, h); report("sha256_%d");' % (n, n) for n in lengths)
+    src = os.path.join(REF, "sha256_common", "sha256_tmr.c")
+    cf = ["-I" + REF, "-I" + os.path.join(REF, "sha256_common")]
+    out = run_case(src, {"sha256_hash", "sha256_transform"}, drv, cflags=cf, rename={"main": "ref_main"})
+    for k, v in run_case(src, {"sha256_hash"}, drv, cflags=cf, rename={"main": "ref_main"}).items():
+        out[k + "_hash_function_alone"] = v
+    return out
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["aes", "mm", "cache_test", "chsha", "crc16"]
+    which = sys.argv[1:] or ["aes", "mm", "cache_test", "chsha", "crc16", "sha256"]
     for w in which:
         print(w, globals()[w]())
