@@ -104,3 +104,22 @@ def test_crc16_counts_equal_the_references_ir(orc):
             data = np.array([[(i * 7 + 1) & 255 for i in range(n)]], dtype=np.uint8)
             base = orc.crc16_xmr(data, n, replicas=3)[1]["sync_count"]
             assert orc.crc16_xmr(data, n, replicas=3, flags=B)[1]["sync_count"] - base == n + 1
+
+
+def test_quicksort_schedule_against_this_toolchains_o3_ir(orc):
+    """tests/quicksort/Makefile:4 runs -O3 in front of the pass; LLVM 7's pipeline cannot be rerun here, this toolchain's can: supporting
+    evidence, not a pin.  After -O3 (tail recursion turned into a loop, the scans' loads kept in registers for the swap) quick_sort executes
+    exactly the branch conditions, load offsets and stored values the oracle's schedule votes; the store offsets differ by where the
+    optimiser puts the A[i] address of the swap (this LLVM hoists it above the `i >= j` test: once per outer iteration instead of once
+    per swap)."""
+    import ir_sync_counts as ir
+
+    rng = np.random.default_rng(5)
+    arr = rng.integers(-2**31, 2**31, 580, dtype=np.int64).astype(np.int32)
+    got = ir.quicksort(arr)["quick_sort"]
+    a2 = arr.reshape(1, -1)
+    f = lambda fl: orc.quicksort_xmr(a2, replicas=3, flags=fl)[1]["sync_count"]  # noqa: E731
+    full, nl, ns, nd = f(0), f(NL), f(NS), f(1)
+    loads, stores, data = full - nl, full - ns, full - nd
+    assert (full - loads - stores - data, loads, data) == (got["branches"], got["gep_loads"], got["stores_to_memory"])
+    assert stores == data and got["gep_stores"] >= stores and got["stores_to_local_allocas"] == 0

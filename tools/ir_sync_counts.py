@@ -89,10 +89,14 @@ static void report(const char *tag) { fprintf(stderr, "%s %lu %lu %lu %lu %lu %l
 '''
 
 
-def run_case(src, funcs, driver, cflags=(), rename=None):
+def run_case(src, funcs, driver, cflags=(), rename=None, opt=None):
+    """opt: an optimisation level to run over the -O0 IR first (`-O3` for the benchmarks whose Makefile puts it in front of the pass) --
+    THIS toolchain's pipeline, not LLVM 7's: supporting evidence, not a pin"""
     with tempfile.TemporaryDirectory() as td:
         ll = os.path.join(td, "ref.ll")
-        subprocess.check_call([CLANG, "-O0", "-S", "-emit-llvm", "-w", *cflags, src, "-o", ll])
+        subprocess.check_call([CLANG, "-O0", "-S", "-emit-llvm", "-w", *(["-Xclang", "-disable-O0-optnone"] if opt else []), *cflags, src, "-o", ll])
+        if opt:
+            subprocess.check_call([os.path.join(os.path.dirname(CLANG), "opt"), opt, "-S", ll, "-o", ll])
         text = open(ll).read()
         for a, b in (rename or {}).items():
             text = re.sub(r"@%s\b" % re.escape(a), "@" + b, text)
@@ -182,6 +186,17 @@ int main(void) { unsigned char h[32], cd[64], m[192]; unsigned bl[2], st[8]; for
     for k, v in run_case(src, {"sha256_hash"}, drv, cflags=cf, rename={"main": "ref_main"}).items():
         out[k + "_hash_function_alone"] = v
     return out
+
+
+def quicksort(values):
+    """tests/quicksort (its Makefile runs -O3 in front of the pass): quick_sort on the given ints, IR after this toolchain's -O3"""
+    drv = r'''
+extern void quick_sort(int *A, int len);
+static int a[%d] = {%s};
+int main(void) { quick_sort(a, %d); report("quick_sort"); return 0; }
+''' % (len(values), ",".join(str(int(v)) for v in values), len(values))
+    return run_case(os.path.join(REF, "quicksort", "quicksort.c"), {"quick_sort"}, drv, cflags=["-I" + REF], rename={"main": "ref_main"},
+                    opt="-O3")
 
 
 if __name__ == "__main__":
