@@ -294,10 +294,11 @@ class MM(Workload):
 
     @staticmethod
     def tile():
-        """blocks2 (default): mm_mfma_blk2_kernel (replica = accumulator block, in-lane vote, two waves per SIMD); blocks:
-        mm_mfma_blk_kernel (the same with one wave per SIMD, COAST_MM_TILE=blocks); lanes: mm_mfma_panel_kernel (COAST_MM_TILE=lanes)"""
+        """blocks3 (default): mm_mfma_blk3_kernel (replica = accumulator block, in-lane vote, two waves per SIMD, every loaded operand
+        replicated: a replica's MFMAs read their own A and B fragments); blocks2: mm_mfma_blk2_kernel (one A fragment set for the three
+        replicas, COAST_MM_TILE=blocks2); blocks: mm_mfma_blk_kernel (blocks2 with one wave per SIMD); lanes: mm_mfma_panel_kernel"""
         t = os.environ.get("COAST_MM_TILE")
-        return t if t in ("lanes", "blocks") else "blocks2"
+        return t if t in ("lanes", "blocks", "blocks2") else "blocks3"
 
     def roofline(self, kern_ms):
         n, batch = self.n, self.batch
@@ -311,9 +312,11 @@ class MM(Workload):
             # computation needs on the matrix core (lane padding 32/30 and ragged tiles are NOT counted)
             ops = 2.0 * macs * 10 * 3
             if self.tile() != "lanes":
-                two = self.tile() == "blocks2"
+                two = self.tile() in ("blocks2", "blocks3")
+                kern = {"blocks3": "mm_mfma_blk3_kernel<3, false>", "blocks2": "mm_mfma_blk2_kernel<3, false>",
+                        "blocks": "mm_mfma_blk_kernel<3, false>"}[self.tile()]
                 return dict(hbm, **{
-                    "bound": "mfma", "kernel": "mm_mfma_blk2_kernel<3, false>" if two else "mm_mfma_blk_kernel<3, false>",
+                    "bound": "mfma", "kernel": kern,
                     "achieved": ops / t * 1e-12, "peak": I8_MFMA_PEAK * 1e-12, "unit": "TOP/s (int8)",
                     "frac": ops / t / I8_MFMA_PEAK,
                     # v_mfma_i32_16x16x64_i8 issued back to back by one wave per SIMD: 2.54-2.76 POP/s, constants or random
@@ -324,7 +327,10 @@ class MM(Workload):
                     "u32_macs_per_s": macs / t, "int8_ops_per_u32_mac": 2 * 10 * 3,
                     "algorithmic_macs_vs_valu_ceiling": macs / t / MAC_PEAK, "executed_macs_vs_valu_ceiling": 3.0 * macs / t / MAC_PEAK,
                     "note": "r = sum_k f*s mod 2^32 as ten int8 GEMMs of signed-byte limbs on v_mfma_i32_16x16x64_i8, the three replicas "
-                            "in three accumulator blocks of the same lane (own B-operand registers, own MFMAs), voted in-lane; "
+                            "in three accumulator blocks of the same lane, voted in-lane; "
+                            + ("every replica's MFMAs read their own A and B fragments from LDS (the loads are replicated, the memory is "
+                               "not: cloning.cpp:2187-2209, 2247-2255); " if self.tile() == "blocks3" else
+                               "own B-operand registers and MFMAs per replica, ONE A fragment set for the three; ")
                             + ("two waves per SIMD, each with half the tile's rows (96 accumulator registers)" if two else
                                "one wave per SIMD (192 accumulator registers)") +
                             "; achieved = 2*N^3*10*3 int8 ops per matrix / kernel time; "

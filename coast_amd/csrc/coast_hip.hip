@@ -22,6 +22,7 @@
 #include "mm_mfma_kernel.hip"
 #include "mm_mfma_blk_kernel.hip"
 #include "mm_mfma_blk2_kernel.hip"
+#include "mm_mfma_blk3_kernel.hip"
 #include "sha256_kernel.hip"
 #include "aes_kernel.hip"
 #include "crc16_kernel.hip"
@@ -758,12 +759,15 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     // side 256: the int8-MFMA limb kernel, injector hooks included; COAST_MM_ENGINE=valu selects the v_mad_u64_u32 kernels
     const char *eng = getenv("COAST_MM_ENGINE");
     const bool mfma = n == 256 && !allGeneral && !(eng && !strcmp(eng, "valu"));
-    // TMR: replicas in register blocks, two waves per SIMD (mm_mfma_blk2_kernel); COAST_MM_TILE=blocks selects its one-wave-per-SIMD
+    // TMR: replicas in register blocks, two waves per SIMD (mm_mfma_blk3_kernel); COAST_MM_TILE=blocks selects the one-wave-per-SIMD
     // predecessor (mm_mfma_blk_kernel), COAST_MM_TILE=lanes the lane-replica kernel (mm_mfma_panel_kernel), which also serves DWC and
     // the unprotected mode
     const char *tileEnv = getenv("COAST_MM_TILE");
     const bool mmBlocks = !(tileEnv && !strcmp(tileEnv, "lanes"));
     const bool mmBlocks2 = !(tileEnv && !strcmp(tileEnv, "blocks"));
+    // default (round 4): mm_mfma_blk3_kernel -- blocks2's geometry with every loaded operand replicated (a replica's MFMAs read their
+    // own A fragments); COAST_MM_TILE=blocks2 selects mm_mfma_blk2_kernel (one A fragment set for the three replicas)
+    const bool mmBlocks3 = !(tileEnv && !strcmp(tileEnv, "blocks2"));
     const uint64_t nbm = (uint64_t)(n / 64) * batch; // workgroups of the panel kernel: 64 rows of one matrix each
     if (mfma && nbm > 0x7fffffffull)
         return fail(c, COAST_EINVAL, "coast_mm_batch: %llu workgroups exceed the grid limit", (unsigned long long)nbm);
@@ -773,7 +777,7 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     const uint32_t *dBlockList = nullptr;
     uint32_t nFaultBlocks = 0;
     if (mfma)
-        rc = arm_faults(c, (uint32_t)nbm, decode_mm_mfma, &h, &ft, &have, nullptr, nullptr, true);
+        rc = arm_faults(c, (uint32_t)nbm, decode_mm_mfma, &h, &ft, &have, nullptr, &nFaultBlocks, true);
     else
         rc = arm_faults(c, g.nblocks, decode_mm, &h, &ft, &have, &dBlockList, &nFaultBlocks);
     if (rc)
@@ -812,7 +816,22 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
                 ftm.list = nullptr, ftm.range = nullptr;                                                        \
             /* one workgroup per CU; four of them (one XCD) share a matrix */                                    \
             const uint32_t gridB = 4u * (uint32_t)std::min<uint64_t>((uint64_t)batch, (uint64_t)std::max(1, c->numCUs / 4)); \
-            if (mmBlocks2) {                                                                                    \
+            if (have) /* the armed upsets are applied inside the matrix-core kernels: the panels that do it */    \
+                hookedBlocks = nFaultBlocks;                                                                    \
+            if (mmBlocks2 && mmBlocks3) {                                                                       \
+                using G2 = MmBlk2<3>;                                                                           \
+                if (d_detected) {                                                                               \
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<3, true>,                  \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
+                    hipLaunchKernelGGL((mm_mfma_blk3_kernel<3, true>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
+                                       c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);        \
+                } else {                                                                                        \
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<3, false>,                 \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
+                    hipLaunchKernelGGL((mm_mfma_blk3_kernel<3, false>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
+                                       c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);        \
+                }                                                                                               \
+            } else if (mmBlocks2) {                                                                             \
                 using G2 = MmBlk2<3>;                                                                           \
                 if (d_detected) {                                                                               \
                     HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk2_kernel<3, true>,                  \
@@ -850,6 +869,8 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
                 ftm.list = nullptr, ftm.range = nullptr;                                                        \
             hipLaunchKernelGGL(mm_mfma_panel_kernel<R>, dim3((uint32_t)nbm), dim3(GP::NTHR), GP::LDS_BYTES,     \
                                c->stream, d_f, d_s, d_r, (uint32_t)nbm, ctr, ftm, d_detected);                  \
+            if (have)                                                                                           \
+                hookedBlocks = nFaultBlocks;                                                                    \
             engine = COAST_ENGINE_MATRIX_CORE;                                                                  \
             fastBlocks = nbm;                                                                                   \
             break;                                                                                              \

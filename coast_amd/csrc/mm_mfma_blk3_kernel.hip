@@ -1,0 +1,514 @@
+// mm_mfma_blk3_kernel.hip -- the register-block TMR matrix_multiply kernel of round 4: mm_mfma_blk2_kernel's geometry (read that
+// file's and mm_mfma_blk_kernel.hip's headers first) with two changes.
+//
+// 1. EVERY LOADED OPERAND IS REPLICATED.  The pass clones every load of the protected region and its users (cloning.cpp:2187-2209;
+//    under -noMemReplication the three loads keep one address, :2247-2255): an upset in a loaded f[i][k] or s[k][j] register is
+//    out-voted (tests/mm_common/mm_common_tmr.c:13).  mm_mfma_blk2_kernel had replica-private B fragments but ONE A fragment set
+//    for the three replicas.  Here a step's 60 MFMAs run as six sets of ten -- set = (row block, replica) -- and a set reads ITS
+//    OWN four A fragments from the LDS panel (the load is replicated, the memory is not): an A register is live for one replica's
+//    1-4 MFMAs, 24 instead of 8 ds_read_b128 per step and wave.
+//
+// 2. THE NON-MFMA WORK IS SPREAD OVER THE STEP.  tools/mfma_probe3 (profiles/r04_mfma_probes.txt): beside v_mfma_i32_16x16x64_i8 on
+//    random bytes every VALU filler and every ds_read_b128 costs matrix-pipe time at any number of resident waves (two waves per
+//    SIMD: 3.76 POP/s bare, 3.36 / 2.97 with one / two fillers per MFMA, 3.29 with a fragment read every other MFMA).
+//    mm_mfma_blk2_kernel packed the s conversion and a tile end into the first 30 slots of a step and left the last 30 bare.  Here
+//      * a slab's conversion takes a full step: the wave that owns slab g + 2 converts its first staging round behind the barrier
+//        of step g (slots 30..57, into the buffer slab g just left) and its second round in slots 0..27 of step g + 1; its partner
+//        on the SIMD does the same one step later -- at any time exactly one wave of a pair converts, at ~1 VALU per slot;
+//      * the background f piece goes into the half steps in which the wave does not convert, and only in the two middle steps of
+//        a tile;
+//      * a set's sums are final ten slots after it started, so the tile end is a chain of 24 small stages (recombine one element
+//        row of one set: 3 VALU; every third set: + vote + store) from slot 13 of a tile's last step to slot 43 of the next
+//        tile's first step, each set recombined before its accumulators restart.
+//    Measured (A/B on one box, profiles/r04_mm_ab.txt): the replicated A loads cost 5 % (7.10 ms against 6.76 with COAST_MM3_KNOCK=1,
+//    one A fragment set per row block) -- 288 instead of 160 fragment reads per workgroup and step, the LDS array 43 % busy
+//    (SQ_LDS_IDX_ACTIVE, profiles/r04_mm_rocprofv3_summary.txt); the even spread itself does not pay: with shared A this schedule runs
+//    3 % behind mm_mfma_blk2_kernel's (6.76 against 6.57), and mm_mfma_blk2_kernel's schedule with this kernel's sets of ten and
+//    private A fragments runs 7.10 against this kernel's 6.99.  Removing the per-step barrier makes it slower (7.26).
+//    One workgroup barrier per step (slot 29), as before; the item hand-over needs none of its own (the next panel is complete
+//    behind the barrier of the item's last step, and its A fragments are read after it).
+//
+// __SYNC_COUNT / TMR_ERROR_CNT: the votes of tiles that do not exist (the first step's look-back, a workgroup without items) are
+// executed on zeroed accumulators and are not counted: `real` is a wave-uniform predicate, not a compensation constant.
+#include <type_traits>
+#include <utility>
+
+#include "xmr.hpp"
+
+// development: timing experiments (1: the replicas of a row block share one A fragment set, as in mm_mfma_blk2_kernel -- results
+// still right; 2: no per-step barrier -- results wrong)
+#ifndef COAST_MM3_KNOCK
+#define COAST_MM3_KNOCK 0
+#endif
+
+namespace coast {
+
+template <int NREP, bool FLAGS>
+__global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(const uint32_t *__restrict__ F,
+                                                                            const uint32_t *__restrict__ S,
+                                                                            uint32_t *__restrict__ R, uint32_t nblocks, Counters ctr,
+                                                                            FaultTab ft, uint8_t *__restrict__ detected)
+{
+    using G = MmBlk2<NREP>;
+    static_assert(NREP == 3, "the step's slots are laid out for six sets of ten MFMAs per wave");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smemP[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wv & 3; // column-tile lane; waves wv and wv + 4 land on the same SIMD
+    const int l16 = lane & 15, kg = lane >> 4;
+    constexpr int kSlabBase = 2 * G::A_PANEL;
+    const int wbufOff = kSlabBase + wave * G::PAIR_LDS; // the pair's slab double buffer
+
+    constexpr size_t nn = (size_t)G::N * G::N;
+    const uint32_t stride = gridDim.x / G::NPANEL;
+    const bool xcdMap = (gridDim.x % 32u) == 0u;
+    const uint32_t slotX = blockIdx.x >> 3;
+    const uint32_t mat0 = xcdMap ? (blockIdx.x & 7u) * (gridDim.x >> 5) + (slotX >> 2) : blockIdx.x >> 2;
+    const int pnl = (int)(xcdMap ? slotX & 3u : blockIdx.x & 3u);
+    auto matOf = [&](int item) __attribute__((always_inline)) { return mat0 + (uint32_t)item * stride; };
+    auto rsrcOf = [&](const void *base, bool live, int bytes) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(live ? base : (const void *)F), 0, live ? bytes : 0, 0x00020000);
+    };
+    auto rsFof = [&](int item) __attribute__((always_inline)) { return rsrcOf(F + matOf(item) * nn, matOf(item) < nblocks, (int)(nn * 4)); };
+    auto rsSof = [&](int item) __attribute__((always_inline)) { return rsrcOf(S + matOf(item) * nn, matOf(item) < nblocks, (int)(nn * 4)); };
+    const uint32_t *f = F + mat0 * nn, *s = S + mat0 * nn;
+    __amdgpu_buffer_rsrc_t rsR = rsrcOf(R + mat0 * nn, true, (int)(nn * 4));
+    auto freshLane = []() __attribute__((always_inline)) { return xmr_fresh_lane(); };
+    auto voffRof = [&]() __attribute__((always_inline)) {
+        const int l = freshLane();
+        return ((4 * (l >> 4)) * G::N + (l & 15)) * 4;
+    };
+    auto flagsOf = [&](uint32_t m) __attribute__((always_inline)) {
+        const bool on = FLAGS && detected != nullptr;
+        return rsrcOf(on ? detected + m * nn : (const uint8_t *)F, on, (int)nn);
+    };
+    __amdgpu_buffer_rsrc_t rsD = flagsOf(mat0);
+
+    // ---- f panels: piece j of a panel for thread t (512 threads): row 8 j + t / 64, k-quad t % 64 (as in mm_mfma_blk2_kernel)
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const int soffFw = wv * G::N * 4;
+    auto voffFof = [&]() __attribute__((always_inline)) { return freshLane() * 16; };
+    auto panelDst = [&](int j) __attribute__((always_inline)) {
+        const int l = freshLane();
+        const int d0 = wv * G::N + (((l >> 2) ^ wv) * 16) + (l & 3) * 4;
+        return (d0 ^ ((j & 1) * 128)) + j * 8 * G::N;
+    };
+    {
+        const __amdgpu_buffer_rsrc_t rsF = rsFof(0);
+        u32x4_t pa[G::A_PER_THR];
+#pragma unroll
+        for (int u = 0; u < G::A_PER_THR; ++u)
+            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffFof(), soffFw + (pnl * G::BM + u * 8) * G::N * 4, COAST_MM_AUX_F);
+#pragma unroll
+        for (int u = 0; u < G::A_PER_THR; ++u) {
+            const uint32_t y[4] = {mm_digits(pa[u][0]), mm_digits(pa[u][1]), mm_digits(pa[u][2]), mm_digits(pa[u][3])};
+            uint32_t w[4];
+            mm_transpose4(y, w);
+            const int dst = panelDst(u);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                *reinterpret_cast<uint32_t *>(smemP + p * G::PLANE_A + dst) = w[p];
+        }
+    }
+    // background piece of a bg step (the two middle steps of a tile): piece 2 * tile + (g % 4 - 1) of the NEXT item's panel
+    auto bgPiece = [](int g) { return 2 * ((g >> 2) & 3) + ((g & 3) - 1); };
+    auto bgLoad = [&](int g) __attribute__((always_inline)) {
+        return __builtin_amdgcn_raw_buffer_load_b128(rsFof((g >> 4) + 1), voffFof(), soffFw + (pnl * G::BM + 8 * bgPiece(g)) * G::N * 4, COAST_MM_AUX_F);
+    };
+
+    auto tileCol0 = [&](int g) __attribute__((always_inline)) { return (wave + G::NLANE * ((g >> 2) & 3)) * G::CT; };
+
+    // s staging and the slab layout: as in mm_mfma_blk_kernel (conflict-free fragment reads and conversion stores)
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    auto colRow = [](int c) { return ((c & 7) << 1) | (c >> 3); };
+    auto colSwz = [](int c) { return (c >> 1) & 3; };
+    const int voffB = ((4 * (lane >> 3)) * G::N + 2 * (lane & 7)) * 4;
+    const int dstB0 = colRow(2 * (lane & 7)) * G::KS + ((((lane >> 3) >> 2) ^ colSwz(2 * (lane & 7))) * 16) + ((lane >> 3) & 3) * 4;
+    auto dstB = [&](int u, int h) __attribute__((always_inline)) { return (dstB0 ^ (u * 32)) + h * 2 * G::KS; };
+    constexpr int kRoundOff = 8 * 4 * G::N * 4;
+    auto slabOff = [&](int g) __attribute__((always_inline)) { return ((g & 3) * G::KS * G::N + tileCol0(g)) * 4; };
+
+    const int aOff = l16 * G::N + ((kg ^ l16) * 16);
+    const int bOff = colRow(l16) * G::KS + ((kg ^ colSwz(l16)) * 16);
+    auto panelOff = [&](int g) __attribute__((always_inline)) { return ((g >> 4) & 1) * G::A_PANEL + (aOff ^ ((g & 3) * 64)); };
+
+    auto run = [&](auto hTag) __attribute__((always_inline)) {
+        constexpr int H = decltype(hTag)::value;
+        uint32_t agree = 0;                 // votes of this lane whose three copies were equal (phantom votes included)
+        uint32_t nExec = 0, nReal = 0;      // wave-uniform: votes executed / votes of tiles that exist (= the lane's __SYNC_COUNT)
+        uint32_t detItems = 0;
+        v4i_t acc[2][NREP][4]; // row blocks 2 H and 2 H + 1
+#pragma unroll
+        for (int rbz = 0; rbz < 2; ++rbz)
+#pragma unroll
+            for (int rz = 0; rz < NREP; ++rz)
+#pragma unroll
+                for (int pz = 0; pz < 4; ++pz)
+                    acc[rbz][rz][pz] = v4i_t{0, 0, 0, 0};
+        // raw s words of this wave's slabs (the slabs of one parity): round 0 of slab g + 2 is converted in the second half of a
+        // step g in which the wave is off duty, round 1 in the first half of step g + 1 (duty); each register set is reloaded in
+        // the duty step with the slab two further on
+        u32x2_t pbs[G::B_ROUNDS][4];
+        u32x4_t bgRaw;
+
+        auto loadRound = [&](int gs, auto uTag) __attribute__((always_inline)) {
+            constexpr int u = decltype(uTag)::value;
+            const int so = slabOff(gs);
+            const __amdgpu_buffer_rsrc_t rs = rsSof(gs >> 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                pbs[u][kk] = __builtin_amdgcn_raw_buffer_load_b64(rs, voffB + kk * G::N * 4, so + u * kRoundOff, 0);
+        };
+        auto convRound = [&](auto uTag, int bufOff) __attribute__((always_inline)) {
+            constexpr int u = decltype(uTag)::value;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t y[4] = {mm_digits(pbs[u][0][h]), mm_digits(pbs[u][1][h]), mm_digits(pbs[u][2][h]), mm_digits(pbs[u][3][h])};
+                uint32_t w[4];
+                mm_transpose4(y, w);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<uint32_t *>(smemP + bufOff + q * G::PLANE_B + dstB(u, h)) = w[q];
+            }
+        };
+        using U0 = std::integral_constant<int, 0>;
+        using U1 = std::integral_constant<int, 1>;
+        // prologue.  Wave 1 of the pair owns the even slabs: slab 0 whole, slab 2 in its registers.  Wave 0 owns the odd ones: slab
+        // 1's first round converted here, its second round in the registers for step 0 (its duty step).
+        if (H == 1) {
+            loadRound(0, U0{});
+            loadRound(0, U1{});
+            convRound(U0{}, wbufOff);
+            convRound(U1{}, wbufOff);
+            loadRound(2, U0{});
+            loadRound(2, U1{});
+        } else {
+            loadRound(1, U0{});
+            loadRound(1, U1{});
+            convRound(U0{}, wbufOff + G::B_BUF);
+        }
+        bgRaw = bgLoad(1); // the first bg step
+        __syncthreads(); // panel 0 and the pairs' slab 0 are complete
+
+        // ---- tile end: 24 stages.  Stage n of a tile's LAST step (n = 0..15, slot 13 + 3 n): sets 0, 1 recombined into teV, set 2
+        // recombined and row block 0 voted and stored, set 3 recombined.  Stage n' of the NEXT step (n' = 0..7, slot 1 + 6 n'): set
+        // 4 recombined, set 5 recombined and row block 1 voted and stored -- through the previous tile's buffer resources.
+        uint32_t teV[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+        __amdgpu_buffer_rsrc_t rsRp = rsrcOf(R, false, 0), rsDp = rsRp;
+        auto recombine = [&](auto rbTag, auto rrTag, auto iTag) __attribute__((always_inline)) {
+            constexpr int rb = decltype(rbTag)::value, rr = decltype(rrTag)::value, i = decltype(iTag)::value;
+            uint32_t t; // Horner: three v_lshl_add_u32 (the compiler reassociates the C form into four instructions)
+            asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(t) : "v"(acc[rb][rr][3][i]), "v"(acc[rb][rr][2][i]));
+            asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(t) : "v"(t), "v"(acc[rb][rr][1][i]));
+            asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(t) : "v"(t), "v"(acc[rb][rr][0][i]));
+            return t;
+        };
+        auto voteStore = [&](int g, int voffR, uint32_t real, auto rbTag, auto iTag, uint32_t v2) __attribute__((always_inline)) {
+            constexpr int rb = decltype(rbTag)::value, i = decltype(iTag)::value;
+            const uint32_t v0 = teV[0][i], v1 = teV[1][i];
+            const bool e01 = v0 == v1, e02 = v0 == v2;
+            const uint32_t voted = e01 ? v0 : v2; // select(a == b, a, c), synchronization.cpp:934-938
+            agree += (e01 && e02) ? 1u : 0u;
+            nExec += 1u;
+            nReal += real; // __SYNC_COUNT is counted where the vote happens
+            const int erow = pnl * G::BM + (2 * H + rb) * 16 + i;
+            __builtin_amdgcn_raw_buffer_store_b32(voted, rb == 0 ? rsR : rsRp, voffR, (erow * G::N + tileCol0(g)) * 4, COAST_MM_AUX_R);
+            if constexpr (FLAGS)
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)1, rb == 0 ? rsD : rsDp, (e01 && e02) ? 0x40000000 : (voffR >> 2),
+                                                     erow * G::N + tileCol0(g), 0);
+        };
+        // stage n (0..15) of the tile's last step
+        auto teLast = [&](int g, int voffR, auto nTag) __attribute__((always_inline)) {
+            constexpr int n = decltype(nTag)::value, k = n / 4;
+            using I = std::integral_constant<int, n % 4>;
+            using RB0 = std::integral_constant<int, 0>;
+            using RB1 = std::integral_constant<int, 1>;
+            if constexpr (k == 0)
+                teV[0][n % 4] = recombine(RB0{}, std::integral_constant<int, 0>{}, I{});
+            else if constexpr (k == 1)
+                teV[1][n % 4] = recombine(RB0{}, std::integral_constant<int, 1>{}, I{});
+            else if constexpr (k == 2)
+                voteStore(g, voffR, 1u, RB0{}, I{}, recombine(RB0{}, std::integral_constant<int, 2>{}, I{}));
+            else
+                teV[0][n % 4] = recombine(RB1{}, std::integral_constant<int, 0>{}, I{});
+        };
+        // stage n' (0..7) of the step behind it (or of the final flush): g = the step of the tile that ends
+        auto teNext = [&](int g, int voffR, uint32_t real, auto nTag) __attribute__((always_inline)) {
+            constexpr int n = decltype(nTag)::value, k = n / 4;
+            using I = std::integral_constant<int, n % 4>;
+            using RB1 = std::integral_constant<int, 1>;
+            if constexpr (k == 0)
+                teV[1][n % 4] = recombine(RB1{}, std::integral_constant<int, 1>{}, I{});
+            else
+                voteStore(g, voffR, real, RB1{}, I{}, recombine(RB1{}, std::integral_constant<int, 2>{}, I{}));
+        };
+
+        uint32_t fFirst = 0, fCount = 0;
+        // ---- injector hook: the consequence of an armed upset on the replica's word is an additive constant (everything downstream
+        // is linear mod 2^32), written on the replica's limb-0 sums before the tile's last step -- see mm_mfma_blk_kernel.hip.  OPA
+        // names replica r's loaded f[i][k]: here that register exists per replica (the A fragment of the replica's set).
+        auto tileHook = [&](int g) __attribute__((always_inline)) {
+            const int col0 = tileCol0(g), prow0 = pnl * G::BM;
+            bool hooked = false;
+#pragma unroll 1
+            for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
+                const int fcol = (int)(__builtin_amdgcn_readfirstlane(ft.list[q].local) & 255u);
+                hooked = hooked || (fcol >= col0 && fcol < col0 + G::CT);
+            }
+            if (!hooked)
+                return;
+            uint32_t curKey = 0xffffffffu, curStep = 0xffffffffu;
+            uint32_t dsum[3] = {0u, 0u, 0u}, am[3] = {0u, 0u, 0u}, bm[3] = {0u, 0u, 0u};
+#pragma unroll 1
+            for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
+                const DevFault *fp = ft.list + q;
+                const uint32_t local = __builtin_amdgcn_readfirstlane(fp->local);
+                const int frow = (int)(local >> 8), fcol = (int)(local & 255u);
+                if (fcol < col0 || fcol >= col0 + G::CT)
+                    continue;
+                const uint32_t fstep = __builtin_amdgcn_readfirstlane(fp->step);
+                const uint32_t packed = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(&fp->replica));
+                const uint32_t frep = packed & 0xffu, fsite = (packed >> 8) & 0xffu, m = 1u << ((packed >> 16) & 31u);
+                if (local != curKey) { // a new element: its replicas start from clean running deltas
+                    curKey = local;
+                    curStep = 0xffffffffu;
+                    dsum[0] = dsum[1] = dsum[2] = 0u;
+                }
+                if (fstep != curStep) { // operand masks belong to one MAC
+                    curStep = fstep;
+                    am[0] = am[1] = am[2] = bm[0] = bm[1] = bm[2] = 0u;
+                }
+                const uint32_t *fr = f + (prow0 + frow) * G::N, *sc = s + fcol;
+                const uint32_t dprev = frep == 0u ? dsum[0] : frep == 1u ? dsum[1] : dsum[2];
+                uint32_t delta = 0u;
+                if (fsite == (uint32_t)SITE_MM_ACC) {
+                    const uint32_t kEnd = fstep < (uint32_t)G::N ? fstep : (uint32_t)G::N;
+                    uint32_t part = 0u; // this replica's accumulator before the MAC of k == step (step >= n: after the loop)
+                    for (uint32_t k = (uint32_t)lane; k < kEnd; k += 64u)
+                        part += fr[k] * sc[k * G::N];
+                    const uint32_t pfx = __builtin_amdgcn_readfirstlane(wave_sum(part)) + dprev;
+                    delta = (pfx ^ m) - pfx;
+                } else if (fstep < (uint32_t)G::N) {
+                    const uint32_t a = __builtin_amdgcn_readfirstlane(fr[fstep]), bq = __builtin_amdgcn_readfirstlane(sc[fstep * G::N]);
+                    const uint32_t ma = frep == 0u ? am[0] : frep == 1u ? am[1] : am[2];
+                    const uint32_t mb = frep == 0u ? bm[0] : frep == 1u ? bm[1] : bm[2];
+                    const uint32_t ma2 = fsite == (uint32_t)SITE_MM_OPA ? ma ^ m : ma, mb2 = fsite == (uint32_t)SITE_MM_OPB ? mb ^ m : mb;
+                    delta = (a ^ ma2) * (bq ^ mb2) - (a ^ ma) * (bq ^ mb);
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr)
+                        if (frep == (uint32_t)rr) {
+                            am[rr] = ma2;
+                            bm[rr] = mb2;
+                        }
+                } else {
+                    continue; // an operand of a MAC that never runs
+                }
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+                    if (frep == (uint32_t)rr)
+                        dsum[rr] += delta;
+                // the replica's register: panel row -> (rb, lane group, i), column -> lane, replica -> block
+                const int r16 = frow & 15;
+                const bool mineLane = lane == (r16 >> 2) * 16 + (fcol - col0);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int rr = 0; rr < NREP; ++rr)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[rb][rr][0][i] += (int)((mineLane && frep == (uint32_t)rr && (frow >> 4) == 2 * H + rb && (r16 & 3) == i) ? delta : 0u);
+            }
+            return;
+        };
+
+        // ---- one pipeline step of this wave: the 60 MFMAs of slab `g` as six sets (row block rb = set / 3, replica rr = set % 3) of
+        // ten -- A plane p = 0..3 against B planes q = 3 - p .. 0.  a[p] is re-read behind its last use in the set, for the NEXT set
+        // (same row block and address for the next replica: the load is the replicated instruction); b[rr][q] is re-read behind its
+        // last use in the second row block, from the other slab buffer.
+        v4i_t a[4], b[NREP][4];
+        int offA = panelOff(0), offB = bOff;
+        auto loadA = [&](auto pTag, int rbl, int off) __attribute__((always_inline)) {
+            constexpr int p = decltype(pTag)::value;
+            a[p] = *reinterpret_cast<const v4i_t *>(smemP + off + p * G::PLANE_A + (2 * H + rbl) * 16 * G::N);
+        };
+        auto loadB = [&](auto rrTag, auto qTag, int bufOff) __attribute__((always_inline)) {
+            constexpr int rr = decltype(rrTag)::value, q = decltype(qTag)::value;
+            b[rr][q] = *reinterpret_cast<const v4i_t *>(smemP + bufOff + offB + q * G::PLANE_B);
+        };
+        for_each_index(std::make_integer_sequence<int, 4>{}, [&](auto pTag) __attribute__((always_inline)) { loadA(pTag, 0, offA); });
+        for_each_index(std::make_integer_sequence<int, NREP>{}, [&](auto rrTag) __attribute__((always_inline)) {
+            asm volatile("" : "+v"(offB)); // one load per replica: not to be merged
+            for_each_index(std::make_integer_sequence<int, 4>{}, [&](auto qTag) __attribute__((always_inline)) { loadB(rrTag, qTag, wbufOff); });
+        });
+        auto step = [&](int g, auto firstTag, auto posTag) __attribute__((always_inline)) {
+            constexpr int FIRST = decltype(firstTag)::value; // first slab of a tile: the sums start from zero, the previous tile's last stages run
+            constexpr int POS = decltype(posTag)::value;     // g % 4
+            constexpr bool DUTY = (POS & 1) == H;            // first half: second staging round of slab g + 1; otherwise second half: first round of slab g + 2
+            constexpr bool BG = POS == 1 || POS == 2;        // a background f piece, in the half without conversion
+            const int soffLoad = slabOff(g + 3);
+            const __amdgpu_buffer_rsrc_t rsLoad = rsSof((g + 3) >> 4);
+            const int bufNext = wbufOff + ((g + 1) & 1) * G::B_BUF;
+            const int bufConv = DUTY ? bufNext : wbufOff + (g & 1) * G::B_BUF;
+            int offAnext = panelOff(g + 1);
+            offA = panelOff(g);
+            const int bgDst = BG ? (((g >> 4) + 1) & 1) * G::A_PANEL + panelDst(bgPiece(g)) : 0;
+            const uint32_t realPrev = g != 0 ? 1u : 0u;
+            int voffR = 0;
+            if constexpr (FIRST != 0 || POS == 3)
+                voffR = voffRof();
+            __builtin_amdgcn_sched_barrier(0);
+
+            uint32_t y[4], t[4];
+            uint32_t (&w)[4] = y;
+            auto digits4 = [&](uint32_t x0, uint32_t x1, auto halfTag) __attribute__((always_inline)) {
+                constexpr int hf = decltype(halfTag)::value;
+                y[2 * hf] = mm_digits(x0);
+                y[2 * hf + 1] = mm_digits(x1);
+            };
+            auto perm1 = [&]() __attribute__((always_inline)) {
+                t[0] = __builtin_amdgcn_perm(y[1], y[0], 0x05010400u);
+                t[1] = __builtin_amdgcn_perm(y[1], y[0], 0x07030602u);
+                t[2] = __builtin_amdgcn_perm(y[3], y[2], 0x05010400u);
+                t[3] = __builtin_amdgcn_perm(y[3], y[2], 0x07030602u);
+            };
+            auto perm2 = [&]() __attribute__((always_inline)) {
+                w[0] = __builtin_amdgcn_perm(t[2], t[0], 0x05040100u);
+                w[1] = __builtin_amdgcn_perm(t[2], t[0], 0x07060302u);
+                w[2] = __builtin_amdgcn_perm(t[3], t[1], 0x05040100u);
+                w[3] = __builtin_amdgcn_perm(t[3], t[1], 0x07060302u);
+            };
+            auto convStage = [&](auto kTag) __attribute__((always_inline)) {
+                constexpr int k = decltype(kTag)::value, u = k / 10, h = (k / 5) % 2, sub = k % 5;
+                if constexpr (sub == 0)
+                    digits4(pbs[u][0][h], pbs[u][1][h], std::integral_constant<int, 0>{});
+                else if constexpr (sub == 1)
+                    digits4(pbs[u][2][h], pbs[u][3][h], std::integral_constant<int, 1>{});
+                else if constexpr (sub == 2)
+                    perm1();
+                else if constexpr (sub == 3)
+                    perm2();
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<uint32_t *>(smemP + bufConv + q * G::PLANE_B + dstB(u, h)) = w[q];
+                }
+            };
+            auto bgStage = [&](auto subTag) __attribute__((always_inline)) {
+                constexpr int sub = decltype(subTag)::value;
+                if constexpr (sub == 0)
+                    digits4(bgRaw[0], bgRaw[1], std::integral_constant<int, 0>{});
+                else if constexpr (sub == 1) {
+                    digits4(bgRaw[2], bgRaw[3], std::integral_constant<int, 1>{});
+                    bgRaw = bgLoad(POS == 1 ? g + 1 : g + 3); // the next bg step: this tile's third step, or the next tile's second
+                } else if constexpr (sub == 2)
+                    perm1();
+                else if constexpr (sub == 3)
+                    perm2();
+                else {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        *reinterpret_cast<uint32_t *>(smemP + bgDst + p * G::PLANE_A) = w[p];
+                }
+            };
+            const v4i_t zero = {0, 0, 0, 0};
+            auto slot = [&](auto mTag) __attribute__((always_inline)) {
+                constexpr int m = decltype(mTag)::value;
+                constexpr int set = m / 10, j = m % 10, rb = set / 3, rr = set % 3;
+                constexpr int p = j < 4 ? 0 : j < 7 ? 1 : j < 9 ? 2 : 3;
+                constexpr int jj = j - (p == 0 ? 0 : p == 1 ? 4 : p == 2 ? 7 : 9);
+                constexpr int q = 3 - p - jj;
+                constexpr bool fromZero = FIRST != 0 && p == 0;
+                if constexpr (j == 0 && set != 0)
+                    asm volatile("" : "+v"(offA)); // this set's A fragments are its own loads
+                acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[p], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
+                if constexpr (jj == 3 - p && !((COAST_MM3_KNOCK & 1) && set % 3 != 2)) { // last use of a[p] in this set: the next set's (the next step's first set behind set 5)
+                    if constexpr (set == 5) {
+                        if constexpr (p == 0)
+                            asm volatile("" : "+v"(offAnext));
+                        loadA(std::integral_constant<int, p>{}, 0, offAnext);
+                    } else {
+                        if constexpr (p == 0)
+                            asm volatile("" : "+v"(offA));
+                        loadA(std::integral_constant<int, p>{}, (set + 1) / 3, offA);
+                    }
+                }
+                if constexpr (m == 29 && !(COAST_MM3_KNOCK & 2))
+                    __syncthreads(); // the workgroup's one barrier per step: slab g + 1 is complete, slab g's buffer is free
+                if constexpr (rb == 1 && jj == 0) { // last use of b[rr][3 - p] in this step
+                    if constexpr (p == 0)
+                        asm volatile("" : "+v"(offB));
+                    loadB(std::integral_constant<int, rr>{}, std::integral_constant<int, 3 - p>{}, bufNext);
+                }
+                if constexpr (DUTY && m < 30 && m % 3 == 0) // second staging round (stages 10..19) of slab g + 1
+                    convStage(std::integral_constant<int, 10 + m / 3>{});
+                if constexpr (!DUTY && m >= 30 && m % 3 == 0) // first staging round (stages 0..9) of slab g + 2
+                    convStage(std::integral_constant<int, (m - 30) / 3>{});
+                if constexpr (DUTY && m % 6 == 5 && m < 24) // round 0's registers: free since the previous step's slot 48
+                    pbs[0][m / 6] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + (m / 6) * G::N * 4, soffLoad, 0);
+                if constexpr (DUTY && m % 6 == 5 && m >= 30 && m < 54) // round 1's: free after stage 16 (slot 18)
+                    pbs[1][(m - 30) / 6] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + ((m - 30) / 6) * G::N * 4, soffLoad + kRoundOff, 0);
+                if constexpr (BG && (m / 30 == (DUTY ? 1 : 0)) && (m % 30) % 6 == 2)
+                    bgStage(std::integral_constant<int, (m % 30) / 6>{});
+                if constexpr (POS == 3 && m >= 13 && m % 3 == 1)
+                    teLast(g, voffR, std::integral_constant<int, (m - 13) / 3>{});
+                if constexpr (FIRST != 0 && m % 6 == 1 && m < 48)
+                    teNext(g - 1, voffR, realPrev, std::integral_constant<int, m / 6>{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for_each_index(std::make_integer_sequence<int, 60>{}, slot);
+        };
+
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, 1>;
+        using T2 = std::integral_constant<int, 2>;
+        using T3 = std::integral_constant<int, 3>;
+        int gLast = 3;
+        uint32_t anyTile = 0u;
+#pragma unroll 1
+        for (int item = 0; matOf(item) < nblocks; ++item) {
+            const uint32_t mat = matOf(item);
+            if (ft.range) {
+                const uint2 rg = ft.range[mat * (uint32_t)G::NPANEL + (uint32_t)pnl];
+                fFirst = __builtin_amdgcn_readfirstlane(rg.x);
+                fCount = __builtin_amdgcn_readfirstlane(rg.y);
+            }
+            if (item > 0) { // hand-over: the panel is complete behind the barrier of the previous item's last step
+                f = F + mat * nn;
+                s = S + mat * nn;
+                rsR = rsrcOf(R + mat * nn, true, (int)(nn * 4));
+                rsD = flagsOf(mat);
+            }
+#pragma unroll 1
+            for (int tile = 0; tile < G::TPW; ++tile) {
+                const int g0 = item * G::SPP + tile * G::NSLAB;
+                step(g0, T1{}, T0{}); // + the previous tile's last eight stages (the previous item's resources at a hand-over)
+                rsRp = rsR;
+                rsDp = rsD;
+                step(g0 + 1, T0{}, T1{});
+                step(g0 + 2, T0{}, T2{});
+                if (fCount != 0u) // armed upsets in this panel (wave-uniform, rare): their deltas go on top of the running limb-0 sums
+                    tileHook(g0);
+                step(g0 + 3, T0{}, T3{}); // + this tile's first sixteen stages
+                gLast = g0 + 3;
+                anyTile = 1u;
+            }
+        }
+        { // the last tile's last eight stages: nothing left to hide them behind
+            const int voffR = voffRof();
+            for_each_index(std::make_integer_sequence<int, 8>{}, [&](auto nTag) __attribute__((always_inline)) { teNext(gLast, voffR, anyTile, nTag); });
+        }
+
+        __syncthreads();
+        uint32_t *sCnt = reinterpret_cast<uint32_t *>(smemP + 2 * G::A_PANEL);
+        if (tid < 4)
+            sCnt[tid] = 0;
+        __syncthreads();
+        block_tally(nExec - agree, nReal, detItems, sCnt, ctr, blockIdx.x);
+    };
+    if (wv >= G::NLANE)
+        run(std::integral_constant<int, 1>{});
+    else
+        run(std::integral_constant<int, 0>{});
+}
+
+} // namespace coast

@@ -1,5 +1,5 @@
 #!/bin/bash
-# development: bench the mm headline with different COAST_MM_TILE values back to back on ONE box: tools/ab_tile.sh blocks blocks2 ...
+# development: bench the mm headline with different COAST_MM_TILE values back to back on ONE box: tools/ab_tile.sh blocks blocks2 blocks3 ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for rep in ${REPS:-1 2}; do
   for t in "$@"; do

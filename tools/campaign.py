@@ -72,29 +72,40 @@ class MM(Bench):
         return (r * n * n, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_MM_I, ca.SITE_MM_J, ca.SITE_MM_K, ca.SITE_MM_ACC])),
                 int(rng.integers(0, (n + 1) * (n * n + n + 1))), int(rng.integers(0, 32)))
 
-    # Register census of one wave of mm_mfma_blk2_kernel<3> (the TMR default at side 256): 256 VGPRs x 64 lanes x 32 bits, named in
-    # the kernel source (tests/test_kernel_budget_cpu.py holds the total).  `getReg()` of the reference draws uniformly from the
-    # register class (simulation/platform/resources/injector.py:70-72, 237-260); here one draw = one bit of one lane of one VGPR.
-    # SGPRs are 32 bits per wave against 2048 per VGPR: < 1 % of the bits, filed under "other".
+    # Register census of one wave of the TMR matrix-core kernel at side 256: 256 VGPRs x 64 lanes x 32 bits, named in the kernel
+    # source (tests/test_kernel_budget_cpu.py holds the total).  `getReg()` of the reference draws uniformly from the register class
+    # (simulation/platform/resources/injector.py:70-72, 237-260); here one draw = one bit of one lane of one VGPR.  SGPRs are 32 bits
+    # per wave against 2048 per VGPR: < 1 % of the bits, filed under "other".
     #   name      regs  what one flipped bit reaches
-    CENSUS_BLK2 = [
+    CENSUS_BLK3 = [  # mm_mfma_blk3_kernel<3> (the default since round 4): every loaded operand is replica-private
         ("acc",     96, "private: limb sum C_t of one replica of one output element (2 row blocks x 3 replicas x 4 limbs x 4)"),
         ("b_frag",  48, "private: 16 plane bytes of s[k..k+15][j] in ONE replica's B-operand registers: that replica of the wave's 32 rows"),
-        ("a_frag",  16, "COMMON: 4 plane bytes of f[i][k..k+3], the shared A operand: all three replicas of the tile's 16 columns"),
+        ("a_frag",  16, "private: 4 plane bytes of f[i][k..k+3] in the A-operand registers of ONE replica's set of ten MFMAs (re-read from "
+                        "the LDS panel per replica): that replica of the tile's 16 columns"),
         ("s_raw",   24, "COMMON: a raw / half-converted word of s[k][j] on its way into the LDS slab both waves of the pair and all "
                         "three replicas read: the panel's 64 rows of column j"),
         ("f_raw",    4, "COMMON: a raw word of f[i][k] of the next panel on its way into the LDS panel: all 256 columns of row i"),
-        ("tally",    8, "vote scratch and counters (teV, teVoted, teMiss, tl.*): the stored words are not reached"),
+        ("tally",    8, "vote scratch and counters (teV, agree, nExec, nReal): the stored words are not reached"),
         ("other",   60, "addresses, lane constants, compiler temporaries (+ the wave's SGPRs): not modelled"),
     ]
+    CENSUS_BLK2 = [  # mm_mfma_blk2_kernel<3> (COAST_MM_TILE=blocks2, the default of rounds 2-3): ONE A fragment set for the three replicas
+        ("acc",     96, "private"), ("b_frag", 48, "private"),
+        ("a_frag",  16, "COMMON: 4 plane bytes of f[i][k..k+3], the shared A operand: all three replicas of the tile's 16 columns"),
+        ("s_raw",   24, "COMMON"), ("f_raw", 4, "COMMON"), ("tally", 8, ""), ("other", 60, ""),
+    ]
+
+    @classmethod
+    def census(cls):
+        return cls.CENSUS_BLK2 if os.environ.get("COAST_MM_TILE") == "blocks2" else cls.CENSUS_BLK3
 
     def reg_event(self, r, nrep, rng):
         """one physical register upset of run r (= matrix r) on the matrix-core TMR kernel -> (class, rows for the injector).
         A limb-sum / plane-byte bit is mapped onto the model's 32-bit registers: limb t bit b = bit 8 t + b of the word (beyond
         bit 31: no architectural effect); the operand sites take the bit of the operand value."""
         n, nn = self.n, self.n * self.n
-        w = np.array([c[1] for c in self.CENSUS_BLK2], dtype=np.float64)
-        cls = self.CENSUS_BLK2[int(rng.choice(len(w), p=w / w.sum()))][0]
+        census = self.census()
+        w = np.array([c[1] for c in census], dtype=np.float64)
+        cls = census[int(rng.choice(len(w), p=w / w.sum()))][0]
         i, j, k = int(rng.integers(0, n)), int(rng.integers(0, n)), int(rng.integers(0, n))
         limb, b = int(rng.integers(0, 4)), int(rng.integers(0, 32 if cls == "acc" else 8))
         bit = 8 * limb + b
@@ -108,9 +119,10 @@ class MM(Bench):
         if cls == "b_frag":  # one replica's copy of s[k][j]: the 32 rows (two row blocks) the wave's accumulators stand for
             rep, i0 = int(rng.integers(0, nrep)), (i // 32) * 32
             return cls, [(item(ii, j), rep, ca.SITE_MM_OPB, k, bit) for ii in range(i0, i0 + 32)]
-        if cls == "a_frag":  # shared by the three replicas and by the 16 columns of the tile
+        if cls == "a_frag":  # the 16 columns of the tile; blocks3: one replica's set of MFMAs, blocks2: shared by the three replicas
             j0 = (j // 16) * 16
-            return cls, [(item(i, jj), ca.REPLICA_ALL, ca.SITE_MM_OPA, k, bit) for jj in range(j0, j0 + 16)]
+            rep = ca.REPLICA_ALL if census is self.CENSUS_BLK2 else int(rng.integers(0, nrep))
+            return cls, [(item(i, jj), rep, ca.SITE_MM_OPA, k, bit) for jj in range(j0, j0 + 16)]
         if cls == "s_raw":   # shared by the three replicas and the 64 rows of the panel
             i0 = (i // 64) * 64
             return cls, [(item(ii, j), ca.REPLICA_ALL, ca.SITE_MM_OPB, k, bit) for ii in range(i0, i0 + 64)]
@@ -453,7 +465,7 @@ def run_campaign(a, eng=None):
         unmodelled = by.get("other", {"runs": 0})["runs"]
         summary.update({
             "reg_model": "physical: one bit of one lane of one of the wave's 256 VGPRs, weighted by the register census",
-            "census": [{"class": c[0], "vgprs": c[1], "reaches": c[2]} for c in MM.CENSUS_BLK2],
+            "census": [{"class": c[0], "vgprs": c[1], "reaches": c[2]} for c in MM.census()],
             "by_class": by, "unmodelled_runs": unmodelled,
             # `other` registers (addresses, lane constants, SGPRs) are not simulated: the two bounds file them under success / error
             "coverage_pct_upper": 100.0 * (runs - counts["errors"]) / runs,
