@@ -660,6 +660,22 @@ __global__ __launch_bounds__(kAesRepThreads) __attribute__((amdgpu_waves_per_eu(
     const int tid = threadIdx.x;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smemAes != 0u)
         __builtin_trap(); // the permuted bytes are the LDS address: the dynamic segment starts at 0
+    // the wave's first tile is requested before the tables are filled: its HBM latency runs under the fill and the barrier
+    const uint64_t tile0 = (uint64_t)blockIdx.x * (kAesRepThreads / kWave) + (tid >> 6);
+    auto loadTile = [&](uint64_t tile, uint4 &svO, uint4 &kvO) __attribute__((always_inline)) {
+        // (the tile's lane map from a fresh lane id: the per-lane array bases of the memory-copies mode are loop invariants the
+        // register allocator would otherwise carry -- spilled -- through every tile)
+        const LaneMap<NREP> lmT(xmr_fresh_lane());
+        const uint64_t item = tile * IPW + (uint64_t)lmT.q;
+        const uint64_t it = (lmT.live && item < nblocksData) ? item : 0;
+        const uint8_t *stBase = states, *kyBase = keys; // (kept in SGPRs up to here: their VGPR copies were hoisted and spilled)
+        asm volatile("" : "+s"(stBase), "+s"(kyBase));
+        svO = reinterpret_cast<const uint4 *>(stBase + (size_t)lmT.r * copyBytes)[it];
+        kvO = reinterpret_cast<const uint4 *>(kyBase + (size_t)lmT.r * copyBytes)[it];
+    };
+    uint4 sv0 = make_uint4(0u, 0u, 0u, 0u), kv0 = sv0;
+    if (tile0 < ntiles)
+        loadTile(tile0, sv0, kv0);
     { // a wave writes whole rows: lane = (slot r, copy c) -- 64 consecutive dwords, two lanes per bank (free for ds_write_b32)
         const int c = tid & (kAesCopies - 1), r = (tid >> 4) & 3, v0 = (tid >> 6) * 16;
 #pragma unroll
@@ -673,19 +689,10 @@ __global__ __launch_bounds__(kAesRepThreads) __attribute__((amdgpu_waves_per_eu(
 #define TE(r, x, b) (*(aes_lds_u32p)(uintptr_t)(aes_rep_addr<b, 0>(x, laneSel) + (r) * 64))
     Tally tl;
     uint32_t detItems = 0;
-    for (uint64_t tile = (uint64_t)blockIdx.x * (kAesRepThreads / kWave) + (tid >> 6); tile < ntiles;
-         tile += (uint64_t)gridDim.x * (kAesRepThreads / kWave)) {
+    for (uint64_t tile = tile0; tile < ntiles; tile += (uint64_t)gridDim.x * (kAesRepThreads / kWave)) {
         const uint2 fr = aes_tile_faults(ft, tile); // this tile's armed upsets (wave-uniform)
-        // (the tile's lane map from a fresh lane id as well: the per-lane array bases of the memory-copies mode are loop invariants
-        // the register allocator would otherwise carry -- spilled -- through every tile)
         const LaneMap<NREP> lmT(xmr_fresh_lane());
-        const uint64_t item = tile * IPW + (uint64_t)lmT.q;
-        const bool live = lmT.live && item < nblocksData;
-        const uint64_t it = live ? item : 0;
-        const uint8_t *stBase = states, *kyBase = keys; // (kept in SGPRs up to here: their VGPR copies were hoisted and spilled)
-        asm volatile("" : "+s"(stBase), "+s"(kyBase));
-        const uint4 sv = reinterpret_cast<const uint4 *>(stBase + (size_t)lmT.r * copyBytes)[it];
-        const uint4 kv = reinterpret_cast<const uint4 *>(kyBase + (size_t)lmT.r * copyBytes)[it];
+        const uint4 sv = sv0, kv = kv0; // requested before the tables were filled / behind the previous tile's stores
         uint32_t s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w;
         uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
         auto rounds = [&](auto hookTag) __attribute__((always_inline)) { // as aes128_enc_fast_kernel, HOOKED included
@@ -791,6 +798,10 @@ __global__ __launch_bounds__(kAesRepThreads) __attribute__((amdgpu_waves_per_eu(
                     detected[itemE] = 1;
             }
         }
+        // the next tile (other blocks: the in-place stores above cannot reach them).  Requested HERE, where nothing else is live -- the
+        // kernel has 64 registers per lane (two workgroups per CU) and no room to carry a prefetch through the rounds
+        if (tile + (uint64_t)gridDim.x * (kAesRepThreads / kWave) < ntiles)
+            loadTile(tile + (uint64_t)gridDim.x * (kAesRepThreads / kWave), sv0, kv0);
     }
 #undef TE
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
@@ -809,6 +820,19 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
     const int tid = threadIdx.x;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smemAes != 0u)
         __builtin_trap(); // the permuted bytes are the LDS address: the dynamic segment starts at 0
+    // the wave's first tile is requested before the tables are filled, every later one a tile ahead (the waves of a workgroup run
+    // their tiles in step: without the prefetch they all wait for HBM at the same time)
+    const uint64_t tile0 = (uint64_t)blockIdx.x * (kAesRepThreads / kWave) + (tid >> 6);
+    const uint64_t tstride = (uint64_t)gridDim.x * (kAesRepThreads / kWave);
+    auto loadTile = [&](uint64_t tile, uint4 &svO, uint4 &kvO) __attribute__((always_inline)) {
+        const uint64_t item = tile * IPW + (uint64_t)lm.q;
+        const uint64_t it = (lm.live && item < nblocksData) ? item : 0;
+        svO = reinterpret_cast<const uint4 *>(states + (size_t)lm.r * copyBytes)[it];
+        kvO = reinterpret_cast<const uint4 *>(keys + (size_t)lm.r * copyBytes)[it];
+    };
+    uint4 svN = make_uint4(0u, 0u, 0u, 0u), kvN = svN;
+    if (tile0 < ntiles)
+        loadTile(tile0, svN, kvN);
     { // block 0: Td_0..3; block 1: {Tis_0[v], S[v] x 4} pairs in slots 0-1, rsbox[v] x 4 in slot 2.  A wave writes whole rows:
       // lane = (slot r, copy c); in block 1 slot group 0 writes the pairs, group 1 the rsbox dwords
         const int c = tid & (kAesCopies - 1), r = (tid >> 4) & 3, v0 = (tid >> 6) * 16;
@@ -836,15 +860,14 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
 #define TDCOL(a, b, c, d, m) aes_xor3(aes_xor3(TD(0, a, 0), TD(1, b, 1), TD(2, c, 2)), TD(3, d, 3), m) /* column ^ InvMix(key) */
     Tally tl;
     uint32_t detItems = 0;
-    for (uint64_t tile = (uint64_t)blockIdx.x * (kAesRepThreads / kWave) + (tid >> 6); tile < ntiles;
-         tile += (uint64_t)gridDim.x * (kAesRepThreads / kWave)) {
+    for (uint64_t tile = tile0; tile < ntiles; tile += tstride) {
         const uint2 fr = aes_tile_faults(ft, tile); // this tile's armed upsets (wave-uniform)
         const uint64_t item = tile * IPW + (uint64_t)lm.q;
         const bool live = lm.live && item < nblocksData;
         const bool cnt = live && lm.r == 0;
-        const uint64_t it = live ? item : 0;
-        const uint4 sv = reinterpret_cast<const uint4 *>(states + (size_t)lm.r * copyBytes)[it];
-        const uint4 kv = reinterpret_cast<const uint4 *>(keys + (size_t)lm.r * copyBytes)[it];
+        const uint4 sv = svN, kv = kvN;
+        if (tile + tstride < ntiles) // the next tile's blocks are other blocks: the in-place stores below cannot reach them
+            loadTile(tile + tstride, svN, kvN);
         uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
         uint32_t x0, x1, x2, x3;
         auto rounds = [&](auto hookTag) __attribute__((always_inline)) { // as aes128_dec_fast_kernel, HOOKED included

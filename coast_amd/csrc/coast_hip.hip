@@ -68,6 +68,10 @@ struct coast_ctx {
         bool consumedPending = false;
         hipEvent_t evUploaded = nullptr; // side: the H2D copies out of hPinned / hBlocks have finished
         bool uploadPending = false;
+        // what dList / dRange / dBlocks hold (their host images are hPinned / hBlocks): a launch that arms the very table this buffer
+        // already carries -- a campaign or a bench step that repeats its upsets -- reuses it instead of uploading it again
+        size_t residentK = 0, residentBlocks = 0;
+        uint32_t residentNblocks = 0;
     } fb[2];
     unsigned armCount = 0; // armed launches so far; selects the buffer
     int curBuf = 0;
@@ -175,7 +179,7 @@ int arm_faults_impl(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *g
     std::vector<DevFault> dv;
     dv.reserve(guard.taken.size());
     for (const coast_fault &f : guard.taken) {
-        DevFault d;
+        DevFault d{};
         if (f.replica == COAST_REPLICA_ALL) { // common-mode upset: the same flip in every replica's copy (the decoder drops
             for (uint8_t r = 0; r < 3; ++r) { // replica numbers the launch does not have)
                 coast_fault fr = f;
@@ -215,6 +219,23 @@ int arm_faults_impl(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *g
         HIP_TRY(c, hipEventSynchronize(b->evUploaded));
         b->uploadPending = false;
     }
+    if (b->residentK == dv.size() && b->residentNblocks == nblocks && b->residentBlocks == blocks.size() && b->residentK <= b->pinnedCap &&
+        !memcmp(b->hPinned, dv.data(), dv.size() * sizeof(DevFault)) && !memcmp(b->hBlocks, blocks.data(), blocks.size() * sizeof(uint32_t))) {
+        // the table is resident (uploaded two armed launches ago, in front of a launch this stream has long passed): nothing to send
+        c->curBuf = nextBuf;
+        c->armCount += 1;
+        guard.commit = true;
+        c->last.armed_faults = dv.size();
+        ft->list = b->dList;
+        ft->range = b->dRange;
+        *have = 1;
+        if (dBlockList)
+            *dBlockList = b->dBlocks;
+        if (nFaultBlocks)
+            *nFaultBlocks = (uint32_t)blocks.size();
+        return COAST_OK;
+    }
+    b->residentK = 0; // (set again below, once the new table is enqueued)
     if (dv.size() > b->pinnedCap) {
         if (b->hPinned)
             HIP_TRY(c, hipHostFree(b->hPinned));
@@ -264,6 +285,9 @@ int arm_faults_impl(coast_ctx *c, uint32_t nblocks, decode_fn dec, const void *g
     c->curBuf = nextBuf;
     c->armCount += 1;
     guard.commit = true;
+    b->residentK = dv.size();
+    b->residentBlocks = blocks.size();
+    b->residentNblocks = nblocks;
     c->last.armed_faults = dv.size();
     ft->list = b->dList;
     ft->range = b->dRange;

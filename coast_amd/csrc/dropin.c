@@ -92,6 +92,7 @@ static coast_cfg dropin_cfg_counters(void)
     if (in && *in && *in != '0' && !(c.flags & COAST_F_HOST_MEMORY_REPLICATED) && c.replicas > 1u) {
         const char *passes = getenv("COAST_OPT_PASSES");
         c.flags |= COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC;
+        c.sync_every = 0u; /* every loop condition is a sync point already: COAST_SYNC_EVERY has nothing to add (the batch entry points reject the pair) */
         if (passes && has_flag(passes, "-noLoadSync"))
             c.flags |= COAST_F_NO_LOAD_SYNC;
         if (passes && has_flag(passes, "-noStoreAddrSync"))

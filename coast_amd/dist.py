@@ -16,8 +16,11 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_counters(engine, dist=None, group=None) -> torch.Tensor:
-    """Global {errors_corrected, sync_count, dwc_detected, launches}.  Local totals stay untouched (cumulative)."""
+def allreduce_counters(engine, dist=None, group=None, snapshot: bool = True) -> torch.Tensor:
+    """Global {errors_corrected, sync_count, dwc_detected, launches}.  Local totals stay untouched (cumulative).
+    snapshot=False with no process group: the live totals tensor itself (no copy kernel; it keeps counting)."""
+    if not snapshot and (dist is None or not dist.is_initialized()):
+        return engine.counters
     tot = engine.counters.clone()
     if dist is not None and dist.is_initialized():  # also at world size 1: the same RCCL call the N-rank job issues
         if tot.is_cuda and dist.get_backend(group) == "gloo":  # dry runs of the rank logic without RCCL: stage through the host

@@ -762,36 +762,6 @@ def test_crc16_stream_every_alignment_and_tail(eng, orc, block_len):
                 assert (got == exp).all() and _stats3(eng.stats()) == exp_st, (off, replicas)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("block_len", [16, 48, 64, 256, 336])
-def test_crc16_slicing_walk_vs_oracle(eng, orc, block_len, monkeypatch):
-    """COAST_CRC_WALK=slice4 (development walk, profiles/r03_crc16_shapes.txt): slicing by four over bank-replicated byte tables.
-    Aligned rows, all three replica counts and both chain counts, armed upsets in the slow-walk tiles -- against the oracle."""
-    import torch
-
-    import coast_amd
-
-    monkeypatch.setenv("COAST_CRC_WALK", "slice4")
-    rng = np.random.default_rng(4400 + block_len)
-    nb = 21 * 50 + 7
-    raw = rng.integers(0, 256, nb * block_len, dtype=np.uint8)
-    dev = torch.from_numpy(raw).cuda()
-    data = raw.reshape(nb, block_len)
-    fl = coast_amd.make_faults([(0, 1, 24, 1, 3), (nb - 1, 0, 24, block_len, 9), (500, 2, 24, block_len // 2, 15)])
-    for nt in ("1", "2"):
-        monkeypatch.setenv("COAST_CRC_NT", nt)
-        for replicas in (3, 2, 1):
-            f = fl if replicas == 3 else None
-            exp, exp_st, exp_det = orc.crc16_xmr(data, block_len, replicas=replicas, faults=f)
-            det = torch.zeros(nb, dtype=torch.uint8, device="cuda")
-            eng.reset_stats()
-            if f is not None:
-                eng.inject_faults(f)
-            got = _host(eng.crc16_batch(dev, block_len, cfg=coast_amd.XmrConfig(replicas), detected=det), np.uint16)
-            assert (got == exp).all(), (nt, replicas)
-            assert _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all(), (nt, replicas)
-
-
 def test_crc16_255_byte_stream_prefix(eng, orc):
     """the reference's own maximum block (unsigned char length, crc16.c:21): 16 MiB stream, 1 MiB prefix vs the oracle,
     linearity over the whole stream"""
