@@ -700,6 +700,7 @@ def timed_run(wl, eng, dist, dev, steps, warmup, world):
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    my_dt = dt
     if dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -707,8 +708,48 @@ def timed_run(wl, eng, dist, dev, steps, warmup, world):
     tot = [int(x) for x in tot.cpu().tolist()]
     st = eng.stats()
     kern_ms = st["kernel_ms"] / max(steps, 1)
-    return {"dt": dt, "totals": tot, "kernel_ms": kern_ms, "launch_info": eng.last_launch(),
-            "hbm_bytes_per_step": st["hbm_bytes"] / max(steps, 1)}
+    out = {"dt": dt, "totals": tot, "kernel_ms": kern_ms, "launch_info": eng.last_launch(),
+           "hbm_bytes_per_step": st["hbm_bytes"] / max(steps, 1)}
+    if dist:
+        out["ranks"] = rank_diagnostics(eng, dist, dev, kern_ms, my_dt / steps * 1e3)
+    return out
+
+
+def rank_diagnostics(eng, dist, dev, kern_ms, step_ms, reps=20):
+    """What an N-rank line needs to be read: every rank's kernel time and own step time (the line's ms_per_step is their maximum), and
+    the latency of the one collective -- the all-reduce of the four fault counters -- timed by itself, AFTER the timed region: HIP
+    events on the current stream around the RCCL call (a synchronous torch.distributed op makes the current stream wait for RCCL's)."""
+    from coast_amd.dist import allreduce_counters
+
+    on_host = dist.get_backend() == "gloo"
+    coll_us = None
+    if not on_host:
+        for _ in range(3):
+            allreduce_counters(eng, dist)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = eng.counters.clone()
+        e0.record()
+        for _ in range(reps):
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        e1.record()
+        torch.cuda.synchronize()
+        coll_us = e0.elapsed_time(e1) / reps * 1e3
+    else:  # dry run of the rank logic without RCCL: wall clock around the host-staged all-reduce
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            allreduce_counters(eng, dist)
+        coll_us = (time.perf_counter() - t0) / reps * 1e6
+    mine = torch.tensor([float(dist.get_rank()), kern_ms, step_ms, coll_us], dtype=torch.float64, device="cpu" if on_host else dev)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    rows = [[float(x) for x in t.cpu().tolist()] for t in every]
+    return {"per_rank": [{"rank": int(r[0]), "kernel_ms": r[1], "step_ms": r[2], "collective_us": r[3]} for r in rows],
+            "slowest_rank": int(max(rows, key=lambda r: r[2])[0]),
+            "collective_us": max(r[3] for r in rows),
+            "collective_timing": ("HIP events around %d back-to-back RCCL all_reduce(SUM) of 4 x int64 after the timed region" % reps)
+                                 if not on_host else "wall clock around the gloo (host-staged) all_reduce: a dry run, not xGMI"}
 
 
 def result_fields(wl, run, a, world, steps, warmup, with_cpu):
@@ -717,6 +758,9 @@ def result_fields(wl, run, a, world, steps, warmup, with_cpu):
     traffic, src = pmc_traffic(wl.name, cfg)
     roof["traffic"] = traffic
     if src:
+        # a committed measurement of this same command, looked up by configuration -- NOT a counter pass of this very run (PMC
+        # collection serialises the kernels and needs rocprofv3 around the process: tools/profile.sh)
+        roof["traffic_kind"] = "static: profiles/traffic.json"
         roof["traffic_source"] = src
     tot = run["totals"]
     out = {
@@ -733,6 +777,11 @@ def result_fields(wl, run, a, world, steps, warmup, with_cpu):
     }
     if getattr(wl, "checked", None):
         out["outputs_checked"] = wl.checked
+    if run.get("ranks"):
+        out["ranks"] = run["ranks"]
+        if "algorithmic_bytes" in roof:  # every GPU's own fraction of the HBM roofline (the 8-GPU crc16 stream is priced per GPU)
+            for r in out["ranks"]["per_rank"]:
+                r["hbm_frac"] = roof["algorithmic_bytes"] / (r["kernel_ms"] * 1e-3) * 1e-9 / HBM_PEAK_GBS if r["kernel_ms"] > 0 else None
     if with_cpu:
         out["cpu_baseline"] = wl.cpu()
     return out
@@ -844,6 +893,13 @@ def main():
         legs = extra_legs(a, eng, dist, dev, rank, world, coast_amd)
         if rank == 0:
             out["extra"] = legs
+            # the same legs in < 2000 characters, LAST in the line: what survives where only the tail of the output is kept
+            rnd = lambda x: None if x is None else float("%.5g" % x)
+            out["extra_summary"] = {
+                name: {"value": rnd(leg.get("value")), "unit": leg.get("unit"), "ms_per_step": rnd(leg.get("ms_per_step")),
+                       "kernel_ms": rnd(leg.get("roofline", {}).get("kernel_ms")), "bound": leg.get("roofline", {}).get("bound"),
+                       "frac": rnd(leg.get("roofline", {}).get("frac"))}
+                for name, leg in legs.items()}
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

@@ -12,9 +12,21 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class _FakeEngine:  # stands in for coast_amd.Engine (no device here): only the counters tensor matters to the collective
+class _FakeEngine:  # stands in for coast_amd.Engine where there is no device: only the counters tensor matters to the collective
     def __init__(self, vals):
         self.counters = torch.tensor(vals, dtype=torch.int64)
+
+
+def _engine_with(vals):
+    """the engine whose totals are `vals`: on a GPU box the REAL coast_amd.Engine, its device-resident counters tensor (the one
+    coast_bind_counters gave the C side) set to the values -- the collective then runs on exactly what the product all-reduces"""
+    if torch.cuda.is_available():
+        import coast_amd
+
+        eng = coast_amd.Engine(0)
+        eng.counters.copy_(torch.tensor(vals, dtype=eng.counters.dtype))
+        return eng
+    return _FakeEngine(vals)
 
 
 def _worker(rank, world, port, q):
@@ -25,9 +37,9 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(1001, rank, world)
-    eng = _FakeEngine([10 * (rank + 1), hi - lo, rank, 1])
+    eng = _engine_with([10 * (rank + 1), hi - lo, rank, 1])
     tot = allreduce_counters(eng, dist)
-    q.put((rank, lo, hi, tot.tolist(), eng.counters.tolist(), any_dwc_detected(eng, dist)))
+    q.put((rank, lo, hi, tot.cpu().tolist(), eng.counters.cpu().tolist(), any_dwc_detected(eng, dist)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,8 +77,10 @@ def test_shard_range_partitions():
 def test_single_process_is_identity():
     from coast_amd.dist import allreduce_counters
 
-    eng = _FakeEngine([1, 2, 3, 4])
-    assert allreduce_counters(eng, None).tolist() == [1, 2, 3, 4]
+    eng = _engine_with([1, 2, 3, 4])
+    assert allreduce_counters(eng, None).cpu().tolist() == [1, 2, 3, 4]
+    live = allreduce_counters(eng, None, snapshot=False)  # no process group: the live totals themselves (bench.py's per-step read)
+    assert live.data_ptr() == eng.counters.data_ptr()
 
 
 def test_bench_gpus_n_spawns_n_ranks():

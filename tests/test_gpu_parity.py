@@ -1615,6 +1615,31 @@ def test_bench_rccl_path_on_one_rank():
                       "--no-cpu-baseline"], env_extra={"COAST_BENCH_FORCE_DIST": "1"})
     assert crc["collective"].startswith("nccl all_reduce") and crc["corrected_faults"] > 0 and crc["stepwise_blocks_last_launch"] == 0
     assert crc["hooked_blocks_last_launch"] > 0 and crc["outputs_match_unprotected"]
+    # round 4: what makes an N-rank line readable -- every rank's kernel and step time, the all-reduce timed by itself with HIP events
+    # around the RCCL call, the slowest rank, and each GPU's own fraction of the HBM roofline
+    for line in (out, crc):
+        rk = line["ranks"]
+        assert rk["slowest_rank"] == 0 and len(rk["per_rank"]) == 1 and rk["collective_timing"].startswith("HIP events")
+        r0 = rk["per_rank"][0]
+        assert r0["rank"] == 0 and 0 < r0["kernel_ms"] <= r0["step_ms"] * 1.001 and 0 < rk["collective_us"] < 1e5, rk
+        assert abs(r0["step_ms"] - line["ms_per_step"]) <= 0.02 * line["ms_per_step"] + 0.01
+    assert 0 < crc["ranks"]["per_rank"][0]["hbm_frac"] < 1.0
+
+
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """`bench.py --gpus 2` on RCCL: two processes, two GPUs, the counter all-reduce over xGMI.  Needs two visible devices (the GPU box of
+    this suite has one: skipped there; an 8-GPU node runs it)."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the RCCL path runs at world size 1 in test_bench_rccl_path_on_one_rank")
+    out = _run_bench(["--gpus", "2", "--workload", "crc16", "--batch", "1048576", "--steps", "3", "--warmup", "1", "--no-extra",
+                      "--no-cpu-baseline"])
+    assert out["n_gpus"] == 2 and out["collective"].startswith("nccl all_reduce") and out["outputs_match_unprotected"]
+    assert out["corrected_faults"] == out["injected_faults"] == 2 * 3 * 1024
+    rk = out["ranks"]
+    assert sorted(r["rank"] for r in rk["per_rank"]) == [0, 1] and rk["slowest_rank"] in (0, 1)
+    assert all(0 < r["kernel_ms"] and 0 < r["hbm_frac"] < 1.0 for r in rk["per_rank"]) and 0 < rk["collective_us"] < 1e5
 
 
 def test_multi_gpu_c_host_rccl_allreduce():
