@@ -1106,6 +1106,9 @@ __global__ __launch_bounds__(64) void aes128_indexed_kernel(uint8_t *__restrict_
     lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
     const bool bs = (ctr.flags & kFlagBranchSync) != 0u, as = (ctr.flags & kFlagAddrSync) != 0u;
     const bool ls = as && !(ctr.flags & kFlagNoLoadSync), ss = as && !(ctr.flags & kFlagNoStoreAddrSync);
+    // COAST_F_LOCAL_STORE_SYNC: the data of every store of the -O0 IR -- round++ / i++, buf1..buf4, and every byte stored into state[] /
+    // key[] in place (600 + 779 votes per encryption, 904 + 981 per decryption: tools/ir_sync_counts.py)
+    const bool lss = xmr_local_sync_on(ctr.flags);
     const uint32_t tile = blockIdx.x;
     const int slot = lm.q;
     const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
@@ -1150,11 +1153,14 @@ __global__ __launch_bounds__(64) void aes128_indexed_kernel(uint8_t *__restrict_
             const uint32_t o = xmr_steer<NREP>((uint32_t)idx, lm, ls, cnt, tl);
             return o < 16u ? (uint32_t)arr[o] : 0u;
         };
+        auto lsy = [&](uint32_t v) __attribute__((always_inline)) { return xmr_local_sync<NREP>(v, lm, lss, cnt, tl); };
         auto st = [&](uint8_t *arr, int32_t idx, uint32_t v) __attribute__((always_inline)) {
             const uint32_t o = xmr_steer<NREP>((uint32_t)idx, lm, ss, cnt, tl);
+            const uint32_t dv = lsy(v & 0xffu); // the data of the in-place store
             if (o < 16u)
-                arr[o] = (uint8_t)v;
+                arr[o] = (uint8_t)dv;
         };
+        auto mov = [&](uint8_t *arr, int dst, uint32_t v) __attribute__((always_inline)) { arr[dst] = (uint8_t)lsy(v & 0xffu); }; // constant index
         auto tab = [&](const uint8_t *t, uint32_t size, uint32_t x) __attribute__((always_inline)) -> uint32_t {
             const uint32_t o = xmr_steer<NREP>(x, lm, ls, cnt, tl);
             return o < size ? (uint32_t)t[o] : 0u;
@@ -1165,10 +1171,10 @@ __global__ __launch_bounds__(64) void aes128_indexed_kernel(uint8_t *__restrict_
         };
         auto keyCore = [&](uint32_t rc) __attribute__((always_inline)) { // key[0..3] ^= sbox[key[13, 14, 15, 12]] (^ Rcon[rc])
             const uint32_t s0 = tab(sSb, 256u, K[13]) ^ rcon(rc);
-            K[0] ^= (uint8_t)s0;
-            K[1] ^= (uint8_t)tab(sSb, 256u, K[14]);
-            K[2] ^= (uint8_t)tab(sSb, 256u, K[15]);
-            K[3] ^= (uint8_t)tab(sSb, 256u, K[12]);
+            mov(K, 0, (uint32_t)K[0] ^ (s0 & 0xffu));
+            mov(K, 1, (uint32_t)K[1] ^ tab(sSb, 256u, K[14]));
+            mov(K, 2, (uint32_t)K[2] ^ tab(sSb, 256u, K[15]));
+            mov(K, 3, (uint32_t)K[3] ^ tab(sSb, 256u, K[12]));
         };
         auto keyXor = [&]() __attribute__((always_inline)) { // key[i] = key[i] ^ key[i-4]
             const uint32_t a = ld(K, (int32_t)i), b = ld(K, (int32_t)i - 4);
@@ -1187,36 +1193,36 @@ __global__ __launch_bounds__(64) void aes128_indexed_kernel(uint8_t *__restrict_
                     K[byteIdx] ^= bm;
             }
         };
+        (void)lsy(d ? 1u : 0u);                                              // the parameter `dir` into its alloca (-O0)
         if (ifc(d)) {                                                        // if (dir)                                  :111
-            for (round = 0u; loopc(round, 10u, false); round = (round + 1u) & 0xffu) { // for (round = 0; round < 10; round++) :113
+            for (round = 0u; loopc(round, 10u, false); round = lsy((round + 1u) & 0xffu)) { // for (round = 0; round < 10; round++) :113
                 keyCore(round);
-                for (i = 4u; loopc(i, 16u, false); i = (i + 1u) & 0xffu)     //   for (i = 4; i < 16; i++)                :119
+                for (i = 4u; loopc(i, 16u, false); i = lsy((i + 1u) & 0xffu))     //   for (i = 4; i < 16; i++)                :119
                     keyXor();
             }
-            for (i = 0u; loopc(i, 16u, false); i = (i + 1u) & 0xffu) {       // first AddRoundKey                         :125
+            for (i = 0u; loopc(i, 16u, false); i = lsy((i + 1u) & 0xffu)) {       // first AddRoundKey                         :125
                 const uint32_t a = ld(S, (int32_t)i), b = ld(K, (int32_t)i);
                 st(S, (int32_t)i, a ^ b);
             }
         }
         uint32_t iter = 0u;
-        for (round = 0u; loopc(round, 10u, false); round = (round + 1u) & 0xffu) { // main loop                           :131
+        for (round = 0u; loopc(round, 10u, false); round = lsy((round + 1u) & 0xffu)) { // main loop                           :131
             dataHook(iter < 10u ? iter : 0xffffffffu);
             ++iter;
             if (ifc(d)) {                                                    //   if (dir): inverse key schedule          :132-141
-                for (i = 15u; loopc(i, 3u, true); i = (i - 1u) & 0xffu)
+                for (i = 15u; loopc(i, 3u, true); i = lsy((i - 1u) & 0xffu))
                     keyXor();
                 keyCore((uint32_t)(9 - (int32_t)round));
             } else {
-                for (i = 0u; loopc(i, 16u, false); i = (i + 1u) & 0xffu) {   //   state[i] = sbox[state[i] ^ key[i]]      :143-146
+                for (i = 0u; loopc(i, 16u, false); i = lsy((i + 1u) & 0xffu)) {   //   state[i] = sbox[state[i] ^ key[i]]      :143-146
                     const uint32_t a = ld(S, (int32_t)i), b = ld(K, (int32_t)i);
                     const uint32_t v = tab(sSb, 256u, a ^ b);
                     st(S, (int32_t)i, v);
                 }
-                uint8_t t;                                                   //   shift rows: constant indices            :148-166
-                t = S[1], S[1] = S[5], S[5] = S[9], S[9] = S[13], S[13] = t;
-                t = S[2], S[2] = S[10], S[10] = t;
-                t = S[6], S[6] = S[14], S[14] = t;
-                t = S[15], S[15] = S[11], S[11] = S[7], S[7] = S[3], S[3] = t;
+                uint32_t b1, b2;                                             //   shift rows: constant indices            :148-166
+                b1 = lsy(S[1]), mov(S, 1, S[5]), mov(S, 5, S[9]), mov(S, 9, S[13]), mov(S, 13, b1);
+                b1 = lsy(S[2]), b2 = lsy(S[6]), mov(S, 2, S[10]), mov(S, 6, S[14]), mov(S, 10, b1), mov(S, 14, b2);
+                b1 = lsy(S[15]), mov(S, 15, S[11]), mov(S, 11, S[7]), mov(S, 7, S[3]), mov(S, 3, b1);
             }
             bool mix = false;                                                //   if ((round > 0 && dir) || (round < 9 && !dir)) :168
             if (ifc(round > 0u))
@@ -1224,44 +1230,45 @@ __global__ __launch_bounds__(64) void aes128_indexed_kernel(uint8_t *__restrict_
             if (!mix && ifc(round < 9u))
                 mix = ifc(!d);
             if (mix) {
-                for (i = 0u; loopc(i, 4u, false); i = (i + 1u) & 0xffu) {    //   for (i = 0; i < 4; i++)                 :169
-                    const int32_t b4 = (int32_t)((i << 2) & 0xffu);          //     buf4 = (i << 2), an unsigned char
+                for (i = 0u; loopc(i, 4u, false); i = lsy((i + 1u) & 0xffu)) {    //   for (i = 0; i < 4; i++)                 :169
+                    const int32_t b4 = (int32_t)lsy((i << 2) & 0xffu);       //     buf4 = (i << 2), an unsigned char
                     uint32_t buf1, buf2, buf3;
                     if (ifc(d)) {                                            //     if (dir): precompute                  :171-175
                         const uint32_t a0 = ld(S, b4), a2 = ld(S, b4 + 2);
-                        buf1 = xtime(xtime(a0 ^ a2));
+                        buf1 = lsy(xtime(xtime(a0 ^ a2)));
                         const uint32_t a1 = ld(S, b4 + 1), a3 = ld(S, b4 + 3);
-                        buf2 = xtime(xtime(a1 ^ a3));
+                        buf2 = lsy(xtime(xtime(a1 ^ a3)));
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc) { // state[buf4 + cc] ^= buf: ONE GEP serves the load and the store of a compound
                             // assignment, and its first user is the load (user_back(), synchronization.cpp:341-351): load class
                             const uint32_t o = xmr_steer<NREP>((uint32_t)(b4 + cc), lm, ls, cnt, tl);
+                            const uint32_t xv = lsy((o < 16u ? (uint32_t)S[o] : 0u) ^ (((cc & 1) ? buf2 : buf1) & 0xffu)); // ... the stored byte: a data vote
                             if (o < 16u)
-                                S[o] ^= (uint8_t)((cc & 1) ? buf2 : buf1);
+                                S[o] = (uint8_t)xv;
                         }
                     }
                     {
                         const uint32_t a = ld(S, b4), b = ld(S, b4 + 1), cv = ld(S, b4 + 2), dv = ld(S, b4 + 3);
-                        buf1 = a ^ b ^ cv ^ dv;                              //     the column's xor                      :177
+                        buf1 = lsy(a ^ b ^ cv ^ dv);                         //     the column's xor                      :177
                     }
-                    buf2 = ld(S, b4);                                        //     buf2 = state[buf4]                    :178
+                    buf2 = lsy(ld(S, b4));                                   //     buf2 = state[buf4]                    :178
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {                         //     the four rows                         :179-182
                         const uint32_t a = ld(S, b4 + cc);
                         const uint32_t b = cc < 3 ? ld(S, b4 + cc + 1) : buf2;
-                        buf3 = xtime(a ^ b);
+                        buf3 = lsy((a ^ b) & 0xffu);                         //     buf3 = state[..] ^ state[..]
+                        buf3 = lsy(xtime(buf3));                             //     buf3 = galois_mul2(buf3)
                         const uint32_t a2 = ld(S, b4 + cc);
                         st(S, b4 + cc, a2 ^ buf3 ^ buf1);
                     }
                 }
             }
             if (ifc(d)) {                                                    //   if (dir): inverse shift rows, rsbox     :187-211
-                uint8_t t;
-                t = S[13], S[13] = S[9], S[9] = S[5], S[5] = S[1], S[1] = t;
-                t = S[10], S[10] = S[2], S[2] = t;
-                t = S[14], S[14] = S[6], S[6] = t;
-                t = S[3], S[3] = S[7], S[7] = S[11], S[11] = S[15], S[15] = t;
-                for (i = 0u; loopc(i, 16u, false); i = (i + 1u) & 0xffu) {   //   state[i] = rsbox[state[i]] ^ key[i]     :208-211
+                uint32_t b1, b2;
+                b1 = lsy(S[13]), mov(S, 13, S[9]), mov(S, 9, S[5]), mov(S, 5, S[1]), mov(S, 1, b1);           // Row 1
+                b1 = lsy(S[10]), b2 = lsy(S[14]), mov(S, 10, S[2]), mov(S, 14, S[6]), mov(S, 2, b1), mov(S, 6, b2); // Row 2
+                b1 = lsy(S[3]), mov(S, 3, S[7]), mov(S, 7, S[11]), mov(S, 11, S[15]), mov(S, 15, b1);         // Row 3
+                for (i = 0u; loopc(i, 16u, false); i = lsy((i + 1u) & 0xffu)) {   //   state[i] = rsbox[state[i]] ^ key[i]     :208-211
                     const uint32_t a = ld(S, (int32_t)i);
                     const uint32_t x = tab(sRsb, 256u, a);
                     const uint32_t b = ld(K, (int32_t)i);
@@ -1269,13 +1276,13 @@ __global__ __launch_bounds__(64) void aes128_indexed_kernel(uint8_t *__restrict_
                 }
             } else {                                                         //   key schedule                            :213-226
                 keyCore(round);
-                for (i = 4u; loopc(i, 16u, false); i = (i + 1u) & 0xffu)
+                for (i = 4u; loopc(i, 16u, false); i = lsy((i + 1u) & 0xffu))
                     keyXor();
             }
         }
         dataHook(10u);
         if (ifc(!d))                                                         // if (!dir): last AddRoundKey               :228-233
-            for (i = 0u; loopc(i, 16u, false); i = (i + 1u) & 0xffu) {
+            for (i = 0u; loopc(i, 16u, false); i = lsy((i + 1u) & 0xffu)) {
                 const uint32_t a = ld(S, (int32_t)i), b = ld(K, (int32_t)i);
                 st(S, (int32_t)i, a ^ b);
             }

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(64) void cache_test_indexed_kernel(uint32_t *__rest
     lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
     const bool bs = (ctr.flags & kFlagBranchSync) != 0u, as = (ctr.flags & kFlagAddrSync) != 0u;
     const bool ls = as && !(ctr.flags & kFlagNoLoadSync), ss = as && !(ctr.flags & kFlagNoStoreAddrSync);
+    const bool lss = xmr_local_sync_on(ctr.flags); // COAST_F_LOCAL_STORE_SYNC: sum += .., numberOfErrors++, local_errors++, i++ are stores at -O0
     const uint32_t tile = blockIdx.x;
     const int slot = lm.q;
     const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
@@ -293,11 +294,11 @@ __global__ __launch_bounds__(64) void cache_test_indexed_kernel(uint32_t *__rest
         const uint32_t o1 = xmr_steer<NREP>(i, lm, ls, cnt, tl);     // sum += array[i]                             :108
         uint32_t v = o1 < N ? a[o1] : 0u;
         hook(t, true, v);
-        sum += v;
+        sum = xmr_local_sync<NREP>(sum + v, lm, lss, cnt, tl);
         (void)xmr_steer<NREP>(i, lm, ls, cnt, tl);                   // if (array[i] != i): the same offset, voted again :110
         const bool taken = xmr_steer<NREP>(v != i ? 1u : 0u, lm, true, cnt, tl) != 0u; // (the element as loaded above)
         if (taken) {
-            nerr += 1u;                                              // numberOfErrors++                            :111
+            nerr = xmr_local_sync<NREP>(nerr + 1u, lm, lss, cnt, tl); // numberOfErrors++                            :111
             // the report block (:114-131), its printing aside: `if (!first_error)`, for the first bad element `if (!in_block && ..)`
             // (in_block and local_errors are the program's globals: 0 when the call starts, in this batch model), and the
             // `array[i]` argument of the printf -- one more load offset
@@ -313,8 +314,9 @@ __global__ __launch_bounds__(64) void cache_test_indexed_kernel(uint32_t *__rest
                 d = xmr_rep0<NREP>(d, lm);
             if (writer && os < N)
                 a[os] = d;
+            (void)xmr_local_sync<NREP>(localErrors, lm, lss, cnt, tl); // local_errors++ (a global: equal in every copy)     :128
         }
-        i += 1u;
+        i = xmr_local_sync<NREP>(i + 1u, lm, lss, cnt, tl);
     }
     // after the loop: `if (first_error && robust_printing)` (:139) and `if (sum != golden)` (:157), golden = n (n - 1) / 2; a wrong sum
     // looks at `local_errors == 0` (:161) and, with no element error behind it, at `!in_block` (:165)
@@ -322,8 +324,11 @@ __global__ __launch_bounds__(64) void cache_test_indexed_kernel(uint32_t *__rest
         (void)xmr_steer<NREP>(firstError ? 1u : 0u, lm, bs, cnt, tl);
         const uint32_t golden = (uint32_t)(((uint64_t)N * (uint64_t)(N - 1u)) / 2u);
         if (xmr_steer<NREP>(sum != golden ? 1u : 0u, lm, bs, cnt, tl) != 0u)
-            if (xmr_steer<NREP>(localErrors == 0u ? 1u : 0u, lm, bs, cnt, tl) != 0u)
+            if (xmr_steer<NREP>(localErrors == 0u ? 1u : 0u, lm, bs, cnt, tl) != 0u) {
+                (void)xmr_local_sync<NREP>(1u, lm, lss, cnt, tl); // sum_errors++; local_errors++ (globals)           :162-163
+                (void)xmr_local_sync<NREP>(1u, lm, lss, cnt, tl);
                 (void)xmr_steer<NREP>(!inBlock ? 1u : 0u, lm, bs, cnt, tl);
+            }
     }
     sum = xmr_sync<NREP>(sum, lm, cnt, tl);          // return sum
     nerr = xmr_store_sync<NREP>(nerr, lm, cnt, tl);  // stored to the caller's error count

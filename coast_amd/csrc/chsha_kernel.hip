@@ -231,6 +231,9 @@ __global__ __launch_bounds__(64) void chsha_indexed_kernel(const uint8_t *__rest
     lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
     const bool bs = (ctr.flags & kFlagBranchSync) != 0u, as = (ctr.flags & kFlagAddrSync) != 0u;
     const bool ls = as && !(ctr.flags & kFlagNoLoadSync), ss = as && !(ctr.flags & kFlagNoStoreAddrSync);
+    // COAST_F_LOCAL_STORE_SYNC: the data of every store of the -O0 IR -- ++i, W[i] = .., A..E = .., temp / E / D / C / B / A of FUNC,
+    // count and its bit counts, sha_info_data[14 / 15]
+    const bool lss = xmr_local_sync_on(ctr.flags);
     const uint32_t tile = blockIdx.x;
     const int slot = lm.q;
     const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
@@ -297,46 +300,61 @@ __global__ __launch_bounds__(64) void chsha_indexed_kernel(const uint8_t *__rest
             };
             for (int t = 0; t < 80; ++t)
                 W[t * 64] = 0u;
-            for (i = 0u; loopc(16, false, false); i += 1u) {                 // W[i] = sha_info_data[i]          :88-90
+            auto lsy = [&](uint32_t v) __attribute__((always_inline)) { return xmr_local_sync<NREP>(v, lm, lss, cnt, tl); };
+            for (i = 0u; loopc(16, false, false); i = lsy(i + 1u)) {           // W[i] = sha_info_data[i]          :88-90
                 const uint32_t ol = off(0, false), os = off(0, true);
-                if (os < 80u)
-                    W[os * 64u] = inWord(ol);
-            }
-            for (i = 16u; loopc(80, false, false); i += 1u) {                // the expansion                     :91-93
-                const uint32_t o3 = off(-3, false), o8 = off(-8, false), o14 = off(-14, false), o16 = off(-16, false);
-                const uint32_t os = off(0, true);
-                const uint32_t x = (o3 < 80u ? W[o3 * 64u] : 0u) ^ (o8 < 80u ? W[o8 * 64u] : 0u) ^ (o14 < 80u ? W[o14 * 64u] : 0u) ^
-                                   (o16 < 80u ? W[o16 * 64u] : 0u);
+                const uint32_t x = lsy(inWord(ol));
                 if (os < 80u)
                     W[os * 64u] = x;
             }
-            uint32_t A = dg[0], B = dg[1], C = dg[2], D = dg[3], E = dg[4];
+            for (i = 16u; loopc(80, false, false); i = lsy(i + 1u)) {          // the expansion                     :91-93
+                const uint32_t o3 = off(-3, false), o8 = off(-8, false), o14 = off(-14, false), o16 = off(-16, false);
+                const uint32_t os = off(0, true);
+                const uint32_t x = lsy((o3 < 80u ? W[o3 * 64u] : 0u) ^ (o8 < 80u ? W[o8 * 64u] : 0u) ^ (o14 < 80u ? W[o14 * 64u] : 0u) ^
+                                       (o16 < 80u ? W[o16 * 64u] : 0u));
+                if (os < 80u)
+                    W[os * 64u] = x;
+            }
+            uint32_t A = lsy(dg[0]), B = lsy(dg[1]), C = lsy(dg[2]), D = lsy(dg[3]), E = lsy(dg[4]);
 #pragma unroll 1
             for (int seg = 0; seg < 4; ++seg)                                   // FUNC(1..4, i)                     :100-111
-                for (i = 20u * (uint32_t)seg; loopc(20 * (seg + 1), false, false); i += 1u) {
+                for (i = 20u * (uint32_t)seg; loopc(20 * (seg + 1), false, false); i = lsy(i + 1u)) {
                     const uint32_t o = off(0, false);
                     const uint32_t f = seg == 0 ? ((B & C) | (~B & D)) : seg == 2 ? ((B & C) | (B & D) | (C & D)) : (B ^ C ^ D);
                     const uint32_t k = seg == 0 ? 0x5a827999u : seg == 1 ? 0x6ed9eba1u : seg == 2 ? 0x8f1bbcdcu : 0xca62c1d6u;
-                    const uint32_t temp = chsha_rotl(A, 5) + f + E + (o < 80u ? W[o * 64u] : 0u) + k;
-                    E = D, D = C, C = chsha_rotl(B, 30), B = A, A = temp;
+                    const uint32_t temp = lsy(chsha_rotl(A, 5) + f + E + (o < 80u ? W[o * 64u] : 0u) + k);
+                    E = lsy(D);
+                    D = lsy(C);
+                    C = lsy(chsha_rotl(B, 30));
+                    B = lsy(A);
+                    A = lsy(temp);
                 }
             dg[0] += A, dg[1] += B, dg[2] += C, dg[3] += D, dg[4] += E;
 #pragma unroll
             for (int w = 0; w < 5; ++w)                                         // sha_info_digest[w] += ...: stored  :113-117
                 dg[w] = xmr_store_sync<NREP>(dg[w], lm, cnt, tl);
         };
+        count = xmr_local_sync<NREP>(count, lm, lss, cnt, tl);                  // the parameter `count` into its alloca
         (void)xmr_steer<NREP>(0u, lm, bs, cnt, tl);                             // the carry test of sha_update      :136
+        (void)xmr_local_sync<NREP>(count << 3, lm, lss, cnt, tl);               // sha_info_count_lo += (LONG) count << 3   :139
+        (void)xmr_local_sync<NREP>(count >> 29, lm, lss, cnt, tl);              // sha_info_count_hi += (LONG) count >> 29  :140
         uint32_t cidx = 0u;
-        for (;; count -= 64u) {                                                 // while (count >= SHA_BLOCKSIZE)     :141
+        for (;; count = xmr_local_sync<NREP>(count - 64u, lm, lss, cnt, tl)) {  // while (count >= SHA_BLOCKSIZE)     :141
             if (!loopc(64, true, true))
                 break;
             digestHook(cidx);
             transform(cidx, false);
             ++cidx;
         }
+        (void)xmr_local_sync<NREP>(len << 3, lm, lss, cnt, tl);                 // sha_final: lo_bit_count = sha_info_count_lo  :157
+        (void)xmr_local_sync<NREP>(len >> 29, lm, lss, cnt, tl);                //            hi_bit_count = sha_info_count_hi  :158
+        (void)xmr_local_sync<NREP>(0u, lm, lss, cnt, tl);                       //            count = (lo_bit_count >> 3) & 0x3f :159
         (void)xmr_steer<NREP>(0u, lm, ss, cnt, tl);                             // sha_final: sha_info_data[count++] = 0x80 -- a store
                                                                                 //   through a variable index (count = 0 here)  :161
+        (void)xmr_local_sync<NREP>(1u, lm, lss, cnt, tl);                       //            count++
         (void)xmr_steer<NREP>(0u, lm, bs, cnt, tl);                             // sha_final: if (count > 56)        :162
+        (void)xmr_local_sync<NREP>(len >> 29, lm, lss, cnt, tl);                // sha_info_data[14] = hi_bit_count  :168
+        (void)xmr_local_sync<NREP>(len << 3, lm, lss, cnt, tl);                 // sha_info_data[15] = lo_bit_count  :169
         digestHook(cidx);
         transform(0u, true); // the padding block -- a derailed walk pads all the same (sha_final does)
     }

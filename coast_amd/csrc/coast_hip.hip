@@ -127,8 +127,12 @@ int check_cfg(coast_ctx *ctx, const coast_cfg *cfg, bool indexedOk = false, bool
     if (!cfg || cfg->replicas < 1 || cfg->replicas > 3)
         return fail(ctx, COAST_EINVAL, "coast_cfg.replicas must be 1 (none), 2 (DWC) or 3 (TMR)");
     const uint32_t indexed = COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC | COAST_F_NO_LOAD_SYNC | COAST_F_NO_STORE_ADDR_SYNC;
-    if (cfg->flags & ~((uint32_t)COAST_F_NO_STORE_DATA_SYNC | indexed | (uint32_t)COAST_F_MEMORY_COPIES))
+    if (cfg->flags & ~((uint32_t)COAST_F_NO_STORE_DATA_SYNC | indexed | (uint32_t)COAST_F_MEMORY_COPIES | (uint32_t)COAST_F_LOCAL_STORE_SYNC))
         return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: unknown bits", cfg->flags);
+    if ((cfg->flags & COAST_F_LOCAL_STORE_SYNC) &&
+        (cfg->flags & (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC)) != (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC))
+        return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: COAST_F_LOCAL_STORE_SYNC qualifies COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC "
+                                       "(the statement-by-statement walks)", cfg->flags);
     if (cfg->flags & COAST_F_MEMORY_COPIES) {
         if (!copiesOk)
             return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: COAST_F_MEMORY_COPIES is implemented for sha256, aes128 and crc16",

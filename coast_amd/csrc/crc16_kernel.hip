@@ -528,6 +528,8 @@ __global__ __launch_bounds__(64) void crc16_general_kernel(const uint8_t *__rest
         // offset: no address vote in this function.  Mirrors oracle/coast_oracle.c:crc_item_branch (watchdog, bounded reads).
         uint32_t ln = blockLen & 0xffu;
         const uint32_t cap = 4u * blockLen + 256u;
+        const bool lss = xmr_local_sync_on(ctr.flags); // COAST_F_LOCAL_STORE_SYNC: length, x (twice) and crc are stored into allocas at -O0
+        ln = xmr_local_sync<NREP>(ln, lm, lss, cnt, tl); // the parameter into its alloca
         for (uint32_t it = 0;; ++it) {
             uint32_t xm = 0u, cm = 0u;
             for (uint32_t q = 0; q < fr.y; ++q) {
@@ -541,16 +543,18 @@ __global__ __launch_bounds__(64) void crc16_general_kernel(const uint8_t *__rest
                 else if (df.site == SITE_CRC_X && it < blockLen)
                     xm ^= (1u << (df.bit & 31u)) & 0xffu;
             }
-            const uint32_t go = xmr_steer<NREP>(ln != 0u ? 1u : 0u, lm, true, cnt, tl);
-            ln = (ln - 1u) & 0xffu; // length--: on both exits
+            // while (length--): load, decrement, STORE (the data vote), then the branch on the loaded value
+            const uint32_t old = ln;
+            ln = xmr_local_sync<NREP>((ln - 1u) & 0xffu, lm, lss, cnt, tl); // length--: on both exits
+            const uint32_t go = xmr_steer<NREP>(old != 0u ? 1u : 0u, lm, true, cnt, tl);
             if (!go || it >= cap)
                 break;
             const uint32_t byte = (live && it < blockLen) ? (uint32_t)p[it] : 0u;
             crc ^= cm;
-            uint32_t x = ((crc >> 8) ^ byte) & 0xffu;
-            x ^= x >> 4;
+            uint32_t x = xmr_local_sync<NREP>(((crc >> 8) ^ byte) & 0xffu, lm, lss, cnt, tl);
+            x = xmr_local_sync<NREP>(x ^ (x >> 4), lm, lss, cnt, tl);
             x ^= xm;
-            crc = ((crc << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xffffu;
+            crc = xmr_local_sync<NREP>(((crc << 8) ^ (x << 12) ^ (x << 5) ^ x) & 0xffffu, lm, lss, cnt, tl);
             if (syncEvery && ((it + 1u) % syncEvery) == 0u && (it + 1u) < blockLen)
                 crc = xmr_sync<NREP>(crc, lm, cnt, tl);
         }

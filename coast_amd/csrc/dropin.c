@@ -97,6 +97,8 @@ static coast_cfg dropin_cfg_counters(void)
             c.flags |= COAST_F_NO_LOAD_SYNC;
         if (passes && has_flag(passes, "-noStoreAddrSync"))
             c.flags |= COAST_F_NO_STORE_ADDR_SYNC;
+        if (in[0] == '2') /* COAST_COUNTERS_IN_SOR=2: + the -O0 IR's stores into locals / in-place arrays as data votes (__SYNC_COUNT = the IR's branches + GEPs + stores) */
+            c.flags |= COAST_F_LOCAL_STORE_SYNC;
     }
     return c;
 }
@@ -182,7 +184,7 @@ void quick_sort(int *A, int len)
 {
     const coast_cfg cfg = dropin_cfg_counters();
     coast_cfg q = cfg; /* the sort's indices are data: branch / address votes are its default, the -no...Sync flags its knobs */
-    q.flags &= ~(uint32_t)(COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC);
+    q.flags &= ~(uint32_t)(COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC | COAST_F_LOCAL_STORE_SYNC);
     const char *passes = getenv("COAST_OPT_PASSES");
     if (passes && !(q.flags & COAST_F_HOST_MEMORY_REPLICATED)) {
         if (has_flag(passes, "-noLoadSync"))
@@ -210,7 +212,8 @@ void aes_enc_dec(unsigned char *state, unsigned char *key, unsigned char dir)
 void sha256_hash(unsigned char ctx_data[], uint32_t ctx_bitlen[], uint32_t ctx_state[], unsigned char data[],
                  uint32_t len, unsigned char hash[])
 {
-    const coast_cfg cfg = dropin_cfg_counters();
+    coast_cfg cfg = dropin_cfg_counters();
+    cfg.flags &= ~(uint32_t)COAST_F_LOCAL_STORE_SYNC; /* sha256_hash's counters-in-the-SoR walk is the post--O3 shape: no -O0 store census */
     dropin_maybe_inject();
     uint32_t st[8];
     const int rc = coast_sha256_host(data, len, hash, st, &cfg);

@@ -585,6 +585,7 @@ __global__ __launch_bounds__(64) void mm_indexed_kernel(const uint32_t *__restri
     lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
     const bool bs = (ctr.flags & kFlagBranchSync) != 0u, as = (ctr.flags & kFlagAddrSync) != 0u;
     const bool ls = as && !(ctr.flags & kFlagNoLoadSync), ss = as && !(ctr.flags & kFlagNoStoreAddrSync);
+    const bool lss = xmr_local_sync_on(ctr.flags); // COAST_F_LOCAL_STORE_SYNC: sum += .., k++, j++, i++ are stores into allocas at -O0
     const uint32_t tile = blockIdx.x;
     const int slot = lm.q;
     const uint64_t mat = (uint64_t)tile * IPW + (uint64_t)slot;
@@ -651,8 +652,8 @@ __global__ __launch_bounds__(64) void mm_indexed_kernel(const uint32_t *__restri
                 const uint32_t sk = xmr_steer<NREP>(k, lm, ls, cnt, tl), sj = xmr_steer<NREP>(j, lm, ls, cnt, tl); // s[k][j]
                 const uint32_t a = (fi < N && fk < N) ? f[(uint64_t)fi * n + fk] : 0u;
                 const uint32_t b = (sk < N && sj < N) ? s[(uint64_t)sk * n + sj] : 0u;
-                sum += a * b;
-                k += 1u;
+                sum = xmr_local_sync<NREP>(sum + a * b, lm, lss, cnt, tl);
+                k = xmr_local_sync<NREP>(k + 1u, lm, lss, cnt, tl);
             }
             const uint32_t ri = xmr_steer<NREP>(i, lm, ss, cnt, tl), rj = xmr_steer<NREP>(j, lm, ss, cnt, tl);     // r[i][j] = sum
             uint32_t v = xmr_store_sync<NREP>(sum, lm, cnt, tl);
@@ -660,9 +661,9 @@ __global__ __launch_bounds__(64) void mm_indexed_kernel(const uint32_t *__restri
                 v = xmr_rep0<NREP>(v, lm);
             if (writer && ri < N && rj < N)
                 r[(uint64_t)ri * n + rj] = v;
-            j += 1u;
+            j = xmr_local_sync<NREP>(j + 1u, lm, lss, cnt, tl);
         }
-        i += 1u;
+        i = xmr_local_sync<NREP>(i + 1u, lm, lss, cnt, tl);
     }
     uint32_t detItems = 0;
     if (cnt && tl.det) { // unequal copies at a sync point of this call (DWC: detected, TMR: corrected)

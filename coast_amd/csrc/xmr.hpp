@@ -37,6 +37,7 @@ constexpr uint32_t kFlagAddrSync = 4u;        // == COAST_F_ADDR_SYNC: GEP offse
 constexpr uint32_t kFlagNoLoadSync = 8u;      // == COAST_F_NO_LOAD_SYNC: ... except load addresses
 constexpr uint32_t kFlagNoStoreAddrSync = 16u; // == COAST_F_NO_STORE_ADDR_SYNC: ... except store addresses
 constexpr uint32_t kFlagIndexed = kFlagBranchSync | kFlagAddrSync;
+constexpr uint32_t kFlagLocalStoreSync = 64u; // == COAST_F_LOCAL_STORE_SYNC: the -O0 IR's stores into locals / in-place arrays are data votes
 
 template <int NREP> struct LaneMap {
     static constexpr int kItemsPerWave = kWave / NREP;
@@ -118,6 +119,19 @@ __device__ __forceinline__ uint32_t xmr_store_sync(uint32_t v, const LaneMap<NRE
     if (!lm.storeSync)
         return v;
     return xmr_sync<NREP>(v, lm, count, t);
+}
+
+// COAST_F_LOCAL_STORE_SYNC: the data vote of a store into a local's alloca or into an array in place, on the -O0 IR
+// (synchronization.cpp:197-224, 476-561).  `on` = the flag is set and -noStoreDataSync is not.  TMR: every copy continues from the
+// voted value (what the single memory copy holds and every copy reloads); DWC: compared, the copies keep their values.
+__device__ __forceinline__ bool xmr_local_sync_on(uint32_t flags)
+{
+    return (flags & kFlagLocalStoreSync) != 0u && (flags & kFlagNoStoreDataSync) == 0u;
+}
+template <int NREP>
+__device__ __forceinline__ uint32_t xmr_local_sync(uint32_t v, const LaneMap<NREP> &lm, bool on, bool count, Tally &t)
+{
+    return on ? xmr_sync<NREP>(v, lm, count, t) : v;
 }
 
 // replica 0's copy of a value: what the ORIGINAL instruction consumes when a use is not a sync point

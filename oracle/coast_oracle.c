@@ -109,6 +109,14 @@ static void store_sync32(sync_ctx *c, uint32_t v[3])
         sync32(c, v);
 }
 
+/* ORC_F_LOCAL_STORE_SYNC: the data vote of a store into a local's alloca / into an array in place, on the -O0 IR (:197-224, 476-561).
+ * TMR: the voted value is what reaches the single memory copy, every copy reloads it; DWC: compared, the copies keep their values. */
+static void local_sync32(sync_ctx *c, uint32_t v[3])
+{
+    if ((c->flags & ORC_F_LOCAL_STORE_SYNC) && !(c->flags & ORC_F_NO_STORE_DATA_SYNC))
+        sync32(c, v);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* matrix multiply                                                                            */
 /* ------------------------------------------------------------------------------------------ */
@@ -220,10 +228,12 @@ static int mm_call_indexed(const uint32_t *f, const uint32_t *s, uint32_t *r, in
                 const uint32_t sk = gep_offset(c, k, ls), sj = gep_offset(c, j, ls);  /* s[k][j]                    */
                 const uint32_t a = (fi < N && fk < N) ? f[(size_t)fi * N + fk] : 0u;
                 const uint32_t b = (sk < N && sj < N) ? s[(size_t)sk * N + sj] : 0u;
-                for (unsigned q = 0; q < 3; ++q) {
+                for (unsigned q = 0; q < 3; ++q)
                     sum[q] += a * b;
+                local_sync32(c, sum);                            /* store sum (its alloca)                          */
+                for (unsigned q = 0; q < 3; ++q)
                     k[q] += 1;
-                }
+                local_sync32(c, k);                              /* k++                                             */
             }
             const uint32_t ri = gep_offset(c, i, ss), rj = gep_offset(c, j, ss);      /* r[i][j] = sum          :16 */
             uint32_t v[3] = {sum[0], sum[1], sum[2]};
@@ -232,9 +242,11 @@ static int mm_call_indexed(const uint32_t *f, const uint32_t *s, uint32_t *r, in
                 r[(size_t)ri * N + rj] = v[0];
             for (unsigned q = 0; q < 3; ++q)
                 j[q] += 1;
+            local_sync32(c, j);                                  /* j++                                             */
         }
         for (unsigned q = 0; q < 3; ++q)
             i[q] += 1;
+        local_sync32(c, i);                                      /* i++                                             */
     }
 #undef MM_HOOK
 #undef MM_COND
@@ -885,11 +897,6 @@ static int aesx_loop(aesx *m, int c0, int c1, int c2, const uint32_t cur[3], uin
               : branch_cond(m->c, cur[0] < limit, cur[1] < limit, cur[2] < limit, m->bs);
 }
 static void aesx_set(uint32_t reg[3], uint32_t v) { reg[0] = reg[1] = reg[2] = v; }
-static void aesx_add(uint32_t reg[3], uint32_t d) /* unsigned char arithmetic */
-{
-    for (int r = 0; r < 3; ++r)
-        reg[r] = (reg[r] + d) & 0xffu;
-}
 static int aesx_if(aesx *m, int c0, int c1, int c2) { return branch_cond(m->c, (uint32_t)c0, (uint32_t)c1, (uint32_t)c2, m->bs); }
 static uint32_t aesx_off(aesx *m, const int32_t idx[3], int store)
 {
@@ -905,9 +912,33 @@ static void aesx_ld(aesx *m, uint8_t (*arr)[16], const int32_t idx[3], uint32_t 
 static void aesx_st(aesx *m, uint8_t (*arr)[16], const int32_t idx[3], const uint32_t v[3])
 {
     const uint32_t o = aesx_off(m, idx, 1);
+    uint32_t d[3] = {v[0] & 0xffu, v[1] & 0xffu, v[2] & 0xffu};
+    local_sync32(m->c, d); /* ORC_F_LOCAL_STORE_SYNC: the data of the in-place store */
     if (o < 16u)
         for (int r = 0; r < 3; ++r)
-            arr[r][o] = (uint8_t)v[r];
+            arr[r][o] = (uint8_t)d[r];
+}
+/* a counter update as the -O0 IR has it: load, add, STORE -- the store's data vote under ORC_F_LOCAL_STORE_SYNC */
+static void aesx_upd(aesx *m, uint32_t reg[3], uint32_t d)
+{
+    for (int r = 0; r < 3; ++r)
+        reg[r] = (reg[r] + d) & 0xffu;
+    local_sync32(m->c, reg);
+}
+/* arr[dst] = arr[src] with constant indices (the shift rows): an in-place store, its data voted under ORC_F_LOCAL_STORE_SYNC */
+static void aesx_mov(aesx *m, uint8_t (*arr)[16], int dst, const uint32_t v[3])
+{
+    uint32_t d[3] = {v[0] & 0xffu, v[1] & 0xffu, v[2] & 0xffu};
+    local_sync32(m->c, d);
+    for (int r = 0; r < 3; ++r)
+        arr[r][dst] = (uint8_t)d[r];
+}
+/* buf = arr[src]: a store into a local's alloca */
+static void aesx_buf(aesx *m, uint32_t buf[3], uint8_t (*arr)[16], int src)
+{
+    for (int r = 0; r < 3; ++r)
+        buf[r] = arr[r][src];
+    local_sync32(m->c, buf);
 }
 static void aesx_tab(aesx *m, const uint8_t *tab, uint32_t size, const uint32_t x[3], uint32_t out[3])
 {
@@ -936,8 +967,10 @@ static void aesx_key_core(aesx *m, const uint32_t rc[3])
             aesx_tab(m, AES_RCON, 10u, rc, rcv);
             AX3(sb, sb[r] ^ rcv[r]);
         }
+        uint32_t kv[3];
         for (int r = 0; r < 3; ++r)
-            m->k[r][b] ^= (uint8_t)sb[r];
+            kv[r] = (uint32_t)m->k[r][b] ^ (sb[r] & 0xffu);
+        aesx_mov(m, m->k, b, kv);
     }
 }
 static void aesx_key_xor(aesx *m) /* key[i] = key[i] ^ key[i-4] with the replicas' own i */
@@ -967,9 +1000,13 @@ static int aes_item_indexed(uint8_t *state, uint8_t *key, int dir, sync_ctx *c, 
         memcpy(m->k[r], key, 16);
     }
     const int d = dir ? 1 : 0;
+    {
+        uint32_t dv[3] = {(uint32_t)d, (uint32_t)d, (uint32_t)d};
+        local_sync32(c, dv); /* the parameter `dir` into its alloca (-O0) */
+    }
 #define LOOP_LT(reg, lim) aesx_loop(m, 0, 0, 0, m->reg, (lim), 0)
 #define LOOP_GT(reg, lim) aesx_loop(m, 0, 0, 0, m->reg, (lim), 1)
-#define INC(reg) aesx_add(m->reg, 1u)
+#define INC(reg) aesx_upd(m, m->reg, 1u)
 #define SET(reg, v) aesx_set(m->reg, (uint32_t)(v))
     if (aesx_if(m, d, d, d)) {                                              /* if (dir)                                  :111 */
         for (SET(round, 0); LOOP_LT(round, 10u); INC(round)) {              /*   for (round = 0; round < 10; round++)    :113 */
@@ -992,7 +1029,7 @@ static int aes_item_indexed(uint8_t *state, uint8_t *key, int dir, sync_ctx *c, 
         aes_faults(m->s, m->k, m->R, iter < 10u ? iter : 0xffffffffu, fl, nf);
         ++iter;
         if (aesx_if(m, d, d, d)) {                                          /*   if (dir): inverse key schedule          :132-141 */
-            for (SET(i, 15); LOOP_GT(i, 3u); aesx_add(m->i, 0xffu))
+            for (SET(i, 15); LOOP_GT(i, 3u); aesx_upd(m, m->i, 0xffu))
                 aesx_key_xor(m);
             uint32_t rc[3];
             AX3(rc, (uint32_t)(9 - (int32_t)m->round[r]));
@@ -1008,12 +1045,25 @@ static int aes_item_indexed(uint8_t *state, uint8_t *key, int dir, sync_ctx *c, 
                 aesx_tab(m, AES_S, 256u, x, v);
                 aesx_st(m, m->s, ii, v);
             }
-            for (int r = 0; r < 3; ++r) {                                   /*   shift rows: constant indices            :148-166 */
-                uint8_t *st = m->s[r], t;
-                t = st[1], st[1] = st[5], st[5] = st[9], st[9] = st[13], st[13] = t;
-                t = st[2], st[2] = st[10], st[10] = t;
-                t = st[6], st[6] = st[14], st[14] = t;
-                t = st[15], st[15] = st[11], st[11] = st[7], st[7] = st[3], st[3] = t;
+            {                                                               /*   shift rows: constant indices            :148-166 */
+                uint32_t b1[3], b2[3], t[3];
+#define ST_MOV(dst, src) do { AX3(t, m->s[r][src]); aesx_mov(m, m->s, dst, t); } while (0)
+                aesx_buf(m, b1, m->s, 1);
+                ST_MOV(1, 5);
+                ST_MOV(5, 9);
+                ST_MOV(9, 13);
+                aesx_mov(m, m->s, 13, b1);
+                aesx_buf(m, b1, m->s, 2);
+                aesx_buf(m, b2, m->s, 6);
+                ST_MOV(2, 10);
+                ST_MOV(6, 14);
+                aesx_mov(m, m->s, 10, b1);
+                aesx_mov(m, m->s, 14, b2);
+                aesx_buf(m, b1, m->s, 15);
+                ST_MOV(15, 11);
+                ST_MOV(11, 7);
+                ST_MOV(7, 3);
+                aesx_mov(m, m->s, 3, b1);
             }
         }
         /* if ((round > 0 && dir) || (round < 9 && !dir))                                                           :168 */
@@ -1030,18 +1080,31 @@ static int aes_item_indexed(uint8_t *state, uint8_t *key, int dir, sync_ctx *c, 
                         b4[r][cc] = (int32_t)(((m->i[r] << 2) & 0xffu) + (uint32_t)cc); /* buf4 = (i << 2), an unsigned char */
 #define IDX(cc) ((const int32_t[3]){b4[0][cc], b4[1][cc], b4[2][cc]})
                 uint32_t a[3], b[3], cv[3], dv[3], buf1[3], buf2[3], buf3[3], v[3];
+                {
+                    uint32_t b4v[3] = {(uint32_t)b4[0][0], (uint32_t)b4[1][0], (uint32_t)b4[2][0]};
+                    local_sync32(m->c, b4v);                                /*     buf4 = (i << 2): a local's store      :170 */
+                    for (int r = 0; r < 3; ++r)
+                        for (int cc = 0; cc < 4; ++cc)
+                            b4[r][cc] = (int32_t)(b4v[r] + (uint32_t)cc);
+                }
                 if (aesx_if(m, d, d, d)) {                                  /*     if (dir): precompute                  :171-175 */
                     aesx_ld(m, m->s, IDX(0), a);
                     aesx_ld(m, m->s, IDX(2), b);
                     AX3(buf1, xtime(xtime((uint8_t)(a[r] ^ b[r]))));
+                    local_sync32(m->c, buf1);
                     aesx_ld(m, m->s, IDX(1), a);
                     aesx_ld(m, m->s, IDX(3), b);
                     AX3(buf2, xtime(xtime((uint8_t)(a[r] ^ b[r]))));
+                    local_sync32(m->c, buf2);
                     for (int cc = 0; cc < 4; ++cc) {                        /*     state[buf4 + cc] ^= buf1 / buf2: ONE GEP serves the   */
                         const uint32_t o = aesx_off(m, IDX(cc), 0);          /*     load and the store of a compound assignment; its first */
-                        if (o < 16u)                                        /*     user is the load (user_back(), :341-351): load class    */
+                        uint32_t x[3];                                      /*     user is the load (user_back(), :341-351): load class    */
+                        for (int r = 0; r < 3; ++r)
+                            x[r] = (o < 16u ? (uint32_t)m->s[r][o] : 0u) ^ (((cc & 1) ? buf2[r] : buf1[r]) & 0xffu);
+                        local_sync32(m->c, x);                              /*     ... and the stored byte is a data vote                  */
+                        if (o < 16u)
                             for (int r = 0; r < 3; ++r)
-                                m->s[r][o] ^= (uint8_t)((cc & 1) ? buf2[r] : buf1[r]);
+                                m->s[r][o] = (uint8_t)x[r];
                     }
                 }
                 aesx_ld(m, m->s, IDX(0), a);                                /*     buf1 = the column's xor               :177 */
@@ -1049,14 +1112,19 @@ static int aes_item_indexed(uint8_t *state, uint8_t *key, int dir, sync_ctx *c, 
                 aesx_ld(m, m->s, IDX(2), cv);
                 aesx_ld(m, m->s, IDX(3), dv);
                 AX3(buf1, a[r] ^ b[r] ^ cv[r] ^ dv[r]);
+                local_sync32(m->c, buf1);
                 aesx_ld(m, m->s, IDX(0), buf2);                             /*     buf2 = state[buf4]                    :178 */
+                local_sync32(m->c, buf2);
                 for (int cc = 0; cc < 4; ++cc) {                            /*     the four rows                         :179-182 */
                     aesx_ld(m, m->s, IDX(cc), a);
                     if (cc < 3)
                         aesx_ld(m, m->s, IDX(cc + 1), b);
                     else
                         AX3(b, buf2[r]);
-                    AX3(buf3, xtime((uint8_t)(a[r] ^ b[r])));
+                    AX3(buf3, (uint32_t)(uint8_t)(a[r] ^ b[r]));
+                    local_sync32(m->c, buf3);                               /*     buf3 = state[..] ^ state[..]                           */
+                    AX3(buf3, xtime((uint8_t)buf3[r]));
+                    local_sync32(m->c, buf3);                               /*     buf3 = galois_mul2(buf3)                               */
                     aesx_ld(m, m->s, IDX(cc), a);
                     AX3(v, a[r] ^ buf3[r] ^ buf1[r]);
                     aesx_st(m, m->s, IDX(cc), v);
@@ -1065,12 +1133,24 @@ static int aes_item_indexed(uint8_t *state, uint8_t *key, int dir, sync_ctx *c, 
             }
         }
         if (aesx_if(m, d, d, d)) {                                          /*   if (dir): inverse shift rows, rsbox     :187-211 */
-            for (int r = 0; r < 3; ++r) {
-                uint8_t *st = m->s[r], t;
-                t = st[13], st[13] = st[9], st[9] = st[5], st[5] = st[1], st[1] = t;
-                t = st[10], st[10] = st[2], st[2] = t;
-                t = st[14], st[14] = st[6], st[6] = t;
-                t = st[3], st[3] = st[7], st[7] = st[11], st[11] = st[15], st[15] = t;
+            {
+                uint32_t b1[3], b2[3], t[3];
+                aesx_buf(m, b1, m->s, 13);                                  /*   Row 1                                                    */
+                ST_MOV(13, 9);
+                ST_MOV(9, 5);
+                ST_MOV(5, 1);
+                aesx_mov(m, m->s, 1, b1);
+                aesx_buf(m, b1, m->s, 10);                                  /*   Row 2                                                    */
+                aesx_buf(m, b2, m->s, 14);
+                ST_MOV(10, 2);
+                ST_MOV(14, 6);
+                aesx_mov(m, m->s, 2, b1);
+                aesx_mov(m, m->s, 6, b2);
+                aesx_buf(m, b1, m->s, 3);                                   /*   Row 3                                                    */
+                ST_MOV(3, 7);
+                ST_MOV(7, 11);
+                ST_MOV(11, 15);
+                aesx_mov(m, m->s, 15, b1);
             }
             for (SET(i, 0); LOOP_LT(i, 16u); INC(i)) {                      /*   state[i] = rsbox[state[i]] ^ key[i]     :208-211 */
                 int32_t ii[3];
@@ -1103,6 +1183,7 @@ static int aes_item_indexed(uint8_t *state, uint8_t *key, int dir, sync_ctx *c, 
 #undef LOOP_GT
 #undef INC
 #undef SET
+#undef ST_MOV
     aes_sync(c, m->s, m->k);
     memcpy(state, m->s[0], 16);
     memcpy(key, m->k[0], 16);
@@ -1185,28 +1266,39 @@ static uint16_t crc_item_branch(const uint8_t *data, uint32_t len, sync_ctx *c, 
     const unsigned R = c->nrep;
     const int bs = (c->flags & ORC_F_BRANCH_SYNC) != 0;
     const uint64_t cap = 4ull * len + 256ull;
+    local_sync32(c, ln); /* the parameter `length` into its alloca (-O0) */
     for (uint32_t it = 0;; ++it) {
         for (size_t q = 0; q < nf; ++q)
             if (fl[q].site == ORC_SITE_CRC_LEN && fl[q].step == it && fl[q].replica < R)
                 ln[fl[q].replica] = flip(ln[fl[q].replica], fl[q].bit, 0xffu);
-        const int go = branch_cond(c, ln[0] != 0, ln[R > 1 ? 1 : 0] != 0, ln[R > 2 ? 2 : 0] != 0, bs);
+        /* while (length--): load, decrement, STORE (the data vote of ORC_F_LOCAL_STORE_SYNC), then the branch on the loaded value */
+        const uint32_t old[3] = {ln[0], ln[1], ln[2]};
         for (unsigned r = 0; r < 3; ++r)
             ln[r] = (ln[r] - 1u) & 0xffu; /* length-- : the decrement happens on both exits */
+        local_sync32(c, ln);
+        const int go = branch_cond(c, old[0] != 0, old[R > 1 ? 1 : 0] != 0, old[R > 2 ? 2 : 0] != 0, bs);
         if (!go || it >= cap)
             break;
         const uint8_t byte = it < len ? data[it] : 0;
+        uint32_t x[3] = {0, 0, 0};
         for (unsigned r = 0; r < R; ++r) {
             for (size_t q = 0; q < nf; ++q)
                 if (fl[q].site == ORC_SITE_CRC_CRC && fl[q].step == it && it < len && fl[q].replica == r)
                     crc[r] = flip(crc[r], fl[q].bit, 0xffffu);
-            uint8_t x = (uint8_t)((crc[r] >> 8) ^ byte);
-            x ^= (uint8_t)(x >> 4);
+            x[r] = (uint8_t)((crc[r] >> 8) ^ byte);
+        }
+        local_sync32(c, x);                                   /* x = crc >> 8 ^ *data_p++      :26 */
+        for (unsigned r = 0; r < R; ++r)
+            x[r] = (uint8_t)(x[r] ^ (x[r] >> 4));
+        local_sync32(c, x);                                   /* x ^= x >> 4                   :27 */
+        for (unsigned r = 0; r < R; ++r) {
             for (size_t q = 0; q < nf; ++q)
                 if (fl[q].site == ORC_SITE_CRC_X && fl[q].step == it && it < len && fl[q].replica == r)
-                    x = (uint8_t)flip(x, fl[q].bit, 0xffu);
-            crc[r] = (uint16_t)((uint16_t)(crc[r] << 8) ^ (uint16_t)((uint16_t)x << 12) ^
-                                (uint16_t)((uint16_t)x << 5) ^ (uint16_t)x);
+                    x[r] = (uint8_t)flip(x[r], fl[q].bit, 0xffu);
+            crc[r] = (uint16_t)((uint16_t)(crc[r] << 8) ^ (uint16_t)((uint16_t)x[r] << 12) ^
+                                (uint16_t)((uint16_t)x[r] << 5) ^ (uint16_t)x[r]);
         }
+        local_sync32(c, crc);                                 /* crc = ...                     :28 */
         if (c->sync_every && ((it + 1) % c->sync_every) == 0 && (it + 1) < len)
             sync32(c, crc);
     }
@@ -1436,40 +1528,71 @@ static void chx_add(uint32_t reg[3], uint32_t d)
     for (int r = 0; r < 3; ++r)
         reg[r] += d;
 }
+/* a counter update as the -O0 IR has it: load, add, STORE -- the store's data vote under ORC_F_LOCAL_STORE_SYNC */
+static void chx_upd(chx *m, uint32_t reg[3], uint32_t d)
+{
+    chx_add(reg, d);
+    local_sync32(m->c, reg);
+}
 
 static void chx_transform(chx *m, uint32_t dg[3][5], const uint32_t in[16])
 {
     uint32_t W[3][80], v[3][5];
     memset(W, 0, sizeof W);
-    for (chx_set(m->i, 0); chx_loop(m, m->i, 16, 0); chx_add(m->i, 1)) {      /* W[i] = sha_info_data[i]          :88-90 */
+    /* ORC_F_LOCAL_STORE_SYNC: the data of every store of the -O0 IR -- ++i, W[i] = .., A..E = .., temp / E / D / C / B / A of FUNC */
+    for (chx_set(m->i, 0); chx_loop(m, m->i, 16, 0); chx_upd(m, m->i, 1)) {   /* W[i] = sha_info_data[i]          :88-90 */
         const uint32_t ol = chx_off(m, 0, 0), os = chx_off(m, 0, 1);
+        uint32_t x[3];
+        for (int r = 0; r < 3; ++r)
+            x[r] = ol < 16u ? in[ol] : 0u;
+        local_sync32(m->c, x);
         if (os < 80u)
             for (int r = 0; r < 3; ++r)
-                W[r][os] = ol < 16u ? in[ol] : 0u;
+                W[r][os] = x[r];
     }
-    for (chx_set(m->i, 16); chx_loop(m, m->i, 80, 0); chx_add(m->i, 1)) {     /* the expansion                     :91-93 */
+    for (chx_set(m->i, 16); chx_loop(m, m->i, 80, 0); chx_upd(m, m->i, 1)) {  /* the expansion                     :91-93 */
         const uint32_t o3 = chx_off(m, -3, 0), o8 = chx_off(m, -8, 0), o14 = chx_off(m, -14, 0), o16 = chx_off(m, -16, 0);
         const uint32_t os = chx_off(m, 0, 1);
-        for (int r = 0; r < 3; ++r) {
-            const uint32_t x = (o3 < 80u ? W[r][o3] : 0u) ^ (o8 < 80u ? W[r][o8] : 0u) ^ (o14 < 80u ? W[r][o14] : 0u) ^
-                               (o16 < 80u ? W[r][o16] : 0u);
-            if (os < 80u)
-                W[r][os] = x;
-        }
+        uint32_t x[3];
+        for (int r = 0; r < 3; ++r)
+            x[r] = (o3 < 80u ? W[r][o3] : 0u) ^ (o8 < 80u ? W[r][o8] : 0u) ^ (o14 < 80u ? W[r][o14] : 0u) ^
+                   (o16 < 80u ? W[r][o16] : 0u);
+        local_sync32(m->c, x);
+        if (os < 80u)
+            for (int r = 0; r < 3; ++r)
+                W[r][os] = x[r];
     }
-    for (int r = 0; r < 3; ++r)
-        for (int w = 0; w < 5; ++w)
-            v[r][w] = dg[r][w];
+    for (int w = 0; w < 5; ++w) {                                             /* A = sha_info_digest[0] ..         :94-98 */
+        uint32_t x[3] = {dg[0][w], dg[1][w], dg[2][w]};
+        local_sync32(m->c, x);
+        for (int r = 0; r < 3; ++r)
+            v[r][w] = x[r];
+    }
     for (int seg = 0; seg < 4; ++seg)                                         /* FUNC(1..4, i)                     :100-111 */
-        for (chx_set(m->i, 20u * (uint32_t)seg); chx_loop(m, m->i, 20 * (seg + 1), 0); chx_add(m->i, 1)) {
+        for (chx_set(m->i, 20u * (uint32_t)seg); chx_loop(m, m->i, 20 * (seg + 1), 0); chx_upd(m, m->i, 1)) {
             const uint32_t o = chx_off(m, 0, 0);
+            uint32_t temp[3], x[3];
             for (int r = 0; r < 3; ++r) {
                 const uint32_t A = v[r][0], B = v[r][1], C = v[r][2], D = v[r][3], E = v[r][4];
                 const uint32_t f = seg == 0 ? ((B & C) | (~B & D)) : seg == 2 ? ((B & C) | (B & D) | (C & D)) : (B ^ C ^ D);
                 const uint32_t k = seg == 0 ? 0x5a827999u : seg == 1 ? 0x6ed9eba1u : seg == 2 ? 0x8f1bbcdcu : 0xca62c1d6u;
-                const uint32_t temp = rotl(A, 5) + f + E + (o < 80u ? W[r][o] : 0u) + k;
-                v[r][4] = D, v[r][3] = C, v[r][2] = rotl(B, 30), v[r][1] = A, v[r][0] = temp;
+                temp[r] = rotl(A, 5) + f + E + (o < 80u ? W[r][o] : 0u) + k;
             }
+            local_sync32(m->c, temp);                                         /* temp = ..                                  */
+#define CHX_MOVE(dst, expr)                                                                                    \
+    do {                                                                                                       \
+        for (int r = 0; r < 3; ++r)                                                                            \
+            x[r] = (expr);                                                                                     \
+        local_sync32(m->c, x);                                                                                 \
+        for (int r = 0; r < 3; ++r)                                                                            \
+            v[r][dst] = x[r];                                                                                  \
+    } while (0)
+            CHX_MOVE(4, v[r][3]);                                             /* E = D                                      */
+            CHX_MOVE(3, v[r][2]);                                             /* D = C                                      */
+            CHX_MOVE(2, rotl(v[r][1], 30));                                   /* C = ROT32(B, 30)                           */
+            CHX_MOVE(1, v[r][0]);                                             /* B = A                                      */
+            CHX_MOVE(0, temp[r]);                                             /* A = temp                                   */
+#undef CHX_MOVE
         }
     for (int r = 0; r < 3; ++r)
         for (int w = 0; w < 5; ++w)
@@ -1498,10 +1621,16 @@ static void chsha_item_indexed(const uint8_t *data, uint32_t len, uint32_t out[5
         for (unsigned w = 0; w < 5; ++w)
             dg[r][w] = IV[w];
     chx_set(m->count, len);
+    local_sync32(c, m->count); /* the parameter `count` into its alloca (-O0) */
     /* if ((sha_info_count_lo + ((LONG) count << 3)) < sha_info_count_lo): count_lo is 0 on entry                  :136 */
     (void)branch_cond(c, 0u, 0u, 0u, m->bs); /* (0 + x < 0 is false whatever a replica's count holds) */
+    {
+        uint32_t lo[3] = {m->count[0] << 3, m->count[1] << 3, m->count[2] << 3}, hi[3] = {m->count[0] >> 29, m->count[1] >> 29, m->count[2] >> 29};
+        local_sync32(c, lo); /* sha_info_count_lo += (LONG) count << 3                                              :139 */
+        local_sync32(c, hi); /* sha_info_count_hi += (LONG) count >> 29                                             :140 */
+    }
     uint32_t cidx = 0;
-    for (;; chx_add(m->count, (uint32_t)-64)) {                               /* while (count >= SHA_BLOCKSIZE)     :141 */
+    for (;; chx_upd(m, m->count, (uint32_t)-64)) {                            /* while (count >= SHA_BLOCKSIZE)     :141 */
         if (!chx_loop(m, m->count, 64, 1))
             break;
         uint32_t in[16];
@@ -1518,7 +1647,12 @@ static void chsha_item_indexed(const uint8_t *data, uint32_t len, uint32_t out[5
     /* sha_final: count = (lo_bit_count >> 3) & 0x3f = 0; sha_info_data[count++] = 0x80; if (count > 56)           :159-162 */
     {
         const uint32_t zero[3] = {0u, 0u, 0u};
+        uint32_t lo[3] = {len << 3, len << 3, len << 3}, hi[3] = {len >> 29, len >> 29, len >> 29}, cn[3] = {0u, 0u, 0u}, c1[3] = {1u, 1u, 1u};
+        local_sync32(c, lo);              /* lo_bit_count = sha_info_count_lo (memory: one copy, equal in every replica)          :157 */
+        local_sync32(c, hi);              /* hi_bit_count = sha_info_count_hi                                                     :158 */
+        local_sync32(c, cn);              /* count = (int) ((lo_bit_count >> 3) & 0x3f)                                           :159 */
         (void)gep_offset(c, zero, m->ss); /* sha_info_data[count++] = 0x80: a store through a variable index (count = 0 here)   :161 */
+        local_sync32(c, c1);              /* count++                                                                              */
     }
     (void)branch_cond(c, 0u, 0u, 0u, m->bs);
     uint32_t in[16];
@@ -1526,6 +1660,11 @@ static void chsha_item_indexed(const uint8_t *data, uint32_t len, uint32_t out[5
     in[0] = 0x80u;
     in[14] = len >> 29;
     in[15] = len << 3;
+    {
+        uint32_t hi[3] = {in[14], in[14], in[14]}, lo[3] = {in[15], in[15], in[15]};
+        local_sync32(c, hi);              /* sha_info_data[14] = hi_bit_count                                                     :168 */
+        local_sync32(c, lo);              /* sha_info_data[15] = lo_bit_count                                                     :169 */
+    }
     for (size_t q = 0; q < nf; ++q)
         if (fl[q].site == ORC_SITE_CHSHA_DIGEST && fl[q].step == cidx && fl[q].replica < m->R)
             dg[fl[q].replica][fl[q].index % 5] = flip(dg[fl[q].replica][fl[q].index % 5], fl[q].bit, 0xffffffffu);
@@ -1674,12 +1813,14 @@ static void ct_item_indexed(int32_t *a, uint32_t n, int32_t *sum_out, uint32_t *
                     v[r] = flip(v[r], fl[q].bit, 0xffffffffu);
             sum[r] += v[r];
         }
+        local_sync32(c, sum);                                     /* store sum (its alloca) */
         (void)gep_offset(c, i, ls);                               /* if (array[i] != i)     :110 */
         for (unsigned r = 0; r < 3; ++r)
             cond[r] = (v[r < R ? r : 0] != i[r < R ? r : 0]) ? 1u : 0u;
         if (branch_cond(c, cond[0], cond[1], cond[2], 1)) {
             for (unsigned r = 0; r < 3; ++r)
                 nerr[r] += 1;                                     /* numberOfErrors++       :111 */
+            local_sync32(c, nerr);
             /* the report block (:114-131), its printing aside: `if (!first_error)`, for the first bad element `if (!in_block && ..)`
              * (in_block and local_errors are the program's globals: 0 when the call starts, in this batch model), and the
              * `array[i]` argument of the printf -- one more load offset */
@@ -1694,9 +1835,14 @@ static void ct_item_indexed(int32_t *a, uint32_t n, int32_t *sum_out, uint32_t *
             store_sync32(c, d);
             if (os < n)
                 a[os] = (int32_t)d[0];
+            {
+                uint32_t le[3] = {local_errors, local_errors, local_errors}; /* local_errors++ (a global: equal in every copy)  :128 */
+                local_sync32(c, le);
+            }
         }
         for (unsigned r = 0; r < 3; ++r)
             i[r] += 1;
+        local_sync32(c, i);                                       /* i++ */
     }
     /* after the loop: `if (first_error && robust_printing)` (:139) and `if (sum != golden)` (:157) with golden = n (n - 1) / 2; a
      * wrong sum looks at `local_errors == 0` (:161) and, with no element error behind it, at `!in_block` (:165) */
@@ -1704,8 +1850,12 @@ static void ct_item_indexed(int32_t *a, uint32_t n, int32_t *sum_out, uint32_t *
     {
         const uint32_t golden = (uint32_t)(((uint64_t)n * (n - 1u)) / 2u);
         if (branch_cond(c, sum[0] != golden, sum[R > 1 ? 1 : 0] != golden, sum[R > 2 ? 2 : 0] != golden, bs))
-            if (branch_cond(c, local_errors == 0u, local_errors == 0u, local_errors == 0u, bs))
+            if (branch_cond(c, local_errors == 0u, local_errors == 0u, local_errors == 0u, bs)) {
+                uint32_t se[3] = {1u, 1u, 1u};                    /* sum_errors++; local_errors++ (globals)      :162-163 */
+                local_sync32(c, se);
+                local_sync32(c, se);
                 (void)branch_cond(c, !in_block, !in_block, !in_block, bs);
+            }
     }
     uint32_t vs[3] = {sum[0], sum[R > 1 ? 1 : 0], sum[R > 2 ? 2 : 0]}, vn[3] = {nerr[0], nerr[R > 1 ? 1 : 0], nerr[R > 2 ? 2 : 0]};
     sync32(c, vs);        /* return value */

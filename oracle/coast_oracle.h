@@ -119,7 +119,12 @@ enum {
     ORC_F_NO_STORE_ADDR_SYNC = 16u, /* ... except store addresses (-noStoreAddrSync, :354-367) */
     /* the reference's memory-replicated mode with -storeDataSync (sha256 / aes / crc16): every array is `replicas` copies back
      * to back, replica r loads from copy r, the data of every store is voted, every replica stores the voted value to its copy */
-    ORC_F_MEMORY_COPIES = 32u
+    ORC_F_MEMORY_COPIES = 32u,
+    /* with ORC_F_BRANCH_SYNC | ORC_F_ADDR_SYNC: the store-data votes the pass emits on the -O0 IR under -noMemReplication for the stores
+     * the default schedules do not have -- every store of a computed value into one of the function's own locals (i++, sum += ..:
+     * their allocas stay single-copy) and into state[] / key[] / ctx_data[] in place (synchronization.cpp:197-224, 476-561).  With it
+     * sync_count = branches + GEP offsets + stores of tools/ir_sync_counts.py.  Off under -noStoreDataSync, like every data vote. */
+    ORC_F_LOCAL_STORE_SYNC = 64u
 };
 #define ORC_F_INDEXED (ORC_F_BRANCH_SYNC | ORC_F_ADDR_SYNC)
 

@@ -930,7 +930,8 @@ def test_cache_test_loop_counter_in_the_sor_vs_oracle(eng, orc, n, na, replicas)
     nbad = int((a != np.arange(n, dtype=np.int32)).sum())
     c_a, c_s, c_e, _, _ = orc.cache_test_xmr(a, replicas=1)
     B, A, NL, NS, ND = ca.F_BRANCH_SYNC, ca.F_ADDR_SYNC, ca.F_NO_LOAD_SYNC, ca.F_NO_STORE_ADDR_SYNC, ca.F_NO_STORE_DATA_SYNC
-    for flags in (B, B | A, B | A | NL, B | A | NS, A, B | A | ND, B | A | NL | NS | ND):
+    L = ca.F_LOCAL_STORE_SYNC  # round 4: + sum += .., numberOfErrors++, local_errors++, i++ (and sum_errors++ / local_errors++ behind a wrong sum)
+    for flags in (B, B | A, B | A | NL, B | A | NS, A, B | A | ND, B | A | NL | NS | ND, B | A | L, B | A | L | NS, B | A | L | ND):
         d = torch.from_numpy(a.copy()).cuda()
         eng.reset_stats()
         sums, nerrs = eng.cache_test_batch(d, cfg=ca.XmrConfig(replicas, 0, flags))
@@ -948,6 +949,8 @@ def test_cache_test_loop_counter_in_the_sor_vs_oracle(eng, orc, n, na, replicas)
                 votes += na * (n + 1 + 2) + nbad + int((bad_k > 0).sum()) + int(wrong_k.sum()) + int((wrong_k & (bad_k == 0)).sum())
             if flags & A:
                 votes += (0 if flags & NL else 2 * n * na + nbad) + (0 if flags & NS else nbad)
+            if flags & L and not flags & ND:
+                votes += 2 * n * na + 2 * nbad + 2 * int((wrong_k & (bad_k == 0)).sum())
             assert w_st["sync_count"] == votes, (flags, w_st, votes)
         if replicas == 1:
             continue
@@ -966,7 +969,7 @@ def test_cache_test_loop_counter_in_the_sor_vs_oracle(eng, orc, n, na, replicas)
         assert (d.cpu().numpy() == w_a).all(), flags
         assert (sums.cpu().numpy() == w_s).all() and (nerrs.cpu().numpy().view(np.uint32) == w_e).all(), flags
         assert _stats3(eng.stats()) == w_st and (det.cpu().numpy() == w_det).all(), flags
-        if replicas == 3 and flags == (B | A):  # everything voted: one upset per array is always out-voted
+        if replicas == 3 and flags in (B | A, B | A | L):  # everything voted: one upset per array is always out-voted
             one = ca.make_faults(rows[::2])
             d = torch.from_numpy(a.copy()).cuda()
             eng.reset_stats()
@@ -1776,24 +1779,29 @@ def test_crc16_branch_sync_vs_oracle(eng, orc, block_len, replicas, sync_every):
     rng = np.random.default_rng(block_len * 5 + replicas + sync_every)
     nb = 300
     data = rng.integers(0, 256, (nb, block_len), dtype=np.uint8)
-    for flags in (ca.F_BRANCH_SYNC, ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC):
+    BAL = ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC | ca.F_LOCAL_STORE_SYNC  # round 4: + length (entry, every length--), x (twice) and crc per byte
+    flag_sets = (ca.F_BRANCH_SYNC, ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC) + ((BAL, BAL | ca.F_NO_STORE_DATA_SYNC) if sync_every == 0 else ())
+    for flags in flag_sets:
         exp, exp_st, _ = orc.crc16_xmr(data, block_len, replicas=replicas, sync_every=sync_every, flags=flags)
         eng.reset_stats()
         got = _host(eng.crc16_batch(torch.from_numpy(data).cuda(), block_len, cfg=ca.XmrConfig(replicas, sync_every, flags)), np.uint16)
         assert (got == exp).all() and _stats3(eng.stats()) == exp_st
-        if replicas > 1:
+        if replicas > 1 and not flags & ca.F_NO_STORE_DATA_SYNC:
             assert exp_st["sync_count"] >= nb * (block_len + 2)
+        if replicas > 1 and flags == BAL:  # the reference's -O0 IR: block_len + 1 branches, 4 block_len + 2 stores, + the return value
+            assert exp_st["sync_count"] == nb * (5 * block_len + 4)
     if replicas == 1:
         return
     fl = _rand_faults(rng, 120, nb, replicas, [24, 25, 26, 26], block_len + 1)
-    exp, exp_st, exp_det = orc.crc16_xmr(data, block_len, replicas=replicas, sync_every=sync_every, flags=ca.F_BRANCH_SYNC, faults=fl)
-    det = torch.zeros(nb, dtype=torch.uint8, device="cuda")
-    eng.reset_stats()
-    eng.inject_faults(fl)
-    got = _host(eng.crc16_batch(torch.from_numpy(data).cuda(), block_len, cfg=ca.XmrConfig(replicas, sync_every, ca.F_BRANCH_SYNC),
-                                detected=det), np.uint16)
-    assert (got == exp).all()
-    assert _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all()
+    for flags in (ca.F_BRANCH_SYNC,) + ((BAL,) if sync_every == 0 else ()):
+        exp, exp_st, exp_det = orc.crc16_xmr(data, block_len, replicas=replicas, sync_every=sync_every, flags=flags, faults=fl)
+        det = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        got = _host(eng.crc16_batch(torch.from_numpy(data).cuda(), block_len, cfg=ca.XmrConfig(replicas, sync_every, flags),
+                                    detected=det), np.uint16)
+        assert (got == exp).all(), flags
+        assert _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all(), flags
 
 
 @pytest.mark.parametrize("replicas", [3, 2, 1])
@@ -1813,7 +1821,8 @@ def test_mm_loop_counters_in_the_sor_vs_oracle(eng, orc, n, batch, replicas):
     clean, _, _ = orc.mm_xmr(f, s, replicas=1)
     nconds = (n + 1) * (n * n + n + 1)
     B, A, NL, NS, ND = ca.F_BRANCH_SYNC, ca.F_ADDR_SYNC, ca.F_NO_LOAD_SYNC, ca.F_NO_STORE_ADDR_SYNC, ca.F_NO_STORE_DATA_SYNC
-    for flags in (B | ND, B, B | A, B | A | NL, B | A | NS, A, B | A | NL | NS | ND):
+    L = ca.F_LOCAL_STORE_SYNC  # round 4: + the -O0 IR's stores into the locals' allocas (sum += .., k++, j++, i++) as data votes
+    for flags in (B | ND, B, B | A, B | A | NL, B | A | NS, A, B | A | NL | NS | ND, B | A | L, B | A | L | NL, B | A | L | ND):
         # clean run: the counts are the schedule
         eng.reset_stats()
         got = _host(eng.mm_batch(_dev(f), _dev(s), cfg=ca.XmrConfig(replicas, 0, flags)), np.uint32)
@@ -1824,6 +1833,8 @@ def test_mm_loop_counters_in_the_sor_vs_oracle(eng, orc, n, batch, replicas):
             votes = (nconds if flags & B else 0) + (0 if flags & ND else n * n)
             if flags & A:
                 votes += (0 if flags & NL else 4 * n ** 3) + (0 if flags & NS else 2 * n * n)
+            if flags & L and not flags & ND:
+                votes += n + n * n + 2 * n ** 3  # i++, j++, k++ and sum += ..: side 9 -> 5617 in all (tools/ir_sync_counts.py)
             assert want_st["sync_count"] == batch * votes, (flags, want_st)
         if replicas == 1:
             continue
@@ -1841,7 +1852,7 @@ def test_mm_loop_counters_in_the_sor_vs_oracle(eng, orc, n, batch, replicas):
         got = _host(eng.mm_batch(_dev(f), _dev(s), cfg=ca.XmrConfig(replicas, 0, flags), detected=det), np.uint32)
         assert (got == want).all(), flags
         assert _stats3(eng.stats()) == want_st and (det.cpu().numpy() == want_det).all(), flags
-        if replicas == 3 and flags == (B | A):  # everything voted: a single upset per call is always out-voted (two upsets of one
+        if replicas == 3 and flags in (B | A, B | A | L):  # everything voted: a single upset per call is always out-voted (two upsets of one
             one = ca.make_faults(rows[::3])      # counter in replicas 0 and 2 are not: select(a == b, a, c) then takes the wrong c)
             eng.reset_stats()
             eng.inject_faults(one)
@@ -1895,13 +1906,17 @@ def test_aes_loop_counters_in_the_sor_vs_oracle(eng, orc, direction, replicas):
     ref_s, ref_k, _, _ = orc.aes128_xmr(st, ky, direction, replicas=1)
     B, A, NL, NS, ND = ca.F_BRANCH_SYNC, ca.F_ADDR_SYNC, ca.F_NO_LOAD_SYNC, ca.F_NO_STORE_ADDR_SYNC, ca.F_NO_STORE_DATA_SYNC
     nloop = 514 if direction else 373  # loop conditions of a clean call
-    for flags in (B, B | A, B | A | NL, B | A | NS, A, B | A | NL | NS | ND):
+    L = ca.F_LOCAL_STORE_SYNC  # round 4: + round++ / i++ / buf1..4 and every byte stored into state[] / key[] in place
+    for flags in (B, B | A, B | A | NL, B | A | NS, A, B | A | NL | NS | ND, B | A | L, B | A | L | NL | NS, B | A | L | ND):
         ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky.copy()).cuda()
         eng.reset_stats()
         eng.aes128_batch(ds, dk, direction, cfg=ca.XmrConfig(replicas, 0, flags))
         w_s, w_k, w_st, _ = orc.aes128_xmr(st, ky, direction, replicas=replicas, flags=flags)
         assert (ds.cpu().numpy() == w_s).all() and (dk.cpu().numpy() == w_k).all() and (w_s == ref_s).all() and (w_k == ref_k).all(), flags
         assert _stats3(eng.stats()) == w_st and eng.last_launch()["engine"] == "stepwise", flags
+        if replicas > 1 and flags & L:  # the reference's own -O0 IR: 600 + 779 stores per encryption, 904 + 981 per decryption
+            base = orc.aes128_xmr(st, ky, direction, replicas=replicas, flags=flags & ~L)[2]["sync_count"]
+            assert w_st["sync_count"] - base == (0 if flags & ND else nb * (1885 if direction else 1379)), flags
         if replicas == 1:
             continue
         rows = []
@@ -1919,7 +1934,7 @@ def test_aes_loop_counters_in_the_sor_vs_oracle(eng, orc, direction, replicas):
         eng.aes128_batch(ds, dk, direction, cfg=ca.XmrConfig(replicas, 0, flags), detected=det)
         assert (ds.cpu().numpy() == w_s).all() and (dk.cpu().numpy() == w_k).all(), flags
         assert _stats3(eng.stats()) == w_st and (det.cpu().numpy() == w_det).all(), flags
-        if replicas == 3 and flags == (B | A):  # everything voted: one counter upset per block is always out-voted
+        if replicas == 3 and flags in (B | A, B | A | L):  # everything voted: one counter upset per block is always out-voted
             one = ca.make_faults([r for r in rows if r[2] in (18, 19)])
             ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky.copy()).cuda()
             eng.reset_stats()
@@ -1946,7 +1961,8 @@ def test_chsha_loop_counters_in_the_sor_vs_oracle(eng, orc, length, replicas):
     ref, _, _ = orc.chsha_xmr(msgs, length, replicas=1)
     nt = length // 64 + 1
     B, A, NL, NS, ND = ca.F_BRANCH_SYNC, ca.F_ADDR_SYNC, ca.F_NO_LOAD_SYNC, ca.F_NO_STORE_ADDR_SYNC, ca.F_NO_STORE_DATA_SYNC
-    for flags in (B, B | A, B | A | NL, B | A | NS, A, B | A | NL | NS | ND):
+    L = ca.F_LOCAL_STORE_SYNC  # round 4: + ++i, W[i] = .., A..E = .., FUNC's temp / E / D / C / B / A, count and the bit counts, data[14 / 15]
+    for flags in (B, B | A, B | A | NL, B | A | NS, A, B | A | NL | NS | ND, B | A | L, B | A | L | NL, B | A | L | ND):
         eng.reset_stats()
         got = _host(eng.chsha_batch(_dev(msgs), length, cfg=ca.XmrConfig(replicas, 0, flags)), np.uint32)
         want, want_st, _ = orc.chsha_xmr(msgs, length, replicas=replicas, flags=flags)
@@ -1956,6 +1972,8 @@ def test_chsha_loop_counters_in_the_sor_vs_oracle(eng, orc, length, replicas):
             votes = (0 if flags & ND else 5 * nt) + (nt * 166 + nt + 2 if flags & B else 0)
             if flags & A:
                 votes += (0 if flags & NL else nt * (16 + 4 * 64 + 80)) + (0 if flags & NS else nt * (16 + 64) + 1)
+            if flags & L and not flags & ND:  # per transform 160 (++i) + 80 (W[i]) + 5 (A..E) + 480 (FUNC); per call 9 + the blocks
+                votes += nt * 725 + 9 + (nt - 1)
             assert want_st["sync_count"] == nm * votes, (flags, want_st)
         if replicas == 1:
             continue
@@ -1973,7 +1991,7 @@ def test_chsha_loop_counters_in_the_sor_vs_oracle(eng, orc, length, replicas):
         got = _host(eng.chsha_batch(_dev(msgs), length, cfg=ca.XmrConfig(replicas, 0, flags), detected=det), np.uint32)
         assert (got == want).all(), flags
         assert _stats3(eng.stats()) == want_st and (det.cpu().numpy() == want_det).all(), flags
-        if replicas == 3 and flags == (B | A):  # everything voted: one counter upset per message is always out-voted
+        if replicas == 3 and flags in (B | A, B | A | L):  # everything voted: one counter upset per message is always out-voted
             one = ca.make_faults([r for r in rows if r[2] in (43, 44)])
             eng.reset_stats()
             eng.inject_faults(one)

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 pytestmark = pytest.mark.skipif(not (os.path.isdir("/root/reference/tests") and os.path.exists("/opt/rocm/lib/llvm/bin/clang")),
                                 reason="needs the reference checkout and clang (container-side pin)")
-B, A, NL, NS = 2, 4, 8, 16
+B, A, NL, NS, L = 2, 4, 8, 16, 64
 
 
 def _classes(sync):
@@ -44,6 +44,11 @@ def test_mm_counts_equal_the_references_ir(orc):
     # the function's locals in registers (the mem2reg view), where those stores do not exist -- reported, not modelled
     data_votes = orc.mm_xmr(f, s, replicas=3, flags=B | A)[1]["sync_count"] - orc.mm_xmr(f, s, replicas=3, flags=B | A | nd)[1]["sync_count"]
     assert data_votes == got["stores_to_memory"] == n * n and got["stores_to_local_allocas"] > 0
+    # round 4, COAST_F_LOCAL_STORE_SYNC: those stores are data votes too -- sum += .., k++, j++, i++ -- and the call's sync_count IS the
+    # executed branches + variable GEPs + stores of the reference's IR: 910 + 2916 + 162 + 81 + 1548 = 5617 at side 9
+    full = orc.mm_xmr(f, s, replicas=3, flags=B | A | L)[1]["sync_count"]
+    assert full == sum(got[k] for k in ("branches", "gep_loads", "gep_stores", "stores_to_memory", "stores_to_local_allocas")) == 5617
+    assert full - orc.mm_xmr(f, s, replicas=3, flags=B | A)[1]["sync_count"] == got["stores_to_local_allocas"] == n + n * n + 2 * n**3
 
 
 def test_aes_counts_equal_the_references_ir(orc):
@@ -58,7 +63,13 @@ def test_aes_counts_equal_the_references_ir(orc):
         br, ld, sto = _classes(lambda fl: orc.aes128_xmr(s_, k_, d, replicas=3, flags=fl)[2]["sync_count"])
         assert (br - base, ld, sto) == (got[tag]["branches"], got[tag]["gep_loads"], got[tag]["gep_stores"]), tag
         assert got[tag]["gep_other"] == 0
+        # round 4, COAST_F_LOCAL_STORE_SYNC: every store of the -O0 IR is a data vote -- into state[] / key[] in place and into the
+        # allocas of round, i, buf1..buf4, dir: the call's sync_count is the IR's branches + GEPs + stores (+ the schedule's 8 exit votes)
+        full = orc.aes128_xmr(s_, k_, d, replicas=3, flags=B | A | L)[2]["sync_count"]
+        assert full - base == sum(got[tag][k] for k in ("branches", "gep_loads", "gep_stores", "stores_to_memory", "stores_to_local_allocas")), tag
     assert (got["aes_enc"]["branches"], got["aes_dec"]["branches"]) == (469, 593)
+    assert (got["aes_enc"]["stores_to_memory"], got["aes_enc"]["stores_to_local_allocas"]) == (600, 779)
+    assert (got["aes_dec"]["stores_to_memory"], got["aes_dec"]["stores_to_local_allocas"]) == (904, 981)
 
 
 @pytest.mark.parametrize("bad", [(), (40,), (40, 41), (40, 100, 599), (0,), (599,)])
@@ -77,6 +88,12 @@ def test_cache_test_counts_equal_the_references_ir(orc, bad):
     base_nd = orc.cache_test_xmr(a, replicas=3, flags=nd)[3]["sync_count"] - n
     assert (br - base_nd, ld, sto) == (got["branches"], got["gep_loads"], got["gep_stores"]), (bad, base)
     assert got["gep_other"] == 0
+    # round 4, COAST_F_LOCAL_STORE_SYNC: sum += .., i++, numberOfErrors++ (locals) and local_errors++ (a global) are data votes as well;
+    # `array[i] = i` is the store the schedule has always voted
+    full = orc.cache_test_xmr(a.copy(), replicas=3, flags=B | A | L)[3]["sync_count"]
+    ba = orc.cache_test_xmr(a.copy(), replicas=3, flags=B | A)[3]["sync_count"]
+    assert full - ba == got["stores_to_local_allocas"] + got["stores_to_memory"] - len(bad)
+    assert full - base == sum(got[k] for k in ("branches", "gep_loads", "gep_stores", "stores_to_memory", "stores_to_local_allocas"))
 
 
 @pytest.mark.parametrize("nbytes", [0, 64, 128, 1024])
@@ -89,6 +106,10 @@ def test_chsha_counts_equal_the_references_ir(orc, nbytes):
     br, ld, sto = _classes(lambda fl: orc.chsha_xmr(m, nbytes, replicas=3, flags=fl)[1]["sync_count"])
     assert (br - base, ld, sto) == (got["branches"], got["gep_loads"], got["gep_stores"]), nbytes
     assert got["gep_other"] == 0
+    # round 4, COAST_F_LOCAL_STORE_SYNC: ++i, W[i] = .., A..E = .., FUNC's six stores, count and the bit counts, sha_info_data[14 / 15];
+    # the five digest words per transform are the stores the schedule has always voted (`base`)
+    full = orc.chsha_xmr(m, nbytes, replicas=3, flags=B | A | L)[1]["sync_count"]
+    assert full == sum(got[k] for k in ("branches", "gep_loads", "gep_stores", "stores_to_memory", "stores_to_local_allocas")), nbytes
 
 
 def test_crc16_counts_equal_the_references_ir(orc):
@@ -104,6 +125,9 @@ def test_crc16_counts_equal_the_references_ir(orc):
             data = np.array([[(i * 7 + 1) & 255 for i in range(n)]], dtype=np.uint8)
             base = orc.crc16_xmr(data, n, replicas=3)[1]["sync_count"]
             assert orc.crc16_xmr(data, n, replicas=3, flags=B)[1]["sync_count"] - base == n + 1
+            # round 4, COAST_F_LOCAL_STORE_SYNC: `length` (entry and every length--), x (twice) and crc per byte: 4 n + 2 stores
+            assert orc.crc16_xmr(data, n, replicas=3, flags=B | A | L)[1]["sync_count"] - base == n + 1 + g["stores_to_local_allocas"]
+            assert g["stores_to_local_allocas"] == 4 * n + 2 and g["stores_to_memory"] == 0
 
 
 def test_quicksort_schedule_against_this_toolchains_o3_ir(orc):
