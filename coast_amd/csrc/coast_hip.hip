@@ -120,15 +120,19 @@ int fail(coast_ctx *ctx, int code, const char *fmt, ...)
 unsigned long long *totals_of(coast_ctx *c) { return c->dBound ? c->dBound : c->dTotals; }
 
 // `indexedOk`: this kernel implements the index-in-the-sphere-of-replication flags (mm, sha256, crc16)
-int check_cfg(coast_ctx *ctx, const coast_cfg *cfg, bool indexedOk = false, bool copiesOk = false)
+int check_cfg(coast_ctx *ctx, const coast_cfg *cfg, bool indexedOk = false, bool copiesOk = false, bool o0Ok = false)
 {
     if (!ctx)
         return COAST_EINVAL;
     if (!cfg || cfg->replicas < 1 || cfg->replicas > 3)
         return fail(ctx, COAST_EINVAL, "coast_cfg.replicas must be 1 (none), 2 (DWC) or 3 (TMR)");
     const uint32_t indexed = COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC | COAST_F_NO_LOAD_SYNC | COAST_F_NO_STORE_ADDR_SYNC;
-    if (cfg->flags & ~((uint32_t)COAST_F_NO_STORE_DATA_SYNC | indexed | (uint32_t)COAST_F_MEMORY_COPIES | (uint32_t)COAST_F_LOCAL_STORE_SYNC))
+    if (cfg->flags & ~((uint32_t)COAST_F_NO_STORE_DATA_SYNC | indexed | (uint32_t)COAST_F_MEMORY_COPIES | (uint32_t)COAST_F_LOCAL_STORE_SYNC |
+                       (uint32_t)COAST_F_O0_SHAPE))
         return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: unknown bits", cfg->flags);
+    if ((cfg->flags & COAST_F_O0_SHAPE) && (!o0Ok || (cfg->flags & (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC)) != (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC)))
+        return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: COAST_F_O0_SHAPE selects sha256's -O0 walk under COAST_F_BRANCH_SYNC | "
+                                       "COAST_F_ADDR_SYNC (every other statement-by-statement walk IS the -O0 shape)", cfg->flags);
     if ((cfg->flags & COAST_F_LOCAL_STORE_SYNC) &&
         (cfg->flags & (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC)) != (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC))
         return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: COAST_F_LOCAL_STORE_SYNC qualifies COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC "

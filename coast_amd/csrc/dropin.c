@@ -213,7 +213,14 @@ void sha256_hash(unsigned char ctx_data[], uint32_t ctx_bitlen[], uint32_t ctx_s
                  uint32_t len, unsigned char hash[])
 {
     coast_cfg cfg = dropin_cfg_counters();
-    cfg.flags &= ~(uint32_t)COAST_F_LOCAL_STORE_SYNC; /* sha256_hash's counters-in-the-SoR walk is the post--O3 shape: no -O0 store census */
+    {   /* COAST_SHA256_O0=1 (with COAST_COUNTERS_IN_SOR): the walk in the -O0 IR's shape, what tests/sha256_common/Makefile (no OPT_FLAGS)
+         * hands the pass; default: the post--O3 shape of the hifive1 flow, which has no -O0 store census */
+        const char *o0 = getenv("COAST_SHA256_O0");
+        if (o0 && *o0 && *o0 != '0' && (cfg.flags & COAST_F_BRANCH_SYNC))
+            cfg.flags |= COAST_F_O0_SHAPE;
+        else
+            cfg.flags &= ~(uint32_t)COAST_F_LOCAL_STORE_SYNC;
+    }
     dropin_maybe_inject();
     uint32_t st[8];
     const int rc = coast_sha256_host(data, len, hash, st, &cfg);

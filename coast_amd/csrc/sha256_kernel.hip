@@ -414,6 +414,276 @@ __device__ void sha_item_indexed(const uint8_t *msg, uint32_t len, uint32_t st[8
     sha_state_hook(st, cidx, ft, fr, slot, lm.r, lm.live); // step == ncompress: before the digest
 }
 
+// ------------------------------------------------------------------------------------------------ the -O0 shape
+// sha256_hash + sha256_transform as the x86 / lli flow hands them to the pass (tests/sha256_common/Makefile: OPT_FLAGS empty -- the -O0 IR
+// of sha256_common_tmr.c:27-178), for COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC | COAST_F_O0_SHAPE: every loop is a loop -- the byte loop,
+// `while (i < 56 / 64)`, the long pad's `while (n--)`, the output loop, the three loops of sha256_transform -- with replica-private
+// counters; every evaluated condition is a branch vote, every variable-index GEP an offset vote (3-byte message: 198 / 387 / 152,
+// tools/ir_sync_counts.py).  COAST_F_LOCAL_STORE_SYNC adds the store-data votes of that IR (2009 into locals + 116 into memory at 3
+// bytes); the digest then leaves as its 32 byte stores.  One lane per (message, replica), one sequential walk; ctx_data[64] is one LDS
+// copy per message written by the original store (replica 0's lane), m[64] is the lane's own (64 words of LDS, indexed at run time).
+// Mirrors oracle/coast_oracle.c:sha_item_o0 / sh0_transform statement by statement.  The sync-point-parity form, not the throughput form.
+template <int NREP>
+__global__ __launch_bounds__(64) void sha256_o0_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t lenArg, uint64_t nmsgs,
+                                                       uint8_t *__restrict__ digests, Counters ctr, FaultTab ft,
+                                                       uint8_t *__restrict__ detected)
+{
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    __shared__ __attribute__((aligned(16))) uint8_t sCtxData[IPW + 1][64];
+    __shared__ uint32_t sW[64 * 64]; // m[t] of lane l at t * 64 + l
+    LaneMap<NREP> lm;
+    lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
+    const bool bs = (ctr.flags & kFlagBranchSync) != 0u, as = (ctr.flags & kFlagAddrSync) != 0u;
+    const bool ls = as && !(ctr.flags & kFlagNoLoadSync), ss = as && !(ctr.flags & kFlagNoStoreAddrSync);
+    const bool lss = xmr_local_sync_on(ctr.flags);
+    const uint32_t tile = blockIdx.x;
+    const int slot = lm.q;
+    const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
+    const bool live = lm.live && item < nmsgs;
+    const bool cnt = live && lm.r == 0;
+    const bool writer = cnt; // the single memory copies (ctx_data, hash) are written by the original instruction
+    const uint8_t *msg = msgs + (live ? item : 0) * stride;
+    const uint32_t len = live ? lenArg : 0u;
+    uint8_t *buf = sCtxData[slot];
+    uint32_t *W = sW + lm.lane;
+    if (threadIdx.x < 4)
+        sCnt[threadIdx.x] = 0;
+    if (writer)
+        for (int t = 0; t < 16; ++t)
+            reinterpret_cast<uint32_t *>(buf)[t] = 0u;
+    __syncthreads();
+    uint2 fr = make_uint2(0u, 0u);
+    if (ft.range)
+        fr = ft.range[tile];
+    Tally tl;
+    // (the idle lane of a TMR wave has no message of its own -- its replica group would wrap to lanes 0, 1: it walks on its own values)
+    auto br = [&](bool c) __attribute__((always_inline)) { return lm.live ? xmr_steer<NREP>(c ? 1u : 0u, lm, bs, cnt, tl) != 0u : c; };
+    auto off = [&](uint32_t idx, bool store) __attribute__((always_inline)) {
+        return lm.live ? xmr_steer<NREP>(idx, lm, store ? ss : ls, cnt, tl) : idx;
+    };
+    auto lsy = [&](uint32_t v) __attribute__((always_inline)) { return lm.live ? xmr_local_sync<NREP>(v, lm, lss, cnt, tl) : v; };
+    auto ssy = [&](uint32_t v) __attribute__((always_inline)) { return lm.live ? xmr_store_sync<NREP>(v, lm, cnt, tl) : v; };
+    uint32_t st[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    uint32_t cidx = 0u;
+    auto mFault = [&](uint32_t t) __attribute__((always_inline)) { // SITE_SHA_M: m[t] right after it is produced
+        for (uint32_t q = 0; q < fr.y; ++q) {
+            const DevFault df = ft.list[fr.x + q];
+            if (df.site == SITE_SHA_M && df.step == cidx * 64u + t && (int)df.local == slot && (int)df.replica == lm.r && lm.live)
+                W[t * 64u] ^= 1u << (df.bit & 31u);
+        }
+    };
+    auto transform = [&]() __attribute__((noinline)) {
+        wave_lds_sync(); // ctx_data was written by replica 0's lane: the other replicas' loads must not overtake its stores
+        for (int t = 0; t < 64; ++t)
+            W[t * 64] = 0u;
+        uint32_t i = 0u, j = 0u, temp = 0u;
+        for (;;) {                                                       // for (i = 0, j = 0; i < 16; ++i, j += 4)   :34
+            if (!br(i < 16u))
+                break;
+#pragma unroll 1
+            for (uint32_t b = 0; b < 4u; ++b) {                          //   temp = data[j] << 24; temp |= ..        :35-38
+                const uint32_t o = off(j + b, false);
+                const uint32_t byte = o < 64u ? (uint32_t)buf[o] : 0u;
+                temp = lsy((b ? temp : 0u) | (byte << (24u - 8u * b)));
+            }
+            const uint32_t os = off(i, true);                            //   m[i] = temp                              :39
+            temp = lsy(temp);
+            if (os < 64u) {
+                W[os * 64u] = temp;
+                mFault(os);
+            }
+            i = lsy(i + 1u);
+            j = lsy(j + 4u);
+        }
+        for (;;) {                                                       // for (; i < 64; ++i)                       :42
+            if (!br(i < 64u))
+                break;
+            uint32_t o = off(i - 2u, false);
+            uint32_t sv = lsy(o < 64u ? W[o * 64u] : 0u);                //   s = m[i - 2]                            :43
+            uint32_t sig1 = lsy(rotr32(sv, 17));
+            sig1 = lsy(sig1 ^ rotr32(sv, 19));
+            sig1 = lsy(sig1 ^ (sv >> 10));
+            o = off(i - 15u, false);
+            sv = lsy(o < 64u ? W[o * 64u] : 0u);                         //   s = m[i - 15]                           :48
+            uint32_t sig0 = lsy(rotr32(sv, 7));
+            sig0 = lsy(sig0 ^ rotr32(sv, 18));
+            sig0 = lsy(sig0 ^ (sv >> 3));
+            temp = lsy(sig1);                                            //   temp = sig1; += m[i-7]; += sig0; += m[i-16]  :53-56
+            o = off(i - 7u, false);
+            temp = lsy(temp + (o < 64u ? W[o * 64u] : 0u));
+            temp = lsy(temp + sig0);
+            o = off(i - 16u, false);
+            temp = lsy(temp + (o < 64u ? W[o * 64u] : 0u));
+            const uint32_t os = off(i, true);                            //   m[i] = temp                              :57
+            temp = lsy(temp);
+            if (os < 64u) {
+                W[os * 64u] = temp;
+                mFault(os);
+            }
+            i = lsy(i + 1u);
+        }
+        uint32_t v[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w)                                      // a = ctx_state[0] ..                       :60-67
+            v[w] = lsy(st[w]);
+        i = 0u;
+        for (uint32_t t = 0;; ++t) {                                     // for (i = 0; i < 64; ++i)                  :69
+            if (!br(i < 64u) || t >= 64u)
+                break;
+            for (uint32_t q = 0; q < fr.y; ++q) {                        // SITE_SHA_WV: a..h before round t
+                const DevFault df = ft.list[fr.x + q];
+                if (df.site != SITE_SHA_WV || df.step != cidx * 64u + t || (int)df.local != slot || (int)df.replica != lm.r || !lm.live)
+                    continue;
+#pragma unroll
+                for (int w = 0; w < 8; ++w)
+                    if (w == (df.index & 7))
+                        v[w] ^= 1u << (df.bit & 31u);
+            }
+            uint32_t ep0 = lsy(rotr32(v[0], 2));
+            ep0 = lsy(ep0 ^ rotr32(v[0], 13));
+            ep0 = lsy(ep0 ^ rotr32(v[0], 22));
+            uint32_t ep1 = lsy(rotr32(v[4], 6));
+            ep1 = lsy(ep1 ^ rotr32(v[4], 11));
+            ep1 = lsy(ep1 ^ rotr32(v[4], 25));
+            const uint32_t ch = lsy((v[4] & v[5]) ^ (~v[4] & v[6]));
+            const uint32_t maj = lsy((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+            const uint32_t ok = off(i, false), om = off(i, false);       //   k[i], m[i]                               :78
+            const uint32_t t1 = lsy(v[7] + ep1 + ch + (ok < 64u ? kShaK[ok] : 0u) + (om < 64u ? W[om * 64u] : 0u));
+            const uint32_t t2 = lsy(ep0 + maj);
+            v[7] = lsy(v[6]);                                            //   h = g .. a = t1 + t2                    :80-87
+            v[6] = lsy(v[5]);
+            v[5] = lsy(v[4]);
+            v[4] = lsy(v[3] + t1);
+            v[3] = lsy(v[2]);
+            v[2] = lsy(v[1]);
+            v[1] = lsy(v[0]);
+            v[0] = lsy(t1 + t2);
+            i = lsy(i + 1u);
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w)                                      // ctx_state[w] += ..: stored                :90-97
+            st[w] = ssy(st[w] + v[w]);
+        wave_lds_sync(); // ... and replica 0's next ctx_data stores must not overtake the loads above
+        ++cidx;
+    };
+    uint32_t ir = 0u, dl = 0u, bl0 = 0u, bl1 = 0u;
+    const uint32_t cap = 4u * len + 256u;
+    (void)lsy(len);                                                      // the parameter `len` into its alloca
+    for (uint32_t it = 0;; ++it) {
+        for (uint32_t q = 0; q < fr.y; ++q) {
+            const DevFault df = ft.list[fr.x + q];
+            if (df.step != it || (int)df.local != slot || (int)df.replica != lm.r || !lm.live)
+                continue;
+            if (df.site == SITE_SHA_I)
+                ir ^= 1u << (df.bit & 31u);
+            else if (df.site == SITE_SHA_DATALEN)
+                dl ^= 1u << (df.bit & 31u);
+        }
+        if (!br(ir < len) || it >= cap)                                  // for (i = 0; i < len; ++i)                    :119
+            break;
+        const uint32_t li = off(ir, false);                              // data[i]                                       :120
+        const uint32_t byte = li < len ? (uint32_t)msg[li] : 0u;
+        const uint32_t si = off(dl, true);                               // ctx_data[ctx_datalen] = ...                   :120
+        const uint32_t bv = lsy(byte);
+        if (writer && si < 64u)
+            buf[si] = (uint8_t)bv;
+        dl = lsy(dl + 1u);                                               // ctx_datalen++                                 :121
+        if (br(dl == 64u)) {                                             // if (ctx_datalen == 64)                        :122
+            sha_state_hook(st, cidx, ft, fr, slot, lm.r, lm.live);
+            transform();
+            if (br(bl0 > 0xffffffffu - 512u))                            // DBL_INT_ADD(ctx_bitlen[0], ctx_bitlen[1], 512)  :2-5
+                bl1 = lsy(bl1 + 1u);
+            bl0 = lsy(bl0 + 512u);
+            dl = 0u;                                                     // ctx_datalen = 0                               :125
+        }
+        ir = lsy(ir + 1u);
+    }
+    ir = lsy(dl);                                                        // i = ctx_datalen                               :129
+    const bool shortPad = br(dl < 56u);                                  // if (ctx_datalen < 56)                         :132
+    {
+        const uint32_t lim = shortPad ? 56u : 64u;
+        uint32_t o = off(ir, true);                                      // ctx_data[i++] = 0x80                       :133,137
+        if (writer && o < 64u)
+            buf[o] = 0x80u;
+        ir = lsy(ir + 1u);
+        for (uint32_t guard = 0;; ++guard) {                             // while (i < 56 / 64) ctx_data[i++] = 0x00   :134,138
+            if (!br(ir < lim) || guard >= 256u)
+                break;
+            o = off(ir, true);
+            if (writer && o < 64u)
+                buf[o] = 0u;
+            ir = lsy(ir + 1u);
+        }
+    }
+    if (!shortPad) {
+        sha_state_hook(st, cidx, ft, fr, slot, lm.r, lm.live);
+        transform();
+        uint32_t n = 56u;                                                // the inlined sha_memset(ctx_data, 0, 56)    :143-150
+        (void)lsy(0u);                                                   // c = c & 0xFF
+        for (uint32_t p = 0;; ++p) {
+            const uint32_t old = n;
+            n = lsy(n - 1u);                                             // while (n--): load, decrement, store, branch
+            if (!br(old != 0u) || p >= 256u)
+                break;
+            (void)lsy(0u);                                               // *p++ = c: a constant-offset GEP, the stored c
+            if (writer && p < 64u)
+                buf[p] = 0u;
+        }
+    }
+    {
+        const uint32_t add = dl * 8u;                                    // DBL_INT_ADD(..., ctx_datalen * 8)             :150
+        if (br(bl0 > 0xffffffffu - add))
+            bl1 = lsy(bl1 + 1u);
+        uint32_t sum = ssy(bl0 + add);                                   // a += c: a replicated value into the single ctx_bitlen[0]
+        if (NREP != 3 || !lm.storeSync)
+            sum = lm.live ? xmr_rep0<NREP>(sum, lm) : sum;
+        bl0 = sum;
+    }
+#pragma unroll 1
+    for (uint32_t b = 0; b < 4u; ++b) {                                  // ctx_data[63 - b] = ctx_bitlen[0] >> 8 b ..  :151-158
+        const uint32_t x = lsy((bl0 >> (8u * b)) & 0xffu);
+        if (writer)
+            buf[63u - b] = (uint8_t)x;
+    }
+#pragma unroll 1
+    for (uint32_t b = 0; b < 4u; ++b) {
+        const uint32_t x = lsy((bl1 >> (8u * b)) & 0xffu);
+        if (writer)
+            buf[59u - b] = (uint8_t)x;
+    }
+    sha_state_hook(st, cidx, ft, fr, slot, lm.r, lm.live);
+    transform();
+    sha_state_hook(st, cidx, ft, fr, slot, lm.r, lm.live); // step == ncompress: before the digest
+    if (!lss) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w)                                      // the digest: 8 words (the default schedule's exit votes)
+            st[w] = ssy(st[w]);
+    }
+    uint8_t *out = digests + (live ? item : 0) * 32u;
+    ir = 0u;
+    for (uint32_t guard = 0;; ++guard) {                                 // for (i = 0; i < 4; ++i) hash[i + 4 w] = ..  :164-173
+        if (!br(ir < 4u) || guard >= 4u)
+            break;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const uint32_t o = off(ir + 4u * (uint32_t)w, true);
+            const uint32_t x = lsy((st[w] >> ((24u - ir * 8u) & 31u)) & 0xffu);
+            if (writer && o < 32u)
+                out[o] = (uint8_t)x;
+        }
+        ir = lsy(ir + 1u);
+    }
+    uint32_t detItems = 0;
+    if (cnt && tl.det) {
+        if (NREP == 2)
+            detItems = 1;
+        if (detected)
+            detected[item] = 1;
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, tile);
+}
+
 // one wave (64-thread workgroup) per tile
 template <int NREP>
 __global__ __launch_bounds__(64) void sha256_general_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,

@@ -37,6 +37,7 @@ constexpr uint32_t kFlagAddrSync = 4u;        // == COAST_F_ADDR_SYNC: GEP offse
 constexpr uint32_t kFlagNoLoadSync = 8u;      // == COAST_F_NO_LOAD_SYNC: ... except load addresses
 constexpr uint32_t kFlagNoStoreAddrSync = 16u; // == COAST_F_NO_STORE_ADDR_SYNC: ... except store addresses
 constexpr uint32_t kFlagIndexed = kFlagBranchSync | kFlagAddrSync;
+constexpr uint32_t kFlagO0Shape = 128u;       // == COAST_F_O0_SHAPE: sha256's walk in the -O0 IR's shape
 constexpr uint32_t kFlagLocalStoreSync = 64u; // == COAST_F_LOCAL_STORE_SYNC: the -O0 IR's stores into locals / in-place arrays are data votes
 
 template <int NREP> struct LaneMap {

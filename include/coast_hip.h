@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define COAST_HIP_ABI_VERSION 6 /* 6: COAST_F_LOCAL_STORE_SYNC; 2: coast_cfg.flags; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info, new flags/sites;
+#define COAST_HIP_ABI_VERSION 6 /* 6: COAST_F_LOCAL_STORE_SYNC, COAST_F_O0_SHAPE; 2: coast_cfg.flags; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info, new flags/sites;
                                  * 4: control-flow signatures (coast_cfcss_assign, coast_crazycf_*), additive;
                                  * 5: COAST_REPLICA_ALL, COAST_ETIMEOUT, coast_launch_info.hooked_blocks, additive */
 
@@ -102,13 +102,19 @@ enum {
      * result array).  One launch; 3x the memory traffic, as on the reference.  Without it (the default) memory is a single copy
      * (-noMemReplication).  Not combined with sync_every or the other flags. */
     COAST_F_MEMORY_COPIES = 32u,
-    /* With COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC (mm, aes128, crc16, cache_test, CHStone sha): the store-data votes the pass emits
+    /* With COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC (mm, aes128, crc16, cache_test, CHStone sha; sha256 with COAST_F_O0_SHAPE): the store-data votes the pass emits
      * on the -O0 IR under -noMemReplication for the stores the default schedules do not have -- every store of a computed value into
      * one of the function's own locals (i++, sum += ..: their allocas stay single-copy) and into state[] / key[] / W[] / the bit counts
      * in place (synchronization.cpp:197-224, 476-561).  With it coast_stats.sync_count of a call = executed conditional branches +
      * variable GEP offsets + stores of the reference's own clang -O0 IR (tools/ir_sync_counts.py; mm side 9: 5617), and an upset in a
      * counter or accumulator is out-voted at its next store.  Dropped by COAST_F_NO_STORE_DATA_SYNC, like every data vote. */
     COAST_F_LOCAL_STORE_SYNC = 64u,
+    /* sha256 with COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC: the walk in the shape the x86 / lli flow hands the pass.  tests/sha256_common/
+     * Makefile has no OPT_FLAGS, so sha256_hash and sha256_transform arrive as -O0 IR: the padding loops, the output loop and the three
+     * loops of sha256_transform are loops with replica-private counters, every evaluated condition and every variable GEP offset a vote
+     * (3-byte message: 198 branches, 387 load and 152 store offsets).  Without it the walk is the post--O3 shape of the hifive1 flow
+     * (byte loop only).  With COAST_F_LOCAL_STORE_SYNC: + this shape's stores (2009 into locals, 116 into memory at 3 bytes). */
+    COAST_F_O0_SHAPE = 128u,
     /* single-call host shims only (the batch entry points reject it): run the region in the reference's DEFAULT mode,
      * memory replicated as well -- one unprotected launch per memory copy + the exit vote of coast_sync_copies(scrub).
      * Without it the shims use the lane-replicated -noMemReplication engine. */

@@ -604,6 +604,331 @@ static void sha_item_indexed(const uint8_t *data, uint32_t len, uint8_t hash[32]
             hash[4 * w + b] = (uint8_t)(st[0][w] >> (24 - 8 * b));
 }
 
+/* sha256_hash + sha256_transform in the shape the x86 / lli flow gives the pass (tests/sha256_common/Makefile: OPT_FLAGS empty, i.e. the
+ * -O0 IR of sha256_common_tmr.c:27-178), for ORC_F_BRANCH_SYNC | ORC_F_ADDR_SYNC | ORC_F_O0_SHAPE: every loop is a loop -- the byte
+ * loop, `while (i < 56 / 64)`, the long pad's `while (n--)`, the output loop, the three loops of sha256_transform -- with replica-private
+ * counters (i, ctx_datalen, n; the transform's i, j), every evaluated condition a branch vote, every variable-index GEP an offset vote by
+ * the class of its first user (data[j..j+3], m[i-2], m[i-15], m[i-7], m[i-16], k[i], m[i], data[i]: loads; m[i], ctx_data[ctx_datalen],
+ * ctx_data[i++], hash[i + 4 w]: stores).  The data votes of the default schedule stay: ctx_state[w] += (8 per transform), the bit count's
+ * `a += ctx_datalen * 8`, the digest (8 words).  ORC_F_LOCAL_STORE_SYNC adds every other store of a computed value of the -O0 IR (1944
+ * into locals + 64 m[i] per transform; the byte stores of ctx_data[] / hash[], the counters) -- the digest then leaves as its 32 byte
+ * stores.  Fault sites as in the default schedule (SHA_STATE / _M / _WV) and the byte loop's SHA_I / SHA_DATALEN; the transform's own
+ * counters have no site: their votes always agree.  A wild index reads 0 / stores nothing; the byte loop has the watchdog of
+ * sha_item_indexed, the padding loops are cut after 256 iterations. */
+#define O0_ALL(dst, expr)                                                                                      \
+    do {                                                                                                       \
+        for (unsigned r = 0; r < 3; ++r)                                                                       \
+            (dst)[r] = (expr);                                                                                 \
+    } while (0)
+typedef struct {
+    sync_ctx *c;
+    int bs, ls, ss;
+    unsigned R;
+    const orc_fault *fl;
+    size_t nf;
+} sh0;
+static int sh0_br(sh0 *m, const uint32_t cnd[3]) { return branch_cond(m->c, cnd[0], cnd[m->R > 1 ? 1 : 0], cnd[m->R > 2 ? 2 : 0], m->bs); }
+static uint32_t sh0_off(sh0 *m, const uint32_t idx[3], int store) { return gep_offset(m->c, idx, store ? m->ss : m->ls); }
+
+static void sh0_transform(sh0 *m, uint32_t st[3][8], const uint8_t buf[64], uint32_t cidx)
+{
+    sync_ctx *c = m->c;
+    uint32_t W[3][64], i[3] = {0, 0, 0}, j[3] = {0, 0, 0}, temp[3], s[3], sig0[3], sig1[3], idx[3], cnd[3];
+    memset(W, 0, sizeof W);
+#define O0_M_FAULT(t)                                                                                          \
+    for (size_t q_ = 0; q_ < m->nf; ++q_)                                                                      \
+        if (m->fl[q_].site == ORC_SITE_SHA_M && m->fl[q_].replica < m->R && m->fl[q_].step == cidx * 64 + (t)) \
+            W[m->fl[q_].replica][t] = flip(W[m->fl[q_].replica][t], m->fl[q_].bit, 0xffffffffu)
+    for (;;) {                                                       /* for (i = 0, j = 0; i < 16; ++i, j += 4)   :34 */
+        O0_ALL(cnd, i[r] < 16u);
+        if (!sh0_br(m, cnd))
+            break;
+        for (unsigned b = 0; b < 4; ++b) {                           /*   temp = data[j] << 24; temp |= ..        :35-38 */
+            O0_ALL(idx, j[r] + b);
+            const uint32_t o = sh0_off(m, idx, 0);
+            const uint32_t byte = o < 64u ? buf[o] : 0u;
+            O0_ALL(temp, (b ? temp[r] : 0u) | (byte << (24 - 8 * b)));
+            local_sync32(c, temp);
+        }
+        const uint32_t os = sh0_off(m, i, 1);                        /*   m[i] = temp                              :39 */
+        local_sync32(c, temp);
+        if (os < 64u) {
+            for (unsigned r = 0; r < 3; ++r)
+                W[r][os] = temp[r];
+            O0_M_FAULT(os);
+        }
+        O0_ALL(i, i[r] + 1u);
+        local_sync32(c, i);
+        O0_ALL(j, j[r] + 4u);
+        local_sync32(c, j);
+    }
+    for (;;) {                                                       /* for (; i < 64; ++i)                       :42 */
+        O0_ALL(cnd, i[r] < 64u);
+        if (!sh0_br(m, cnd))
+            break;
+        uint32_t o;
+        O0_ALL(idx, i[r] - 2u);
+        o = sh0_off(m, idx, 0);
+        O0_ALL(s, o < 64u ? W[r][o] : 0u);                           /*   s = m[i - 2]                            :43 */
+        local_sync32(c, s);
+        O0_ALL(sig1, rotr(s[r], 17));
+        local_sync32(c, sig1);
+        O0_ALL(sig1, sig1[r] ^ rotr(s[r], 19));
+        local_sync32(c, sig1);
+        O0_ALL(sig1, sig1[r] ^ (s[r] >> 10));
+        local_sync32(c, sig1);
+        O0_ALL(idx, i[r] - 15u);
+        o = sh0_off(m, idx, 0);
+        O0_ALL(s, o < 64u ? W[r][o] : 0u);                           /*   s = m[i - 15]                           :48 */
+        local_sync32(c, s);
+        O0_ALL(sig0, rotr(s[r], 7));
+        local_sync32(c, sig0);
+        O0_ALL(sig0, sig0[r] ^ rotr(s[r], 18));
+        local_sync32(c, sig0);
+        O0_ALL(sig0, sig0[r] ^ (s[r] >> 3));
+        local_sync32(c, sig0);
+        O0_ALL(temp, sig1[r]);                                       /*   temp = sig1; += m[i-7]; += sig0; += m[i-16]  :53-56 */
+        local_sync32(c, temp);
+        O0_ALL(idx, i[r] - 7u);
+        o = sh0_off(m, idx, 0);
+        O0_ALL(temp, temp[r] + (o < 64u ? W[r][o] : 0u));
+        local_sync32(c, temp);
+        O0_ALL(temp, temp[r] + sig0[r]);
+        local_sync32(c, temp);
+        O0_ALL(idx, i[r] - 16u);
+        o = sh0_off(m, idx, 0);
+        O0_ALL(temp, temp[r] + (o < 64u ? W[r][o] : 0u));
+        local_sync32(c, temp);
+        const uint32_t os = sh0_off(m, i, 1);                        /*   m[i] = temp                              :57 */
+        local_sync32(c, temp);
+        if (os < 64u) {
+            for (unsigned r = 0; r < 3; ++r)
+                W[r][os] = temp[r];
+            O0_M_FAULT(os);
+        }
+        O0_ALL(i, i[r] + 1u);
+        local_sync32(c, i);
+    }
+#undef O0_M_FAULT
+    uint32_t v[8][3];
+    for (unsigned w = 0; w < 8; ++w) {                               /* a = ctx_state[0] ..                       :60-67 */
+        O0_ALL(v[w], st[r][w]);
+        local_sync32(c, v[w]);
+    }
+    O0_ALL(i, 0u);
+    for (uint32_t t = 0;; ++t) {                                     /* for (i = 0; i < 64; ++i)                  :69 */
+        O0_ALL(cnd, i[r] < 64u);
+        if (!sh0_br(m, cnd) || t >= 64u)
+            break;
+        for (size_t q = 0; q < m->nf; ++q)
+            if (m->fl[q].site == ORC_SITE_SHA_WV && m->fl[q].replica < m->R && m->fl[q].step == cidx * 64 + t)
+                v[m->fl[q].index & 7][m->fl[q].replica] = flip(v[m->fl[q].index & 7][m->fl[q].replica], m->fl[q].bit, 0xffffffffu);
+        uint32_t ep0[3], ep1[3], ch[3], maj[3], t1[3], t2[3], x[3];
+        O0_ALL(ep0, rotr(v[0][r], 2));
+        local_sync32(c, ep0);
+        O0_ALL(ep0, ep0[r] ^ rotr(v[0][r], 13));
+        local_sync32(c, ep0);
+        O0_ALL(ep0, ep0[r] ^ rotr(v[0][r], 22));
+        local_sync32(c, ep0);
+        O0_ALL(ep1, rotr(v[4][r], 6));
+        local_sync32(c, ep1);
+        O0_ALL(ep1, ep1[r] ^ rotr(v[4][r], 11));
+        local_sync32(c, ep1);
+        O0_ALL(ep1, ep1[r] ^ rotr(v[4][r], 25));
+        local_sync32(c, ep1);
+        O0_ALL(ch, (v[4][r] & v[5][r]) ^ (~v[4][r] & v[6][r]));
+        local_sync32(c, ch);
+        O0_ALL(maj, (v[0][r] & v[1][r]) ^ (v[0][r] & v[2][r]) ^ (v[1][r] & v[2][r]));
+        local_sync32(c, maj);
+        const uint32_t ok = sh0_off(m, i, 0), om = sh0_off(m, i, 0); /*   k[i], m[i]                               :78 */
+        O0_ALL(t1, v[7][r] + ep1[r] + ch[r] + (ok < 64u ? SHA_K[ok] : 0u) + (om < 64u ? W[r][om] : 0u));
+        local_sync32(c, t1);
+        O0_ALL(t2, ep0[r] + maj[r]);
+        local_sync32(c, t2);
+#define O0_MOVE(dst, expr)                                                                                     \
+    do {                                                                                                       \
+        O0_ALL(x, (expr));                                                                                     \
+        local_sync32(c, x);                                                                                    \
+        O0_ALL(v[dst], x[r]);                                                                                  \
+    } while (0)
+        O0_MOVE(7, v[6][r]);                                         /*   h = g .. a = t1 + t2                    :80-87 */
+        O0_MOVE(6, v[5][r]);
+        O0_MOVE(5, v[4][r]);
+        O0_MOVE(4, v[3][r] + t1[r]);
+        O0_MOVE(3, v[2][r]);
+        O0_MOVE(2, v[1][r]);
+        O0_MOVE(1, v[0][r]);
+        O0_MOVE(0, t1[r] + t2[r]);
+#undef O0_MOVE
+        O0_ALL(i, i[r] + 1u);
+        local_sync32(c, i);
+    }
+    for (unsigned w = 0; w < 8; ++w) {                               /* ctx_state[w] += ..: stored                :90-97 */
+        uint32_t x[3];
+        O0_ALL(x, st[r][w] + v[w][r]);
+        store_sync32(c, x);
+        for (unsigned r = 0; r < 3; ++r)
+            st[r][w] = x[r];
+    }
+}
+
+static void sha_item_o0(const uint8_t *data, uint32_t len, uint8_t hash[32], sync_ctx *c, const orc_fault *fl, size_t nf)
+{
+    sh0 mm = {c, (c->flags & ORC_F_BRANCH_SYNC) != 0, 0, 0, c->nrep, fl, nf}, *m = &mm;
+    const int as = (c->flags & ORC_F_ADDR_SYNC) != 0;
+    m->ls = as && !(c->flags & ORC_F_NO_LOAD_SYNC);
+    m->ss = as && !(c->flags & ORC_F_NO_STORE_ADDR_SYNC);
+    const int lss = (c->flags & ORC_F_LOCAL_STORE_SYNC) && !(c->flags & ORC_F_NO_STORE_DATA_SYNC);
+    uint32_t st[3][8], ir[3] = {0, 0, 0}, dl[3] = {0, 0, 0}, cnd[3], x[3];
+    uint8_t buf[64];
+    uint32_t bitlen[2] = {0, 0};
+    uint32_t cidx = 0, it = 0;
+    const unsigned R = c->nrep;
+    const uint64_t cap = 4ull * len + 256ull;
+    memset(buf, 0, sizeof buf);
+    for (unsigned r = 0; r < 3; ++r)
+        for (unsigned w = 0; w < 8; ++w)
+            st[r][w] = SHA_IV[w];
+    O0_ALL(x, len);
+    local_sync32(c, x);                                        /* the parameter `len` into its alloca */
+#define O0_BITLEN_ADD(cv)                                      /* DBL_INT_ADD(ctx_bitlen[0], ctx_bitlen[1], cv) :2-5 */ \
+    do {                                                                                                       \
+        const uint32_t carry_ = bitlen[0] > 0xffffffffu - (cv);                                                \
+        O0_ALL(cnd, carry_);                                                                                   \
+        if (sh0_br(m, cnd)) {                                                                                  \
+            ++bitlen[1];                                                                                       \
+            O0_ALL(x, bitlen[1]);                                                                              \
+            local_sync32(c, x);                                                                                \
+        }                                                                                                      \
+        bitlen[0] += (cv);                                                                                     \
+    } while (0)
+    for (;; ++it) {
+        for (size_t q = 0; q < nf; ++q)
+            if (fl[q].step == it && fl[q].replica < R) {
+                if (fl[q].site == ORC_SITE_SHA_I)
+                    ir[fl[q].replica] = flip(ir[fl[q].replica], fl[q].bit, 0xffffffffu);
+                else if (fl[q].site == ORC_SITE_SHA_DATALEN)
+                    dl[fl[q].replica] = flip(dl[fl[q].replica], fl[q].bit, 0xffffffffu);
+            }
+        O0_ALL(cnd, ir[r] < len);
+        if (!sh0_br(m, cnd) || it >= cap)
+            break;                                             /* for (i = 0; i < len; ++i)                    :119 */
+        const uint32_t li = sh0_off(m, ir, 0);                 /* data[i]                                       :120 */
+        const uint8_t byte = li < len ? data[li] : 0;
+        const uint32_t si = sh0_off(m, dl, 1);                 /* ctx_data[ctx_datalen] = ...                   :120 */
+        O0_ALL(x, byte);
+        local_sync32(c, x);
+        if (si < 64)
+            buf[si] = (uint8_t)x[0];
+        O0_ALL(dl, dl[r] + 1u);                                /* ctx_datalen++                                 :121 */
+        local_sync32(c, dl);
+        O0_ALL(cnd, dl[r] == 64u);
+        if (sh0_br(m, cnd)) {                                  /* if (ctx_datalen == 64)                        :122 */
+            sha_state_faults(st, R, cidx, fl, nf);
+            sh0_transform(m, st, buf, cidx);
+            ++cidx;
+            O0_BITLEN_ADD(512u);
+            O0_ALL(x, bitlen[0]);
+            local_sync32(c, x);                                /* the store of a += c                                */
+            O0_ALL(dl, 0u);                                    /* ctx_datalen = 0                               :125 */
+        }
+        O0_ALL(ir, ir[r] + 1u);
+        local_sync32(c, ir);
+    }
+    O0_ALL(ir, dl[r]);                                         /* i = ctx_datalen                               :129 */
+    local_sync32(c, ir);
+    O0_ALL(cnd, dl[r] < 56u);
+    const int shortPad = sh0_br(m, cnd);                       /* if (ctx_datalen < 56)                         :132 */
+    {
+        const uint32_t lim = shortPad ? 56u : 64u;
+        uint32_t o = sh0_off(m, ir, 1);                        /* ctx_data[i++] = 0x80                       :133,137 */
+        if (o < 64)
+            buf[o] = 0x80;
+        O0_ALL(ir, ir[r] + 1u);
+        local_sync32(c, ir);
+        for (uint32_t guard = 0;; ++guard) {                   /* while (i < 56 / 64) ctx_data[i++] = 0x00   :134,138 */
+            O0_ALL(cnd, ir[r] < lim);
+            if (!sh0_br(m, cnd) || guard >= 256u)
+                break;
+            o = sh0_off(m, ir, 1);
+            if (o < 64)
+                buf[o] = 0;
+            O0_ALL(ir, ir[r] + 1u);
+            local_sync32(c, ir);
+        }
+    }
+    if (!shortPad) {
+        sha_state_faults(st, R, cidx, fl, nf);
+        sh0_transform(m, st, buf, cidx);
+        ++cidx;
+        uint32_t n[3] = {56u, 56u, 56u};                       /* the inlined sha_memset(ctx_data, 0, 56)    :143-150 */
+        O0_ALL(x, 0u);
+        local_sync32(c, x);                                    /* c = c & 0xFF                                       */
+        for (uint32_t p = 0;; ++p) {
+            const uint32_t old[3] = {n[0], n[1], n[2]};
+            O0_ALL(n, n[r] - 1u);                              /* while (n--): load, decrement, store, branch        */
+            local_sync32(c, n);
+            O0_ALL(cnd, old[r] != 0u);
+            if (!sh0_br(m, cnd) || p >= 256u)
+                break;
+            O0_ALL(x, 0u);
+            local_sync32(c, x);                                /* *p++ = c: a constant-offset GEP, the stored c       */
+            if (p < 64)
+                buf[p] = 0;
+        }
+    }
+    uint32_t add[3] = {dl[0] * 8u, dl[1] * 8u, dl[2] * 8u};    /* DBL_INT_ADD(..., ctx_datalen * 8)             :150 */
+    {
+        const uint32_t carry = bitlen[0] > 0xffffffffu - add[0];
+        O0_ALL(cnd, bitlen[0] > 0xffffffffu - add[r]);
+        (void)carry;
+        if (sh0_br(m, cnd)) {
+            ++bitlen[1];
+            O0_ALL(x, bitlen[1]);
+            local_sync32(c, x);
+        }
+    }
+    O0_ALL(add, bitlen[0] + add[r]);                           /* a += c: the store of a replicated value (the default schedule's vote) */
+    store_sync32(c, add);
+    bitlen[0] = add[0];
+    for (unsigned b = 0; b < 4; ++b) {                         /* ctx_data[63 - b] = ctx_bitlen[0] >> 8 b ..  :151-158 */
+        O0_ALL(x, (bitlen[0] >> (8 * b)) & 0xffu);
+        local_sync32(c, x);
+        buf[63 - b] = (uint8_t)x[0];
+    }
+    for (unsigned b = 0; b < 4; ++b) {
+        O0_ALL(x, (bitlen[1] >> (8 * b)) & 0xffu);
+        local_sync32(c, x);
+        buf[59 - b] = (uint8_t)x[0];
+    }
+    sha_state_faults(st, R, cidx, fl, nf);
+    sh0_transform(m, st, buf, cidx);
+    ++cidx;
+    sha_state_faults(st, R, cidx, fl, nf);
+    if (!lss)
+        sha_sync_state(c, st);                                 /* the digest: 8 words (the default schedule's exit votes) */
+    memset(hash, 0, 32);
+    O0_ALL(ir, 0u);
+    for (uint32_t guard = 0;; ++guard) {                       /* for (i = 0; i < 4; ++i) hash[i + 4 w] = ..  :164-173 */
+        O0_ALL(cnd, ir[r] < 4u);
+        if (!sh0_br(m, cnd) || guard >= 4u)
+            break;
+        for (unsigned w = 0; w < 8; ++w) {
+            uint32_t idx[3];
+            O0_ALL(idx, ir[r] + 4u * w);
+            const uint32_t o = sh0_off(m, idx, 1);
+            O0_ALL(x, (st[r][w] >> ((24u - ir[r] * 8u) & 31u)) & 0xffu);
+            local_sync32(c, x);                                /* (ORC_F_LOCAL_STORE_SYNC: the digest's 32 byte stores) */
+            if (o < 32)
+                hash[o] = (uint8_t)x[0];
+        }
+        O0_ALL(ir, ir[r] + 1u);
+        local_sync32(c, ir);
+    }
+#undef O0_BITLEN_ADD
+}
+#undef O0_ALL
+
 void orc_sha256_plain(const uint8_t *data, uint32_t len, uint8_t hash[32])
 {
     orc_stats st = {0, 0, 0, 0};
@@ -624,7 +949,9 @@ void orc_sha256_xmr(const uint8_t *msgs, size_t stride, uint32_t len, size_t nms
         while (fe < nfaults && fs[fe].item == m)
             ++fe;
         c.detected = 0;
-        if (cfg->flags & ORC_F_INDEXED) {
+        if ((cfg->flags & ORC_F_INDEXED) && (cfg->flags & ORC_F_O0_SHAPE)) {
+            sha_item_o0(msgs + m * stride, len, digests + 32 * m, &c, fs + fp, fe - fp);
+        } else if (cfg->flags & ORC_F_INDEXED) {
             sha_item_indexed(msgs + m * stride, len, digests + 32 * m, &c, fs + fp, fe - fp);
         } else if (cfg->flags & ORC_F_MEMORY_COPIES) { /* the arrays are `replicas` copies back to back */
             const size_t cin = nmsgs * stride, cout = nmsgs * 32;

@@ -124,7 +124,13 @@ enum {
      * the default schedules do not have -- every store of a computed value into one of the function's own locals (i++, sum += ..:
      * their allocas stay single-copy) and into state[] / key[] / ctx_data[] in place (synchronization.cpp:197-224, 476-561).  With it
      * sync_count = branches + GEP offsets + stores of tools/ir_sync_counts.py.  Off under -noStoreDataSync, like every data vote. */
-    ORC_F_LOCAL_STORE_SYNC = 64u
+    ORC_F_LOCAL_STORE_SYNC = 64u,
+    /* sha256 with ORC_F_BRANCH_SYNC | ORC_F_ADDR_SYNC: the walk in the shape the x86 / lli flow hands the pass -- tests/sha256_common/
+     * Makefile has no OPT_FLAGS, so sha256_hash and sha256_transform arrive as -O0 IR: the padding loops, the output loop and the three
+     * loops of sha256_transform are loops with replica-private counters, every evaluated condition and every variable GEP offset a vote
+     * (3-byte message: 198 branches, 387 load and 152 store offsets; tools/ir_sync_counts.py).  Without it the walk is the post--O3 shape
+     * of the hifive1 flow (byte loop only).  ORC_F_LOCAL_STORE_SYNC adds this shape's 2009 + 116 stores. */
+    ORC_F_O0_SHAPE = 128u
 };
 #define ORC_F_INDEXED (ORC_F_BRANCH_SYNC | ORC_F_ADDR_SYNC)
 

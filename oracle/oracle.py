@@ -115,6 +115,7 @@ def ref_chsha_vectors():
 
 REPLICA_ALL = 255  # include/coast_hip.h COAST_REPLICA_ALL
 F_LOCAL_STORE_SYNC = 64  # ORC_F_LOCAL_STORE_SYNC: with BRANCH_SYNC | ADDR_SYNC, the data votes of the -O0 IR's stores into locals / in-place arrays
+F_O0_SHAPE = 128  # ORC_F_O0_SHAPE: sha256 with BRANCH_SYNC | ADDR_SYNC: the -O0 IR's shape (padding / output / transform loops are loops)
 F_MEMORY_COPIES = 32  # ORC_F_MEMORY_COPIES: arrays are (replicas, n, ...) -- replica r works on copy r, stores are voted into every copy
 
 

@@ -1718,7 +1718,11 @@ def test_sha256_indexed_flags_vs_oracle(eng, orc, length, replicas):
     nm = 45
     msgs = rng.integers(0, 256, (nm, max(length, 4)), dtype=np.uint8)
     B, A, NL, NS = ca.F_BRANCH_SYNC, ca.F_ADDR_SYNC, ca.F_NO_LOAD_SYNC, ca.F_NO_STORE_ADDR_SYNC
-    for flags in (B | A, B, A, A | NL, A | NS, B | A | NL | NS, B | A | ca.F_NO_STORE_DATA_SYNC):
+    # round 4: COAST_F_O0_SHAPE -- the walk as the x86 / lli flow's -O0 IR has it (padding / output / transform loops are loops with voted
+    # counters: 198 / 387 / 152 votes at 3 bytes), alone, with -noLoadSync / -noStoreAddrSync, and with the IR's store-data votes on top
+    O0, L = ca.F_O0_SHAPE, ca.F_LOCAL_STORE_SYNC
+    for flags in (B | A, B, A, A | NL, A | NS, B | A | NL | NS, B | A | ca.F_NO_STORE_DATA_SYNC,
+                  B | A | O0, B | A | O0 | NL, B | A | O0 | NS | ca.F_NO_STORE_DATA_SYNC, B | A | O0 | L):
         exp, exp_st, _ = orc.sha256_xmr(msgs, length, replicas=replicas, flags=flags)
         eng.reset_stats()
         got = _host(eng.sha256_batch(_dev(msgs), length, cfg=ca.XmrConfig(replicas, 0, flags)), np.uint8)

@@ -173,7 +173,7 @@ int main(void) { unsigned char d[255]; for (int i = 0; i < 255; i++) d[i] = (uns
     return run_case(os.path.join(REF, "crc16", "crc16.c"), {"crc16"}, drv, cflags=["-I" + REF], rename={"main": "ref_main"})
 
 
-def sha256(lengths=(0, 3, 64)):
+def sha256(lengths=(0, 3, 64, 56, 119)):
     """tests/sha256_common (OPT_FLAGS empty: the -O0 shape; the hifive1 build of the same source runs -O3 in front of the pass)"""
     drv = r'''
 void sha256_hash(unsigned char ctx_data[], unsigned ctx_bitlen[], unsigned ctx_state[], unsigned char data[], unsigned len, unsigned char hash[]);
