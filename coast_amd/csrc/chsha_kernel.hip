@@ -104,8 +104,10 @@ __device__ __forceinline__ void chsha_transform(uint32_t dg[5], uint32_t W[16], 
         dg[w] += v[w];
 }
 
-// four waves per workgroup, one tile of IPW messages per wave.  Main launch (tileList == nullptr): every tile except those
-// an armed fault points into; side launch: exactly those, with the injector hooks, beside the main one (disjoint messages).
+// four waves per workgroup, one tile of IPW messages per wave, every tile in the one launch.  HOOKS = the launch has armed upsets: a
+// transform that one of them points into takes the hooked (wave-uniform) branch, the digest hooks sit between the transforms; the
+// clean launch is the HOOKS = false instance.  (tileList: a launch over a list of tiles -- rounds 1-3 ran the armed tiles that way,
+// beside the main launch on a side stream.)
 template <int NREP, bool HOOKS>
 __global__ __launch_bounds__(256) void chsha_kernel(const uint8_t *__restrict__ msgs, size_t stride, uint32_t len,
                                                     uint64_t nmsgs, uint64_t ntiles, uint32_t *__restrict__ digests,

@@ -870,6 +870,8 @@ def test_chstone_sha_faults_vs_oracle(eng, orc, replicas, length, stride):
     got = _host(eng.chsha_batch(torch.from_numpy(msgs).cuda(), length, cfg=coast_amd.XmrConfig(replicas), detected=det), np.uint32)
     assert (got == exp).all()
     assert _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all()
+    li = eng.last_launch()  # round 4: the armed tiles are hooked inside the one launch -- no side-stream twin
+    assert li["engine"] == "valu" and li["general_blocks"] == 0 and (li["hooked_blocks"] > 0) == (len(rows) > 0), li
     with pytest.raises(Exception):  # sha_final pads only block-aligned totals
         eng.chsha_batch(torch.from_numpy(msgs).cuda(), 63 if stride >= 63 else 1)
 
