@@ -674,8 +674,12 @@ __global__ __launch_bounds__(kAesRepThreads) __attribute__((amdgpu_waves_per_eu(
         kvO = reinterpret_cast<const uint4 *>(kyBase + (size_t)lmT.r * copyBytes)[it];
     };
     uint4 sv0 = make_uint4(0u, 0u, 0u, 0u), kv0 = sv0;
-    if (tile0 < ntiles)
+    uint2 fr0 = make_uint2(0u, 0u); // the tile's armed upsets (wave-uniform), requested with its blocks: a load per tile in front of a branch otherwise
+    if (tile0 < ntiles) {
         loadTile(tile0, sv0, kv0);
+        if (ft.range)
+            fr0 = ft.range[tile0];
+    }
     { // a wave writes whole rows: lane = (slot r, copy c) -- 64 consecutive dwords, two lanes per bank (free for ds_write_b32)
         const int c = tid & (kAesCopies - 1), r = (tid >> 4) & 3, v0 = (tid >> 6) * 16;
 #pragma unroll
@@ -690,76 +694,64 @@ __global__ __launch_bounds__(kAesRepThreads) __attribute__((amdgpu_waves_per_eu(
     Tally tl;
     uint32_t detItems = 0;
     for (uint64_t tile = tile0; tile < ntiles; tile += (uint64_t)gridDim.x * (kAesRepThreads / kWave)) {
-        const uint2 fr = aes_tile_faults(ft, tile); // this tile's armed upsets (wave-uniform)
+        const uint2 fr = make_uint2(__builtin_amdgcn_readfirstlane(fr0.x), __builtin_amdgcn_readfirstlane(fr0.y)); // this tile's armed upsets
         const LaneMap<NREP> lmT(xmr_fresh_lane());
         const uint4 sv = sv0, kv = kv0; // requested before the tables were filled / behind the previous tile's stores
         uint32_t s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w;
         uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
-        auto rounds = [&](auto hookTag) __attribute__((always_inline)) { // as aes128_enc_fast_kernel, HOOKED included
+        // One formulation for clean and armed tiles (round 4): AddRoundKey of the next round folded into the column sums, x = s ^ k carried.
+        // An armed upset of round rd lands on the registers as they are at that point: a flipped state register is x ^= mask, a flipped key
+        // register x ^= mask and k ^= mask (x holds their xor) -- exact, the same values the separate s / k form produced.  (Rounds 1-3 ran
+        // armed tiles through an unfolded copy of the rounds: 45 % more instructions on one tile of a wave that owns four -- the wave, and with
+        // it the persistent workgroup, finished 11 us late: 59 instead of 47 us per 1 Mi blocks with 1024 armed upsets.)
+        auto rounds = [&](auto hookTag) __attribute__((always_inline)) {
             constexpr bool HOOKED = decltype(hookTag)::value;
             AesLaneFaults lf; // this lane's armed upsets (read once)
             if constexpr (HOOKED)
                 lf = aes_gather_faults((aes_lds_rec_p)(sLf + tid), ft, fr, lmT.q, lmT.r, lmT.live);
-            auto hook = [&](int rd) __attribute__((always_inline)) {
+            uint32_t x0 = 0u, x1 = 0u, x2 = 0u, x3 = 0u;
+            auto hook = [&](int rd, bool folded) __attribute__((always_inline)) {
                 if constexpr (HOOKED) {
                     bool any;
                     const AesDue d = aes_due_masks(lf, ft, fr, (uint32_t)rd, lmT.q, lmT.r, lmT.live, any);
                     if (any) {
-                        s0 ^= d.s0, s1 ^= d.s1, s2 ^= d.s2, s3 ^= d.s3;
+                        if (folded)
+                            x0 ^= d.s0 ^ d.k0, x1 ^= d.s1 ^ d.k1, x2 ^= d.s2 ^ d.k2, x3 ^= d.s3 ^ d.k3;
+                        else
+                            s0 ^= d.s0, s1 ^= d.s1, s2 ^= d.s2, s3 ^= d.s3;
                         k0 ^= d.k0, k1 ^= d.k1, k2 ^= d.k2, k3 ^= d.k3;
                     }
                 }
             };
-            if constexpr (!HOOKED) { // clean tiles: AddRoundKey of the next round folded into the column sums (x = s ^ k carried)
-                uint32_t x0 = s0 ^ k0, x1 = s1 ^ k1, x2 = s2 ^ k2, x3 = s3 ^ k3;
-#pragma unroll
-                for (int rd = 0; rd < 10; ++rd) {
-                    uint32_t a0, a1, a2, a3, d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
-                    if (rd < 9) {
-                        a0 = aes_xor3(TE(0, x0, 0), TE(1, x1, 1), TE(2, x2, 2)), d0 = TE(3, x3, 3);
-                        a1 = aes_xor3(TE(0, x1, 0), TE(1, x2, 1), TE(2, x3, 2)), d1 = TE(3, x0, 3);
-                        a2 = aes_xor3(TE(0, x2, 0), TE(1, x3, 1), TE(2, x0, 2)), d2 = TE(3, x1, 3);
-                        a3 = aes_xor3(TE(0, x3, 0), TE(1, x0, 1), TE(2, x1, 2)), d3 = TE(3, x2, 3);
-                    } else {
-                        a0 = aes_pick_b1(TE(0, x0, 0), TE(0, x1, 1), TE(0, x2, 2), TE(0, x3, 3));
-                        a1 = aes_pick_b1(TE(0, x1, 0), TE(0, x2, 1), TE(0, x3, 2), TE(0, x0, 3));
-                        a2 = aes_pick_b1(TE(0, x2, 0), TE(0, x3, 1), TE(0, x0, 2), TE(0, x1, 3));
-                        a3 = aes_pick_b1(TE(0, x3, 0), TE(0, x0, 1), TE(0, x1, 2), TE(0, x2, 3));
-                    }
-                    const uint32_t sw = aes_pick_b1(TE(0, k3, 1), TE(0, k3, 2), TE(0, k3, 3), TE(0, k3, 0));
-                    k0 = aes_xor3(k0, sw, (uint32_t)kAesRcon[rd]);
-                    k1 ^= k0;
-                    k2 ^= k1;
-                    k3 ^= k2;
-                    if (rd < 9)
-                        x0 = aes_xor3(a0, d0, k0), x1 = aes_xor3(a1, d1, k1), x2 = aes_xor3(a2, d2, k2), x3 = aes_xor3(a3, d3, k3);
-                    else
-                        s0 = a0, s1 = a1, s2 = a2, s3 = a3; // the last AddRoundKey follows the loop
-                }
-                return;
-            }
+            hook(0, false);
+            x0 = s0 ^ k0, x1 = s1 ^ k1, x2 = s2 ^ k2, x3 = s3 ^ k3;
 #pragma unroll
             for (int rd = 0; rd < 10; ++rd) {
-                hook(rd);
-                const uint32_t x0 = s0 ^ k0, x1 = s1 ^ k1, x2 = s2 ^ k2, x3 = s3 ^ k3;
+                if (rd > 0)
+                    hook(rd, true);
+                uint32_t a0, a1, a2, a3, d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
                 if (rd < 9) {
-                    s0 = aes_xor3(TE(0, x0, 0), TE(1, x1, 1), TE(2, x2, 2)) ^ TE(3, x3, 3);
-                    s1 = aes_xor3(TE(0, x1, 0), TE(1, x2, 1), TE(2, x3, 2)) ^ TE(3, x0, 3);
-                    s2 = aes_xor3(TE(0, x2, 0), TE(1, x3, 1), TE(2, x0, 2)) ^ TE(3, x1, 3);
-                    s3 = aes_xor3(TE(0, x3, 0), TE(1, x0, 1), TE(2, x1, 2)) ^ TE(3, x2, 3);
+                    a0 = aes_xor3(TE(0, x0, 0), TE(1, x1, 1), TE(2, x2, 2)), d0 = TE(3, x3, 3);
+                    a1 = aes_xor3(TE(0, x1, 0), TE(1, x2, 1), TE(2, x3, 2)), d1 = TE(3, x0, 3);
+                    a2 = aes_xor3(TE(0, x2, 0), TE(1, x3, 1), TE(2, x0, 2)), d2 = TE(3, x1, 3);
+                    a3 = aes_xor3(TE(0, x3, 0), TE(1, x0, 1), TE(2, x1, 2)), d3 = TE(3, x2, 3);
                 } else {
-                    s0 = aes_pick_b1(TE(0, x0, 0), TE(0, x1, 1), TE(0, x2, 2), TE(0, x3, 3));
-                    s1 = aes_pick_b1(TE(0, x1, 0), TE(0, x2, 1), TE(0, x3, 2), TE(0, x0, 3));
-                    s2 = aes_pick_b1(TE(0, x2, 0), TE(0, x3, 1), TE(0, x0, 2), TE(0, x1, 3));
-                    s3 = aes_pick_b1(TE(0, x3, 0), TE(0, x0, 1), TE(0, x1, 2), TE(0, x2, 3));
+                    a0 = aes_pick_b1(TE(0, x0, 0), TE(0, x1, 1), TE(0, x2, 2), TE(0, x3, 3));
+                    a1 = aes_pick_b1(TE(0, x1, 0), TE(0, x2, 1), TE(0, x3, 2), TE(0, x0, 3));
+                    a2 = aes_pick_b1(TE(0, x2, 0), TE(0, x3, 1), TE(0, x0, 2), TE(0, x1, 3));
+                    a3 = aes_pick_b1(TE(0, x3, 0), TE(0, x0, 1), TE(0, x1, 2), TE(0, x2, 3));
                 }
                 const uint32_t sw = aes_pick_b1(TE(0, k3, 1), TE(0, k3, 2), TE(0, k3, 3), TE(0, k3, 0));
                 k0 = aes_xor3(k0, sw, (uint32_t)kAesRcon[rd]);
                 k1 ^= k0;
                 k2 ^= k1;
                 k3 ^= k2;
+                if (rd < 9)
+                    x0 = aes_xor3(a0, d0, k0), x1 = aes_xor3(a1, d1, k1), x2 = aes_xor3(a2, d2, k2), x3 = aes_xor3(a3, d3, k3);
+                else
+                    s0 = a0, s1 = a1, s2 = a2, s3 = a3; // the last AddRoundKey follows the loop
             }
-            hook(10);
+            hook(10, false);
         };
         if (fr.y != 0u)
             rounds(std::true_type{});
@@ -800,8 +792,11 @@ __global__ __launch_bounds__(kAesRepThreads) __attribute__((amdgpu_waves_per_eu(
         }
         // the next tile (other blocks: the in-place stores above cannot reach them).  Requested HERE, where nothing else is live -- the
         // kernel has 64 registers per lane (two workgroups per CU) and no room to carry a prefetch through the rounds
-        if (tile + (uint64_t)gridDim.x * (kAesRepThreads / kWave) < ntiles)
+        if (tile + (uint64_t)gridDim.x * (kAesRepThreads / kWave) < ntiles) {
             loadTile(tile + (uint64_t)gridDim.x * (kAesRepThreads / kWave), sv0, kv0);
+            if (ft.range)
+                fr0 = ft.range[tile + (uint64_t)gridDim.x * (kAesRepThreads / kWave)];
+        }
     }
 #undef TE
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
@@ -831,8 +826,12 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
         kvO = reinterpret_cast<const uint4 *>(keys + (size_t)lm.r * copyBytes)[it];
     };
     uint4 svN = make_uint4(0u, 0u, 0u, 0u), kvN = svN;
-    if (tile0 < ntiles)
+    uint2 frN = make_uint2(0u, 0u); // the tile's armed upsets (wave-uniform), requested a tile ahead with its blocks
+    if (tile0 < ntiles) {
         loadTile(tile0, svN, kvN);
+        if (ft.range)
+            frN = ft.range[tile0];
+    }
     { // block 0: Td_0..3; block 1: {Tis_0[v], S[v] x 4} pairs in slots 0-1, rsbox[v] x 4 in slot 2.  A wave writes whole rows:
       // lane = (slot r, copy c); in block 1 slot group 0 writes the pairs, group 1 the rsbox dwords
         const int c = tid & (kAesCopies - 1), r = (tid >> 4) & 3, v0 = (tid >> 6) * 16;
@@ -861,13 +860,16 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
     Tally tl;
     uint32_t detItems = 0;
     for (uint64_t tile = tile0; tile < ntiles; tile += tstride) {
-        const uint2 fr = aes_tile_faults(ft, tile); // this tile's armed upsets (wave-uniform)
+        const uint2 fr = make_uint2(__builtin_amdgcn_readfirstlane(frN.x), __builtin_amdgcn_readfirstlane(frN.y)); // this tile's armed upsets
         const uint64_t item = tile * IPW + (uint64_t)lm.q;
         const bool live = lm.live && item < nblocksData;
         const bool cnt = live && lm.r == 0;
         const uint4 sv = svN, kv = kvN;
-        if (tile + tstride < ntiles) // the next tile's blocks are other blocks: the in-place stores below cannot reach them
+        if (tile + tstride < ntiles) { // the next tile's blocks are other blocks: the in-place stores below cannot reach them
             loadTile(tile + tstride, svN, kvN);
+            if (ft.range)
+                frN = ft.range[tile + tstride];
+        }
         uint32_t k0 = kv.x, k1 = kv.y, k2 = kv.z, k3 = kv.w;
         uint32_t x0, x1, x2, x3;
         auto rounds = [&](auto hookTag) __attribute__((always_inline)) { // as aes128_dec_fast_kernel, HOOKED included
