@@ -891,6 +891,29 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
             fastBlocks = nbm;                                                                                   \
             break;                                                                                              \
         }                                                                                                       \
+        if (mfma && mmBlocks && mmBlocks2 && mmBlocks3) { /* DWC / unprotected (round 4): the register-block kernel with four / two sets per step */ \
+            using G2 = MmBlk2<R>;                                                                               \
+            FaultTab ftm = ft;                                                                                  \
+            if (!have)                                                                                          \
+                ftm.list = nullptr, ftm.range = nullptr;                                                        \
+            const uint32_t gridB = 4u * (uint32_t)std::min<uint64_t>((uint64_t)batch, (uint64_t)std::max(1, c->numCUs / 4)); \
+            if (have)                                                                                           \
+                hookedBlocks = nFaultBlocks;                                                                    \
+            if (d_detected && R == 2) {                                                                         \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<R, true>,                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
+                hipLaunchKernelGGL((mm_mfma_blk3_kernel<R, true>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES,  \
+                                   c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);            \
+            } else {                                                                                            \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<R, false>,                     \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
+                hipLaunchKernelGGL((mm_mfma_blk3_kernel<R, false>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
+                                   c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);            \
+            }                                                                                                   \
+            engine = COAST_ENGINE_MATRIX_CORE;                                                                  \
+            fastBlocks = nbm;                                                                                   \
+            break;                                                                                              \
+        }                                                                                                       \
         if (mfma) { /* armed upsets are applied and out-voted inside the panel kernel: no VALU workgroup runs */ \
             using GP = MmPanel<R>;                                                                              \
             static_assert(GP::BPM == 256 / 64, "panel geometry");                                               \

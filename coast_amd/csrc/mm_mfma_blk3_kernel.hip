@@ -28,6 +28,10 @@
 //    One workgroup barrier per step (slot 29), as before; the item hand-over needs none of its own (the next panel is complete
 //    behind the barrier of the item's last step, and its A fragments are read after it).
 //
+// DWC and the unprotected mode run the same kernel (NREP = 2 / 1): 2 NREP sets of ten MFMAs per step, one conversion / background stage per
+// NREP slots, the barrier behind the first half's last slot, the tile end set by set (DWC: replica 0's value is stored, a failed compare flags
+// the element; unprotected: recombine and store).
+//
 // __SYNC_COUNT / TMR_ERROR_CNT: the votes of tiles that do not exist (the first step's look-back, a workgroup without items) are
 // executed on zeroed accumulators and are not counted: `real` is a wave-uniform predicate, not a compensation constant.
 #include <type_traits>
@@ -50,7 +54,10 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                                                                             FaultTab ft, uint8_t *__restrict__ detected)
 {
     using G = MmBlk2<NREP>;
-    static_assert(NREP == 3, "the step's slots are laid out for six sets of ten MFMAs per wave");
+    static_assert(NREP >= 1 && NREP <= 3, "a step = 2 NREP sets of ten MFMAs per wave");
+    // DWC and the unprotected mode (round 4) run the same kernel with four / two sets per step: NS = 20 NREP slots, the conversion and
+    // background stages at the same relative places (one per NREP slots), the barrier in the middle, the tile end set by set.
+    constexpr int NS = 20 * NREP, HALF = NS / 2, NSET = 2 * NREP;
     extern __shared__ __attribute__((aligned(16))) uint8_t smemP[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,10 +197,13 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         bgRaw = bgLoad(1); // the first bg step
         __syncthreads(); // panel 0 and the pairs' slab 0 are complete
 
-        // ---- tile end: 24 stages.  Stage n of a tile's LAST step (n = 0..15, slot 13 + 3 n): sets 0, 1 recombined into teV, set 2
-        // recombined and row block 0 voted and stored, set 3 recombined.  Stage n' of the NEXT step (n' = 0..7, slot 1 + 6 n'): set
-        // 4 recombined, set 5 recombined and row block 1 voted and stored -- through the previous tile's buffer resources.
-        uint32_t teV[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+        // ---- tile end, set by set.  A set's sums are final ten slots after it started in the tile's LAST step; the sets that are through
+        // in time leave behind that step's remaining MFMAs, the others behind the first MFMAs of the NEXT step (through the previous tile's
+        // buffer resources), each before its accumulators restart.  Stage = (set, element row i): recombine; the last replica's set of a
+        // row block also votes and stores.  NREP = 3: sets 0-3 at slot 13 + 3 n of the last step, sets 4, 5 at slot 1 + 6 n' of the next;
+        // NREP = 2: sets 0-2 at slot 10 set + 11 + 2 i, set 3 at 1 + 6 i; NREP = 1: set 0 at 11 + 2 i, set 1 at 1 + 2 i.
+        constexpr int NNEXT = NREP == 1 ? 1 : NREP - 1, NLAST = NSET - NNEXT;
+        uint32_t teV[NREP > 1 ? NREP - 1 : 1][4] = {};
         __amdgpu_buffer_rsrc_t rsRp = rsrcOf(R, false, 0), rsDp = rsRp;
         auto recombine = [&](auto rbTag, auto rrTag, auto iTag) __attribute__((always_inline)) {
             constexpr int rb = decltype(rbTag)::value, rr = decltype(rrTag)::value, i = decltype(iTag)::value;
@@ -203,45 +213,56 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(t) : "v"(t), "v"(acc[rb][rr][0][i]));
             return t;
         };
-        auto voteStore = [&](int g, int voffR, uint32_t real, auto rbTag, auto iTag, uint32_t v2) __attribute__((always_inline)) {
+        auto voteStore = [&](int g, int voffR, uint32_t real, auto rbTag, auto iTag, uint32_t vLast) __attribute__((always_inline)) {
             constexpr int rb = decltype(rbTag)::value, i = decltype(iTag)::value;
-            const uint32_t v0 = teV[0][i], v1 = teV[1][i];
-            const bool e01 = v0 == v1, e02 = v0 == v2;
-            const uint32_t voted = e01 ? v0 : v2; // select(a == b, a, c), synchronization.cpp:934-938
-            agree += (e01 && e02) ? 1u : 0u;
-            nExec += 1u;
-            nReal += real; // __SYNC_COUNT is counted where the vote happens
+            uint32_t voted = vLast;
+            bool same = true;
+            if constexpr (NREP == 3) {
+                const uint32_t v0 = teV[0][i], v1 = teV[1][i];
+                const bool e01 = v0 == v1, e02 = v0 == vLast;
+                voted = e01 ? v0 : vLast; // select(a == b, a, c), synchronization.cpp:934-938
+                same = e01 && e02;
+            } else if constexpr (NREP == 2) {
+                voted = teV[0][i]; // DWC: a compare, replica 0's value is what the original store writes (:1117-1192)
+                same = voted == vLast;
+            }
+            if constexpr (NREP > 1) {
+                agree += same ? 1u : 0u;
+                nExec += 1u;
+                nReal += real; // __SYNC_COUNT is counted where the vote happens
+            }
             const int erow = pnl * G::BM + (2 * H + rb) * 16 + i;
             __builtin_amdgcn_raw_buffer_store_b32(voted, rb == 0 ? rsR : rsRp, voffR, (erow * G::N + tileCol0(g)) * 4, COAST_MM_AUX_R);
-            if constexpr (FLAGS)
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)1, rb == 0 ? rsD : rsDp, (e01 && e02) ? 0x40000000 : (voffR >> 2),
+            if constexpr (FLAGS && NREP > 1)
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)1, rb == 0 ? rsD : rsDp, same ? 0x40000000 : (voffR >> 2),
                                                      erow * G::N + tileCol0(g), 0);
         };
-        // stage n (0..15) of the tile's last step
-        auto teLast = [&](int g, int voffR, auto nTag) __attribute__((always_inline)) {
-            constexpr int n = decltype(nTag)::value, k = n / 4;
-            using I = std::integral_constant<int, n % 4>;
-            using RB0 = std::integral_constant<int, 0>;
-            using RB1 = std::integral_constant<int, 1>;
-            if constexpr (k == 0)
-                teV[0][n % 4] = recombine(RB0{}, std::integral_constant<int, 0>{}, I{});
-            else if constexpr (k == 1)
-                teV[1][n % 4] = recombine(RB0{}, std::integral_constant<int, 1>{}, I{});
-            else if constexpr (k == 2)
-                voteStore(g, voffR, 1u, RB0{}, I{}, recombine(RB0{}, std::integral_constant<int, 2>{}, I{}));
+        auto teStage = [&](int g, int voffR, uint32_t real, auto setTag, auto iTag) __attribute__((always_inline)) {
+            constexpr int set = decltype(setTag)::value, rb = set / NREP, rr = set % NREP;
+            using RB = std::integral_constant<int, rb>;
+            const uint32_t v = recombine(RB{}, std::integral_constant<int, rr>{}, iTag);
+            if constexpr (rr == NREP - 1)
+                voteStore(g, voffR, real, RB{}, iTag, v);
             else
-                teV[0][n % 4] = recombine(RB1{}, std::integral_constant<int, 0>{}, I{});
+                teV[rr][decltype(iTag)::value] = v;
         };
-        // stage n' (0..7) of the step behind it (or of the final flush): g = the step of the tile that ends
-        auto teNext = [&](int g, int voffR, uint32_t real, auto nTag) __attribute__((always_inline)) {
-            constexpr int n = decltype(nTag)::value, k = n / 4;
-            using I = std::integral_constant<int, n % 4>;
-            using RB1 = std::integral_constant<int, 1>;
-            if constexpr (k == 0)
-                teV[1][n % 4] = recombine(RB1{}, std::integral_constant<int, 1>{}, I{});
-            else
-                voteStore(g, voffR, real, RB1{}, I{}, recombine(RB1{}, std::integral_constant<int, 2>{}, I{}));
+        // the stage of slot m of the tile's last step / of the step behind it (or of the final flush), if any
+        auto teLast = [&](int g, int voffR, auto mTag) __attribute__((always_inline)) {
+            constexpr int m = decltype(mTag)::value;
+            if constexpr (NREP == 3) {
+                if constexpr (m >= 13 && m % 3 == 1)
+                    teStage(g, voffR, 1u, std::integral_constant<int, (m - 13) / 12>{}, std::integral_constant<int, ((m - 13) / 3) % 4>{});
+            } else {
+                constexpr int set = (m - 11) / 10, off = m - 11 - 10 * set;
+                if constexpr (m >= 11 && set < NLAST && off < 8 && off % 2 == 0)
+                    teStage(g, voffR, 1u, std::integral_constant<int, set>{}, std::integral_constant<int, off / 2>{});
+            }
         };
+        auto teNext = [&](int g, int voffR, uint32_t real, auto nTag) __attribute__((always_inline)) { // stage n' = 0 .. 4 NNEXT - 1
+            constexpr int n = decltype(nTag)::value;
+            teStage(g, voffR, real, std::integral_constant<int, NLAST + n / 4>{}, std::integral_constant<int, n % 4>{});
+        };
+        constexpr int kNextStride = NREP == 1 ? 2 : 6; // slots between the stages of the next step
 
         uint32_t fFirst = 0, fCount = 0;
         // ---- injector hook: the consequence of an armed upset on the replica's word is an additive constant (everything downstream
@@ -413,7 +434,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             const v4i_t zero = {0, 0, 0, 0};
             auto slot = [&](auto mTag) __attribute__((always_inline)) {
                 constexpr int m = decltype(mTag)::value;
-                constexpr int set = m / 10, j = m % 10, rb = set / 3, rr = set % 3;
+                constexpr int set = m / 10, j = m % 10, rb = set / NREP, rr = set % NREP;
                 constexpr int p = j < 4 ? 0 : j < 7 ? 1 : j < 9 ? 2 : 3;
                 constexpr int jj = j - (p == 0 ? 0 : p == 1 ? 4 : p == 2 ? 7 : 9);
                 constexpr int q = 3 - p - jj;
@@ -421,41 +442,45 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 if constexpr (j == 0 && set != 0)
                     asm volatile("" : "+v"(offA)); // this set's A fragments are its own loads
                 acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[p], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
-                if constexpr (jj == 3 - p && !((COAST_MM3_KNOCK & 1) && set % 3 != 2)) { // last use of a[p] in this set: the next set's (the next step's first set behind set 5)
-                    if constexpr (set == 5) {
+                if constexpr (jj == 3 - p && !((COAST_MM3_KNOCK & 1) && set % NREP != NREP - 1)) { // last use of a[p] in this set: the next set's (the next step's first set behind the last)
+                    if constexpr (set == NSET - 1) {
                         if constexpr (p == 0)
                             asm volatile("" : "+v"(offAnext));
                         loadA(std::integral_constant<int, p>{}, 0, offAnext);
                     } else {
                         if constexpr (p == 0)
                             asm volatile("" : "+v"(offA));
-                        loadA(std::integral_constant<int, p>{}, (set + 1) / 3, offA);
+                        loadA(std::integral_constant<int, p>{}, (set + 1) / NREP, offA);
                     }
                 }
-                if constexpr (m == 29 && !(COAST_MM3_KNOCK & 2))
-                    __syncthreads(); // the workgroup's one barrier per step: slab g + 1 is complete, slab g's buffer is free
                 if constexpr (rb == 1 && jj == 0) { // last use of b[rr][3 - p] in this step
                     if constexpr (p == 0)
                         asm volatile("" : "+v"(offB));
                     loadB(std::integral_constant<int, rr>{}, std::integral_constant<int, 3 - p>{}, bufNext);
                 }
-                if constexpr (DUTY && m < 30 && m % 3 == 0) // second staging round (stages 10..19) of slab g + 1
-                    convStage(std::integral_constant<int, 10 + m / 3>{});
-                if constexpr (!DUTY && m >= 30 && m % 3 == 0) // first staging round (stages 0..9) of slab g + 2
-                    convStage(std::integral_constant<int, (m - 30) / 3>{});
-                if constexpr (DUTY && m % 6 == 5 && m < 24) // round 0's registers: free since the previous step's slot 48
-                    pbs[0][m / 6] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + (m / 6) * G::N * 4, soffLoad, 0);
-                if constexpr (DUTY && m % 6 == 5 && m >= 30 && m < 54) // round 1's: free after stage 16 (slot 18)
-                    pbs[1][(m - 30) / 6] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + ((m - 30) / 6) * G::N * 4, soffLoad + kRoundOff, 0);
-                if constexpr (BG && (m / 30 == (DUTY ? 1 : 0)) && (m % 30) % 6 == 2)
-                    bgStage(std::integral_constant<int, (m % 30) / 6>{});
-                if constexpr (POS == 3 && m >= 13 && m % 3 == 1)
-                    teLast(g, voffR, std::integral_constant<int, (m - 13) / 3>{});
-                if constexpr (FIRST != 0 && m % 6 == 1 && m < 48)
-                    teNext(g - 1, voffR, realPrev, std::integral_constant<int, m / 6>{});
+                // (slot numbers of the TMR step, NREP = 3: one stage per three slots; DWC / unprotected: per two / one)
+                if constexpr (DUTY && m < HALF && m % NREP == 0) // second staging round (stages 10..19) of slab g + 1
+                    convStage(std::integral_constant<int, 10 + m / NREP>{});
+                if constexpr (!DUTY && m >= HALF && (m - HALF) % NREP == 0) // first staging round (stages 0..9) of slab g + 2
+                    convStage(std::integral_constant<int, (m - HALF) / NREP>{});
+                if constexpr (DUTY && m % (2 * NREP) == 2 * NREP - 1 && m < 8 * NREP) // round 0's registers: free since the previous step's second half
+                    pbs[0][m / (2 * NREP)] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + (m / (2 * NREP)) * G::N * 4, soffLoad, 0);
+                if constexpr (DUTY && m % (2 * NREP) == 2 * NREP - 1 && m >= HALF && m < HALF + 8 * NREP) // round 1's: free after stage 16
+                    pbs[1][(m - HALF) / (2 * NREP)] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + ((m - HALF) / (2 * NREP)) * G::N * 4, soffLoad + kRoundOff, 0);
+                if constexpr (BG && (m / HALF == (DUTY ? 1 : 0)) && (m % HALF) % (2 * NREP) == (NREP == 1 ? 0 : 2))
+                    bgStage(std::integral_constant<int, (m % HALF) / (2 * NREP)>{});
+                if constexpr (POS == 3)
+                    teLast(g, voffR, mTag);
+                if constexpr (FIRST != 0 && m % kNextStride == 1 && m / kNextStride < 4 * NNEXT)
+                    teNext(g - 1, voffR, realPrev, std::integral_constant<int, m / kNextStride>{});
+                // the workgroup's one barrier per step, behind the last slot of the first half (and behind the conversion stage that slot may
+                // carry: NREP = 1 has one in every slot): slab g + 1 is complete, slab g's buffer is free; the B fragments of slab g + 1 are
+                // read from the next slot on
+                if constexpr (m == HALF - 1 && !(COAST_MM3_KNOCK & 2))
+                    __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
             };
-            for_each_index(std::make_integer_sequence<int, 60>{}, slot);
+            for_each_index(std::make_integer_sequence<int, NS>{}, slot);
         };
 
         using T0 = std::integral_constant<int, 0>;
@@ -495,7 +520,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         }
         { // the last tile's last eight stages: nothing left to hide them behind
             const int voffR = voffRof();
-            for_each_index(std::make_integer_sequence<int, 8>{}, [&](auto nTag) __attribute__((always_inline)) { teNext(gLast, voffR, anyTile, nTag); });
+            for_each_index(std::make_integer_sequence<int, 4 * NNEXT>{}, [&](auto nTag) __attribute__((always_inline)) { teNext(gLast, voffR, anyTile, nTag); });
         }
 
         __syncthreads();
@@ -503,7 +528,9 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         if (tid < 4)
             sCnt[tid] = 0;
         __syncthreads();
-        block_tally(nExec - agree, nReal, detItems, sCnt, ctr, blockIdx.x);
+        // TMR: TMR_ERROR_CNT = the votes whose copies were not all equal; DWC: every element is an item with one compare -- a failed one is
+        // a detected item; __SYNC_COUNT = the votes of tiles that exist (none in the unprotected mode)
+        block_tally(NREP == 3 ? nExec - agree : 0u, nReal, NREP == 2 ? detItems + (nExec - agree) : 0u, sCnt, ctr, blockIdx.x);
     };
     if (wv >= G::NLANE)
         run(std::integral_constant<int, 1>{});

@@ -2516,6 +2516,46 @@ def test_campaign_chaes(eng):
     assert m["errors"] == 0 and m["faults"] > 500
 
 
+@pytest.mark.parametrize("replicas", [2, 1])
+@pytest.mark.parametrize("batch", [1, 3, 64, 65, 130])
+def test_mm_256_register_block_kernel_dwc_and_unprotected(eng, orc, batch, replicas, monkeypatch):
+    """round 4: DWC and the unprotected mode run the register-block kernel too (mm_mfma_blk3_kernel<2 / 1>: four / two sets of ten MFMAs per
+    step).  Outputs, counters and per-item flags equal the lane-replica kernel's (COAST_MM_TILE=lanes) word for word, clean and under
+    upsets, for batches that leave panel groups empty or give a workgroup several items; a sparse sample equals the oracle."""
+    import torch
+
+    import coast_amd as ca
+
+    n = 256
+    g = torch.Generator(device="cuda").manual_seed(100 * replicas + batch)
+    f = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device="cuda", generator=g)
+    s = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device="cuda", generator=g)
+    rng = np.random.default_rng(batch + replicas)
+    items = np.unique(np.concatenate([rng.integers(0, batch * n * n, 40), [0, batch * n * n - 1]]))
+    rows = [(int(it), int(rng.integers(0, replicas)), int(rng.integers(0, 3)), int(rng.integers(0, n + 1)), int(rng.integers(0, 32)))
+            for it in items] if replicas > 1 else []
+    fl = ca.make_faults(rows)
+    out = {}
+    for tile in ("default", "lanes"):
+        if tile == "lanes":
+            monkeypatch.setenv("COAST_MM_TILE", "lanes")
+        det = torch.zeros(batch * n * n, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        if len(rows):
+            eng.inject_faults(fl)
+        r = eng.mm_batch(f, s, cfg=ca.XmrConfig(replicas), detected=det)
+        li = eng.last_launch()
+        assert li["engine"] == "matrix_core" and li["general_blocks"] == 0, li
+        out[tile] = (r.clone(), _stats3(eng.stats()), det.clone())
+    assert torch.equal(out["default"][0], out["lanes"][0]) and out["default"][1] == out["lanes"][1]
+    assert torch.equal(out["default"][2], out["lanes"][2])
+    if replicas == 2:
+        assert out["default"][1]["sync_count"] == batch * n * n and out["default"][1]["dwc_detected"] > 0
+    fh, sh = f.cpu().numpy().view(np.uint32), s.cpu().numpy().view(np.uint32)
+    want, _, _ = orc.mm_xmr_items(fh, sh, items, replicas=replicas, faults=fl if len(rows) else None)
+    assert (out["default"][0].cpu().numpy().view(np.uint32).reshape(-1)[items.astype(np.int64)] == want).all()
+
+
 @pytest.mark.parametrize("tile", ["blocks3", "blocks2", "blocks"])
 @pytest.mark.parametrize("batch", [1, 2, 5, 63, 64, 65, 130, 200])
 def test_mm_256_register_block_kernel_batch_shapes(eng, orc, batch, tile, monkeypatch):

@@ -47,7 +47,10 @@ def main():
             cfg = coast_amd.XmrConfig(rep)
             mn, av = timeit(lambda: eng.mm_batch(f, s, out=r, cfg=cfg))
             res["mm256_rep%d" % rep] = {"ms": mn, "elems_per_s": batch * n * n / mn * 1e3,
-                                        "TMAC_alg": batch * n**3 / mn * 1e-9}
+                                        "TMAC_alg": batch * n**3 / mn * 1e-9,
+                                        # the replica count's own int8 work (ten limb products per MAC and replica) against 5.0 POP/s
+                                        "frac_of_int8_peak": 2.0 * batch * n**3 * 10 * rep / (mn * 1e-3) / 5.0e15,
+                                        "tile": os.environ.get("COAST_MM_TILE", "default")}
             del f, s, r
     if want("sha"):
         nm = 1 << 22
