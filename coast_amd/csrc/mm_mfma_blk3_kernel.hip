@@ -40,9 +40,18 @@
 #include "xmr.hpp"
 
 // development: timing experiments (1: the replicas of a row block share one A fragment set, as in mm_mfma_blk2_kernel -- results
-// still right; 2: no per-step barrier -- results wrong)
+// still right; 2: no per-step barrier; 4: no r stores; 8: no tile end at all; 16: no s conversion arithmetic / stores; 32: no MFMAs;
+// 64: no background f piece; 128: no s loads; 256: no fragment reads behind the first; 512: fragment reads of fixed data; 1024: no B
+// reloads; 2048: no A reloads -- results wrong from 2 on.  CAREFUL: without the tile end (8) the accumulators are dead and the MFMAs go with
+// them; without A reloads (256, 2048) both row blocks multiply the same registers and the compiler keeps one of them -- those builds time
+// less work than they name (profiles/r04_mm_knockouts.txt))
 #ifndef COAST_MM3_KNOCK
 #define COAST_MM3_KNOCK 0
+#endif
+// two A fragment sets: a set's four A fragments are requested a whole set (ten MFMAs) ahead, into the other buffer (0: one set, re-read behind
+// each fragment's last use).  1.4 % faster (7.10 -> 7.00 ms, profiles/r04_mm_ab.txt) and the allocator fits it: 256 VGPRs, 1 spill outside the steps.
+#ifndef COAST_MM3_ABUF
+#define COAST_MM3_ABUF 1
 #endif
 
 namespace coast {
@@ -232,7 +241,8 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 nReal += real; // __SYNC_COUNT is counted where the vote happens
             }
             const int erow = pnl * G::BM + (2 * H + rb) * 16 + i;
-            __builtin_amdgcn_raw_buffer_store_b32(voted, rb == 0 ? rsR : rsRp, voffR, (erow * G::N + tileCol0(g)) * 4, COAST_MM_AUX_R);
+            if constexpr (!(COAST_MM3_KNOCK & 4))
+                __builtin_amdgcn_raw_buffer_store_b32(voted, rb == 0 ? rsR : rsRp, voffR, (erow * G::N + tileCol0(g)) * 4, COAST_MM_AUX_R);
             if constexpr (FLAGS && NREP > 1)
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)1, rb == 0 ? rsD : rsDp, same ? 0x40000000 : (voffR >> 2),
                                                      erow * G::N + tileCol0(g), 0);
@@ -346,15 +356,26 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         // ten -- A plane p = 0..3 against B planes q = 3 - p .. 0.  a[p] is re-read behind its last use in the set, for the NEXT set
         // (same row block and address for the next replica: the load is the replicated instruction); b[rr][q] is re-read behind its
         // last use in the second row block, from the other slab buffer.
-        v4i_t a[4], b[NREP][4];
+        constexpr bool ABUF = COAST_MM3_ABUF != 0;
+        v4i_t a[ABUF ? 2 : 1][4], b[NREP][4];
         int offA = panelOff(0), offB = bOff;
         auto loadA = [&](auto pTag, int rbl, int off) __attribute__((always_inline)) {
             constexpr int p = decltype(pTag)::value;
-            a[p] = *reinterpret_cast<const v4i_t *>(smemP + off + p * G::PLANE_A + (2 * H + rbl) * 16 * G::N);
+            if constexpr (COAST_MM3_KNOCK & 512) // timing: the read is issued and awaited, but always of the same 16 bytes per lane
+                a[0][p] = *reinterpret_cast<const v4i_t *>(smemP + (off & 0) + aOff + p * G::PLANE_A);
+            else
+                a[0][p] = *reinterpret_cast<const v4i_t *>(smemP + off + p * G::PLANE_A + (2 * H + rbl) * 16 * G::N);
+        };
+        auto loadA2 = [&](auto bufTag, auto pTag, int rbl, int off) __attribute__((always_inline)) {
+            constexpr int p = decltype(pTag)::value, bf = decltype(bufTag)::value;
+            a[ABUF ? bf : 0][p] = *reinterpret_cast<const v4i_t *>(smemP + off + p * G::PLANE_A + (2 * H + rbl) * 16 * G::N);
         };
         auto loadB = [&](auto rrTag, auto qTag, int bufOff) __attribute__((always_inline)) {
             constexpr int rr = decltype(rrTag)::value, q = decltype(qTag)::value;
-            b[rr][q] = *reinterpret_cast<const v4i_t *>(smemP + bufOff + offB + q * G::PLANE_B);
+            if constexpr (COAST_MM3_KNOCK & 512)
+                b[rr][q] = *reinterpret_cast<const v4i_t *>(smemP + (bufOff & 0) + kSlabBase + offB + q * G::PLANE_B);
+            else
+                b[rr][q] = *reinterpret_cast<const v4i_t *>(smemP + bufOff + offB + q * G::PLANE_B);
         };
         for_each_index(std::make_integer_sequence<int, 4>{}, [&](auto pTag) __attribute__((always_inline)) { loadA(pTag, 0, offA); });
         for_each_index(std::make_integer_sequence<int, NREP>{}, [&](auto rrTag) __attribute__((always_inline)) {
@@ -441,8 +462,20 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 constexpr bool fromZero = FIRST != 0 && p == 0;
                 if constexpr (j == 0 && set != 0)
                     asm volatile("" : "+v"(offA)); // this set's A fragments are its own loads
-                acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[p], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
-                if constexpr (jj == 3 - p && !((COAST_MM3_KNOCK & 1) && set % NREP != NREP - 1)) { // last use of a[p] in this set: the next set's (the next step's first set behind the last)
+                if constexpr (!(COAST_MM3_KNOCK & 32))
+                    acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ABUF ? set & 1 : 0][p], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
+                if constexpr (ABUF && j < 4) { // the NEXT set's fragment j, into the other buffer: a whole set ahead of its first use
+                    if constexpr (set == NSET - 1) {
+                        if constexpr (j == 0)
+                            asm volatile("" : "+v"(offAnext));
+                        loadA2(std::integral_constant<int, (set + 1) & 1>{}, std::integral_constant<int, j>{}, 0, offAnext);
+                    } else {
+                        if constexpr (j == 0)
+                            asm volatile("" : "+v"(offA));
+                        loadA2(std::integral_constant<int, (set + 1) & 1>{}, std::integral_constant<int, j>{}, (set + 1) / NREP, offA);
+                    }
+                }
+                if constexpr (!ABUF && jj == 3 - p && !((COAST_MM3_KNOCK & 1) && set % NREP != NREP - 1) && !(COAST_MM3_KNOCK & (256 | 2048))) { // last use of a[p] in this set: the next set's (the next step's first set behind the last)
                     if constexpr (set == NSET - 1) {
                         if constexpr (p == 0)
                             asm volatile("" : "+v"(offAnext));
@@ -453,25 +486,25 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                         loadA(std::integral_constant<int, p>{}, (set + 1) / NREP, offA);
                     }
                 }
-                if constexpr (rb == 1 && jj == 0) { // last use of b[rr][3 - p] in this step
+                if constexpr (rb == 1 && jj == 0 && !(COAST_MM3_KNOCK & (256 | 1024))) { // last use of b[rr][3 - p] in this step
                     if constexpr (p == 0)
                         asm volatile("" : "+v"(offB));
                     loadB(std::integral_constant<int, rr>{}, std::integral_constant<int, 3 - p>{}, bufNext);
                 }
                 // (slot numbers of the TMR step, NREP = 3: one stage per three slots; DWC / unprotected: per two / one)
-                if constexpr (DUTY && m < HALF && m % NREP == 0) // second staging round (stages 10..19) of slab g + 1
+                if constexpr (DUTY && m < HALF && m % NREP == 0 && !(COAST_MM3_KNOCK & 16)) // second staging round (stages 10..19) of slab g + 1
                     convStage(std::integral_constant<int, 10 + m / NREP>{});
-                if constexpr (!DUTY && m >= HALF && (m - HALF) % NREP == 0) // first staging round (stages 0..9) of slab g + 2
+                if constexpr (!DUTY && m >= HALF && (m - HALF) % NREP == 0 && !(COAST_MM3_KNOCK & 16)) // first staging round (stages 0..9) of slab g + 2
                     convStage(std::integral_constant<int, (m - HALF) / NREP>{});
-                if constexpr (DUTY && m % (2 * NREP) == 2 * NREP - 1 && m < 8 * NREP) // round 0's registers: free since the previous step's second half
+                if constexpr (DUTY && m % (2 * NREP) == 2 * NREP - 1 && m < 8 * NREP && !(COAST_MM3_KNOCK & 128)) // round 0's registers: free since the previous step's second half
                     pbs[0][m / (2 * NREP)] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + (m / (2 * NREP)) * G::N * 4, soffLoad, 0);
-                if constexpr (DUTY && m % (2 * NREP) == 2 * NREP - 1 && m >= HALF && m < HALF + 8 * NREP) // round 1's: free after stage 16
+                if constexpr (DUTY && m % (2 * NREP) == 2 * NREP - 1 && m >= HALF && m < HALF + 8 * NREP && !(COAST_MM3_KNOCK & 128)) // round 1's: free after stage 16
                     pbs[1][(m - HALF) / (2 * NREP)] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + ((m - HALF) / (2 * NREP)) * G::N * 4, soffLoad + kRoundOff, 0);
-                if constexpr (BG && (m / HALF == (DUTY ? 1 : 0)) && (m % HALF) % (2 * NREP) == (NREP == 1 ? 0 : 2))
+                if constexpr (BG && (m / HALF == (DUTY ? 1 : 0)) && (m % HALF) % (2 * NREP) == (NREP == 1 ? 0 : 2) && !(COAST_MM3_KNOCK & 64))
                     bgStage(std::integral_constant<int, (m % HALF) / (2 * NREP)>{});
-                if constexpr (POS == 3)
+                if constexpr (POS == 3 && !(COAST_MM3_KNOCK & 8))
                     teLast(g, voffR, mTag);
-                if constexpr (FIRST != 0 && m % kNextStride == 1 && m / kNextStride < 4 * NNEXT)
+                if constexpr (FIRST != 0 && m % kNextStride == 1 && m / kNextStride < 4 * NNEXT && !(COAST_MM3_KNOCK & 8))
                     teNext(g - 1, voffR, realPrev, std::integral_constant<int, m / kNextStride>{});
                 // the workgroup's one barrier per step, behind the last slot of the first half (and behind the conversion stage that slot may
                 // carry: NREP = 1 has one in every slot): slab g + 1 is complete, slab g's buffer is free; the B fragments of slab g + 1 are
