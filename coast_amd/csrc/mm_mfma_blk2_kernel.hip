@@ -153,10 +153,8 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
     // row blocks the accumulators stand for); a wave takes its branch once.
     auto run = [&](auto hTag) __attribute__((always_inline)) {
         constexpr int H = decltype(hTag)::value;
-        Tally tl;
-        // every lane executes exactly four votes on a tile that does not exist (the first step's look-back at zeroed accumulators;
-        // in a workgroup without an item, the final flush): they are the only votes not in the schedule
-        tl.syncs = 0u - 4u;
+        Tally tl; // votes of a tile that does not exist (the first step's look-back at zeroed accumulators; in a workgroup without an
+                  // item, the final flush) are executed but not counted: `real` is a wave-uniform predicate (no compensation constant)
         uint32_t detItems = 0;
         v4i_t acc[2][NREP][4]; // row blocks 2 H and 2 H + 1
 #pragma unroll
@@ -204,7 +202,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
         // ---- tile end (branch-free, see mm_mfma_blk_kernel): this wave's two row blocks
         uint32_t teV[3], teVoted = 0u, teMiss = 0u;
         __amdgpu_buffer_rsrc_t rsRp = rsrcOf(R, false, 0), rsDp = rsRp; // where the previous tile's second row block goes (nowhere before the first tile)
-        auto teStage = [&](int g, int voffR, auto rbTag, auto kTag) __attribute__((always_inline)) {
+        auto teStage = [&](int g, int voffR, uint32_t real, auto rbTag, auto kTag) __attribute__((always_inline)) {
             constexpr int rb = decltype(rbTag)::value, k = decltype(kTag)::value;
             constexpr int i = k / 5, sub = k % 5;
             if constexpr (sub < 3) {
@@ -215,7 +213,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
                 const bool e01 = teV[0] == teV[1], e02 = teV[0] == teV[2];
                 teVoted = (NREP == 3 && !e01) ? teV[2] : teV[0];
                 teMiss = (e01 && e02) ? 0u : 1u;
-                tl.syncs += 1u; // __SYNC_COUNT is counted where the vote happens: a tile whose vote were skipped would be missed
+                tl.syncs += real; // __SYNC_COUNT is counted where the vote of a tile that exists happens
                 if (NREP == 3)
                     tl.miss += teMiss;
                 else
@@ -227,10 +225,10 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
                     __builtin_amdgcn_raw_buffer_store_b8((uint8_t)1, rb == 0 ? rsD : rsDp, teMiss ? (voffR >> 2) : 0x40000000, erow * G::N + tileCol0(g), 0);
             }
         };
-        auto flushTile = [&](int g) __attribute__((always_inline)) {
+        auto flushTile = [&](int g, uint32_t real) __attribute__((always_inline)) {
             const int voffR = voffRof();
             for_each_index(std::make_integer_sequence<int, 20>{}, [&](auto kTag) __attribute__((always_inline)) {
-                teStage(g, voffR, std::integral_constant<int, 1>{}, kTag); // the first row block's went out inside the last step
+                teStage(g, voffR, real, std::integral_constant<int, 1>{}, kTag); // the first row block's went out inside the last step
             });
         };
 
@@ -428,9 +426,9 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
                 if constexpr (!DUTY && (m & 3) == 0 && m < 20)
                     bgStage(std::integral_constant<int, m / 4>{});
                 if constexpr (POS == 3 && m >= 30 && (m - 30) % 3 != 2) // last slab: the first row block's sums are final after slot 29
-                    teStage(g, voffR, std::integral_constant<int, 0>{}, std::integral_constant<int, (m - 30) - (m - 30) / 3>{});
+                    teStage(g, voffR, 1u, std::integral_constant<int, 0>{}, std::integral_constant<int, (m - 30) - (m - 30) / 3>{});
                 if constexpr (FIRST != 0 && m < 30 && m % 3 != 1) // the previous tile's second row block, before slot 30 restarts its sums
-                    teStage(g - 1, voffR, std::integral_constant<int, 1>{}, std::integral_constant<int, m - (m + 2) / 3>{});
+                    teStage(g - 1, voffR, g != 0 ? 1u : 0u, std::integral_constant<int, 1>{}, std::integral_constant<int, m - (m + 2) / 3>{});
                 __builtin_amdgcn_sched_barrier(0);
             };
             for_each_index(std::make_integer_sequence<int, 60>{}, slot);
@@ -441,6 +439,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
         using T2 = std::integral_constant<int, 2>;
         using T3 = std::integral_constant<int, 3>;
         int gLast = 3;
+        uint32_t anyTile = 0u;
 #pragma unroll 1
         for (int item = 0; matOf(item) < nblocks; ++item) {
             const uint32_t mat = matOf(item);
@@ -469,9 +468,10 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
                     tileHook(g0);
                 step(g0 + 3, T0{}, T3{}); // + this tile's first row block
                 gLast = g0 + 3;
+                anyTile = 1u;
             }
         }
-        flushTile(gLast); // the last tile's second row block: nothing left to hide it behind
+        flushTile(gLast, anyTile); // the last tile's second row block: nothing left to hide it behind
 
         __syncthreads();
         uint32_t *sCnt = reinterpret_cast<uint32_t *>(smemP + 2 * G::A_PANEL);
