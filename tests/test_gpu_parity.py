@@ -580,7 +580,7 @@ def test_campaign_physical_register_model_mm256(eng, tmp_path, tile, monkeypatch
     assert common_runs > 40 and common >= 0.9 * common_runs, by   # (a flip can hit an operand whose product it does not change)
     assert summ["coverage_pct_upper"] < 95.0 and summ["coverage_pct_lower"] < summ["coverage_pct_upper"]
     if tile == "blocks3":
-        assert summ["coverage_pct_upper"] > 85.0 and summ["coverage_pct_lower"] > 60.0, summ
+        assert summ["coverage_pct_upper"] > 84.0 and summ["coverage_pct_lower"] > 57.0, summ  # (expected 89 / 66 at 600 runs; r04_campaign_physical.txt: 89.4 / 65.9 at 2 x 5000)
     assert summ["TMR_ERROR_CNT"] > 0 and summ["errors"] == common
 
 # ------------------------------------------------------------------------------------------------ lean kernels vote on real disagreement
