@@ -2028,7 +2028,7 @@ def test_indexed_flags_are_rejected_where_not_implemented(eng):
         eng.crc16_batch(torch.zeros(512, dtype=torch.uint8, device="cuda"), 256, cfg=ca.XmrConfig(3, 0, ca.F_BRANCH_SYNC))
 
 
-def test_dropin_counters_in_sor_env():
+def test_dropin_counters_in_sor_env(orc):
     """COAST_COUNTERS_IN_SOR=1: the unmodified C program's matrix_multiply() / crc16() / sha256_hash() run with their loop counters replicated and
     the reference's -noMemReplication votes on them; -noLoadSync / -noStoreAddrSync of COAST_OPT_PASSES then change __SYNC_COUNT."""
     import os
@@ -2038,10 +2038,12 @@ def test_dropin_counters_in_sor_env():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "examples", "host_c_demo")
 
-    def syncs(passes, sor):
+    def syncs(passes, sor, sha_o0=False):
         env = dict(os.environ, COAST_OPT_PASSES=passes)
         if sor:
-            env["COAST_COUNTERS_IN_SOR"] = "1"
+            env["COAST_COUNTERS_IN_SOR"] = str(int(sor))
+        if sha_o0:
+            env["COAST_SHA256_O0"] = "1"
         p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0 and "result: 5ba3" in p.stdout and "E:0" in p.stdout, (p.stdout, p.stderr)
         return int(re.search(r"syncs: (\d+)", p.stdout).group(1))
@@ -2054,6 +2056,15 @@ def test_dropin_counters_in_sor_env():
     # matrix_multiply at side 4 (round 3): + (N+1)(N^2+N+1) = 105 loop conditions, 4 N^3 = 256 load offsets, 2 N^2 = 32 store offsets
     assert full == base + 14 + 16 + 105 + 256 + 32
     assert nl == full - 3 - 256 and ns == full - 4 - 32
+    # round 4.  COAST_COUNTERS_IN_SOR=2 adds the -O0 IR's store-data votes (COAST_F_LOCAL_STORE_SYNC): crc16 4 x 13 + 2, matrix_multiply at
+    # side 4 N + N^2 + 2 N^3; sha256_hash keeps the post--O3 walk (no -O0 store census) unless COAST_SHA256_O0=1 selects the -O0 shape
+    assert syncs("-TMR -noMemReplication", 2) == full + (4 * 13 + 2) + (4 + 16 + 2 * 64)
+    abc = np.frombuffer(b"abc", dtype=np.uint8)[None].copy()
+    B, A, L, O0 = 2, 4, 64, 128
+    sha = lambda fl: orc.sha256_xmr(abc, 3, replicas=3, flags=fl)[1]["sync_count"]  # noqa: E731
+    assert syncs("-TMR -noMemReplication", 1, sha_o0=True) == full + sha(B | A | O0) - sha(B | A)
+    assert syncs("-TMR -noMemReplication", 2, sha_o0=True) == full + (4 * 13 + 2) + (4 + 16 + 2 * 64) + sha(B | A | O0 | L) - sha(B | A)
+    assert sha(B | A | O0 | L) == 2862  # the reference's -O0 IR of sha256_hash + sha256_transform on 3 bytes (tests/test_ir_counts_cpu.py)
 
 
 # ------------------------------------------------------------------------------------------------ campaign front-end
