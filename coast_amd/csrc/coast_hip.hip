@@ -147,7 +147,7 @@ int check_cfg(coast_ctx *ctx, const coast_cfg *cfg, bool indexedOk = false, bool
     }
     if ((cfg->flags & indexed) && !indexedOk)
         return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC are implemented for mm, sha256, "
-                                       "aes128, crc16, cache_test and CHStone sha (quicksort votes its indices by default)", cfg->flags);
+                                       "aes128, crc16, cache_test, CHStone sha and CHStone aes (quicksort votes its indices by default)", cfg->flags);
     if ((cfg->flags & (COAST_F_NO_LOAD_SYNC | COAST_F_NO_STORE_ADDR_SYNC)) && !(cfg->flags & COAST_F_ADDR_SYNC))
         return fail(ctx, COAST_EINVAL, "coast_cfg.flags 0x%x: -noLoadSync / -noStoreAddrSync qualify COAST_F_ADDR_SYNC", cfg->flags);
     return COAST_OK;

@@ -27,7 +27,7 @@
  *       -noStoreDataSync               COAST_F_NO_STORE_DATA_SYNC (only meaningful next to -noMemReplication, as in the reference)
  *       -countErrors -countSyncs -storeDataSync -i -s   accepted; always on / no effect here (include/coast_hip.h says why; the
  *                                      batch ABI has the memory-replicated -storeDataSync form as COAST_F_MEMORY_COPIES)
- *       -noLoadSync -noStoreAddrSync   accepted; real knobs for matrix_multiply / crc16 / sha256_hash / calc_sum once COAST_COUNTERS_IN_SOR=1 puts their loop
+ *       -noLoadSync -noStoreAddrSync   accepted; real knobs for matrix_multiply / crc16 / sha256_hash / calc_sum / aes_enc_dec / CHStone sha / aes once COAST_COUNTERS_IN_SOR=1 puts their loop
  *                                      counters inside the sphere of replication (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC, the
  *                                      reference's -noMemReplication rule set for them); otherwise no replicated address exists
  *   or, shorter, COAST_MODE = TMR (default) | DWC | NONE  (lane-replicated engine);
@@ -84,7 +84,7 @@ static coast_cfg dropin_cfg(void)
     return c;
 }
 
-/* matrix_multiply / crc16 / sha256_hash / calc_sum: the kernels whose loop counters can be put inside the sphere of replication */
+/* matrix_multiply / crc16 / sha256_hash / calc_sum / aes_enc_dec / CHStone sha and aes: the kernels whose loop counters can be put inside the sphere of replication */
 static coast_cfg dropin_cfg_counters(void)
 {
     coast_cfg c = dropin_cfg();
@@ -201,7 +201,7 @@ void quick_sort(int *A, int len)
 
 void aes_enc_dec(unsigned char *state, unsigned char *key, unsigned char dir)
 {
-    const coast_cfg cfg = dropin_cfg();
+    const coast_cfg cfg = dropin_cfg_counters(); /* COAST_COUNTERS_IN_SOR=1: `round` and `i` replica-private, their conditions and GEP offsets voted */
     dropin_maybe_inject();
     const int rc = coast_aes_enc_dec_host(state, key, dir, &cfg);
     if (rc)
@@ -320,7 +320,7 @@ int coast_dropin_calc_sum(int *array, int n)
  * the reference's sha_update keeps no partial block across calls and its sha_final pads only block-aligned totals. */
 void coast_dropin_sha_stream(const unsigned char *indata, const int *in_i, int vsize, int block_size, unsigned int *digest)
 {
-    const coast_cfg cfg = dropin_cfg();
+    const coast_cfg cfg = dropin_cfg_counters(); /* COAST_COUNTERS_IN_SOR=1: sha_transform's / sha_update's loop counters inside the sphere of replication */
     size_t total = 0;
     for (int j = 0; j < vsize; ++j) {
         if (in_i[j] < 0 || in_i[j] > block_size || (in_i[j] & 63))
@@ -356,7 +356,8 @@ int coast_dropin_chstone_aes(int *statemt, const int *key, int type, int dir)
     const int kb = type / 1000, bb = type % 1000;
     if ((kb != 128 && kb != 192 && kb != 256) || (bb != 128 && bb != 192 && bb != 256))
         return -1; /* KeySchedule's default case (aes_key.c:132-133) */
-    coast_cfg cfg = dropin_cfg();
+    coast_cfg cfg = dropin_cfg_counters(); /* COAST_COUNTERS_IN_SOR=1: the round counter, the callees' j / i, switches, returns and GEP offsets voted */
+    cfg.flags &= ~(uint32_t)COAST_F_LOCAL_STORE_SYNC; /* (=2: this walk has no store-data votes of locals) */
     unsigned char st[32], k[32];
     for (int i = 0; i < bb / 8; ++i)
         st[i] = (unsigned char)statemt[i];

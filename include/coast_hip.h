@@ -198,6 +198,12 @@ enum {
      * r = 1 .. Nr: before the r-th (Invers)ShiftRow / ByteSub, Nr + 1: before the result is stored */
     COAST_SITE_CHAES_STATE = 64,
     COAST_SITE_CHAES_WORD = 65, /* expanded-key column `step` (word[0..3][step], packed), right after KeySchedule produced it */
+    /* coast_chaes_batch under COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC: a loop counter (32 bits live) of one replica, flipped right before
+     * loop condition number `step` of the call reads it; STATE then lands before the `step`-th (Invers)ShiftRow call, WORD after the
+     * `step`-th key-schedule column */
+    COAST_SITE_CHAES_RND = 66, /* encrypt's / decrypt's round counter `i` (aes_enc.c:113, aes_dec.c:121) */
+    COAST_SITE_CHAES_J = 67,   /* the running callee's `j` (KeySchedule, AddRoundKey, the two MixColumn functions) */
+    COAST_SITE_CHAES_I = 68,   /* the running callee's `i` (KeySchedule, AddRoundKey_InversMixColumn) */
     /* control-flow signatures (coast_crazycf_batch): `step` = how many block transitions the item has made; replica = 0 */
     COAST_SITE_CFC_PC = 56,   /* the branch target of transition `step`: execution lands at the START of block (target ^ 1<<bit) */
     COAST_SITE_CFC_RTS = 57,  /* BasicBlockSignatureTracker, after the leaving block stored it, before the next block checks it */

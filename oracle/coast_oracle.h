@@ -80,6 +80,10 @@ enum {
     /* CHStone aes (chaes_oracle.inc) */
     ORC_SITE_CHAES_STATE = 64, /* packed state column `index` at round boundary `step` (0 entry; r: before the r-th ShiftRow/ByteSub; Nr+1: exit) */
     ORC_SITE_CHAES_WORD = 65,  /* expanded-key column `step`, right after KeySchedule produced it */
+    /* ORC_F_BRANCH_SYNC / ADDR_SYNC (chaes_indexed.inc): a loop counter (32 bits live) of one replica before loop condition `step` of the call */
+    ORC_SITE_CHAES_RND = 66,   /* encrypt's / decrypt's round counter `i` */
+    ORC_SITE_CHAES_J = 67,     /* the running callee's `j` (KeySchedule, AddRoundKey, the two MixColumn functions) */
+    ORC_SITE_CHAES_I = 68,     /* the running callee's `i` (KeySchedule, AddRoundKey_InversMixColumn) */
     /* control-flow signatures (cfcss_oracle.c): `step` = block transitions made so far */
     ORC_SITE_CFC_PC = 56,   /* the branch target of transition `step` */
     ORC_SITE_CFC_RTS = 57,  /* BasicBlockSignatureTracker between the store and the next check */

@@ -2011,8 +2011,10 @@ def test_indexed_flags_are_rejected_where_not_implemented(eng):
     import coast_amd as ca
 
     cs, ck = torch.zeros((4, 16), dtype=torch.uint8, device="cuda"), torch.zeros((4, 16), dtype=torch.uint8, device="cuda")
-    with pytest.raises(RuntimeError, match="are implemented for mm, sha256"):
-        eng.chaes_batch(cs, ck, 128128, 0, ca.XmrConfig(2, 0, ca.F_BRANCH_SYNC))
+    with pytest.raises(RuntimeError, match="sync_every and the counter flags do not combine"):
+        eng.chaes_batch(cs, ck, 128128, 0, ca.XmrConfig(2, 1, ca.F_BRANCH_SYNC))
+    with pytest.raises(RuntimeError, match="COAST_F_LOCAL_STORE_SYNC is not implemented for CHStone aes"):
+        eng.chaes_batch(cs, ck, 128128, 0, ca.XmrConfig(3, 0, ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC | ca.F_LOCAL_STORE_SYNC))
     msgs = torch.zeros((4, 64), dtype=torch.uint8, device="cuda")
     with pytest.raises(RuntimeError, match="sync_every and the counter flags do not combine"):
         eng.chsha_batch(msgs, 64, cfg=ca.XmrConfig(3, 2, ca.F_BRANCH_SYNC))
@@ -2053,17 +2055,28 @@ def test_dropin_counters_in_sor_env(orc):
     nl = syncs("-TMR -noMemReplication -noLoadSync", True)
     ns = syncs("-TMR -noMemReplication -noStoreAddrSync", True)
     # crc16("Automated TMR", 13): + 14 loop conditions; sha256_hash("abc", 3): + (3+1) + 3 + 3 + 3 + 1 + 1 + 1;
-    # matrix_multiply at side 4 (round 3): + (N+1)(N^2+N+1) = 105 loop conditions, 4 N^3 = 256 load offsets, 2 N^2 = 32 store offsets
-    assert full == base + 14 + 16 + 105 + 256 + 32
-    assert nl == full - 3 - 256 and ns == full - 4 - 32
+    # matrix_multiply at side 4 (round 3): + (N+1)(N^2+N+1) = 105 loop conditions, 4 N^3 = 256 load offsets, 2 N^2 = 32 store offsets;
+    # aes_enc_dec on the FIPS-197 appendix B block, both directions (round 4: the drop-in passes the counter flags on): the oracle's walk
+    B, A, NL, NS, L, O0 = 2, 4, 8, 16, 64, 128
+    pt = np.frombuffer(bytes.fromhex("3243f6a8885a308d313198a2e0370734"), dtype=np.uint8)[None].copy()
+    ky = np.frombuffer(bytes.fromhex("2b7e151628aed2a6abf7158809cf4f3c"), dtype=np.uint8)[None].copy()
+    ct = orc.aes128_xmr(pt, ky, 0, replicas=3)[0]
+
+    def aes(fl):
+        return (orc.aes128_xmr(pt, ky, 0, replicas=3, flags=fl)[2]["sync_count"] + orc.aes128_xmr(ct, ky, 1, replicas=3, flags=fl)[2]["sync_count"]
+                - orc.aes128_xmr(pt, ky, 0, replicas=3)[2]["sync_count"] - orc.aes128_xmr(ct, ky, 1, replicas=3)[2]["sync_count"])
+
+    assert full == base + 14 + 16 + 105 + 256 + 32 + aes(B | A)
+    assert nl == full - 3 - 256 - (aes(B | A) - aes(B | A | NL)) and ns == full - 4 - 32 - (aes(B | A) - aes(B | A | NS))
     # round 4.  COAST_COUNTERS_IN_SOR=2 adds the -O0 IR's store-data votes (COAST_F_LOCAL_STORE_SYNC): crc16 4 x 13 + 2, matrix_multiply at
-    # side 4 N + N^2 + 2 N^3; sha256_hash keeps the post--O3 walk (no -O0 store census) unless COAST_SHA256_O0=1 selects the -O0 shape
-    assert syncs("-TMR -noMemReplication", 2) == full + (4 * 13 + 2) + (4 + 16 + 2 * 64)
+    # side 4 N + N^2 + 2 N^3, aes_enc_dec its 1379 + 1885; sha256_hash keeps the post--O3 walk (no -O0 store census) unless COAST_SHA256_O0=1
+    # selects the -O0 shape
+    full2 = full + (4 * 13 + 2) + (4 + 16 + 2 * 64) + aes(B | A | L) - aes(B | A)
+    assert syncs("-TMR -noMemReplication", 2) == full2
     abc = np.frombuffer(b"abc", dtype=np.uint8)[None].copy()
-    B, A, L, O0 = 2, 4, 64, 128
     sha = lambda fl: orc.sha256_xmr(abc, 3, replicas=3, flags=fl)[1]["sync_count"]  # noqa: E731
     assert syncs("-TMR -noMemReplication", 1, sha_o0=True) == full + sha(B | A | O0) - sha(B | A)
-    assert syncs("-TMR -noMemReplication", 2, sha_o0=True) == full + (4 * 13 + 2) + (4 + 16 + 2 * 64) + sha(B | A | O0 | L) - sha(B | A)
+    assert syncs("-TMR -noMemReplication", 2, sha_o0=True) == full2 + sha(B | A | O0 | L) - sha(B | A)
     assert sha(B | A | O0 | L) == 2862  # the reference's -O0 IR of sha256_hash + sha256_transform on 3 bytes (tests/test_ir_counts_cpu.py)
 
 
@@ -2474,6 +2487,65 @@ def test_chaes_vs_oracle(eng, orc, type_, replicas):
         assert (dev.cpu().numpy() == clean).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+@pytest.mark.parametrize("type_", [128128, 192192, 256256, 128256, 256128])
+def test_chaes_counters_in_the_sphere_of_replication(eng, orc, type_, replicas):
+    """CHStone aes under COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC: the statement-by-statement walk (chaes_indexed_kernel) against
+    oracle/chaes_indexed.inc -- results, counters, detected flags -- clean and with upsets in the round counter, the callees' j / i,
+    the state and the expanded key.  The clean counts are the ones of the reference's IR (tests/test_ir_counts_cpu.py)."""
+    import torch
+
+    import coast_amd as ca
+
+    B, A, NL, NS = ca.F_BRANCH_SYNC, ca.F_ADDR_SYNC, ca.F_NO_LOAD_SYNC, ca.F_NO_STORE_ADDR_SYNC
+    nk, nb, nr = orc.chaes_geom(type_)
+    rng = np.random.default_rng(type_ + replicas)
+    n = 45 if type_ == 128128 else 23
+    st = rng.integers(0, 256, (n, 4 * nb), dtype=np.uint8)
+    ky = rng.integers(0, 256, (n, 4 * nk), dtype=np.uint8)
+    flagsets = (B | A, B, A, A | NL, A | NS, B | A | ca.F_NO_STORE_DATA_SYNC) if type_ == 128128 else (B | A, A | NL)
+    for dir_ in (0, 1):
+        plain, _, _ = orc.chaes_xmr(st, ky, type_, dir_, replicas=1)
+        for flags in flagsets:
+            exp, exp_st, _ = orc.chaes_xmr(st, ky, type_, dir_, replicas=replicas, flags=flags)
+            assert (exp == plain).all()
+            dev, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky).cuda()
+            eng.reset_stats()
+            eng.chaes_batch(dev, dk, type_, dir_, ca.XmrConfig(replicas, 0, flags))
+            assert (dev.cpu().numpy() == exp).all() and _stats3(eng.stats()) == exp_st, (dir_, flags)
+        rows = []
+        for _ in range(300):
+            q, r, u = int(rng.integers(0, n)), int(rng.integers(0, replicas)), rng.random()
+            if u < 0.6:  # a loop counter, low bits mostly (a high bit ends or starves the loop at once)
+                site = (ca.SITE_CHAES_RND, ca.SITE_CHAES_J, ca.SITE_CHAES_I)[int(rng.integers(0, 3))]
+                bit = int(rng.integers(0, 4)) if rng.random() < 0.8 else int(rng.integers(0, 32))
+                rows.append((q, r, site, int(rng.integers(0, 600)), bit))
+            elif u < 0.8:
+                rows.append((q, r, ca.SITE_CHAES_STATE, int(rng.integers(0, nr + 2)), int(rng.integers(0, 32)), int(rng.integers(0, nb))))
+            else:
+                rows.append((q, r, ca.SITE_CHAES_WORD, int(rng.integers(0, nb * (nr + 1))), int(rng.integers(0, 32))))
+        fl = ca.make_faults(rows)
+        for flags in flagsets:
+            exp, exp_st, exp_det = orc.chaes_xmr(st, ky, type_, dir_, replicas=replicas, flags=flags, faults=fl)
+            dev, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky).cuda()
+            det = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            eng.reset_stats()
+            eng.inject_faults(fl)
+            eng.chaes_batch(dev, dk, type_, dir_, ca.XmrConfig(replicas, 0, flags), detected=det)
+            got = dev.cpu().numpy()
+            assert (got == exp).all(), (dir_, flags, np.nonzero((got != exp).any(axis=1))[0][:8])
+            assert _stats3(eng.stats()) == exp_st and (det.cpu().numpy() == exp_det).all(), (dir_, flags)
+        if replicas == 3:  # everything voted: one counter upset per block is always out-voted
+            one = ca.make_faults([(q, int(rng.integers(0, 3)), (ca.SITE_CHAES_RND, ca.SITE_CHAES_J, ca.SITE_CHAES_I)[q % 3],
+                                   int(rng.integers(0, 300)), int(rng.integers(0, 32))) for q in range(n)])
+            dev, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky).cuda()
+            eng.reset_stats()
+            eng.inject_faults(one)
+            eng.chaes_batch(dev, dk, type_, dir_, ca.XmrConfig(3, 0, B | A))
+            assert (dev.cpu().numpy() == plain).all() and eng.stats()["errors_corrected"] > 0
+
+
 def test_chaes_rejects_bad_arguments(eng):
     import torch
 
@@ -2487,6 +2559,32 @@ def test_chaes_rejects_bad_arguments(eng):
         assert eng._lib.coast_chaes_batch(eng._h, st.data_ptr(), ky.data_ptr(), 4, bad, 0, C.byref(cc), None) == -1
     assert eng._lib.coast_chaes_batch(eng._h, st.data_ptr() + 1, ky.data_ptr(), 4, 128128, 0, C.byref(cc), None) == -1
     assert eng._lib.coast_chaes_batch(eng._h, None, None, 0, 128128, 0, C.byref(cc), None) == 0
+
+
+def test_chaes_dropin_counters_in_sor(orc, monkeypatch):
+    """COAST_COUNTERS_IN_SOR=1 reaches CHStone aes through the symbol its glue binds: same block, __SYNC_COUNT grows by the walk's votes"""
+    import ctypes as C
+    import os
+
+    fx = _chaes_fixtures()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = C.CDLL(os.path.join(root, "coast_amd", "lib", "libcoast_dropin.so"))
+    fn = lib.coast_dropin_chstone_aes
+    fn.restype = C.c_int
+    cnt = C.c_uint64.in_dll(lib, "__SYNC_COUNT")
+    monkeypatch.setenv("COAST_OPT_PASSES", "-TMR -noMemReplication -countSyncs")
+    for t in (128128, 256192):
+        nk, nb = t // 1000 // 32, t % 1000 // 32
+        seen = {}
+        for sor in ("0", "1", "2"):
+            monkeypatch.setenv("COAST_COUNTERS_IN_SOR", sor)
+            st = (C.c_int * 32)(*[int(v) for v in fx["st%d" % t][3]])
+            ky = (C.c_int * 32)(*[int(v) for v in fx["key%d" % t][3]])
+            before = cnt.value
+            assert fn(st, ky, t, 0) == 0 and list(st[:4 * nb]) == fx["enc%d" % t][3].tolist()
+            seen[sor] = cnt.value - before
+        want = [orc.chaes_xmr(fx["st%d" % t][3:4], fx["key%d" % t][3:4], t, 0, replicas=3, flags=fl)[1]["sync_count"] for fl in (0, 6)]
+        assert seen["0"] == want[0] == nb and seen["1"] == seen["2"] == want[1] > 3000, (t, seen, want)
 
 
 @pytest.mark.parametrize("passes", ["-TMR -countErrors", "-DWC -noMemReplication", ""])

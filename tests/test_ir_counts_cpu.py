@@ -171,3 +171,31 @@ def test_sha256_o0_shape_counts_equal_the_references_ir(orc):
         full = orc.sha256_xmr(m, n, replicas=3, flags=B | A | O0 | L)
         assert full[1]["sync_count"] == sum(g[k] for k in ("branches", "gep_loads", "gep_stores", "stores_to_memory", "stores_to_local_allocas")), n
         assert bytes(full[0][0]) == hashlib.sha256(bytes(m[0, :n])).digest()
+
+
+def test_chstone_aes_counts_equal_the_references_ir(orc):
+    """CHStone aes (five translation units; the region ends at encrypt's / decrypt's first printf): conditional branches + switches +
+    returns of computed values are the terminator votes of COAST_F_BRANCH_SYNC, variable GEPs by class the offset votes of
+    COAST_F_ADDR_SYNC -- for every block / key size the walk branches differently on (nb = 4, 6, 8; nk = 4, 6, 8: `nk > 6`)"""
+    import ir_sync_counts as ir
+
+    types = (128128, 192192, 256256, 128256, 256128)
+    got = ir.chaes(types)
+    for t in types:
+        nk, nb, nr = orc.chaes_geom(t)
+        st = np.array([[(i * 37 + 11) & 255 for i in range(4 * nb)]], dtype=np.uint8)  # (the driver's block and key)
+        ky = np.array([[(i * 59 + 3) & 255 for i in range(4 * nk)]], dtype=np.uint8)
+        for d, tag in ((0, "enc"), (1, "dec")):
+            k = got["%s_%d" % (tag, t)]
+            out, base, _ = orc.chaes_xmr(st, ky, t, d, replicas=3)
+            assert base["sync_count"] == nb  # the frozen schedule: the result block's packed columns
+            sync = lambda fl: orc.chaes_xmr(st, ky, t, d, replicas=3, flags=fl)[1]["sync_count"] - nb
+            br, ld, sa = _classes(sync)
+            assert br == k["branches"] + k["switches"] + k["returns"], (t, tag)
+            assert (ld, sa) == (k["gep_loads"], k["gep_stores"]) and k["gep_other"] == 0, (t, tag)
+            assert k["switches"] == 4 + nr  # KeySchedule, encrypt / decrypt, two AddRoundKey calls, Nr ShiftRow calls
+            assert (orc.chaes_xmr(st, ky, t, d, replicas=3, flags=B | A)[0] == out).all()
+            if d == 0:
+                st = out  # decrypt what was encrypted, like aes_main
+    assert sum(got["enc_128128"][c] for c in ("branches", "switches", "returns", "gep_loads", "gep_stores")) == 3971
+    assert sum(got["dec_256256"][c] for c in ("branches", "switches", "returns", "gep_loads", "gep_stores")) == 19328

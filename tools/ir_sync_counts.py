@@ -49,6 +49,12 @@ def instrument(ll, funcs):
         if cur:
             if re.match(r"\s+br i1 ", ln):
                 out.append("  call void @__coast_cnt(i32 0)")
+            # a switch votes its operand like a conditional branch does (syncTerminator, :761-767); a `ret` of a computed value votes it
+            # (:755-760; `ret i32 0` has nothing cloned to vote)
+            if re.match(r"\s+switch i\d+ %", ln):
+                out.append("  call void @__coast_cnt(i32 6)")
+            if re.match(r"\s+ret (?!void)\S+ %", ln):
+                out.append("  call void @__coast_cnt(i32 7)")
             # a store of a computed, non-pointer value: a store-data sync point under -noMemReplication (:197-224) -- at -O0 that includes
             # the stores into the allocas of the function's own locals (reported apart: this design keeps locals in registers)
             if re.match(r"\s+store (?!ptr )\S+ %[\w.]+, ptr ", ln):
@@ -83,9 +89,10 @@ def instrument(ll, funcs):
 DRIVER_HEAD = r'''
 #include <stdio.h>
 #include <string.h>
-static unsigned long cnt[6];
-void __coast_cnt(int k) { cnt[k]++; }
-static void report(const char *tag) { fprintf(stderr, "%s %lu %lu %lu %lu %lu %lu\n", tag, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5]); for (int i = 0; i < 6; i++) cnt[i] = 0; }
+static unsigned long cnt[8];
+static int frozen;
+void __coast_cnt(int k) { if (!frozen) cnt[k]++; }
+static void report(const char *tag) { fprintf(stderr, "%s %lu %lu %lu %lu %lu %lu %lu %lu\n", tag, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7]); for (int i = 0; i < 8; i++) cnt[i] = 0; frozen = 0; }
 '''
 
 
@@ -93,23 +100,29 @@ def run_case(src, funcs, driver, cflags=(), rename=None, opt=None):
     """opt: an optimisation level to run over the -O0 IR first (`-O3` for the benchmarks whose Makefile puts it in front of the pass) --
     THIS toolchain's pipeline, not LLVM 7's: supporting evidence, not a pin"""
     with tempfile.TemporaryDirectory() as td:
-        ll = os.path.join(td, "ref.ll")
-        subprocess.check_call([CLANG, "-O0", "-S", "-emit-llvm", "-w", *(["-Xclang", "-disable-O0-optnone"] if opt else []), *cflags, src, "-o", ll])
-        if opt:
-            subprocess.check_call([os.path.join(os.path.dirname(CLANG), "opt"), opt, "-S", ll, "-o", ll])
-        text = open(ll).read()
-        for a, b in (rename or {}).items():
-            text = re.sub(r"@%s\b" % re.escape(a), "@" + b, text)
-        open(ll, "w").write(instrument(text, funcs))
+        lls = []
+        for n, one in enumerate([src] if isinstance(src, str) else list(src)):  # (a benchmark of several translation units: each its own IR)
+            ll = os.path.join(td, "ref%d.ll" % n)
+            subprocess.check_call([CLANG, "-O0", "-S", "-emit-llvm", "-w", *(["-Xclang", "-disable-O0-optnone"] if opt else []), *cflags, one, "-o", ll])
+            if opt:
+                subprocess.check_call([os.path.join(os.path.dirname(CLANG), "opt"), opt, "-S", ll, "-o", ll])
+            text = open(ll).read()
+            for a, b in (rename or {}).items():
+                text = re.sub(r"@%s\b" % re.escape(a), "@" + b, text)
+            text = instrument(text, funcs)
+            if n:
+                text = text.replace("\ndeclare void @__coast_cnt(i32)\n", "\n") if "declare void @__coast_cnt" in text.split("\n")[0] else text
+            open(ll, "w").write(text)
+            lls.append(ll)
         drv = os.path.join(td, "drv.c")
         open(drv, "w").write(DRIVER_HEAD + driver)
         exe = os.path.join(td, "run")
-        subprocess.check_call([CLANG, "-O0", "-w", ll, drv, "-o", exe])
+        subprocess.check_call([CLANG, "-O0", "-w", *lls, drv, "-o", exe])
         res = {}
         for line in subprocess.run([exe], text=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True).stderr.strip().split("\n"):
             tag, *v = line.split()
             res[tag] = {"branches": int(v[0]), "gep_loads": int(v[1]), "gep_stores": int(v[2]), "gep_other": int(v[3]),
-                        "stores_to_memory": int(v[4]), "stores_to_local_allocas": int(v[5])}
+                        "stores_to_memory": int(v[4]), "stores_to_local_allocas": int(v[5]), "switches": int(v[6]), "returns": int(v[7])}
         return res
 
 
@@ -162,6 +175,23 @@ int main(void) { for (int i = 0; i < %d; i++) buf[i] = (BYTE)(i * 31 + 5);
     return run_case(os.path.join(REF, "chstone", "sha", "sha.c"),
                     {"sha_transform", "sha_update", "sha_final"}, drv, cflags=["-I" + os.path.join(REF, "chstone", "sha")],
                     rename={"main": "ref_main", "memcpy": "ch_memcpy", "memset": "ch_memset"})  # (sha.c defines its own, :50-80)
+
+
+def chaes(types=(128128, 192192, 256256, 128256, 256128)):
+    """tests/chstone/aes: encrypt / decrypt of one block (KeySchedule, the rounds); counting stops at the function's first printf --
+    the print-out and the comparison with the golden block behind it are outside what coast_chaes_batch computes"""
+    drv = r'''
+#include <stdarg.h>
+int ch_printf(const char *f, ...) { (void)f; frozen = 1; return 0; }
+extern int encrypt(int *, int *, int); extern int decrypt(int *, int *, int);
+int main(void) { int st[32], ky[32];
+%s return 0; }
+''' % " ".join('for (int i = 0; i < 32; i++) st[i] = (i * 37 + 11) & 255, ky[i] = (i * 59 + 3) & 255; encrypt(st, ky, %d); report("enc_%d"); '
+                  'decrypt(st, ky, %d); report("dec_%d");' % (t, t, t, t) for t in types)
+    d = os.path.join(REF, "chstone", "aes")
+    return run_case([os.path.join(d, f) for f in ("aes.c", "aes_enc.c", "aes_dec.c", "aes_key.c", "aes_func.c")], {"encrypt", "decrypt", "KeySchedule", "SubByte", "ByteSub_ShiftRow", "InversShiftRow_ByteSub",
+                                                  "MixColumn_AddRoundKey", "AddRoundKey_InversMixColumn", "AddRoundKey"}, drv,
+                    cflags=["-I" + d, "-include", "stdio.h"], rename={"main": "ref_main", "printf": "ch_printf"})
 
 
 def crc16(lengths=(0, 13, 255)):
