@@ -2095,7 +2095,7 @@ def _campaign(argv, eng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bench", ["aes", "cache_test", "chsha"])
+@pytest.mark.parametrize("bench", ["aes", "cache_test", "chsha", "chaes"])
 def test_campaign_aimed_at_the_loop_counters(eng, bench):
     """tools/campaign.py --counters-in-sor (profiles/r03_campaign_counters.txt): every upset hits a loop counter that COAST_F_BRANCH_SYNC |
     COAST_F_ADDR_SYNC put inside the sphere of replication -- unprotected runs mostly go wrong, TMR corrects all of them, DWC stops all

@@ -272,6 +272,17 @@ class ChAes(Bench):
         return (r, int(rng.integers(0, nrep)), ca.SITE_CHAES_WORD, int(rng.integers(0, self.nb * (self.nr + 1))),
                 int(rng.integers(0, 32)))
 
+    def counter_fault(self, r, nrep, rng):  # encrypt's round counter / the callees' j, i before loop condition `step` of the encryption walk
+        nk, nb, nr = self.nk, self.nb, self.nr
+        cols = nb * (nr + 1)
+        ks = ((nk + 1) + 5 * nk) + ((cols - nk + 1) + 5 * (cols - nk) + (5 * ((cols - nk) // nk) if nk > 6 else 0))  # KeySchedule's two loops
+        ticks = ks + 2 * (nb + 1) + nr + (nr - 1) * 2 * (nb + 1)  # + two AddRoundKey calls, the round loop, MixColumn's two loops
+        step = int(rng.integers(0, ticks))
+        # aim at a counter that is live at that point: KeySchedule runs on j (i only inside its inner loops), the rounds on the round
+        # counter and the callees' j
+        site = ca.SITE_CHAES_J if step < ks and rng.random() < 0.8 else ca.SITE_CHAES_I if step < ks else int(rng.choice([ca.SITE_CHAES_RND, ca.SITE_CHAES_J]))
+        return (r, int(rng.integers(0, nrep)), site, step, int(rng.integers(0, 32)))
+
 
 class CrazyCF(Bench):
     """tests/crazyCF/crazyCF.c under `opt -CFCSS` (-m CFCSS) or bare (-m NONE): the upset is a corrupted branch target -- execution
@@ -356,7 +367,7 @@ def run_campaign(a, eng=None):
         else:
             if a.counters_in_sor:  # the loop counters are members of the sphere of replication and the campaign aims at THEM
                 if not hasattr(bench, "counter_fault") or (a.benchmark == "mm" and a.side > 32):
-                    raise SystemExit("--counters-in-sor: mm (--side <= 32), sha256, aes, crc16, chsha, cache_test")
+                    raise SystemExit("--counters-in-sor: mm (--side <= 32), sha256, aes, crc16, chsha, chaes, cache_test")
                 rows = [bench.counter_fault(r, nrep, rng) for r in range(runs)]
             else:
                 rows = [bench.reg_fault(r, nrep, rng) for r in range(runs)]
