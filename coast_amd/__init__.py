@@ -22,5 +22,6 @@ SITE_CHSHA_W, SITE_CHSHA_WV, SITE_CHSHA_DIGEST, SITE_CHSHA_I, SITE_CHSHA_COUNT =
 SITE_QS_I, SITE_QS_J, SITE_QS_PIVOT, SITE_QS_VI, SITE_QS_VJ = 48, 49, 50, 51, 52
 SITE_CFC_PC, SITE_CFC_RTS, SITE_CFC_RTSA = 56, 57, 58
 SITE_CHAES_STATE, SITE_CHAES_WORD = 64, 65
+SITE_CCF_I, SITE_CCF_TOTAL, SITE_CCF_TIMES, SITE_CCF_FI = 72, 73, 74, 75  # crazyCF under -TMR / -DWC (crazycf_xmr_batch)
 SITE_CHAES_RND, SITE_CHAES_J, SITE_CHAES_I = 66, 67, 68  # CHStone aes under F_BRANCH_SYNC / F_ADDR_SYNC: the loop counters
 CFC_OK, CFC_DETECTED, CFC_WATCHDOG, CFC_WILD = 0, 1, 2, 3

@@ -82,6 +82,7 @@ SYMBOLS = {
     "coast_crazycf_graph": (C.c_int, [C.POINTER(CoastCfcGraph)]),
     "coast_crazycf_tables": (C.c_int, [C.POINTER(CoastCfcTables)]),
     "coast_crazycf_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]),
+    "coast_crazycf_xmr_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(CoastCfg), C.c_void_p]),
     "coast_sync_copies": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_void_p, C.c_int,
                                     C.c_void_p]),
     "coast_sync_copies_typed": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_void_p, C.c_int,

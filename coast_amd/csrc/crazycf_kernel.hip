@@ -247,4 +247,131 @@ __global__ __launch_bounds__(64) void crazycf_kernel(const coast_crazycf_params 
     }
 }
 
+// crazyCF under -TMR / -DWC (unittest/cfg/full_tmr.yml:8 runs the program with `-TMR`): main() (crazyCF.c:29-69) and fillArray() (:20-27)
+// statement by statement, one lane group per run (NREP adjacent lanes, one per replica).  Replica-private: main's i, total,
+// timesThroughWhile and fillArray's i.  `size` is a global (one copy); srand / rand / printf are library calls -- rand's value fans out to
+// the copies (every replica lane keeps the same generator state and steps it on the same, group-uniform path).  array[] is filled and
+// never read: its stores have an address and a datum to vote, nothing else.  Sync points:
+//   always                   the arguments of the two printf calls (`total`): values handed to an unprotected call
+//                            (processCallSync, synchronization.cpp:951-1100) -- the frozen schedule
+//   COAST_F_BRANCH_SYNC      the three loop conditions, the operand of `switch (i)`, main's return value (through %retval)  :741-949
+//   COAST_F_ADDR_SYNC        the offset of `array[i] = ..` (a store address: off with -noStoreAddrSync)                     :413-474
+//   COAST_F_LOCAL_STORE_SYNC the data of every store of a computed value: the VLA's element count, array[i], fillArray's i++, every
+//                            update of total, timesThroughWhile--, main's i++                                    :197-224, 476-561
+// All of them on the program's own constants: 82 + 30 + 1 + 20 + 20 + 90 + the 2 printf arguments = 245, the counts of the reference's
+// -O0 IR (tools/ir_sync_counts.py crazycf).  Fault sites SITE_CCF_I / _TOTAL / _TIMES / _FI: a bit of that register of one replica right
+// before branch condition `step` of the run.  Watchdog as crazycf_kernel's.  Oracle: oracle/crazycf_xmr.inc.
+enum { SITE_CCF_I = 72, SITE_CCF_TOTAL = 73, SITE_CCF_TIMES = 74, SITE_CCF_FI = 75 };
+template <int NREP>
+__global__ __launch_bounds__(64) void crazycf_xmr_kernel(const coast_crazycf_params *__restrict__ params, uint64_t nitems,
+                                                         coast_crazycf_result *__restrict__ results, uint8_t *__restrict__ status,
+                                                         Counters ctr, FaultTab ft, uint8_t *__restrict__ detected)
+{
+    __shared__ int32_t ring[31][64];
+    __shared__ uint32_t sCnt[4];
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    LaneMap<NREP> lm;
+    lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
+    const bool bs = (ctr.flags & kFlagBranchSync) != 0u;
+    const bool ss = (ctr.flags & kFlagAddrSync) != 0u && !(ctr.flags & kFlagNoStoreAddrSync);
+    const bool lss = xmr_local_sync_on(ctr.flags);
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+    const int slot = lm.q;
+    const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
+    const bool live = lm.live && item < nitems;
+    const bool cnt = live && lm.r == 0;
+    if (lane < 4)
+        sCnt[lane] = 0;
+    coast_crazycf_params pr = params[live ? item : 0];
+    uint2 fr = make_uint2(0u, 0u);
+    if (ft.range)
+        fr = ft.range[tile];
+    Tally tl;
+    LaneRand rnd{&ring[0][lane], 3u, 0u};
+    rnd.seed((uint32_t)pr.seed);                                                     // srand(seed)                            :35
+    int32_t i = 0, total = 0, times = pr.times, fi = 0, printed = 0, final = 0;
+    uint32_t nprints = 0u, tick = 0u;
+    bool wd = false;
+    const long long span = (long long)(pr.size > 0 ? pr.size : 0) + (long long)(pr.times > 0 ? pr.times : 0);
+    const uint32_t cap = (uint32_t)(16ll * span + 256ll < (1ll << 28) ? 16ll * span + 256ll : (1ll << 28));
+    if (lm.live) { // (the idle lane of a TMR wave has no run of its own)
+        auto cond = [&](const int32_t &reg, int32_t lim, bool gt) { // one evaluated loop condition
+            for (uint32_t q = 0; q < fr.y; ++q) { // the registers' upsets land right before the condition reads them
+                const DevFault df = ft.list[fr.x + q];
+                if (df.step != tick || (int)df.local != slot || (int)df.replica != lm.r)
+                    continue;
+                const int32_t m = (int32_t)(1u << (df.bit & 31u));
+                if (df.site == SITE_CCF_I)
+                    i ^= m;
+                else if (df.site == SITE_CCF_TOTAL)
+                    total ^= m;
+                else if (df.site == SITE_CCF_TIMES)
+                    times ^= m;
+                else if (df.site == SITE_CCF_FI)
+                    fi ^= m;
+            }
+            if (tick >= cap) {
+                wd = true;
+                return false;
+            }
+            ++tick;
+            return xmr_steer<NREP>((gt ? reg > lim : reg < lim) ? 1u : 0u, lm, bs, cnt, tl) != 0u;
+        };
+        auto lsy = [&](int32_t v) { return (int32_t)xmr_local_sync<NREP>((uint32_t)v, lm, lss, cnt, tl); }; // the data of a store (L)
+        (void)lsy(pr.size);                                                          // int array[size]: the VLA's element count :32
+        for (; cond(fi, pr.size, false); fi = lsy((int32_t)((uint32_t)fi + 1u))) {   // fillArray: for (i = 0; i < size; i++)  :22
+            const uint32_t rv = rnd.next() % 100u;                                   //   array[i] = rand() % 100             :23
+            (void)xmr_steer<NREP>((uint32_t)fi, lm, ss, cnt, tl);
+            (void)lsy((int32_t)rv);
+        }
+        times = pr.times, i = 0;                                                     // int timesThroughWhile = 10; int i = 0; :40-41
+        for (;;) {                                                                   // LOOP: for (; i < size; i++)            :43
+            if (!cond(i, pr.size, false))
+                break;
+            const int32_t sw = (int32_t)xmr_steer<NREP>((uint32_t)i, lm, bs, cnt, tl); // switch (i): the voted operand steers  :44
+            if (sw == 0)
+                total = lsy((int32_t)((uint32_t)total + rnd.next() % 10u));          //   case 0: total += rand() % 10         :46
+            else if (sw == 5)
+                total = lsy((int32_t)((uint32_t)total + 127u));                      //   case 5                               :49
+            else if (sw == 17) {                                                     //   case 17: printf("total so far: %d")  :52
+                const uint32_t v = xmr_sync<NREP>((uint32_t)total, lm, cnt, tl);     //   (the argument of an unprotected call is voted)
+                printed = (int32_t)(NREP == 3 ? v : xmr_rep0<NREP>((uint32_t)total, lm));
+                ++nprints;
+            } else if (sw == 25)
+                total = lsy((int32_t)((uint32_t)total + 25u));                       //   case 25: falls into case 37: goto WHILE :55-58
+            else if (sw != 37)
+                total = lsy((int32_t)((uint32_t)total - 10u));                       //   default                              :60
+            if (cond(times, 0, true)) {                                              // WHILE: while (timesThroughWhile > 0)   :62
+                total = lsy((int32_t)((uint32_t)total - 1u));
+                times = lsy((int32_t)((uint32_t)times - 1u));
+                continue;                                                            //   goto LOOP: back to the condition, no i++ :65
+            }
+            i = lsy((int32_t)((uint32_t)i + 1u));
+        }
+        {                                                                            // printf("Total = %d\n", total)          :67
+            const uint32_t v = xmr_sync<NREP>((uint32_t)total, lm, cnt, tl);
+            final = (int32_t)(NREP == 3 ? v : xmr_rep0<NREP>((uint32_t)total, lm));
+        }
+        if (bs)
+            (void)xmr_sync<NREP>(0u, lm, cnt, tl);                                   // return 0, through %retval              :69
+    }
+    uint32_t detItems = 0;
+    if (cnt) {
+        coast_crazycf_result rs;
+        rs.total = final;
+        rs.printed = printed;
+        rs.n_prints = nprints;
+        rs.blocks = tick;
+        results[item] = rs;
+        status[item] = (uint8_t)(wd ? kCfcWatchdog : kCfcOk);
+        if (tl.det) {
+            if (NREP == 2)
+                detItems = 1;
+            if (detected)
+                detected[item] = 1;
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, tile);
+}
+
 } // namespace coast

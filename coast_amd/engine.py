@@ -231,6 +231,22 @@ class Engine:
         self._check(self._lib.coast_crazycf_batch(self._h, _ptr(params), n, _ptr(results), _ptr(status), int(bool(cfcss))))
         return results, status
 
+    def crazycf_xmr_batch(self, params, cfg: XmrConfig = XmrConfig(), results=None, status=None, detected=None):
+        """params: (n, 3) int32 rows of (seed, size, timesThroughWhile): n runs of tests/crazyCF/crazyCF.c's main() under -TMR / -DWC
+        (unittest/cfg/full_tmr.yml:8), the printf arguments voted; F_BRANCH_SYNC / F_ADDR_SYNC / F_LOCAL_STORE_SYNC add the loop
+        conditions, the switch operand, array[i]'s offset, the stored data.  Returns (results (n, 4) int32, status uint8)."""
+        assert params.is_cuda and params.dtype == torch.int32 and params.dim() == 2 and params.shape[1] == 3
+        assert params.is_contiguous()
+        n = params.shape[0]
+        if results is None:
+            results = torch.zeros((n, 4), dtype=torch.int32, device=params.device)
+        if status is None:
+            status = torch.zeros(n, dtype=torch.uint8, device=params.device)
+        cc = cfg.c()
+        self._check(self._lib.coast_crazycf_xmr_batch(self._h, _ptr(params), n, _ptr(results), _ptr(status), C.byref(cc),
+                                                      _ptr(detected) if detected is not None else None))
+        return results, status
+
     # -- default mode (memory replicated x3 / x2): vote where the copies re-converge
     def sync_copies(self, copies, out=None, scrub=True, detected=None, fp=False, vector_width=1):
         """copies: 3 (TMR) or 2 (DWC) equally shaped contiguous GPU tensors holding the per-copy results of replicas=1

@@ -204,6 +204,11 @@ enum {
     COAST_SITE_CHAES_RND = 66, /* encrypt's / decrypt's round counter `i` (aes_enc.c:113, aes_dec.c:121) */
     COAST_SITE_CHAES_J = 67,   /* the running callee's `j` (KeySchedule, AddRoundKey, the two MixColumn functions) */
     COAST_SITE_CHAES_I = 68,   /* the running callee's `i` (KeySchedule, AddRoundKey_InversMixColumn) */
+    /* coast_crazycf_xmr_batch: a register of one replica, flipped right before branch condition number `step` of the run reads it */
+    COAST_SITE_CCF_I = 72,     /* main's i (crazyCF.c:42) */
+    COAST_SITE_CCF_TOTAL = 73, /* total */
+    COAST_SITE_CCF_TIMES = 74, /* timesThroughWhile */
+    COAST_SITE_CCF_FI = 75,    /* fillArray's i (:22) */
     /* control-flow signatures (coast_crazycf_batch): `step` = how many block transitions the item has made; replica = 0 */
     COAST_SITE_CFC_PC = 56,   /* the branch target of transition `step`: execution lands at the START of block (target ^ 1<<bit) */
     COAST_SITE_CFC_RTS = 57,  /* BasicBlockSignatureTracker, after the leaving block stored it, before the next block checks it */
@@ -393,6 +398,18 @@ int coast_crazycf_graph(coast_cfc_graph *out);   /* the -O0 control-flow graph o
 int coast_crazycf_tables(coast_cfc_tables *out); /* = coast_cfcss_assign(coast_crazycf_graph) */
 int coast_crazycf_batch(coast_ctx *ctx, const coast_crazycf_params *d_params, size_t n, coast_crazycf_result *d_results,
                         uint8_t *d_status, int cfcss);
+
+/* The same program under -TMR / -DWC (unittest/cfg/full_tmr.yml:8 runs crazyCF with `-TMR`): NREP lanes per run, main's i, total,
+ * timesThroughWhile and fillArray's i replica-private; `size` (a global), srand / rand / printf (library calls, rand's value fans out)
+ * single.  Sync points: the arguments of the two printf calls (`total`) always -- values handed to an unprotected call,
+ * synchronization.cpp:951-1100 --; COAST_F_BRANCH_SYNC the three loop conditions, the operand of `switch (i)` and main's return value;
+ * COAST_F_ADDR_SYNC the offset of `array[i] = ..`; COAST_F_LOCAL_STORE_SYNC (with the two) the data of every store of a computed value.
+ * With all three a run of the program's constants (42, 20, 10) has the 245 sync points of the reference's -O0 IR
+ * (tools/ir_sync_counts.py crazycf).  result.total / .printed = what the printf calls received (TMR: the voted value, DWC: replica
+ * 0's), .blocks = branch conditions evaluated; d_status: COAST_CFC_OK or COAST_CFC_WATCHDOG; d_detected (optional) one byte per run.
+ * Fault sites COAST_SITE_CCF_*.  sync_every and -noLoadSync are rejected (nothing to act on). */
+int coast_crazycf_xmr_batch(coast_ctx *ctx, const coast_crazycf_params *d_params, size_t n, coast_crazycf_result *d_results,
+                            uint8_t *d_status, const coast_cfg *cfg, uint8_t *d_detected);
 
 /* ---- default-mode TMR / DWC: memory replicated as well (docs/source/passes.rst:329,337; cloning.cpp:2417-2462) ----
  * In COAST's default mode the clones of a region run on their own copies of the data and stores are not voted

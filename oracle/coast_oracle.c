@@ -2461,3 +2461,4 @@ void orc_sync_copies(uint32_t *c0, uint32_t *c1, uint32_t *c2, int ncopies, size
 }
 
 #include "chaes_oracle.inc"
+#include "crazycf_xmr.inc"

@@ -84,6 +84,11 @@ enum {
     ORC_SITE_CHAES_RND = 66,   /* encrypt's / decrypt's round counter `i` */
     ORC_SITE_CHAES_J = 67,     /* the running callee's `j` (KeySchedule, AddRoundKey, the two MixColumn functions) */
     ORC_SITE_CHAES_I = 68,     /* the running callee's `i` (KeySchedule, AddRoundKey_InversMixColumn) */
+    /* crazyCF under -TMR / -DWC (crazycf_xmr.inc): a register of one replica before branch condition `step` of the run */
+    ORC_SITE_CCF_I = 72,     /* main's i */
+    ORC_SITE_CCF_TOTAL = 73, /* total */
+    ORC_SITE_CCF_TIMES = 74, /* timesThroughWhile */
+    ORC_SITE_CCF_FI = 75,    /* fillArray's i */
     /* control-flow signatures (cfcss_oracle.c): `step` = block transitions made so far */
     ORC_SITE_CFC_PC = 56,   /* the branch target of transition `step` */
     ORC_SITE_CFC_RTS = 57,  /* BasicBlockSignatureTracker between the store and the next check */
@@ -216,6 +221,9 @@ void orc_crazycf_run(const orc_cfc_tables *T, int cfcss, int32_t seed, int32_t s
 void orc_crazycf_batch(const orc_cfc_tables *T, int cfcss, const int32_t *params, size_t n, const orc_fault *fl, size_t nf,
                        orc_crazycf_result *res, uint8_t *status);
 void orc_glibc_rand_seq(uint32_t seed, uint32_t *out, size_t k);
+/* crazyCF under -TMR / -DWC (unittest/cfg/full_tmr.yml:8): params = n x (seed, size, timesThroughWhile); status 0 ok, 2 watchdog */
+void orc_crazycf_xmr(const int32_t *params, size_t n, const orc_cfg *cfg, const orc_fault *faults, size_t nfaults, orc_stats *st,
+                     orc_crazycf_result *res, uint8_t *status, uint8_t *detected);
 
 /* sparse variants: evaluate only the listed items (used to check huge batches) */
 void orc_mm_xmr_items(const uint32_t *f, const uint32_t *s, int n, const uint64_t *items, size_t nitems,

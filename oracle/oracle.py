@@ -491,6 +491,22 @@ def crazycf_batch(params, cfcss=True, faults=None, tables=None):
     return res, status
 
 
+def crazycf_xmr(params, replicas=3, flags=0, faults=None):
+    """crazyCF under -TMR / -DWC (crazycf_xmr.inc): params (n, 3) int32 rows of (seed, size, timesThroughWhile).
+    Returns (results structured array, status, stats dict, detected)."""
+    prm = np.ascontiguousarray(params, dtype=np.int32).reshape(-1, 3)
+    n = prm.shape[0]
+    fl = _faults(faults)
+    res = np.zeros(n, CRAZYCF_RESULT)
+    status = np.zeros(n, np.uint8)
+    det = np.zeros(n, np.uint8)
+    st = Stats()
+    cfg = Cfg(replicas, 0, flags)
+    lib().orc_crazycf_xmr(_p(prm, C.c_int32), C.c_size_t(n), C.byref(cfg), fl.ctypes.data_as(C.c_void_p), C.c_size_t(len(fl)),
+                          C.byref(st), res.ctypes.data_as(C.c_void_p), _p(status, C.c_uint8), _p(det, C.c_uint8))
+    return res, status, st.as_dict(), det
+
+
 def glibc_rand_seq(seed, k):
     out = np.zeros(k, np.uint32)
     lib().orc_glibc_rand_seq(C.c_uint32(seed & 0xFFFFFFFF), _p(out, C.c_uint32), C.c_size_t(k))

@@ -2374,6 +2374,69 @@ def test_crazycf_vs_oracle_under_upsets(eng, orc, cfcss):
     assert not st2.cpu().numpy().any()
 
 
+@pytest.mark.parametrize("replicas", [3, 2, 1])
+def test_crazycf_under_tmr_and_dwc(eng, orc, replicas):
+    """crazyCF as unittest/cfg/full_tmr.yml:8 runs it (-TMR; here also -DWC / unprotected): lane-replicated runs of main(), the printf
+    arguments voted, the counter flags adding loop conditions / switch / return / array offsets / stored data -- results, counters,
+    flags and status equal oracle/crazycf_xmr.inc, clean and under upsets of i, total, timesThroughWhile and fillArray's i"""
+    import torch
+
+    import coast_amd as ca
+
+    B, A, NS, L, ND = ca.F_BRANCH_SYNC, ca.F_ADDR_SYNC, ca.F_NO_STORE_ADDR_SYNC, ca.F_LOCAL_STORE_SYNC, ca.F_NO_STORE_DATA_SYNC
+    rng = np.random.default_rng(77 + replicas)
+    n = 50
+    prm = np.stack([rng.integers(0, 2**31 - 1, n), rng.integers(0, 45, n), rng.integers(0, 14, n)], axis=1).astype(np.int32)
+    prm[0] = (42, 20, 10)  # the program's own constants
+    flagsets = (0, B, A, B | A, B | A | NS, B | A | L, B | A | L | ND)
+    dev = torch.from_numpy(prm).cuda()
+    for flags in flagsets:
+        exp, exp_s, exp_st, _ = orc.crazycf_xmr(prm, replicas, flags)
+        eng.reset_stats()
+        res, status = eng.crazycf_xmr_batch(dev, ca.XmrConfig(replicas, 0, flags))
+        got = res.cpu().numpy()
+        assert (got[:, 0] == exp["total"]).all() and (got[:, 1] == exp["printed"]).all(), flags
+        assert (got[:, 2] == exp["n_prints"].astype(np.int32)).all() and (got[:, 3] == exp["blocks"].astype(np.int32)).all(), flags
+        assert (status.cpu().numpy() == exp_s).all() and _stats3(eng.stats()) == exp_st, flags
+        for q in range(n):
+            assert (int(got[q, 0]), int(got[q, 1]), int(got[q, 2])) == orc.crazycf_plain(*[int(v) for v in prm[q]])
+    if replicas == 3:
+        eng.reset_stats()
+        eng.crazycf_xmr_batch(dev[:1], ca.XmrConfig(3, 0, B | A | L))
+        assert eng.stats()["sync_count"] == 245  # the reference's -O0 IR (tests/test_ir_counts_cpu.py)
+    rows = []
+    for _ in range(250):
+        q, r = int(rng.integers(0, n)), int(rng.integers(0, replicas))
+        site = (ca.SITE_CCF_I, ca.SITE_CCF_TOTAL, ca.SITE_CCF_TIMES, ca.SITE_CCF_FI)[int(rng.integers(0, 4))]
+        bit = int(rng.integers(0, 5)) if rng.random() < 0.7 else int(rng.integers(0, 32))
+        rows.append((q, r, site, int(rng.integers(0, 2 * (int(prm[q, 1]) + int(prm[q, 2])) + 3)), bit))
+    fl = ca.make_faults(rows)
+    for flags in flagsets:
+        exp, exp_s, exp_st, exp_det = orc.crazycf_xmr(prm, replicas, flags, fl)
+        det = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        eng.reset_stats()
+        eng.inject_faults(fl)
+        res, status = eng.crazycf_xmr_batch(dev, ca.XmrConfig(replicas, 0, flags), detected=det)
+        got = res.cpu().numpy()
+        assert (got[:, 0] == exp["total"]).all() and (got[:, 1] == exp["printed"]).all(), flags
+        assert (got[:, 2] == exp["n_prints"].astype(np.int32)).all() and (got[:, 3] == exp["blocks"].astype(np.int32)).all(), flags
+        assert (status.cpu().numpy() == exp_s).all() and (det.cpu().numpy() == exp_det).all() and _stats3(eng.stats()) == exp_st, flags
+    if replicas == 3:  # everything voted: one upset per run is always out-voted
+        one = ca.make_faults([(q, int(rng.integers(0, 3)), (ca.SITE_CCF_I, ca.SITE_CCF_TOTAL, ca.SITE_CCF_TIMES, ca.SITE_CCF_FI)[q % 4],
+                               int(rng.integers(0, 2 * (int(prm[q, 1]) + int(prm[q, 2])) + 3)), int(rng.integers(0, 32))) for q in range(n)])
+        eng.reset_stats()
+        eng.inject_faults(one)
+        res, status = eng.crazycf_xmr_batch(dev, ca.XmrConfig(3, 0, B | A | L))
+        got = res.cpu().numpy()
+        for q in range(n):
+            assert (int(got[q, 0]), int(got[q, 1]), int(got[q, 2])) == orc.crazycf_plain(*[int(v) for v in prm[q]]), q
+        assert (status.cpu().numpy() == 0).all() and eng.stats()["errors_corrected"] > 0
+    with pytest.raises(RuntimeError, match="sync_every has no meaning"):
+        eng.crazycf_xmr_batch(dev, ca.XmrConfig(3, 1, 0))
+    with pytest.raises(RuntimeError, match="no load with a replicated address"):
+        eng.crazycf_xmr_batch(dev, ca.XmrConfig(3, 0, B | A | ca.F_NO_LOAD_SYNC))
+
+
 def test_crazycf_rejects_bad_arguments(eng):
     import torch
 
@@ -2612,6 +2675,16 @@ def test_chaes_dropin_all_types(passes, monkeypatch):
             assert list(st[:4 * nb]) == fx["st%d" % t][q].tolist()
     st = (C.c_int * 32)()
     assert fn(st, st, 128000, 0) == -1  # KeySchedule's default case
+
+
+def test_campaign_crazycf_under_tmr(eng):
+    """tools/campaign.py -b crazycf -m TMR / DWC (full_tmr.yml:8): upsets of i / total / timesThroughWhile / fillArray's i"""
+    _, _, _, t = _campaign(["-b", "crazycf", "-m", "TMR", "-t", "500", "-n"], eng)
+    _, _, _, d = _campaign(["-b", "crazycf", "-m", "DWC", "-t", "500", "-n"], eng)
+    _, _, _, u = _campaign(["-b", "crazycf", "-m", "NONE", "-t", "500", "-n", "--counters-in-sor"], eng)
+    assert t["errors"] == 0 and t["faults"] > 300 and t["timeouts"] == 0
+    assert d["errors"] == 0 and d["aborts"] > 300
+    assert u["errors"] + u["timeouts"] > 250 and u["TMR_ERROR_CNT"] == 0
 
 
 def test_campaign_chaes(eng):

@@ -199,3 +199,22 @@ def test_chstone_aes_counts_equal_the_references_ir(orc):
                 st = out  # decrypt what was encrypted, like aes_main
     assert sum(got["enc_128128"][c] for c in ("branches", "switches", "returns", "gep_loads", "gep_stores")) == 3971
     assert sum(got["dec_256256"][c] for c in ("branches", "switches", "returns", "gep_loads", "gep_stores")) == 19328
+
+
+def test_crazycf_counts_equal_the_references_ir(orc):
+    """crazyCF under -TMR (unittest/cfg/full_tmr.yml:8): main() + fillArray() on the program's own constants -- loop conditions, the
+    switch, the return value, array[i]'s offset, and with COAST_F_LOCAL_STORE_SYNC every stored datum"""
+    import ir_sync_counts as ir
+
+    k = ir.crazycf()["crazycf"]
+    prm = np.array([[42, 20, 10]], dtype=np.int32)
+    sync = lambda fl: orc.crazycf_xmr(prm, 3, fl)[2]["sync_count"]  # noqa: E731
+    res = orc.crazycf_xmr(prm, 3, B | A | L)[0]
+    assert (int(res["total"][0]), int(res["printed"][0]), int(res["n_prints"][0])) == orc.crazycf_plain(42, 20, 10)
+    base = sync(0)
+    assert base == 1 + int(res["n_prints"][0])  # the printf arguments
+    assert sync(B) - base == k["branches"] + k["switches"] + k["returns"] == 82 + 30 + 1
+    assert sync(B | A) - sync(B) == k["gep_stores"] == 20 and k["gep_loads"] == k["gep_other"] == 0
+    assert sync(B | A | NS) == sync(B)
+    assert sync(B | A | L) - sync(B | A) == k["stores_to_memory"] + k["stores_to_local_allocas"] == 20 + 90
+    assert sync(B | A | L) == 245

@@ -293,19 +293,35 @@ class CrazyCF(Bench):
     def __init__(self, a, eng, g):
         self.eng, self.cfcss = eng, a.mode == "CFCSS"
         self.status = None
+        # -m TMR / DWC (unittest/cfg/full_tmr.yml:8 runs the program with -TMR), or -m NONE --counters-in-sor for the same upsets on the
+        # unprotected run: lane-replicated runs of main() (coast_crazycf_xmr_batch), the upset is a bit of i / total / timesThroughWhile /
+        # fillArray's i before one of the run's 82 branch conditions
+        self.xmr = a.mode in ("TMR", "DWC") or bool(getattr(a, "counters_in_sor", False))
 
     def inputs(self, runs, g):
         prm = torch.tensor([[42, 20, 10]], dtype=torch.int32, device="cuda").repeat(runs, 1)  # crazyCF.c:36, 11, 41
         return [prm]
 
     def run(self, inp, cfg, det=None):
+        if self.xmr:
+            if cfg.replicas > 1:  # the replicated registers ARE the program's counters: their branch / switch / offset votes belong to the mode
+                cfg = ca.XmrConfig(cfg.replicas, 0, cfg.flags | ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC)
+            res, st = self.eng.crazycf_xmr_batch(inp[0], cfg, detected=det)
+            self.status = (st == ca.CFC_WATCHDOG).to(torch.uint8)
+            return res[:, :3].contiguous()
         res, st = self.eng.crazycf_batch(inp[0], cfcss=self.cfcss)
         if det is not None:
             det.copy_((st == ca.CFC_DETECTED).to(torch.uint8))
             self.status = ((st == ca.CFC_WATCHDOG) | (st == ca.CFC_WILD)).to(torch.uint8)
         return res[:, :3].contiguous()  # Total, the "total so far" value, how many such lines
 
+    def counter_fault(self, r, nrep, rng):
+        return (r, int(rng.integers(0, nrep)), int(rng.choice([ca.SITE_CCF_I, ca.SITE_CCF_TOTAL, ca.SITE_CCF_TIMES, ca.SITE_CCF_FI])),
+                int(rng.integers(0, 82)), int(rng.integers(0, 32)))
+
     def reg_fault(self, r, nrep, rng):
+        if self.xmr:
+            return self.counter_fault(r, nrep, rng)
         site = ca.SITE_CFC_PC
         if self.cfcss and rng.random() < 0.4:
             site = ca.SITE_CFC_RTS if rng.random() < 0.5 else ca.SITE_CFC_RTSA
@@ -338,8 +354,8 @@ def run_campaign(a, eng=None):
     rep = MODES[a.mode]
     if (a.mode == "CFCSS") != (a.benchmark == "crazycf" and a.mode == "CFCSS"):
         raise SystemExit("-m CFCSS applies to -b crazycf (the reference's CFCSS test program)")
-    if a.benchmark == "crazycf" and (a.mode not in ("CFCSS", "NONE") or a.section != "registers"):
-        raise SystemExit("-b crazycf: -m CFCSS or NONE, -s registers")
+    if a.benchmark == "crazycf" and a.section != "registers":
+        raise SystemExit("-b crazycf: -s registers")
     aborting = rep == ca.DWC or a.mode == "CFCSS"  # a detection calls the handler -> abort()
     nrep = max(rep, 1)
     runs = a.runs
@@ -367,7 +383,7 @@ def run_campaign(a, eng=None):
         else:
             if a.counters_in_sor:  # the loop counters are members of the sphere of replication and the campaign aims at THEM
                 if not hasattr(bench, "counter_fault") or (a.benchmark == "mm" and a.side > 32):
-                    raise SystemExit("--counters-in-sor: mm (--side <= 32), sha256, aes, crc16, chsha, chaes, cache_test")
+                    raise SystemExit("--counters-in-sor: mm (--side <= 32), sha256, aes, crc16, chsha, chaes, crazycf, cache_test")
                 rows = [bench.counter_fault(r, nrep, rng) for r in range(runs)]
             else:
                 rows = [bench.reg_fault(r, nrep, rng) for r in range(runs)]

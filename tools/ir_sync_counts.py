@@ -194,6 +194,18 @@ int main(void) { int st[32], ky[32];
                     cflags=["-I" + d, "-include", "stdio.h"], rename={"main": "ref_main", "printf": "ch_printf"})
 
 
+def crazycf():
+    """tests/crazyCF/crazyCF.c under -TMR (unittest/cfg/full_tmr.yml:8): main() and fillArray() with the program's own constants
+    (srand(42), size 20, timesThroughWhile 10)"""
+    drv = r'''
+#include <stdarg.h>
+int ch_printf(const char *f, ...) { (void)f; return 0; }
+extern int ref_main(void);
+int main(void) { ref_main(); report("crazycf"); return 0; }
+'''
+    return run_case(os.path.join(REF, "crazyCF", "crazyCF.c"), {"ref_main", "fillArray"}, drv, rename={"main": "ref_main", "printf": "ch_printf"})
+
+
 def crc16(lengths=(0, 13, 255)):
     drv = r'''
 unsigned short crc16(const unsigned char *data_p, unsigned char length);
