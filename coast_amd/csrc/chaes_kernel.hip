@@ -197,7 +197,8 @@ __global__ __launch_bounds__(64) void chaes_kernel(uint8_t *__restrict__ states,
 //   COAST_F_ADDR_SYNC    every GEP whose last index is not a constant: both levels of word[i][j] and of Sbox[a][b], the one level of
 //                        word[1][j - 1], key[i + j * 4], statemt[..], ret[..], temp[i], Rcon0[..]; `statemt[k] ^= w` loads first, so
 //                        its address is a LOAD address (:341-367)                                                       :413-474
-// 3 971 / 6 722 sync points per 128-bit encryption / decryption, 11 407 / 19 328 with 256-bit key and block -- the counts of
+//   COAST_F_LOCAL_STORE_SYNC (with the two) the data of every store of a computed value, in place and into the locals' allocas  :197-224, 476-561
+// 3 971 / 6 722 sync points per 128-bit encryption / decryption (5 853 / 12 367 with the stores), 11 407 / 19 328 with 256-bit key and block -- the counts of
 // tools/ir_sync_counts.py `chaes` on the reference's IR (tests/test_ir_counts_cpu.py).  The region ends where encrypt / decrypt start
 // printing.  The locals (the round counter, the callees' j and i, x, temp[4], ret[32]) and statemt[] / word[][] are replica-private: the
 // lane's own strips of LDS, because they are indexed at run time; a voted (or, unvoted, replica 0's) offset selects the element every
@@ -226,6 +227,10 @@ __global__ __launch_bounds__(64) void chaes_indexed_kernel(uint8_t *__restrict__
     lm.storeSync = !(ctr.flags & kFlagNoStoreDataSync);
     const bool bs = (ctr.flags & kFlagBranchSync) != 0u, as = (ctr.flags & kFlagAddrSync) != 0u;
     const bool ls = as && !(ctr.flags & kFlagNoLoadSync), ss = as && !(ctr.flags & kFlagNoStoreAddrSync);
+    // COAST_F_LOCAL_STORE_SYNC: the data of every store of a computed value of the -O0 IR -- the counters' ++ / --, x, the parameters'
+    // spills into their allocas, and every int stored into statemt[] / ret[] / temp[] / word[][] in place (1170 + 712 votes per 128/128
+    // encryption, 1392 + 4253 per decryption: tools/ir_sync_counts.py chaes)
+    const bool lss = xmr_local_sync_on(ctr.flags);
     const uint32_t tile = blockIdx.x, lane = threadIdx.x;
     const int slot = lm.q;
     const uint64_t item = (uint64_t)tile * IPW + (uint64_t)slot;
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(64) void chaes_indexed_kernel(uint8_t *__restrict__
         auto ifc = [&](bool c) { return xmr_steer<NREP>(c ? 1u : 0u, lm, bs, cnt, tl) != 0u; };
         auto sw = [&](int32_t v) { (void)xmr_steer<NREP>((uint32_t)v, lm, bs, cnt, tl); };       // a switch votes its operand (:761-767)
         auto retv = [&](int32_t v) { return bs ? (int32_t)xmr_sync<NREP>((uint32_t)v, lm, cnt, tl) : v; }; // `ret` of a computed value
+        auto lsy = [&](int32_t v) { return (int32_t)xmr_local_sync<NREP>((uint32_t)v, lm, lss, cnt, tl); }; // the data of a store
         auto off = [&](int32_t idx, bool store) { return xmr_steer<NREP>((uint32_t)idx, lm, store ? ss : ls, cnt, tl); };
         auto ld = [&](int32_t (*arr)[64], int32_t idx) -> int32_t {
             const uint32_t o = off(idx, false);
@@ -291,13 +297,15 @@ __global__ __launch_bounds__(64) void chaes_indexed_kernel(uint8_t *__restrict__
         };
         auto stv = [&](int32_t (*arr)[64], int32_t idx, int32_t v) {
             const uint32_t o = off(idx, true);
+            const int32_t d = lsy(v);
             if (o < 32u)
-                arr[o][lane] = v;
+                arr[o][lane] = d;
         };
         auto xr = [&](int32_t (*arr)[64], int32_t idx, int32_t v) { // arr[idx] ^= v: a LOAD address
             const uint32_t o = off(idx, false);
+            const int32_t d = lsy((o < 32u ? arr[o][lane] : 0) ^ v);
             if (o < 32u)
-                arr[o][lane] ^= v;
+                arr[o][lane] = d;
         };
         auto wget = [&](uint32_t f) -> int32_t { return f < 480u ? (int32_t)((sW[f % 120u][lane] >> (8u * (f / 120u))) & 0xffu) : 0; };
         auto wput = [&](uint32_t f, int32_t v) {
@@ -312,7 +320,10 @@ __global__ __launch_bounds__(64) void chaes_indexed_kernel(uint8_t *__restrict__
             const uint32_t o1 = off(a, false), o2 = off(b, false), f = o1 * 16u + o2;
             return f < 256u ? (int32_t)tab[f] : 0;
         };
-        auto subbyte = [&](int32_t in) -> int32_t { return retv(box(sSb, in / 16, in % 16)); }; // aes_func.c:248-252
+        auto subbyte = [&](int32_t in) -> int32_t { // aes_func.c:248-252
+            in = lsy(in); // the parameter into its alloca
+            return retv(box(sSb, in / 16, in % 16));
+        };
         auto wordHook = [&]() {
             for (uint32_t q = 0; q < fr.y; ++q) {
                 const DevFault df = ft.list[fr.x + q];
@@ -329,17 +340,21 @@ __global__ __launch_bounds__(64) void chaes_indexed_kernel(uint8_t *__restrict__
             }
         };
         auto arkLoop = [&](int32_t n) { // statemt[c + j*4] ^= word[c][j + nb*n], c = 0..3, every column j (aes_func.c:535-542, :443-449)
-            for (j = 0; loopc(j, nb, LT); j = (int32_t)((uint32_t)j + 1u))
+            for (j = 0; loopc(j, nb, LT); j = lsy((int32_t)((uint32_t)j + 1u)))
                 for (int cc = 0; cc < 4; ++cc) {
                     const int32_t w = ldw(cc, (int32_t)((uint32_t)j + (uint32_t)nb * (uint32_t)n));
                     xr(sSt, (int32_t)((uint32_t)cc + (uint32_t)j * 4u), w);
                 }
         };
         auto addRoundKey = [&](int32_t n) { // aes_func.c:514-545
+            (void)lsy(type), n = lsy(n); // the parameters type and n into their allocas
             sw(type);
             arkLoop(n);
         };
         auto subShift = [&](bool inverse) { // aes_func.c:135-246, :254-366: 4 nb lookups, statemt's own indices are constants
+            // every looked-up byte is stored once -- into statemt[] or into `temp` --, and the bytes that went through `temp` a second time
+            // (statemt[k] = temp): one per cycle of the row's rotation, 1 / 2 / 1 cycles in rows 1..3 for Nb = 4, 1 / 2 / 3 for 6, 1 / 1 / 4 for 8
+            (void)lsy(nb); // the parameter nb into its alloca
             sw(nb);
             stateHook(++nsub);
             const uint8_t *tab = inverse ? sRsb : sSb;
@@ -348,22 +363,27 @@ __global__ __launch_bounds__(64) void chaes_indexed_kernel(uint8_t *__restrict__
                     const int sh = nb == 8 ? (ii == 0 ? 0 : ii == 1 ? 1 : ii == 2 ? 3 : 4) : ii;
                     const int from = inverse ? (jj - sh + nb) % nb : (jj + sh) % nb;
                     const int32_t v = sSt[ii + 4 * from][lane];
-                    sOut[ii + 4 * jj][lane] = box(tab, v >> 4, v & 0xf);
+                    const int cyc = ii == 0 ? 0 : nb == 4 ? (ii == 2 ? 2 : 1) : nb == 6 ? ii : (ii == 3 ? 4 : 1);
+                    int32_t b = lsy(box(tab, v >> 4, v & 0xf));
+                    if (jj < cyc)
+                        b = lsy(b);
+                    sOut[ii + 4 * jj][lane] = b;
                 }
             for (int k = 0; k < 4 * nb; ++k)
                 sSt[k][lane] = sOut[k][lane];
         };
-        auto reduce = [&](int32_t x) -> int32_t { return ifc((x >> 8) == 1) ? x ^ 283 : x; }; // if ((x >> 8) == 1) x ^= 283;
+        auto reduce = [&](int32_t x) -> int32_t { return ifc((x >> 8) == 1) ? lsy(x ^ 283) : x; }; // if ((x >> 8) == 1) x ^= 283;
         auto mixColArk = [&](int32_t n) { // MixColumn_AddRoundKey, aes_func.c:368-432
-            for (j = 0; loopc(j, nb, LT); j = (int32_t)((uint32_t)j + 1u))
+            (void)lsy(nb), n = lsy(n); // the parameters nb and n into their allocas
+            for (j = 0; loopc(j, nb, LT); j = lsy((int32_t)((uint32_t)j + 1u)))
                 for (int cc = 0; cc < 4; ++cc) {
                     const uint32_t j4 = (uint32_t)j * 4u;
                     const int32_t id = (int32_t)((uint32_t)cc + j4);
                     stv(sRet, id, (int32_t)((uint32_t)ld(sSt, id) << 1));             // ret[c + j*4] = statemt[c + j*4] << 1
                     if (ifc((ld(sRet, id) >> 8) == 1))                                  // if ((ret[..] >> 8) == 1) ret[..] ^= 283
                         xr(sRet, id, 283);
-                    int32_t x = ld(sSt, (int32_t)((uint32_t)((cc + 1) & 3) + j4));     // x = statemt[(c+1)%4 + j*4]; x ^= x << 1
-                    x ^= (int32_t)((uint32_t)x << 1);
+                    int32_t x = lsy(ld(sSt, (int32_t)((uint32_t)((cc + 1) & 3) + j4))); // x = statemt[(c+1)%4 + j*4]; x ^= x << 1
+                    x = lsy(x ^ (int32_t)((uint32_t)x << 1));
                     if (ifc((x >> 8) == 1))                                             // if ((x >> 8) == 1) ret ^= x ^ 283; else ret ^= x
                         xr(sRet, id, x ^ 283);
                     else
@@ -373,31 +393,33 @@ __global__ __launch_bounds__(64) void chaes_indexed_kernel(uint8_t *__restrict__
                     const int32_t w = ldw(cc, (int32_t)((uint32_t)j + (uint32_t)nb * (uint32_t)n));
                     xr(sRet, id, p ^ q ^ w);
                 }
-            for (j = 0; loopc(j, nb, LT); j = (int32_t)((uint32_t)j + 1u))             // statemt[c + j*4] = ret[c + j*4]
+            for (j = 0; loopc(j, nb, LT); j = lsy((int32_t)((uint32_t)j + 1u)))             // statemt[c + j*4] = ret[c + j*4]
                 for (int cc = 0; cc < 4; ++cc) {
                     const int32_t id = (int32_t)((uint32_t)cc + (uint32_t)j * 4u);
                     stv(sSt, id, ld(sRet, id));
                 }
         };
         auto arkInvMix = [&](int32_t n) { // AddRoundKey_InversMixColumn, aes_func.c:434-511
+            (void)lsy(nb), n = lsy(n); // the parameters nb and n into their allocas
             arkLoop(n);
-            for (j = 0; loopc(j, nb, LT); j = (int32_t)((uint32_t)j + 1u))
-                for (i = 0; loopc(i, 4, LT); i = (int32_t)((uint32_t)i + 1u)) {
+            for (j = 0; loopc(j, nb, LT); j = lsy((int32_t)((uint32_t)j + 1u)))
+                for (i = 0; loopc(i, 4, LT); i = lsy((int32_t)((uint32_t)i + 1u))) {
                     const uint32_t j4 = (uint32_t)j * 4u;
                     const int32_t id = (int32_t)((uint32_t)i + j4);
                     auto lds = [&](int k) { return ld(sSt, (int32_t)((uint32_t)((int32_t)((uint32_t)i + (uint32_t)k) % 4) + j4)); };
-                    auto shl = [&](int32_t x) { return reduce((int32_t)((uint32_t)x << 1)); };
+                    auto shl = [&](int32_t x) { return reduce(lsy((int32_t)((uint32_t)x << 1))); };  // x = x << 1; if (..) x ^= 283
+                    auto xk = [&](int32_t x, int k) { return lsy(x ^ lds(k)); };                    // x ^= statemt[(i + k) % 4 + j * 4]
                     int32_t x;
-                    x = shl(lds(0)), x ^= lds(0), x = shl(x), x ^= lds(0), x = shl(x);       // 14 x                       :454-463
+                    x = shl(lds(0)), x = xk(x, 0), x = shl(x), x = xk(x, 0), x = shl(x);     // 14 x                       :454-463
                     stv(sRet, id, x);
-                    x = shl(lds(1)), x = shl(x), x ^= lds(1), x = shl(x), x ^= lds(1);       // 11 x                       :465-475
+                    x = shl(lds(1)), x = shl(x), x = xk(x, 1), x = shl(x), x = xk(x, 1);     // 11 x                       :465-475
                     xr(sRet, id, x);
-                    x = shl(lds(2)), x ^= lds(2), x = shl(x), x = shl(x), x ^= lds(2);       // 13 x                       :477-487
+                    x = shl(lds(2)), x = xk(x, 2), x = shl(x), x = shl(x), x = xk(x, 2);     // 13 x                       :477-487
                     xr(sRet, id, x);
-                    x = shl(lds(3)), x = shl(x), x = shl(x), x ^= lds(3);                    //  9 x                       :489-498
+                    x = shl(lds(3)), x = shl(x), x = shl(x), x = xk(x, 3);                   //  9 x                       :489-498
                     xr(sRet, id, x);
                 }
-            for (i = 0; loopc(i, nb, LT); i = (int32_t)((uint32_t)i + 1u))             // statemt[c + i*4] = ret[c + i*4]    :503-509
+            for (i = 0; loopc(i, nb, LT); i = lsy((int32_t)((uint32_t)i + 1u)))             // statemt[c + i*4] = ret[c + i*4]    :503-509
                 for (int cc = 0; cc < 4; ++cc) {
                     const int32_t id = (int32_t)((uint32_t)cc + (uint32_t)i * 4u);
                     stv(sSt, id, ld(sRet, id));
@@ -405,17 +427,20 @@ __global__ __launch_bounds__(64) void chaes_indexed_kernel(uint8_t *__restrict__
         };
 
         // ---- KeySchedule, aes_key.c:77-165 ----
+        (void)lsy(type);                                                               // (encrypt's / decrypt's parameter `type` into its alloca)
+        (void)lsy(type);                                                               // (KeySchedule's)
         sw(type);                                                                      // switch (type)                       :83
-        for (j = 0; loopc(j, nk, LT); j = (int32_t)((uint32_t)j + 1u)) {               // for (j = 0; j < nk; ++j)            :135
-            for (i = 0; loopc(i, 4, LT); i = (int32_t)((uint32_t)i + 1u)) {            //   for (i = 0; i < 4; ++i)           :136
+        for (j = 0; loopc(j, nk, LT); j = lsy((int32_t)((uint32_t)j + 1u))) {               // for (j = 0; j < nk; ++j)            :135
+            for (i = 0; loopc(i, 4, LT); i = lsy((int32_t)((uint32_t)i + 1u))) {            //   for (i = 0; i < 4; ++i)           :136
                 const uint32_t ok = off((int32_t)((uint32_t)i + (uint32_t)j * 4u), false); // word[i][j] = key[i + j * 4]     :138
                 const int32_t v = ok < 4u * (uint32_t)nk ? (int32_t)kp[ok] : 0;
                 const uint32_t o1 = off(i, true), o2 = off(j, true);
-                wput(o1 * 120u + o2, v);
+                wput(o1 * 120u + o2, lsy(v));
             }
             wordHook();
         }
-        for (j = nk; loopc(j, nb * (nr + 1), LT); j = (int32_t)((uint32_t)j + 1u)) {   // the expanded key                    :141
+        (void)lsy(nk);                                                                 // j = nk: a loaded value              :141
+        for (j = nk; loopc(j, nb * (nr + 1), LT); j = lsy((int32_t)((uint32_t)j + 1u))) {   // the expanded key                    :141
             const int32_t jm = j % nk, jm1 = (int32_t)((uint32_t)j - 1u);
             if (ifc(jm == 0)) {                                                        //   if ((j % nk) == 0): RotByte, SubByte :145-151
                 for (int cc = 0; cc < 4; ++cc) {
@@ -424,28 +449,29 @@ __global__ __launch_bounds__(64) void chaes_indexed_kernel(uint8_t *__restrict__
                         const uint32_t o = off(j / nk - 1, false);                     //     ^ Rcon0[(j / nk) - 1]
                         s ^= o < 30u ? sRc[o] : 0;
                     }
-                    sTemp[cc][lane] = s;
+                    sTemp[cc][lane] = lsy(s);
                 }
             }
             if (ifc(jm != 0))                                                          //   if ((j % nk) != 0)                :152-158
                 for (int cc = 0; cc < 4; ++cc)
-                    sTemp[cc][lane] = ldw(cc, jm1);
+                    sTemp[cc][lane] = lsy(ldw(cc, jm1));
             if (ifc(nk > 6)) {                                                         //   if (nk > 6 && j % nk == 4)        :159-161
                 if (ifc(jm == 4))
-                    for (i = 0; loopc(i, 4, LT); i = (int32_t)((uint32_t)i + 1u)) {
+                    for (i = 0; loopc(i, 4, LT); i = lsy((int32_t)((uint32_t)i + 1u))) {
                         const uint32_t ol = off(i, false);
                         const int32_t s = subbyte(ol < 4u ? sTemp[ol][lane] : 0);
                         const uint32_t os = off(i, true);
+                        const int32_t sd = lsy(s);
                         if (os < 4u)
-                            sTemp[os][lane] = s;
+                            sTemp[os][lane] = sd;
                     }
             }
-            for (i = 0; loopc(i, 4, LT); i = (int32_t)((uint32_t)i + 1u)) {            //   word[i][j] = word[i][j - nk] ^ temp[i] :162-163
+            for (i = 0; loopc(i, 4, LT); i = lsy((int32_t)((uint32_t)i + 1u))) {            //   word[i][j] = word[i][j - nk] ^ temp[i] :162-163
                 const uint32_t a1 = off(i, false), a2 = off((int32_t)((uint32_t)j - (uint32_t)nk), false);
                 const uint32_t ot = off(i, false);
                 const int32_t v = wget(a1 * 120u + a2) ^ (ot < 4u ? sTemp[ot][lane] : 0);
                 const uint32_t o1 = off(i, true), o2 = off(j, true);
-                wput(o1 * 120u + o2, v);
+                wput(o1 * 120u + o2, lsy(v));
             }
             wordHook();
         }
@@ -455,7 +481,7 @@ __global__ __launch_bounds__(64) void chaes_indexed_kernel(uint8_t *__restrict__
         stateHook(0u);
         if (!dir) {
             addRoundKey(0);                                                            // AddRoundKey (statemt, type, 0)      :112
-            for (rnd = 1; loopc(rnd, nr - 1, LE); rnd = (int32_t)((uint32_t)rnd + 1u)) { // i = 1 .. round_val + 9           :113-117
+            for (rnd = 1; loopc(rnd, nr - 1, LE); rnd = lsy((int32_t)((uint32_t)rnd + 1u))) { // i = 1 .. round_val + 9           :113-117
                 subShift(false);
                 mixColArk(rnd);
             }
@@ -464,7 +490,7 @@ __global__ __launch_bounds__(64) void chaes_indexed_kernel(uint8_t *__restrict__
         } else {
             addRoundKey(nr);                                                           // AddRoundKey (statemt, type, round_val) :117
             subShift(true);                                                            // InversShiftRow_ByteSub               :119
-            for (rnd = nr - 1; loopc(rnd, 1, GE); rnd = (int32_t)((uint32_t)rnd - 1u)) { // i = round_val - 1 .. 1             :121-125
+            for (rnd = lsy(nr - 1); loopc(rnd, 1, GE); rnd = lsy((int32_t)((uint32_t)rnd - 1u))) { // i = round_val - 1 .. 1             :121-125
                 arkInvMix(rnd);
                 subShift(true);
             }

@@ -356,8 +356,7 @@ int coast_dropin_chstone_aes(int *statemt, const int *key, int type, int dir)
     const int kb = type / 1000, bb = type % 1000;
     if ((kb != 128 && kb != 192 && kb != 256) || (bb != 128 && bb != 192 && bb != 256))
         return -1; /* KeySchedule's default case (aes_key.c:132-133) */
-    coast_cfg cfg = dropin_cfg_counters(); /* COAST_COUNTERS_IN_SOR=1: the round counter, the callees' j / i, switches, returns and GEP offsets voted */
-    cfg.flags &= ~(uint32_t)COAST_F_LOCAL_STORE_SYNC; /* (=2: this walk has no store-data votes of locals) */
+    coast_cfg cfg = dropin_cfg_counters(); /* COAST_COUNTERS_IN_SOR=1: the round counter, the callees' j / i, switches, returns and GEP offsets voted; =2: the stored data too */
     unsigned char st[32], k[32];
     for (int i = 0; i < bb / 8; ++i)
         st[i] = (unsigned char)statemt[i];

@@ -102,7 +102,7 @@ enum {
      * result array).  One launch; 3x the memory traffic, as on the reference.  Without it (the default) memory is a single copy
      * (-noMemReplication).  Not combined with sync_every or the other flags. */
     COAST_F_MEMORY_COPIES = 32u,
-    /* With COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC (mm, aes128, crc16, cache_test, CHStone sha; sha256 with COAST_F_O0_SHAPE): the store-data votes the pass emits
+    /* With COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC (mm, aes128, crc16, cache_test, CHStone sha and aes, crazyCF's main; sha256 with COAST_F_O0_SHAPE): the store-data votes the pass emits
      * on the -O0 IR under -noMemReplication for the stores the default schedules do not have -- every store of a computed value into
      * one of the function's own locals (i++, sum += ..: their allocas stay single-copy) and into state[] / key[] / W[] / the bit counts
      * in place (synchronization.cpp:197-224, 476-561).  With it coast_stats.sync_count of a call = executed conditional branches +

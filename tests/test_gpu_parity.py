@@ -2013,8 +2013,8 @@ def test_indexed_flags_are_rejected_where_not_implemented(eng):
     cs, ck = torch.zeros((4, 16), dtype=torch.uint8, device="cuda"), torch.zeros((4, 16), dtype=torch.uint8, device="cuda")
     with pytest.raises(RuntimeError, match="sync_every and the counter flags do not combine"):
         eng.chaes_batch(cs, ck, 128128, 0, ca.XmrConfig(2, 1, ca.F_BRANCH_SYNC))
-    with pytest.raises(RuntimeError, match="COAST_F_LOCAL_STORE_SYNC is not implemented for CHStone aes"):
-        eng.chaes_batch(cs, ck, 128128, 0, ca.XmrConfig(3, 0, ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC | ca.F_LOCAL_STORE_SYNC))
+    with pytest.raises(RuntimeError, match="COAST_F_LOCAL_STORE_SYNC qualifies"):
+        eng.chaes_batch(cs, ck, 128128, 0, ca.XmrConfig(3, 0, ca.F_BRANCH_SYNC | ca.F_LOCAL_STORE_SYNC))
     msgs = torch.zeros((4, 64), dtype=torch.uint8, device="cuda")
     with pytest.raises(RuntimeError, match="sync_every and the counter flags do not combine"):
         eng.chsha_batch(msgs, 64, cfg=ca.XmrConfig(3, 2, ca.F_BRANCH_SYNC))
@@ -2561,13 +2561,14 @@ def test_chaes_counters_in_the_sphere_of_replication(eng, orc, type_, replicas):
 
     import coast_amd as ca
 
-    B, A, NL, NS = ca.F_BRANCH_SYNC, ca.F_ADDR_SYNC, ca.F_NO_LOAD_SYNC, ca.F_NO_STORE_ADDR_SYNC
+    B, A, NL, NS, L = ca.F_BRANCH_SYNC, ca.F_ADDR_SYNC, ca.F_NO_LOAD_SYNC, ca.F_NO_STORE_ADDR_SYNC, ca.F_LOCAL_STORE_SYNC
     nk, nb, nr = orc.chaes_geom(type_)
     rng = np.random.default_rng(type_ + replicas)
     n = 45 if type_ == 128128 else 23
     st = rng.integers(0, 256, (n, 4 * nb), dtype=np.uint8)
     ky = rng.integers(0, 256, (n, 4 * nk), dtype=np.uint8)
-    flagsets = (B | A, B, A, A | NL, A | NS, B | A | ca.F_NO_STORE_DATA_SYNC) if type_ == 128128 else (B | A, A | NL)
+    flagsets = ((B | A, B, A, A | NL, A | NS, B | A | ca.F_NO_STORE_DATA_SYNC, B | A | L, B | A | L | ca.F_NO_STORE_DATA_SYNC)
+                if type_ == 128128 else (B | A, A | NL, B | A | L))
     for dir_ in (0, 1):
         plain, _, _ = orc.chaes_xmr(st, ky, type_, dir_, replicas=1)
         for flags in flagsets:
@@ -2649,7 +2650,8 @@ def test_chaes_dropin_counters_in_sor(orc, monkeypatch):
             assert fn(st, ky, t, 0) == 0 and list(st[:4 * nb]) == fx["enc%d" % t][3].tolist()
             seen[sor] = cnt.value - before
         want = [orc.chaes_xmr(fx["st%d" % t][3:4], fx["key%d" % t][3:4], t, 0, replicas=3, flags=fl)[1]["sync_count"] for fl in (0, 6)]
-        assert seen["0"] == want[0] == nb and seen["1"] == seen["2"] == want[1] > 3000, (t, seen, want)
+        want.append(orc.chaes_xmr(fx["st%d" % t][3:4], fx["key%d" % t][3:4], t, 0, replicas=3, flags=6 | 64)[1]["sync_count"])
+        assert seen["0"] == want[0] == nb and seen["1"] == want[1] > 3000 and seen["2"] == want[2] > want[1] + 1500, (t, seen, want)
 
 
 @pytest.mark.parametrize("passes", ["-TMR -countErrors", "-DWC -noMemReplication", ""])

@@ -195,8 +195,15 @@ def test_chstone_aes_counts_equal_the_references_ir(orc):
             assert (ld, sa) == (k["gep_loads"], k["gep_stores"]) and k["gep_other"] == 0, (t, tag)
             assert k["switches"] == 4 + nr  # KeySchedule, encrypt / decrypt, two AddRoundKey calls, Nr ShiftRow calls
             assert (orc.chaes_xmr(st, ky, t, d, replicas=3, flags=B | A)[0] == out).all()
+            # COAST_F_LOCAL_STORE_SYNC: the data of every store of a computed value -- into statemt[] / ret[] / temp[] / word[][] in place
+            # and into the allocas of the counters, x and the parameters
+            full, res_l = sync(B | A | L), orc.chaes_xmr(st, ky, t, d, replicas=3, flags=B | A | L)[0]
+            assert full - sync(B | A) == k["stores_to_memory"] + k["stores_to_local_allocas"] and (res_l == out).all(), (t, tag)
+            assert full == sum(k[c] for c in ("branches", "switches", "returns", "gep_loads", "gep_stores", "stores_to_memory",
+                                              "stores_to_local_allocas")), (t, tag)
             if d == 0:
                 st = out  # decrypt what was encrypted, like aes_main
+    assert got["enc_128128"]["stores_to_memory"] + got["enc_128128"]["stores_to_local_allocas"] == 1170 + 712
     assert sum(got["enc_128128"][c] for c in ("branches", "switches", "returns", "gep_loads", "gep_stores")) == 3971
     assert sum(got["dec_256256"][c] for c in ("branches", "switches", "returns", "gep_loads", "gep_stores")) == 19328
 
