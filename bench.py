@@ -561,8 +561,8 @@ class AES(Workload):
                 "frac": self.n * look / t / LDS_LOOKUP_PEAK, "lookups_per_block_lane": self.LOOKUPS, "kernel_ms": kern_ms,
                 "hbm_achieved_GBs": self.n * 64 / t * 1e-9, "algorithmic_bytes": float(self.n) * 64,
                 "note": "bank-replicated tables: the lookups are conflict-free and their address is one v_perm_b32; the kernels are "
-                        "bound by their VALU instruction count (466 / 717 per block and lane); 1 Mi blocks are a 47-71 us launch (the "
-                        "armed upsets are applied inside it), and the step also carries the key restore copy"}
+                        "bound by their VALU instruction count (466 / 717 per block and lane); 1 Mi blocks are a 46-64 us launch clean, the "
+                        "armed upsets are applied inside it (+ ~12 us: profiles/r04_aes_step.txt); one launch per step, no harness copy"}
 
     def cpu(self):
         return cpu_baseline_items("aes")
