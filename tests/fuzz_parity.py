@@ -40,7 +40,7 @@ def main():
     rng = np.random.default_rng(seed)
     eng = coast_amd.Engine(0)
     t0 = time.time()
-    cases = {"mm": 0, "sha256": 0, "aes": 0, "crc16": 0, "cache_test": 0, "chsha": 0}
+    cases = {"mm": 0, "sha256": 0, "aes": 0, "crc16": 0, "cache_test": 0, "chsha": 0, "chaes_walk": 0, "crazycf_xmr": 0}
     while time.time() - t0 < budget:
         kind = str(rng.choice(list(cases)))
         rep = int(rng.choice([1, 2, 3]))
@@ -123,6 +123,58 @@ def main():
             ok = ((got.cpu().numpy().view(np.uint32) == exp).all() and stats3(eng.stats()) == est
                   and (det.cpu().numpy() == edet).all())
             desc = "chsha len=%d stride=%d nm=%d rep=%d flags=%d k=%d" % (ln, stride, nm, rep, flags, len(fl))
+        elif kind == "chaes_walk":  # CHStone aes statement by statement: any of the nine sizes, any combination of the counter flags
+            type_ = int(rng.choice([128, 192, 256])) * 1000 + int(rng.choice([128, 192, 256]))
+            nk, nb, nr = orc.chaes_geom(type_)
+            n = int(rng.integers(1, 40))
+            d = int(rng.integers(0, 2))
+            flags = int(rng.choice([2, 4, 6, 6, 6 | 8, 6 | 16, 4 | 8 | 16, 6 | 64, 6 | 64, 6 | 64 | 1, 6 | 1]))
+            st = rng.integers(0, 256, (n, 4 * nb), dtype=np.uint8)
+            ky = rng.integers(0, 256, (n, 4 * nk), dtype=np.uint8)
+            hot = rng.integers(0, n, 3)
+            rows = []
+            for _ in range(int(rng.integers(0, 60)) if rep > 1 else 0):
+                item = int(rng.choice(hot)) if rng.random() < 0.5 else int(rng.integers(0, n))
+                site = int(rng.choice([64, 65, 66, 67, 68, 66, 67, 68]))
+                if site == 64:
+                    step, bit, idx = int(rng.integers(0, nr + 2)), int(rng.integers(0, 32)), int(rng.integers(0, nb))
+                elif site == 65:
+                    step, bit, idx = int(rng.integers(0, nb * (nr + 1))), int(rng.integers(0, 32)), 0
+                else:
+                    step, idx = int(rng.integers(0, 700)), 0
+                    bit = int(rng.integers(0, 4)) if rng.random() < 0.7 else int(rng.integers(0, 32))
+                rows.append((item, int(rng.integers(0, nrep)), site, step, bit, idx))
+            fl = coast_amd.make_faults(rows)
+            exp, est, edet = orc.chaes_xmr(st, ky, type_, d, replicas=rep, flags=flags, faults=fl)
+            ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(ky).cuda()
+            det = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            eng.reset_stats()
+            eng.inject_faults(fl)
+            eng.chaes_batch(ds, dk, type_, d, coast_amd.XmrConfig(rep, 0, flags), detected=det)
+            ok = (ds.cpu().numpy() == exp).all() and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all()
+            desc = "chaes_walk type=%d n=%d dir=%d rep=%d flags=%d k=%d" % (type_, n, d, rep, flags, len(fl))
+        elif kind == "crazycf_xmr":  # crazyCF under -TMR / -DWC
+            n = int(rng.integers(1, 80))
+            flags = int(rng.choice([0, 2, 4, 6, 6 | 16, 6 | 64, 6 | 64 | 1, 6 | 1]))
+            prm = np.stack([rng.integers(0, 2**31 - 1, n), rng.integers(0, 60, n), rng.integers(0, 20, n)], axis=1).astype(np.int32)
+            hot = rng.integers(0, n, 3)
+            rows = []
+            for _ in range(int(rng.integers(0, 60)) if rep > 1 else 0):
+                item = int(rng.choice(hot)) if rng.random() < 0.5 else int(rng.integers(0, n))
+                bit = int(rng.integers(0, 5)) if rng.random() < 0.7 else int(rng.integers(0, 32))
+                rows.append((item, int(rng.integers(0, nrep)), int(rng.choice([72, 73, 74, 75])),
+                             int(rng.integers(0, 2 * (int(prm[item, 1]) + int(prm[item, 2])) + 4)), bit, 0))
+            fl = coast_amd.make_faults(rows)
+            eres, estat, est, edet = orc.crazycf_xmr(prm, rep, flags, fl)
+            det = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            eng.reset_stats()
+            eng.inject_faults(fl)
+            res, status = eng.crazycf_xmr_batch(torch.from_numpy(prm).cuda(), coast_amd.XmrConfig(rep, 0, flags), detected=det)
+            g = res.cpu().numpy()
+            ok = ((g[:, 0] == eres["total"]).all() and (g[:, 1] == eres["printed"]).all() and (g[:, 2] == eres["n_prints"].astype(np.int32)).all()
+                  and (g[:, 3] == eres["blocks"].astype(np.int32)).all() and (status.cpu().numpy() == estat).all()
+                  and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all())
+            desc = "crazycf_xmr n=%d rep=%d flags=%d k=%d" % (n, rep, flags, len(fl))
         elif kind == "cache_test":
             n = int(rng.choice([1, 2, 3, 4, 5, 31, 32, 33, 36, 64, 100, 128, 600, 601, 1000]))
             na = int(rng.integers(1, 300))
