@@ -40,7 +40,7 @@ def main():
     rng = np.random.default_rng(seed)
     eng = coast_amd.Engine(0)
     t0 = time.time()
-    cases = {"mm": 0, "sha256": 0, "aes": 0, "crc16": 0, "cache_test": 0, "chsha": 0, "chaes_walk": 0, "crazycf_xmr": 0}
+    cases = {"mm": 0, "sha256": 0, "aes": 0, "crc16": 0, "cache_test": 0, "chsha": 0, "chaes_walk": 0, "crazycf_xmr": 0, "walks": 0}
     while time.time() - t0 < budget:
         kind = str(rng.choice(list(cases)))
         rep = int(rng.choice([1, 2, 3]))
@@ -175,6 +175,111 @@ def main():
                   and (g[:, 3] == eres["blocks"].astype(np.int32)).all() and (status.cpu().numpy() == estat).all()
                   and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all())
             desc = "crazycf_xmr n=%d rep=%d flags=%d k=%d" % (n, rep, flags, len(fl))
+        elif kind == "walks":  # the statement-by-statement forms (counter flags) of mm / aes / crc16 / cache_test / chsha / sha256
+            which = str(rng.choice(["mm", "aes", "crc16", "cache_test", "chsha", "sha256"]))
+            B, A, NL, NS, ND, L, O0 = 2, 4, 8, 16, 1, 64, 128
+            flags = int(rng.choice([B, A, B | A, B | A, B | A | NL, B | A | NS, B | A | NL | NS, B | A | ND, B | A | L, B | A | L, B | A | L | ND]))
+            nf = int(rng.integers(0, 40)) if rep > 1 else 0
+            if which == "mm":
+                n = int(rng.choice([1, 2, 3, 5, 8, 9, 12]))
+                batch = int(rng.integers(1, 6))
+                f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+                sm = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+                nconds = (n + 1) * (n * n + n + 1)
+                rows = [(int(rng.integers(0, batch)) * n * n, int(rng.integers(0, nrep)), int(rng.choice([0, 3, 4, 5])),
+                         int(rng.integers(0, nconds)), int(rng.integers(0, 32)), 0) for _ in range(nf)]
+                fl = coast_amd.make_faults(rows)
+                exp, est, edet = orc.mm_xmr(f, sm, replicas=rep, flags=flags, faults=fl)
+                det = torch.zeros(batch * n * n, dtype=torch.uint8, device="cuda")
+                eng.reset_stats()
+                eng.inject_faults(fl)
+                got = eng.mm_batch(dev(f), dev(sm), cfg=coast_amd.XmrConfig(rep, 0, flags), detected=det).cpu().numpy().view(np.uint32)
+                ok = (got == exp).all() and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all()
+            elif which == "aes":
+                n, d = int(rng.integers(1, 50)), int(rng.integers(0, 2))
+                st = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+                key = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+                rows = []
+                for _ in range(nf):
+                    site = int(rng.choice([16, 17, 18, 19, 18, 19]))
+                    rows.append((int(rng.integers(0, n)), int(rng.integers(0, nrep)), site,
+                                 int(rng.integers(0, 11)) if site < 18 else int(rng.integers(0, 560)),
+                                 int(rng.integers(0, 32)) if site < 18 else int(rng.integers(0, 8)), int(rng.integers(0, 4))))
+                fl = coast_amd.make_faults(rows)
+                es, ek, est, edet = orc.aes128_xmr(st, key, d, replicas=rep, faults=fl, flags=flags)
+                ds, dk = torch.from_numpy(st.copy()).cuda(), torch.from_numpy(key.copy()).cuda()
+                det = torch.zeros(n, dtype=torch.uint8, device="cuda")
+                eng.reset_stats()
+                eng.inject_faults(fl)
+                eng.aes128_batch(ds, dk, d, cfg=coast_amd.XmrConfig(rep, 0, flags), detected=det)
+                ok = ((ds.cpu().numpy() == es).all() and (dk.cpu().numpy() == ek).all() and stats3(eng.stats()) == est
+                      and (det.cpu().numpy() == edet).all())
+            elif which == "crc16":
+                bl, nb = int(rng.choice([1, 2, 13, 64, 200, 255])), int(rng.integers(1, 200))
+                data = rng.integers(0, 256, (nb, bl), dtype=np.uint8)
+                rows = [(int(rng.integers(0, nb)), int(rng.integers(0, nrep)), int(rng.choice([24, 25, 26, 26])), int(rng.integers(0, bl + 1)),
+                         int(rng.integers(0, 16)), 0) for _ in range(nf)]
+                rows = [r if r[2] != 26 else r[:4] + (r[4] & 7, 0) for r in rows]
+                fl = coast_amd.make_faults(rows)
+                exp, est, edet = orc.crc16_xmr(data, bl, replicas=rep, faults=fl, flags=flags)
+                det = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+                eng.reset_stats()
+                eng.inject_faults(fl)
+                got = eng.crc16_batch(torch.from_numpy(data.reshape(-1)).cuda(), bl, cfg=coast_amd.XmrConfig(rep, 0, flags), detected=det)
+                ok = ((got.cpu().numpy().view(np.uint16) == exp).all() and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all())
+            elif which == "cache_test":
+                n, na = int(rng.choice([1, 2, 5, 33, 100])), int(rng.integers(1, 60))
+                a = np.tile(np.arange(n, dtype=np.int32), (na, 1))
+                if rng.random() < 0.5:
+                    hits = rng.integers(0, na * n, int(rng.integers(1, 8)))
+                    a.reshape(-1)[hits] = rng.integers(-2**31, 2**31, hits.size, dtype=np.int64).astype(np.int32)
+                rows = [(int(rng.integers(0, na)), int(rng.integers(0, nrep)), int(rng.choice([32, 33, 34, 35, 35])), int(rng.integers(0, n + 1)),
+                         int(rng.integers(0, 32)), 0) for _ in range(nf)]
+                fl = coast_amd.make_faults(rows)
+                ea, es, ee, est, edet = orc.cache_test_xmr(a, replicas=rep, faults=fl, flags=flags)
+                d = torch.from_numpy(a.copy()).cuda()
+                det = torch.zeros(na, dtype=torch.uint8, device="cuda")
+                eng.reset_stats()
+                eng.inject_faults(fl)
+                sums, nerrs = eng.cache_test_batch(d, cfg=coast_amd.XmrConfig(rep, 0, flags), detected=det)
+                ok = ((d.cpu().numpy() == ea).all() and (sums.cpu().numpy() == es).all() and (nerrs.cpu().numpy().view(np.uint32) == ee).all()
+                      and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all())
+            elif which == "chsha":
+                ln, nm = 64 * int(rng.choice([0, 1, 2, 3])), int(rng.integers(1, 40))
+                msgs = rng.integers(0, 256, (nm, max(ln, 1)), dtype=np.uint8)
+                ncomp = ln // 64 + 1
+                rows = []
+                for _ in range(nf):
+                    site = int(rng.choice([40, 41, 42, 43, 44, 43]))
+                    step = (int(rng.integers(0, ncomp)) if site == 42 else int(rng.integers(0, ncomp * 80)) if site < 42
+                            else int(rng.integers(0, ncomp * 170)))
+                    rows.append((int(rng.integers(0, nm)), int(rng.integers(0, nrep)), site, step, int(rng.integers(0, 32)), int(rng.integers(0, 5))))
+                fl = coast_amd.make_faults(rows)
+                exp, est, edet = orc.chsha_xmr(msgs, ln, replicas=rep, faults=fl, flags=flags)
+                det = torch.zeros(nm, dtype=torch.uint8, device="cuda")
+                eng.reset_stats()
+                eng.inject_faults(fl)
+                got = eng.chsha_batch(torch.from_numpy(msgs).cuda(), ln, cfg=coast_amd.XmrConfig(rep, 0, flags), detected=det)
+                ok = ((got.cpu().numpy().view(np.uint32) == exp).all() and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all())
+            else:
+                ln, nm = int(rng.choice([0, 1, 3, 55, 56, 64, 65, 119, 120, 130])), int(rng.integers(1, 40))
+                if flags & L or (rng.random() < 0.4 and (flags & (B | A)) == (B | A)):  # sha256: the stores' votes belong to the -O0 shape
+                    flags |= O0
+                msgs = rng.integers(0, 256, (nm, max(ln, 4)), dtype=np.uint8)
+                rows = []
+                for _ in range(nf):
+                    site = int(rng.choice([8, 9, 10, 11, 12, 11, 12]))
+                    step = int(rng.integers(0, ln + 2)) if site >= 11 else (int(rng.integers(0, 4)) if site == 10 else int(rng.integers(0, 192)))
+                    bit = int(rng.integers(0, 8)) if site >= 11 else int(rng.integers(0, 32))
+                    rows.append((int(rng.integers(0, nm)), int(rng.integers(0, nrep)), site, step, bit, int(rng.integers(0, 8))))
+                fl = coast_amd.make_faults(rows)
+                exp, est, edet = orc.sha256_xmr(msgs, ln, replicas=rep, faults=fl, flags=flags)
+                det = torch.zeros(nm, dtype=torch.uint8, device="cuda")
+                eng.reset_stats()
+                eng.inject_faults(fl)
+                got = eng.sha256_batch(torch.from_numpy(msgs).cuda(), ln, cfg=coast_amd.XmrConfig(rep, 0, flags), detected=det).cpu().numpy()
+                ok = (got == exp).all() and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all()
+            desc = "walks %s rep=%d flags=%d k=%d" % (which, rep, flags, nf)
         elif kind == "cache_test":
             n = int(rng.choice([1, 2, 3, 4, 5, 31, 32, 33, 36, 64, 100, 128, 600, 601, 1000]))
             na = int(rng.integers(1, 300))
@@ -215,7 +320,7 @@ def main():
             desc = "crc16 bl=%d nb=%d rep=%d V=%d k=%d off=%d" % (bl, nb, rep, sync_every, len(fl), off)
         cases[kind] += 1
         if not ok:
-            print("MISMATCH:", desc, "seed", seed)
+            print("MISMATCH:", desc, "seed", seed, "case", sum(cases.values()))
             sys.exit(1)
     print("fuzz ok:", cases, "in %.0f s" % (time.time() - t0))
 
