@@ -35,6 +35,9 @@ def _kernels(orc):
     arr = np.tile(np.arange(40, dtype=np.int32), (3, 1))
     arr[1, 7] = -3  # one genuine memory upset for the scrub
     ch = rng.integers(0, 256, (3, 128), dtype=np.uint8)
+    cst = rng.integers(0, 256, (3, 32), dtype=np.uint8)   # CHStone aes, 192-bit key, 256-bit block
+    cky = rng.integers(0, 256, (3, 24), dtype=np.uint8)
+    cprm = np.array([[42, 20, 10], [7, 13, 3], [99, 0, 5]], dtype=np.int32)
 
     def w(fn):
         def run(rep, fl):
@@ -49,7 +52,29 @@ def _kernels(orc):
         K("crc16", w(lambda rep, fl: orc.crc16_xmr(data, 40, replicas=rep, sync_every=7, faults=fl)), [24, 25], 40, 1, 3),
         K("cache_test", w(lambda rep, fl: orc.cache_test_xmr(arr, replicas=rep, faults=fl)), [32, 33, 34], 40, 1, 3),
         K("chsha", w(lambda rep, fl: orc.chsha_xmr(ch, 128, replicas=rep, faults=fl)), [40, 41, 42], 3 * 80, 5, 3),
+        # the statement-by-statement walks with every sync class on (COAST_F_BRANCH_SYNC | ADDR_SYNC | LOCAL_STORE_SYNC): the counters are
+        # inside the sphere of replication and are themselves injection sites
+        K("mm_walk", w(lambda rep, fl: orc.mm_xmr(f, s, replicas=rep, faults=[] if fl is None else _items(fl, 25), flags=WALK)),
+          [0, 3, 4, 5], 6 * 31, 1, 2),
+        K("sha256_walk", w(lambda rep, fl: orc.sha256_xmr(msgs, 70, replicas=rep, faults=fl, flags=WALK | 128)), [8, 9, 10, 11, 12], 72, 8, 3),
+        K("aes_walk", w(lambda rep, fl: orc.aes128_xmr(stt, key, 1, replicas=rep, faults=fl, flags=WALK)), [16, 17, 18, 19], 560, 4, 3),
+        K("crc16_walk", w(lambda rep, fl: orc.crc16_xmr(data, 40, replicas=rep, faults=fl, flags=WALK)), [24, 25, 26], 40, 1, 3),
+        K("cache_test_walk", w(lambda rep, fl: orc.cache_test_xmr(arr, replicas=rep, faults=fl, flags=WALK)), [32, 33, 34, 35], 40, 1, 3),
+        K("chsha_walk", w(lambda rep, fl: orc.chsha_xmr(ch, 128, replicas=rep, faults=fl, flags=WALK)), [40, 41, 42, 43, 44], 3 * 167, 5, 3),
+        K("chaes_walk", w(lambda rep, fl: orc.chaes_xmr(cst, cky, 192256, 0, replicas=rep, faults=fl, flags=WALK)), [64, 65, 66, 67, 68], 900, 8, 3),
+        K("crazycf_xmr", w(lambda rep, fl: orc.crazycf_xmr(cprm, rep, WALK, fl)), [72, 73, 74, 75], 70, 1, 3),
     ]
+
+
+WALK = 2 | 4 | 64
+NK = 14
+
+
+def _items(fl, stride):
+    """mm's walk addresses a CALL (item = b * n * n): move the generic rows' items onto the matrices"""
+    fl = fl.copy()
+    fl["item"] = (fl["item"] % 2) * stride
+    return fl
 
 
 fault = st.tuples(st.integers(0, 10**6), st.integers(0, 2), st.integers(0, 10**6), st.integers(0, 10**6), st.integers(0, 31),
@@ -62,7 +87,7 @@ def _row(k, t, replica=None):
             index % k.max_index)
 
 
-@pytest.mark.parametrize("ki", range(6))
+@pytest.mark.parametrize("ki", range(NK))
 @SET
 @given(t=fault)
 def test_tmr_masks_any_single_upset(orc, ki, t):
@@ -75,7 +100,7 @@ def test_tmr_masks_any_single_upset(orc, ki, t):
     assert det.sum() <= 1
 
 
-@pytest.mark.parametrize("ki", range(6))
+@pytest.mark.parametrize("ki", range(NK))
 @SET
 @given(t=fault, u=fault)
 def test_tmr_masks_two_upsets_in_the_same_replica(orc, ki, t, u):
@@ -86,7 +111,7 @@ def test_tmr_masks_two_upsets_in_the_same_replica(orc, ki, t, u):
     assert all((a == b).all() for a, b in zip(out, clean)), k.name
 
 
-@pytest.mark.parametrize("ki", range(6))
+@pytest.mark.parametrize("ki", range(NK))
 @SET
 @given(t=fault)
 def test_dwc_never_corrupts_silently(orc, ki, t):
@@ -101,7 +126,7 @@ def test_dwc_never_corrupts_silently(orc, ki, t):
     assert st1["errors_corrected"] == 0                              # DWC detects, it never corrects
 
 
-@pytest.mark.parametrize("ki", range(6))
+@pytest.mark.parametrize("ki", range(NK))
 @SET
 @given(t=fault)
 def test_unprotected_ignores_other_replicas(orc, ki, t):
