@@ -2569,6 +2569,19 @@ def test_chaes_counters_in_the_sphere_of_replication(eng, orc, type_, replicas):
     ky = rng.integers(0, 256, (n, 4 * nk), dtype=np.uint8)
     flagsets = ((B | A, B, A, A | NL, A | NS, B | A | ca.F_NO_STORE_DATA_SYNC, B | A | L, B | A | L | ca.F_NO_STORE_DATA_SYNC)
                 if type_ == 128128 else (B | A, A | NL, B | A | L))
+    if replicas == 3 and type_ in (128128, 256256):
+        # the block and key tools/ir_sync_counts.py runs through the reference's -O0 IR: the kernel's __SYNC_COUNT is the IR's executed
+        # branches + switches + returns + GEP offsets (+ stores with COAST_F_LOCAL_STORE_SYNC) + the Nb exit votes (tests/test_ir_counts_cpu.py)
+        want = {128128: ((3971, 5853), (6722, 12367)), 256256: ((11407, 16739), (19328, 35361))}[type_]
+        blk = torch.tensor([[(i * 37 + 11) & 255 for i in range(4 * nb)]], dtype=torch.uint8, device="cuda")
+        kk = torch.tensor([[(i * 59 + 3) & 255 for i in range(4 * nk)]], dtype=torch.uint8, device="cuda")
+        for d in (0, 1):
+            for fl, cnt in zip((B | A, B | A | L), want[d]):
+                work = blk.clone()
+                eng.reset_stats()
+                eng.chaes_batch(work, kk, type_, d, ca.XmrConfig(3, 0, fl))
+                assert eng.stats()["sync_count"] == cnt + nb, (d, fl)
+            blk = work if d == 0 else blk  # decrypt what was encrypted, like aes_main
     for dir_ in (0, 1):
         plain, _, _ = orc.chaes_xmr(st, ky, type_, dir_, replicas=1)
         for flags in flagsets:
