@@ -2374,6 +2374,41 @@ def test_crazycf_vs_oracle_under_upsets(eng, orc, cfcss):
     assert not st2.cpu().numpy().any()
 
 
+def test_sync_counts_of_the_walks_equal_the_references_ir(eng):
+    """The numbers tools/ir_sync_counts.py counts on the reference's own clang -O0 IR (executed conditional branches + variable GEP
+    offsets + stores; tests/test_ir_counts_cpu.py pins the oracle on them where the reference checkout is), asserted on the KERNELS'
+    __SYNC_COUNT with every counter flag on -- the GPU box has no reference to recount them from."""
+    import torch
+
+    import coast_amd as ca
+
+    W = ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC | ca.F_LOCAL_STORE_SYNC
+    g = torch.Generator(device="cuda").manual_seed(1)
+
+    def count(run):
+        eng.reset_stats()
+        run()
+        return eng.stats()["sync_count"]
+
+    f = torch.randint(-2**31, 2**31, (1, 9, 9), dtype=torch.int32, device="cuda", generator=g)
+    assert count(lambda: eng.mm_batch(f, f.clone(), cfg=ca.XmrConfig(3, 0, W))) == 5617  # 910 + 2916 + 162 + 81 + 1548
+    data = torch.randint(0, 256, (255,), dtype=torch.uint8, device="cuda", generator=g)
+    assert count(lambda: eng.crc16_batch(data, 255, cfg=ca.XmrConfig(3, 0, W))) == 1278 + 1  # 256 + 1022, + the returned crc
+    msg = torch.randint(0, 256, (1, 128), dtype=torch.uint8, device="cuda", generator=g)
+    assert count(lambda: eng.chsha_batch(msg, 128, cfg=ca.XmrConfig(3, 0, W))) == 4001  # 503 + 1056 + 241 + 259 + 1942
+    for ln, n in ((3, 2862), (64, 5895)):
+        m = torch.randint(0, 256, (1, 64), dtype=torch.uint8, device="cuda", generator=g)
+        assert count(lambda: eng.sha256_batch(m, ln, cfg=ca.XmrConfig(3, 0, W | ca.F_O0_SHAPE))) == n
+    arr = torch.arange(600, dtype=torch.int32, device="cuda")[None].contiguous()
+    assert count(lambda: eng.cache_test_batch(arr, cfg=ca.XmrConfig(3, 0, W))) == 1203 + 1200 + 1200 + 2  # + the returned sum and error count
+    st = torch.tensor([[(17 * i + 3) & 255 for i in range(16)]], dtype=torch.uint8, device="cuda")
+    ky = torch.tensor([[(29 * i + 7) & 255 for i in range(16)]], dtype=torch.uint8, device="cuda")
+    assert count(lambda: eng.aes128_batch(st, ky, 0, cfg=ca.XmrConfig(3, 0, W))) == 469 + 1378 + 440 + 600 + 779 + 8  # + the 8 exit votes
+    assert count(lambda: eng.aes128_batch(st, ky, 1, cfg=ca.XmrConfig(3, 0, W))) == 593 + 1956 + 560 + 904 + 981 + 8
+    prm = torch.tensor([[42, 20, 10]], dtype=torch.int32, device="cuda")
+    assert count(lambda: eng.crazycf_xmr_batch(prm, ca.XmrConfig(3, 0, W))) == 245
+
+
 @pytest.mark.parametrize("replicas", [3, 2, 1])
 def test_crazycf_under_tmr_and_dwc(eng, orc, replicas):
     """crazyCF as unittest/cfg/full_tmr.yml:8 runs it (-TMR; here also -DWC / unprotected): lane-replicated runs of main(), the printf
