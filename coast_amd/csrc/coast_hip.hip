@@ -667,7 +667,7 @@ bool decode_mm_mfma(const coast_fault &f, const void *gp, DevFault &d)
     const uint64_t nn = (uint64_t)h.g.n * h.g.n;
     if (f.item >= nn * h.batch || f.replica >= h.replicas)
         return false;
-    if (f.site > COAST_SITE_MM_OPB || f.step > (uint32_t)h.g.n)
+    if (f.site != COAST_SITE_MM_VGPR && (f.site > COAST_SITE_MM_OPB || f.step > (uint32_t)h.g.n))
         return false;
     const uint64_t mat = f.item / nn, e = f.item % nn;
     const uint32_t i = (uint32_t)(e / h.g.n), j = (uint32_t)(e % h.g.n);
@@ -804,6 +804,13 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     if (mfma && nbm > 0x7fffffffull)
         return fail(c, COAST_EINVAL, "coast_mm_batch: %llu workgroups exceed the grid limit", (unsigned long long)nbm);
 
+    // COAST_SITE_MM_VGPR: a physical upset of a named vector register of the register-block matrix-core kernel (its PHYS instantiation)
+    bool havePhys = false;
+    for (const coast_fault &af : c->armed)
+        havePhys = havePhys || af.site == COAST_SITE_MM_VGPR;
+    if (havePhys && !(mfma && mmBlocks && mmBlocks2 && mmBlocks3))
+        return fail(c, COAST_EINVAL, "coast_mm_batch: COAST_SITE_MM_VGPR names a register of mm_mfma_blk3_kernel: side 256, no sync_every / "
+                                     "flags, COAST_MM_ENGINE / COAST_MM_TILE at their defaults");
     FaultTab ft;
     int have = 0;
     const uint32_t *dBlockList = nullptr;
@@ -852,7 +859,12 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
                 hookedBlocks = nFaultBlocks;                                                                    \
             if (mmBlocks2 && mmBlocks3) {                                                                       \
                 using G2 = MmBlk2<3>;                                                                           \
-                if (d_detected) {                                                                               \
+                if (havePhys) {                                                                                 \
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<3, true, true>,            \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
+                    hipLaunchKernelGGL((mm_mfma_blk3_kernel<3, true, true>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
+                                       c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);        \
+                } else if (d_detected) {                                                                               \
                     HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<3, true>,                  \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
                     hipLaunchKernelGGL((mm_mfma_blk3_kernel<3, true>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
@@ -899,7 +911,12 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
             const uint32_t gridB = 4u * (uint32_t)std::min<uint64_t>((uint64_t)batch, (uint64_t)std::max(1, c->numCUs / 4)); \
             if (have)                                                                                           \
                 hookedBlocks = nFaultBlocks;                                                                    \
-            if (d_detected && R == 2) {                                                                         \
+            if (havePhys) {                                                                                     \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<R, true, true>,                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
+                hipLaunchKernelGGL((mm_mfma_blk3_kernel<R, true, true>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
+                                   c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);            \
+            } else if (d_detected && R == 2) {                                                                  \
                 HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<R, true>,                      \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
                 hipLaunchKernelGGL((mm_mfma_blk3_kernel<R, true>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES,  \

@@ -56,7 +56,14 @@
 
 namespace coast {
 
-template <int NREP, bool FLAGS>
+// PHYS (round 4): the instantiation that runs when a COAST_SITE_MM_VGPR upset is armed -- a REAL exclusive-or on one bit of one lane of a
+// named vector register of this kernel while it computes: an A-operand fragment of one replica's set of ten MFMAs (flipped before the
+// set's first MFMA; the next set re-reads its own fragment), a B-operand fragment of one replica (flipped at the start of the k-slab's
+// step, used by the replica's sets of both row blocks, re-read for the next step), or a limb-sum accumulator (flipped at the start of a
+// step that is not the tile's first; it stays until the tile's vote).  The hooks sit in front of the MFMAs they precede; the clean
+// instantiations do not contain them.
+enum { SITE_MM_VGPR = 6 };
+template <int NREP, bool FLAGS, bool PHYS = false>
 __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(const uint32_t *__restrict__ F,
                                                                             const uint32_t *__restrict__ S,
                                                                             uint32_t *__restrict__ R, uint32_t nblocks, Counters ctr,
@@ -300,6 +307,8 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 const uint32_t fstep = __builtin_amdgcn_readfirstlane(fp->step);
                 const uint32_t packed = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(&fp->replica));
                 const uint32_t frep = packed & 0xffu, fsite = (packed >> 8) & 0xffu, m = 1u << ((packed >> 16) & 31u);
+                if (fsite > (uint32_t)SITE_MM_OPB)
+                    continue; // (a physical register upset: applied where the register lives, below)
                 if (local != curKey) { // a new element: its replicas start from clean running deltas
                     curKey = local;
                     curStep = 0xffffffffu;
@@ -382,6 +391,57 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             asm volatile("" : "+v"(offB)); // one load per replica: not to be merged
             for_each_index(std::make_integer_sequence<int, 4>{}, [&](auto qTag) __attribute__((always_inline)) { loadB(rrTag, qTag, wbufOff); });
         });
+        // ---- COAST_SITE_MM_VGPR (PHYS): coast_fault.item names the panel, the row half (row / 32), the row block (row / 16) and the column
+        // tile (column / 16); .replica the replica; .step = k-slab of the tile (bits 1:0) | lane << 8 | dword of the 4-dword fragment << 16 |
+        // register << 24 (0-3: A fragment of byte plane p; 4-7: B fragment of plane q; 8-11: limb-sum accumulator t); .bit the bit.
+        auto physFields = [&](uint32_t q, int g, uint32_t &frep, uint32_t &reg, uint32_t &dword, uint32_t &frb, uint32_t &mask) __attribute__((always_inline)) {
+            const DevFault *fp = ft.list + q;
+            const uint32_t local = __builtin_amdgcn_readfirstlane(fp->local);
+            const uint32_t sw = __builtin_amdgcn_readfirstlane(fp->step);
+            const uint32_t packed = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(&fp->replica));
+            const uint32_t frow = local >> 8, fcol = local & 255u;
+            frep = packed & 0xffu;
+            reg = (sw >> 24) & 15u;
+            dword = (sw >> 16) & 3u;
+            frb = (frow >> 4) & 1u;
+            mask = lane == (int)((sw >> 8) & 63u) ? 1u << ((packed >> 16) & 31u) : 0u;
+            return ((packed >> 8) & 0xffu) == (uint32_t)SITE_MM_VGPR && (frow >> 5) == (uint32_t)H && (sw & 3u) == (uint32_t)(g & 3) &&
+                   (int)(fcol / (uint32_t)G::CT) * G::CT == tileCol0(g);
+        };
+        auto physA = [&](int g, auto setTag) __attribute__((always_inline)) { // in front of the first MFMA of set `set`
+            constexpr int set = decltype(setTag)::value;
+#pragma unroll 1
+            for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
+                uint32_t frep, reg, dword, frb, mask;
+                if (!physFields(q, g, frep, reg, dword, frb, mask) || reg > 3u || frb != (uint32_t)(set / NREP) || frep != (uint32_t)(set % NREP))
+                    continue;
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        a[ABUF ? set & 1 : 0][pp][d] ^= (int)((reg == (uint32_t)pp && dword == (uint32_t)d) ? mask : 0u);
+            }
+        };
+        auto physStart = [&](int g, bool accLive) __attribute__((always_inline)) { // at the start of a step: B fragments, accumulators
+#pragma unroll 1
+            for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
+                uint32_t frep, reg, dword, frb, mask;
+                if (!physFields(q, g, frep, reg, dword, frb, mask) || reg < 4u || reg > 11u || frep >= (uint32_t)NREP)
+                    continue;
+#pragma unroll
+                for (int rr = 0; rr < NREP; ++rr)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const bool sel = frep == (uint32_t)rr && dword == (uint32_t)d;
+                            b[rr][qq][d] ^= (int)((sel && reg == (uint32_t)(4 + qq)) ? mask : 0u);
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb)
+                                acc[rb][rr][qq][d] ^= (int)((sel && accLive && reg == (uint32_t)(8 + qq) && frb == (uint32_t)rb) ? mask : 0u);
+                        }
+            }
+        };
         auto step = [&](int g, auto firstTag, auto posTag) __attribute__((always_inline)) {
             constexpr int FIRST = decltype(firstTag)::value; // first slab of a tile: the sums start from zero, the previous tile's last stages run
             constexpr int POS = decltype(posTag)::value;     // g % 4
@@ -453,6 +513,9 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 }
             };
             const v4i_t zero = {0, 0, 0, 0};
+            if constexpr (PHYS)
+                if (fCount != 0u)
+                    physStart(g, FIRST == 0);
             auto slot = [&](auto mTag) __attribute__((always_inline)) {
                 constexpr int m = decltype(mTag)::value;
                 constexpr int set = m / 10, j = m % 10, rb = set / NREP, rr = set % NREP;
@@ -462,6 +525,9 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 constexpr bool fromZero = FIRST != 0 && p == 0;
                 if constexpr (j == 0 && set != 0)
                     asm volatile("" : "+v"(offA)); // this set's A fragments are its own loads
+                if constexpr (PHYS && j == 0)
+                    if (fCount != 0u)
+                        physA(g, std::integral_constant<int, set>{});
                 if constexpr (!(COAST_MM3_KNOCK & 32))
                     acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ABUF ? set & 1 : 0][p], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
                 if constexpr (ABUF && j < 4) { // the NEXT set's fragment j, into the other buffer: a whole set ahead of its first use

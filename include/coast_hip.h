@@ -163,6 +163,16 @@ enum {
                             * i of a replica, flipped right before loop condition number `step` of the call is evaluated */
     COAST_SITE_MM_J = 4,   /* ... j */
     COAST_SITE_MM_K = 5,   /* ... k; COAST_SITE_MM_ACC is `sum` with the same timing in that mode */
+    /* A PHYSICAL upset of the default side-256 matrix-core kernel (mm_mfma_blk3_kernel): one bit of one lane of a named vector register is
+     * flipped by a real exclusive-or while the kernel computes.  item = b n^2 + i n + j names the 64-row panel (i / 64), the wave's row half
+     * (i / 32), the 16-row block (i / 16) and the 16-column tile (j / 16); replica the replica whose register it is; step = k-slab of the
+     * tile (bits 1:0: k / 64) | lane << 8 | dword of the 4-dword fragment << 16 | register << 24 -- 0-3: the A-operand fragment of byte plane p
+     * of that replica's set of ten MFMAs (flipped in front of the set; the next set reads its own), 4-7: the B-operand fragment of plane q of
+     * that replica (flipped at the start of the slab's step, used by both row blocks), 8-11: the limb-sum accumulator t of (row block,
+     * replica) (flipped at the start of the step, k-slabs 1-3: it stays until the tile's vote); bit = the bit.  The effect is whatever the
+     * hardware computes from the flipped register: TMR out-votes it, DWC flags the items it reaches, an unprotected run returns the wrong
+     * words (tests/test_gpu_parity.py::test_mm_physical_register_upsets).  Rejected by every other mm engine. */
+    COAST_SITE_MM_VGPR = 6,
     COAST_SITE_SHA_M = 8,  /* schedule word m[step%64] of compression step/64, right after it is produced */
     COAST_SITE_SHA_WV = 9, /* working variable index 0..7 (a..h) before round step%64 of compression step/64 */
     COAST_SITE_SHA_STATE = 10, /* ctx_state[index] before compression `step` (== ncompress: before the digest) */

@@ -2750,6 +2750,88 @@ def test_campaign_chaes(eng):
     assert m["errors"] == 0 and m["faults"] > 500
 
 
+@pytest.mark.parametrize("cls", ["a_frag", "b_frag", "acc"])
+def test_mm_physical_register_upsets(eng, cls):
+    """COAST_SITE_MM_VGPR: a REAL exclusive-or on one bit of one lane of a named vector register of the side-256 matrix-core kernel while
+    it computes (the other mm sites are applied as the additive consequence of a flip of the LOGICAL register).  No model
+    predicts the outcome here -- the hardware computes it.  Unprotected: the wrong words have exactly the structure a single-operand /
+    single-accumulator upset must have (an A fragment byte of f[i][k]: row i of one 16-column tile moves by +-2^e s[k][j]; a B fragment
+    byte of s[k][j]: column j of the wave's 32 rows moves by +-2^e f[i][k]; a limb sum: one word moves by +-2^e).  TMR, the same register
+    of any replica: every word is the clean one and TMR_ERROR_CNT counts exactly the words the unprotected run got wrong.  DWC: those words
+    are the detected items."""
+    import torch
+
+    import coast_amd as ca
+
+    n, batch = 256, 3
+    rng = np.random.default_rng({"a_frag": 1, "b_frag": 2, "acc": 3}[cls])
+    f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    df, ds = _dev(f), _dev(s)
+    clean = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(1)), np.uint32)
+    assert (clean == _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(3)), np.uint32)).all()
+    seen = 0
+    for trial in range(10):
+        b, i, j = int(rng.integers(0, batch)), int(rng.integers(0, n)), int(rng.integers(0, n))
+        slab, lane, dword, idx = int(rng.integers(0, 4)), int(rng.integers(0, 64)), int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        if cls == "acc":
+            slab = int(rng.integers(1, 4))                   # (the first step of a tile starts the sums from zero)
+            bit = int(rng.integers(0, 32 - 8 * idx))         # limb t bit b weighs 2^(8 t + b): beyond bit 31 nothing architectural is left
+            e = 8 * idx + bit
+        else:
+            bit = int(rng.integers(0, 32))                   # byte (bit / 8) of the dword, bit (bit % 8) of the plane byte
+            e = 8 * idx + bit % 8
+        reg = {"a_frag": 0, "b_frag": 4, "acc": 8}[cls] + idx
+        step = slab | (lane << 8) | (dword << 16) | (reg << 24)
+        item = b * n * n + i * n + j
+
+        def run(replicas, replica):
+            eng.reset_stats()
+            eng.inject_faults(ca.make_faults([(item, replica, ca.SITE_MM_VGPR, step, bit)]))
+            out = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(replicas)), np.uint32)
+            assert eng.last_launch()["engine"] == "matrix_core" and eng.last_launch()["armed_faults"] == 1
+            return out, eng.stats()
+
+        bad, _ = run(1, 0)
+        diff = np.argwhere(bad != clean)
+        assert len(diff) == 0 or (diff[:, 0] == b).all()
+        half0, blk0, col0 = (i // 32) * 32, (i // 16) * 16, (j // 16) * 16
+        delta = (bad[b].astype(np.int64) - clean[b].astype(np.int64)) % 2**32
+        cands = [(1 << e) % 2**32, (-(1 << e)) % 2**32]
+        if cls == "a_frag":   # one row of the 16-row block, the tile's 16 columns, one k of the slab
+            rows = np.unique(diff[:, 1])
+            assert len(rows) <= 1 and all(blk0 <= r < blk0 + 16 for r in rows) and all(col0 <= c < col0 + 16 for c in diff[:, 2])
+            if len(rows):
+                d = delta[rows[0], col0:col0 + 16]
+                ok = [(k, c) for k in range(64 * slab, 64 * slab + 64) for c in cands
+                      if ((c * s[b, k, col0:col0 + 16].astype(np.uint64)) % 2**32 == d).all()]
+                assert ok, (trial, d)
+        elif cls == "b_frag":  # one column of the tile, the wave's 32 rows, one k of the slab
+            cols = np.unique(diff[:, 2])
+            assert len(cols) <= 1 and all(col0 <= c < col0 + 16 for c in cols) and all(half0 <= r < half0 + 32 for r in diff[:, 1])
+            if len(cols):
+                d = delta[half0:half0 + 32, cols[0]]
+                ok = [(k, c) for k in range(64 * slab, 64 * slab + 64) for c in cands
+                      if ((c * f[b, half0:half0 + 32, k].astype(np.uint64)) % 2**32 == d).all()]
+                assert ok, (trial, d)
+        else:                  # one word of the row block x tile, moved by +-2^e
+            assert len(diff) == 1 and blk0 <= diff[0, 1] < blk0 + 16 and col0 <= diff[0, 2] < col0 + 16
+            assert int(delta[diff[0, 1], diff[0, 2]]) in cands
+        seen += len(diff) > 0
+        for r in range(3):      # TMR: any replica's register -- out-voted, and counted word by word
+            out, st = run(3, r)
+            assert (out == clean).all() and st["errors_corrected"] == len(diff) and st["dwc_detected"] == 0, (trial, r, st, len(diff))
+        for r in range(2):      # DWC: the words are the detected items; the original's (replica 0's) value is what was stored
+            out, st = run(2, r)
+            assert st["dwc_detected"] == len(diff) and st["errors_corrected"] == 0, (trial, r, st, len(diff))
+            assert (out == (bad if r == 0 else clean)).all()
+    assert seen >= 8  # (an upset whose every consequence is a multiple of 2^32 is possible, not typical)
+    with pytest.raises(RuntimeError, match="COAST_SITE_MM_VGPR names a register of mm_mfma_blk3_kernel"):
+        eng.inject_faults(ca.make_faults([(0, 0, ca.SITE_MM_VGPR, 0, 0)]))
+        eng.mm_batch(_dev(f[:, :64, :64].copy()), _dev(s[:, :64, :64].copy()), cfg=ca.XmrConfig(3))
+    eng.mm_batch(df, ds, cfg=ca.XmrConfig(1))  # (a rejected launch leaves the upsets armed: this one consumes them)
+
+
 @pytest.mark.parametrize("replicas", [2, 1])
 @pytest.mark.parametrize("batch", [1, 3, 64, 65, 130])
 def test_mm_256_register_block_kernel_dwc_and_unprotected(eng, orc, batch, replicas, monkeypatch):
