@@ -560,15 +560,18 @@ def test_common_mode_upsets_lane_kernels_vs_oracle(eng, orc, replicas):
         assert (ds.cpu().numpy() == es).all() and (dk.cpu().numpy() == ek).all() and _stats3(eng.stats()) == exp_st
 
 
-@pytest.mark.parametrize("tile", ["blocks3", "blocks2"])
+@pytest.mark.parametrize("tile", ["blocks3", "blocks2", "blocks3-real"])
 def test_campaign_physical_register_model_mm256(eng, tmp_path, tile, monkeypatch):
     """`campaign.py -b mm --side 256 -m TMR --reg-model physical`: any register of the matrix-core kernel's wave, weighted by its
     census -- the s / f staging registers included.  Coverage is a measurement: private classes are corrected, common-mode classes
     corrupt silently, and the table says how much of the register file each one is.  blocks3 (the default): a replica's MFMAs read
     their own A fragments, so an A-fragment upset is out-voted; blocks2: the three replicas share one A fragment set."""
+    # blocks3-real: the replica-private classes as REAL flips of the running kernel's registers (COAST_SITE_MM_VGPR), not as model sites
+    model = "physical-real" if tile == "blocks3-real" else "physical"
+    tile = tile.split("-")[0]
     if tile != "blocks3":
         monkeypatch.setenv("COAST_MM_TILE", tile)
-    _, _, recs, summ = _campaign(["-b", "mm", "--side", "256", "-m", "TMR", "-t", "600", "--reg-model", "physical", "-n"], eng)
+    _, _, recs, summ = _campaign(["-b", "mm", "--side", "256", "-m", "TMR", "-t", "600", "--reg-model", model, "-n"], eng)
     by = summ["by_class"]
     assert summ["engine"] == "matrix_core" and summ["stepwise_blocks"] == 0
     private = ("acc", "b_frag", "a_frag") if tile == "blocks3" else ("acc", "b_frag")

@@ -93,11 +93,12 @@ def test_mm_register_block_kernels_fit_their_register_files(compiled, flags):
     usage, bodies = compiled
     # two waves per SIMD: 256 VGPRs, no AGPRs; the default TMR kernel (blk3) and its predecessor (blk2)
     for kern, spill_cap in (("mm_mfma_blk3_kernel", 10), ("mm_mfma_blk2_kernel", 8)):
-        u2 = _find(usage, "void coast::%s<3, %s>" % (kern, flags))
+        tail = ", false>" if kern == "mm_mfma_blk3_kernel" else ">"  # (blk3's third parameter: the instantiation with the physical-upset hooks)
+        u2 = _find(usage, "void coast::%s<3, %s%s" % (kern, flags, tail))
         assert u2["VGPRs"] <= 256 and u2["AGPRs"] == 0 and u2["Occupancy [waves/SIMD]"] == 2
         # the armed-upset hook (cold, wave-uniform branch) may park a few registers; the step bodies must not
         assert u2["VGPRs Spill"] <= spill_cap, (kern, u2)
-        b2 = _find(bodies, "void coast::%s<3, %s>" % (kern, flags))
+        b2 = _find(bodies, "void coast::%s<3, %s%s" % (kern, flags, tail))
         # 4 step variants x 60 MFMAs x 2 row halves: every k-slab of a tile issues its 120 MFMAs once
         assert len(re.findall(r"v_mfma_i32_16x16x64_i8", b2)) == 480
         assert len(re.findall(r"scratch_load", b2)) <= 12
@@ -106,7 +107,7 @@ def test_mm_register_block_kernels_fit_their_register_files(compiled, flags):
             if len(re.findall(r"v_mfma_i32_16x16x64_i8", blk)) >= 60:
                 assert len(re.findall(r"scratch_load", blk)) <= 2 and not re.search(r"scratch_store", blk), kern
     # blk3: every set of ten MFMAs reads its own four A fragments (24 + 12 B fragment reads per step and wave)
-    b3 = _find(bodies, "void coast::mm_mfma_blk3_kernel<3, %s>" % flags)
+    b3 = _find(bodies, "void coast::mm_mfma_blk3_kernel<3, %s, false>" % flags)
     assert len(re.findall(r"ds_read_b128", b3)) >= 8 * 36
     # one wave per SIMD: accumulators in AGPRs, nothing spilled
     u1 = _find(usage, "void coast::mm_mfma_blk_kernel<3, %s>" % flags)

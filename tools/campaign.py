@@ -112,6 +112,13 @@ class MM(Bench):
         item = lambda ii, jj: r * nn + ii * n + jj
         if cls in ("tally", "other"):
             return cls, []
+        if getattr(self, "real", False) and cls in ("acc", "b_frag", "a_frag"):
+            # --reg-model physical-real: the replica-private classes are REAL flips (COAST_SITE_MM_VGPR: an exclusive-or on the named
+            # register of the running kernel) -- any lane, any dword of the fragment, any of the 32 bits; the outcome is the hardware's
+            reg = {"a_frag": 0, "b_frag": 4, "acc": 8}[cls] + limb
+            slab = int(rng.integers(1, 4)) if cls == "acc" else int(rng.integers(0, 4))
+            step = slab | (int(rng.integers(0, 64)) << 8) | (int(rng.integers(0, 4)) << 16) | (reg << 24)
+            return cls, [(item(i, j), int(rng.integers(0, nrep)), ca.SITE_MM_VGPR, step, int(rng.integers(0, 32)))]
         if cls == "acc":
             if bit > 31:  # a bit of a limb sum that falls off the 32-bit word: no architectural effect
                 return cls, []
@@ -369,9 +376,10 @@ def run_campaign(a, eng=None):
     eng.reset_stats()
     classes = None
     if a.section == "registers":
-        physical = a.reg_model == "physical" and a.benchmark == "mm" and a.side == 256 and rep == ca.TMR
-        if a.reg_model == "physical" and not physical:
+        physical = a.reg_model in ("physical", "physical-real") and a.benchmark == "mm" and a.side == 256 and rep == ca.TMR
+        if a.reg_model in ("physical", "physical-real") and not physical:
             raise SystemExit("--reg-model physical: the register census is that of the TMR matrix-core kernel (-b mm --side 256 -m TMR)")
+        bench.real = a.reg_model == "physical-real"
         if physical:  # any register of the wave, weighted by the kernel's register census: shared state included
             rows, classes = [], []
             for r in range(runs):
@@ -491,7 +499,9 @@ def run_campaign(a, eng=None):
             d["errors" if records[r]["class"] == "error" else "corrected_or_masked"] += 1
         unmodelled = by.get("other", {"runs": 0})["runs"]
         summary.update({
-            "reg_model": "physical: one bit of one lane of one of the wave's 256 VGPRs, weighted by the register census",
+            "reg_model": "physical: one bit of one lane of one of the wave's 256 VGPRs, weighted by the register census"
+                         + ("; the replica-private classes (acc, b_frag, a_frag) are REAL register flips (COAST_SITE_MM_VGPR), the shared "
+                            "staging classes modelled" if a.reg_model == "physical-real" else ""),
             "census": [{"class": c[0], "vgprs": c[1], "reaches": c[2]} for c in MM.census()],
             "by_class": by, "unmodelled_runs": unmodelled,
             # `other` registers (addresses, lane constants, SGPRs) are not simulated: the two bounds file them under success / error
@@ -552,7 +562,7 @@ def parse(argv=None):
     ap.add_argument("-t", "--runs", type=int, default=5000)
     ap.add_argument("-s", "--section", default="registers", choices=["registers", "memory"])
     ap.add_argument("--mem-mode", default="nomemrep", choices=["nomemrep", "default", "storesync"])
-    ap.add_argument("--reg-model", default="sites", choices=["sites", "physical"],
+    ap.add_argument("--reg-model", default="sites", choices=["sites", "physical", "physical-real"],
                     help="registers: `sites` = a replica-private injector site per run; `physical` (-b mm --side 256 -m TMR) = any "
                          "register of the matrix-core kernel's wave, weighted by its register census, shared state included")
     ap.add_argument("--counters-in-sor", action="store_true",
