@@ -307,8 +307,9 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 const uint32_t fstep = __builtin_amdgcn_readfirstlane(fp->step);
                 const uint32_t packed = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(&fp->replica));
                 const uint32_t frep = packed & 0xffu, fsite = (packed >> 8) & 0xffu, m = 1u << ((packed >> 16) & 31u);
-                if (fsite > (uint32_t)SITE_MM_OPB)
-                    continue; // (a physical register upset: applied where the register lives, below)
+                if constexpr (PHYS)
+                    if (fsite > (uint32_t)SITE_MM_OPB)
+                        continue; // (a physical register upset: applied where the register lives, below)
                 if (local != curKey) { // a new element: its replicas start from clean running deltas
                     curKey = local;
                     curStep = 0xffffffffu;
