@@ -402,7 +402,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             const uint32_t packed = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(&fp->replica));
             const uint32_t frow = local >> 8, fcol = local & 255u;
             frep = packed & 0xffu;
-            reg = (sw >> 24) & 15u;
+            reg = (sw >> 24) & 31u;
             dword = (sw >> 16) & 3u;
             frb = (frow >> 4) & 1u;
             mask = lane == (int)((sw >> 8) & 63u) ? 1u << ((packed >> 16) & 31u) : 0u;
@@ -427,7 +427,23 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
 #pragma unroll 1
             for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
                 uint32_t frep, reg, dword, frb, mask;
-                if (!physFields(q, g, frep, reg, dword, frb, mask) || reg < 4u || reg > 11u || frep >= (uint32_t)NREP)
+                if (!physFields(q, g, frep, reg, dword, frb, mask) || reg < 4u)
+                    continue;
+                if (reg >= 12u) { // the staging registers every replica's data passes through: raw words of s (12-15: round 0, 16-19:
+                                  // round 1; two dwords each) and of the next panel of f (20; four dwords) on their way into LDS
+#pragma unroll
+                    for (int u = 0; u < G::B_ROUNDS; ++u)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+                                pbs[u][kk][h] ^= (reg == (uint32_t)(12 + 4 * u + kk) && dword == (uint32_t)h) ? mask : 0u;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        bgRaw[d] ^= (reg == 20u && dword == (uint32_t)d) ? mask : 0u;
+                    continue;
+                }
+                if (reg > 11u || frep >= (uint32_t)NREP)
                     continue;
 #pragma unroll
                 for (int rr = 0; rr < NREP; ++rr)

@@ -2835,6 +2835,55 @@ def test_mm_physical_register_upsets(eng, cls):
     eng.mm_batch(df, ds, cfg=ca.XmrConfig(1))  # (a rejected launch leaves the upsets armed: this one consumes them)
 
 
+def test_mm_physical_upsets_of_the_shared_staging_registers_are_silent(eng):
+    """COAST_SITE_MM_VGPR registers 12-20: a raw word of s / of the next f panel in the wave's staging registers, on its way into the LDS
+    image every replica (and, for s, both waves of the pair) reads -- the analogue of a memory upset under -noMemReplication.  A real flip
+    there is common-mode: under TMR the wrong words come out with TMR_ERROR_CNT == 0 (every vote agrees), and they have the structure of
+    one corrupted word of s (a column of one 64-row panel moved by +-2^bit f[i][k]) or of f (a row moved by +-2^bit s[k][j])."""
+    import coast_amd as ca
+
+    n, batch = 256, 66  # 66 matrices on 64 workgroup groups: workgroups 0 and 1 own a second matrix, whose f panel they stage ahead
+    rng = np.random.default_rng(11)
+    f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
+    df, ds = _dev(f), _dev(s)
+    eng.reset_stats()
+    clean = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(3)), np.uint32)
+    syncs = eng.stats()["sync_count"]
+    hits = {"s": 0, "f": 0}
+    for trial in range(24):
+        fcls = trial % 3 == 2
+        b, i, j = int(rng.integers(0, 2)) if fcls else int(rng.integers(0, batch)), int(rng.integers(0, n)), int(rng.integers(0, n))
+        reg, dword = (20, int(rng.integers(0, 4))) if fcls else (12 + int(rng.integers(0, 8)), int(rng.integers(0, 2)))
+        bit = int(rng.integers(0, 32))
+        step = int(rng.integers(0, 4)) | (int(rng.integers(0, 64)) << 8) | (dword << 16) | (reg << 24)
+        eng.reset_stats()
+        eng.inject_faults(ca.make_faults([(b * n * n + i * n + j, int(rng.integers(0, 3)), ca.SITE_MM_VGPR, step, bit)]))
+        out = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(3)), np.uint32)
+        st = eng.stats()
+        assert st["errors_corrected"] == 0 and st["dwc_detected"] == 0 and st["sync_count"] == syncs, (trial, st)  # nothing to see for a voter
+        diff = np.argwhere(out != clean)
+        if not len(diff):
+            continue  # (the register held no live word at that moment, or the word's consequence was a multiple of 2^32)
+        m = int(diff[0, 0])
+        assert (diff[:, 0] == m).all()
+        delta = (out[m].astype(np.int64) - clean[m].astype(np.int64)) % 2**32
+        cands = [(1 << bit) % 2**32, (-(1 << bit)) % 2**32]
+        if fcls:    # one row of the staged panel, all columns
+            rows = np.unique(diff[:, 1])
+            assert len(rows) == 1
+            d = delta[rows[0]]
+            assert any(((c * s[m, k].astype(np.uint64)) % 2**32 == d).all() for k in range(n) for c in cands), trial
+            hits["f"] += 1
+        else:       # one column, the rows of one 64-row panel
+            cols, p0 = np.unique(diff[:, 2]), (int(diff[0, 1]) // 64) * 64
+            assert len(cols) == 1 and all(p0 <= r < p0 + 64 for r in diff[:, 1])
+            d = delta[p0:p0 + 64, cols[0]]
+            assert any(((c * f[m, p0:p0 + 64, k].astype(np.uint64)) % 2**32 == d).all() for k in range(n) for c in cands), trial
+            hits["s"] += 1
+    assert hits["s"] >= 3 and hits["f"] >= 1, hits
+
+
 @pytest.mark.parametrize("replicas", [2, 1])
 @pytest.mark.parametrize("batch", [1, 3, 64, 65, 130])
 def test_mm_256_register_block_kernel_dwc_and_unprotected(eng, orc, batch, replicas, monkeypatch):

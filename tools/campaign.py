@@ -112,6 +112,14 @@ class MM(Bench):
         item = lambda ii, jj: r * nn + ii * n + jj
         if cls in ("tally", "other"):
             return cls, []
+        if getattr(self, "real_staging", False) and cls in ("s_raw", "f_raw"):
+            # --reg-model physical-real-all: the shared staging registers as real flips too: raw words of s (16 VGPRs: registers 12-19 x 2 dwords) / of the next f panel
+            # (register 20 x 4 dwords); the conversion temporaries of the census' 24 are dead between stages (a flip there: no effect)
+            if cls == "s_raw" and rng.random() < 8.0 / 24.0:
+                return cls, []
+            reg, dw = (20, int(rng.integers(0, 4))) if cls == "f_raw" else (12 + int(rng.integers(0, 8)), int(rng.integers(0, 2)))
+            step = int(rng.integers(0, 4)) | (int(rng.integers(0, 64)) << 8) | (dw << 16) | (reg << 24)
+            return cls, [(item(i, j), int(rng.integers(0, nrep)), ca.SITE_MM_VGPR, step, int(rng.integers(0, 32)))]
         if getattr(self, "real", False) and cls in ("acc", "b_frag", "a_frag"):
             # --reg-model physical-real: the replica-private classes are REAL flips (COAST_SITE_MM_VGPR: an exclusive-or on the named
             # register of the running kernel) -- any lane, any dword of the fragment, any of the 32 bits; the outcome is the hardware's
@@ -376,10 +384,11 @@ def run_campaign(a, eng=None):
     eng.reset_stats()
     classes = None
     if a.section == "registers":
-        physical = a.reg_model in ("physical", "physical-real") and a.benchmark == "mm" and a.side == 256 and rep == ca.TMR
-        if a.reg_model in ("physical", "physical-real") and not physical:
+        physical = a.reg_model.startswith("physical") and a.benchmark == "mm" and a.side == 256 and rep == ca.TMR
+        if a.reg_model.startswith("physical") and not physical:
             raise SystemExit("--reg-model physical: the register census is that of the TMR matrix-core kernel (-b mm --side 256 -m TMR)")
-        bench.real = a.reg_model == "physical-real"
+        bench.real = a.reg_model in ("physical-real", "physical-real-all")
+        bench.real_staging = a.reg_model == "physical-real-all"
         if physical:  # any register of the wave, weighted by the kernel's register census: shared state included
             rows, classes = [], []
             for r in range(runs):
@@ -493,21 +502,41 @@ def run_campaign(a, eng=None):
     }
     if classes is not None:  # the physical register model: outcome per register class, and what the unmodelled share can change
         by = {}
+        # a REAL flip of a staging register (s_raw / f_raw) can hold a word of the workgroup's NEXT matrix (its slabs and its f panel are
+        # staged ahead): the wrong words then belong to run r + stride (one workgroup group per min(runs, CUs / 4) matrices).  Such an
+        # error is the staging flip's, not the later run's own upset's.
+        stride = min(runs, 64)
+        owner = list(range(runs))
+        if a.reg_model == "physical-real-all":
+            for r in range(runs):
+                if records[r]["class"] == "error" and classes[r] not in ("s_raw", "f_raw") and r >= stride and classes[r - stride] in ("s_raw", "f_raw"):
+                    owner[r] = r - stride
+        leaked = sum(1 for r in range(runs) if owner[r] != r)
         for r in range(runs):
             d = by.setdefault(classes[r], {"runs": 0, "errors": 0, "corrected_or_masked": 0})
             d["runs"] += 1
-            d["errors" if records[r]["class"] == "error" else "corrected_or_masked"] += 1
+            if owner[r] != r:  # its own upset was dealt with; the wrong words are charged to the staging flip of the previous matrix
+                d["corrected_or_masked"] += 1
+                by.setdefault(classes[owner[r]], {"runs": 0, "errors": 0, "corrected_or_masked": 0})["errors"] += 1
+            else:
+                d["errors" if records[r]["class"] == "error" else "corrected_or_masked"] += 1
+        for d in by.values():  # (a staging run that was clean itself and corrupted its successor: one run, one error)
+            d["corrected_or_masked"] = max(0, d["runs"] - d["errors"])
         unmodelled = by.get("other", {"runs": 0})["runs"]
         summary.update({
             "reg_model": "physical: one bit of one lane of one of the wave's 256 VGPRs, weighted by the register census"
                          + ("; the replica-private classes (acc, b_frag, a_frag) are REAL register flips (COAST_SITE_MM_VGPR), the shared "
-                            "staging classes modelled" if a.reg_model == "physical-real" else ""),
+                            "staging classes modelled" if a.reg_model == "physical-real" else "")
+                         + ("; every modelled class (acc, b_frag, a_frag, s_raw, f_raw) is a REAL register flip (COAST_SITE_MM_VGPR) at a "
+                            "random k-slab: a staging register that holds no live word at that moment has no effect" if a.reg_model == "physical-real-all" else ""),
             "census": [{"class": c[0], "vgprs": c[1], "reaches": c[2]} for c in MM.census()],
             "by_class": by, "unmodelled_runs": unmodelled,
             # `other` registers (addresses, lane constants, SGPRs) are not simulated: the two bounds file them under success / error
             "coverage_pct_upper": 100.0 * (runs - counts["errors"]) / runs,
             "coverage_pct_lower": 100.0 * (runs - counts["errors"] - unmodelled) / runs,
         })
+        if a.reg_model == "physical-real-all":
+            summary["errors_landed_in_the_next_matrix_of_the_workgroup"] = leaked
     else:
         summary["reg_model"] = "sites: replica-private injector sites only (what TMR corrects by construction)" if a.section == "registers" else None
     return records, summary
@@ -562,9 +591,11 @@ def parse(argv=None):
     ap.add_argument("-t", "--runs", type=int, default=5000)
     ap.add_argument("-s", "--section", default="registers", choices=["registers", "memory"])
     ap.add_argument("--mem-mode", default="nomemrep", choices=["nomemrep", "default", "storesync"])
-    ap.add_argument("--reg-model", default="sites", choices=["sites", "physical", "physical-real"],
+    ap.add_argument("--reg-model", default="sites", choices=["sites", "physical", "physical-real", "physical-real-all"],
                     help="registers: `sites` = a replica-private injector site per run; `physical` (-b mm --side 256 -m TMR) = any "
-                         "register of the matrix-core kernel's wave, weighted by its register census, shared state included")
+                         "register of the matrix-core kernel's wave, weighted by its register census, shared state included; "
+                         "`physical-real` = the replica-private classes as real flips of the running kernel's VGPRs; "
+                         "`physical-real-all` = the staging registers as real flips too (an error can land in the workgroup's next matrix)")
     ap.add_argument("--counters-in-sor", action="store_true",
                     help="registers: run with COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC (the loop counters replica-private, their branch conditions "
                          "and GEP offsets voted) and aim every upset at a loop counter")
