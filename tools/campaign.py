@@ -382,7 +382,7 @@ def run_campaign(a, eng=None):
     targets = []
     t0 = time.perf_counter()
     eng.reset_stats()
-    classes = None
+    classes = bad_staged = None
     if a.section == "registers":
         physical = a.reg_model.startswith("physical") and a.benchmark == "mm" and a.side == 256 and rep == ca.TMR
         if a.reg_model.startswith("physical") and not physical:
@@ -390,11 +390,14 @@ def run_campaign(a, eng=None):
         bench.real = a.reg_model in ("physical-real", "physical-real-all")
         bench.real_staging = a.reg_model == "physical-real-all"
         if physical:  # any register of the wave, weighted by the kernel's register census: shared state included
-            rows, classes = [], []
+            rows, classes, staged_rows = [], [], []
             for r in range(runs):
                 cls, ev = bench.reg_event(r, nrep, rng)
                 classes.append(cls)
-                rows += ev
+                if bench.real_staging and cls in ("s_raw", "f_raw"):
+                    staged_rows += ev  # physical-real-all: the staging flips run in a launch of their own (below)
+                else:
+                    rows += ev
                 targets.append({"class": cls, "flips": len(ev), "site": ev[0][2] if ev else None, "step": ev[0][3] if ev else None,
                                 "bit": ev[0][4] if ev else None, "replica": ev[0][1] if ev else None})
         else:
@@ -410,6 +413,15 @@ def run_campaign(a, eng=None):
         flags = (ca.F_BRANCH_SYNC if a.benchmark == "crc16" else ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC) if a.counters_in_sor else 0
         out = bench.run(inp, ca.XmrConfig(rep, 0, flags), det)
         engine = eng.last_launch()
+        if physical and bench.real_staging:
+            # a REAL flip of a staging register can hold a word of the workgroup's NEXT matrix (its slabs and its f panel are staged
+            # ahead): the wrong words then belong to run r + stride.  A second launch with only the staging flips armed keeps those
+            # errors apart from the outcome of the other runs' own upsets (first launch) -- exact, no guess about who corrupted what.
+            bad_staged = np.zeros(runs, dtype=bool)
+            if staged_rows:
+                eng.inject_faults(ca.make_faults(staged_rows))
+                out2 = bench.run(inp, ca.XmrConfig(rep, 0, flags), det)
+                bad_staged = (out2.reshape(runs, -1) != gold.reshape(runs, -1)).any(dim=1).cpu().numpy()
     elif a.mem_mode == "nomemrep" or rep == ca.UNPROTECTED:
         for r in range(runs):  # the single memory copy is hit: every replica loads the same corrupted word
             targets.append(flip_memory(eng, inp, r, rng))
@@ -460,6 +472,23 @@ def run_campaign(a, eng=None):
     wall = time.perf_counter() - t0
     st = eng.stats()
     bad = (out.reshape(runs, -1) != gold.reshape(runs, -1)).any(dim=1).cpu().numpy()
+    leaked = unexplained = 0
+    if a.section == "registers" and bad_staged is not None:
+        # wrong matrix m of the staging-only launch: the flip of run m itself, or of run m - stride (the workgroup's previous matrix; an
+        # f-panel word ALWAYS belongs to the next matrix).  stride = one matrix per workgroup group = min(runs, CUs / 4).
+        stride, staging = min(runs, 64), ("s_raw", "f_raw")
+        for m in np.flatnonzero(bad_staged):
+            prev = m - stride
+            if prev >= 0 and classes[prev] == "f_raw":
+                owner = prev
+            elif classes[m] in staging:
+                owner = m
+            elif prev >= 0 and classes[prev] in staging:
+                owner = prev
+            else:
+                owner, unexplained = m, unexplained + 1
+            leaked += int(owner != m)
+            bad[owner] = True
     flagged = det.bool().cpu().numpy()
     hung = np.zeros(runs, dtype=bool)  # quicksort: the watchdog / stack guard cut the run (supervisor: timeout, stack overflow)
     if getattr(bench, "status", None) is not None and a.section == "registers":
@@ -502,26 +531,10 @@ def run_campaign(a, eng=None):
     }
     if classes is not None:  # the physical register model: outcome per register class, and what the unmodelled share can change
         by = {}
-        # a REAL flip of a staging register (s_raw / f_raw) can hold a word of the workgroup's NEXT matrix (its slabs and its f panel are
-        # staged ahead): the wrong words then belong to run r + stride (one workgroup group per min(runs, CUs / 4) matrices).  Such an
-        # error is the staging flip's, not the later run's own upset's.
-        stride = min(runs, 64)
-        owner = list(range(runs))
-        if a.reg_model == "physical-real-all":
-            for r in range(runs):
-                if records[r]["class"] == "error" and classes[r] not in ("s_raw", "f_raw") and r >= stride and classes[r - stride] in ("s_raw", "f_raw"):
-                    owner[r] = r - stride
-        leaked = sum(1 for r in range(runs) if owner[r] != r)
         for r in range(runs):
             d = by.setdefault(classes[r], {"runs": 0, "errors": 0, "corrected_or_masked": 0})
             d["runs"] += 1
-            if owner[r] != r:  # its own upset was dealt with; the wrong words are charged to the staging flip of the previous matrix
-                d["corrected_or_masked"] += 1
-                by.setdefault(classes[owner[r]], {"runs": 0, "errors": 0, "corrected_or_masked": 0})["errors"] += 1
-            else:
-                d["errors" if records[r]["class"] == "error" else "corrected_or_masked"] += 1
-        for d in by.values():  # (a staging run that was clean itself and corrupted its successor: one run, one error)
-            d["corrected_or_masked"] = max(0, d["runs"] - d["errors"])
+            d["errors" if records[r]["class"] == "error" else "corrected_or_masked"] += 1
         unmodelled = by.get("other", {"runs": 0})["runs"]
         summary.update({
             "reg_model": "physical: one bit of one lane of one of the wave's 256 VGPRs, weighted by the register census"
@@ -536,7 +549,9 @@ def run_campaign(a, eng=None):
             "coverage_pct_lower": 100.0 * (runs - counts["errors"] - unmodelled) / runs,
         })
         if a.reg_model == "physical-real-all":
+            summary["launches"] = "two: every other class's upsets, then the staging flips alone (counters are the sum of both)"
             summary["errors_landed_in_the_next_matrix_of_the_workgroup"] = leaked
+            summary["staging_launch_errors_without_a_staging_flip_to_blame"] = unexplained
     else:
         summary["reg_model"] = "sites: replica-private injector sites only (what TMR corrects by construction)" if a.section == "registers" else None
     return records, summary
