@@ -134,6 +134,16 @@ def test_lds_table_kernels_keep_their_occupancy(compiled):
         assert u["VGPRs"] <= 128 and u["VGPRs Spill"] == 0, (name, u)
 
 
+def test_kernels_that_address_lds_from_zero_have_no_static_lds(compiled):
+    """the aes rep kernels (and the matrix-core kernels) build LDS addresses by permuting bytes / from constants that assume
+    the dynamic segment starts at LDS offset 0; they guard it with a run-time trap.  A static `__shared__` added to one of them would
+    move the dynamic segment up -- this holds the layout at build time so that the trap can never be what reports it."""
+    usage, _ = compiled
+    for name in ("aes128_enc_rep_kernel<2>", "aes128_dec_rep_kernel<2>", "mm_mfma_blk3_kernel<3, true, false>",
+                 "mm_mfma_blk3_kernel<3, false, false>", "mm_mfma_blk2_kernel<3, true>", "mm_mfma_blk2_kernel<3, false>"):
+        assert _find(usage, "void coast::" + name)["LDS Size [bytes/block]"] == 0, name
+
+
 def test_injector_hooks_cost_the_lean_kernels_nothing(compiled):
     """round 3: the lean sha256 / aes / crc16 kernels carry their own injector hooks (a tile that owns an armed upset takes a
     wave-uniform branch).  The hooks must not put the kernels on scratch, and must not take occupancy from the clean path."""
