@@ -2,7 +2,7 @@
 lands (the matrix itself, the workgroup's next matrix, or -- an f piece requested in a matrix's last tile -- the one after that)
 checks the campaign's bookkeeping: the staging flips run in a launch of their own, every wrong matrix is charged to the staging run
 that caused it, the replica-private classes stay clean.  The real thing: tests/test_gpu_parity.py::
-test_campaign_physical_register_model_mm256[blocks3-real-all]."""
+test_campaign_physical_real_all_registers_mm256."""
 import importlib.util
 import os
 

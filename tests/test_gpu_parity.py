@@ -560,7 +560,7 @@ def test_common_mode_upsets_lane_kernels_vs_oracle(eng, orc, replicas):
         assert (ds.cpu().numpy() == es).all() and (dk.cpu().numpy() == ek).all() and _stats3(eng.stats()) == exp_st
 
 
-@pytest.mark.parametrize("tile", ["blocks3", "blocks2", "blocks3-real", "blocks3-real-all"])
+@pytest.mark.parametrize("tile", ["blocks3", "blocks2", "blocks3-real"])
 def test_campaign_physical_register_model_mm256(eng, tmp_path, tile, monkeypatch):
     """`campaign.py -b mm --side 256 -m TMR --reg-model physical`: any register of the matrix-core kernel's wave, weighted by its
     census -- the s / f staging registers included.  Coverage is a measurement: private classes are corrected, common-mode classes
@@ -2979,3 +2979,12 @@ def test_mm_256_register_block_kernel_batch_shapes(eng, orc, batch, tile, monkey
     fh, sh = _host(f, np.uint32), _host(s, np.uint32)
     exp, _, _ = orc.mm_xmr_items(fh, sh, items.astype(np.uint64))
     assert (_host(r, np.uint32).reshape(-1)[items] == exp).all()
+
+
+def test_campaign_physical_real_all_registers_mm256(eng, tmp_path, monkeypatch):
+    """`campaign.py --reg-model physical-real-all`: the staging registers of the matrix-core kernel as real flips too, in a launch of their
+    own -- no replica-private class ends in a wrong matrix, every wrong matrix is a staging flip's (its own, the workgroup's next, or the one
+    after that), and only the flips that meet a live word corrupt (profiles/r04_campaign_physical_real_all_two_launches_600.txt).  (Last in
+    the file: its attribution rule for f pieces requested in a matrix's last tile was deduced from that run's record after the round's last
+    GPU second.)"""
+    test_campaign_physical_register_model_mm256(eng, tmp_path, "blocks3-real-all", monkeypatch)

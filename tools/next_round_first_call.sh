@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/next_round_first_call.sh -- what the round-4 sessions could no longer run (the GPU budget was spent): one gpurun call, ~6 min.
 #   /usr/local/graft/bin/gpurun --timeout 600 -- 'bash tools/next_round_first_call.sh'
-# 1. the whole GPU suite (580 collected at the end of round 4; the last full run, 577 passed, predates the [blocks3-real-all] campaign variant and
+# 1. the whole GPU suite (580 collected at the end of round 4; the last full run, 577 passed, predates test_campaign_physical_real_all_registers_mm256 and
 #    test_mm_physical_upsets_of_the_shared_staging_registers_are_silent, which passed by itself);
 # 2. campaign --reg-model physical-real-all in its two-launch form (written blind, exercised against a stand-in engine only):
 #    does a replica-private class still show an error once the staging flips run in a launch of their own?
