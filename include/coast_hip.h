@@ -170,8 +170,9 @@ enum {
      * of that replica's set of ten MFMAs (flipped in front of the set; the next set reads its own), 4-7: the B-operand fragment of plane q of
      * that replica (flipped at the start of the slab's step, used by both row blocks), 8-11: the limb-sum accumulator t of (row block,
      * replica) (flipped at the start of the step, k-slabs 1-3: it stays until the tile's vote), 12-19: a raw word of s in the wave's staging
-     * registers (round 0: 12-15, round 1: 16-19; dwords 0-1) and 20: a raw word of the next f panel (dwords 0-3) on their way into LDS -- state
-     * every replica reads: common-mode, no voter can see it; bit = the bit.  The effect is whatever the
+     * registers (round 0: 12-15, round 1: 16-19; dwords 0-1) and 20: a raw word of an f panel staged ahead (dwords 0-3) on their way into LDS --
+     * state every replica reads: common-mode, no voter can see it; the word can belong to a LATER matrix of the workgroup (s: the next one
+     * in a matrix's last steps; f: the next one, or the one after it for the piece requested in a matrix's last column tile); bit = the bit.  The effect is whatever the
      * hardware computes from the flipped register: TMR out-votes it, DWC flags the items it reaches, an unprotected run returns the wrong
      * words (tests/test_gpu_parity.py::test_mm_physical_register_upsets).  Rejected by every other mm engine. */
     COAST_SITE_MM_VGPR = 6,
