@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--block-len", type=int, default=256, help="crc16 block length in bytes (the reference's maximum is 255)")
     ap.add_argument("--faults", type=int, default=-1,
                     help="single-bit flips injected per GPU per step (default: 4096 for mm, 1024 otherwise)")
+    ap.add_argument("--clone-staging", action="store_true",
+                    help="mm: run with COAST_F_CLONE_STAGING (the matrix-core kernel's global -> LDS staging loads cloned and compared)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline workload only")
     return ap.parse_args()
@@ -245,13 +247,24 @@ class MM(Workload):
         self.f = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device=dev, generator=g)
         self.s = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device=dev, generator=g)
         self.r = torch.empty_like(self.f)
-        self.cfg = coast_amd.XmrConfig(coast_amd.TMR)
+        # --clone-staging: COAST_F_CLONE_STAGING, the global -> LDS staging loads cloned and compared (+ 10 % kernel time for 94.7 -> 97.2 % coverage)
+        self.clone = bool(getattr(a, "clone_staging", False))
+        self.cfg = coast_amd.XmrConfig(coast_amd.TMR, 0, coast_amd.F_CLONE_STAGING if self.clone else 0)
         self.eng, self.ca = eng, coast_amd
         # one accumulator upset in one replica of K distinct output elements: each must be out-voted and counted once
         rng = np.random.default_rng(99 + rank)
         items = rng.choice(batch * n * n, a.faults, replace=False)
         self.fault_rows = [(int(it), int(rng.integers(0, 3)), coast_amd.SITE_MM_ACC, int(rng.integers(0, n + 1)),
                             int(rng.integers(0, 32))) for it in items]
+        if getattr(a, "mm_phys", False):
+            # the same number of upsets, but REAL ones: COAST_SITE_MM_VGPR flips of accumulator / B-fragment / A-fragment registers of the
+            # running kernel (its PHYS instantiation) instead of the analytic delta of a logical accumulator upset
+            self.fault_rows = []
+            for it in items:
+                reg = int(rng.integers(0, 12))  # 0-3 A fragment, 4-7 B fragment, 8-11 limb-sum accumulator
+                slab = int(rng.integers(1, 4)) if reg >= 8 else int(rng.integers(0, 4))
+                step = slab | (int(rng.integers(0, 64)) << 8) | (int(rng.integers(0, 4)) << 16) | (reg << 24)
+                self.fault_rows.append((int(it), int(rng.integers(0, 3)), coast_amd.SITE_MM_VGPR, step, int(rng.integers(0, 32))))
         self.faults = coast_amd.make_faults(self.fault_rows)
         self.units_per_step = batch * n * n
 
@@ -283,7 +296,7 @@ class MM(Workload):
         cfg = {"workload": "matrixMultiply %dx%d uint32 TMR (3 replicas + vote), batch %d matrices/GPU, "
                            "%d injected single-bit faults/GPU/step" % (self.n, self.n, self.batch, len(self.faults)),
                "side": self.n, "batch_per_gpu": self.batch, "replicas": 3, "engine": self.engine(),
-               "parallelism": "dp%d (independent matrices)" % world}
+               "parallelism": "dp%d (independent matrices)" % world, "clone_staging": self.clone}
         if self.engine() == "mfma":
             cfg["tile"] = self.tile()  # where the replicas live on the matrix core (coast_hip.hip LAUNCH_MM)
         return cfg
@@ -361,6 +374,44 @@ class MM(Workload):
 
     def cpu(self):
         return cpu_baseline_mm(self.n)
+
+
+class MMDefaultMode(MM):
+    """COAST's DEFAULT mode (docs/source/passes.rst:329, 337; cloning.cpp:2417-2537): memory is replicated too -- every replica multiplies
+    its own copy of f and s into its own copy of r -- and what leaves the region is voted (and the copies repaired) at the exit.  Here: three
+    unprotected launches on three memory images + coast_sync_copies over the three products.  HBM-bound: 3 x (read f, s; write r) + the
+    vote's 3 reads and 1 write of r."""
+    name = "mm_default_mode"
+    metric = "protected elems/sec, matrixMultiply TMR, memory replicated (COAST default mode)"
+
+    def __init__(self, a, eng, dev, rank, coast_amd):
+        super().__init__(a, eng, dev, rank, coast_amd)
+        self.fs = [(self.f, self.s)] + [(self.f.clone(), self.s.clone()) for _ in range(2)]
+        self.rs = [torch.empty_like(self.f) for _ in range(3)]
+        self.faults = coast_amd.make_faults([])  # (memory upsets of a copy: tools/campaign.py -s memory --mem-mode default)
+        self.fault_rows = []
+        self.clean = coast_amd.XmrConfig(coast_amd.UNPROTECTED)
+        self.kernels_per_step = 4
+
+    def launch(self):
+        for (f, s), r in zip(self.fs, self.rs):
+            self.eng.mm_batch(f, s, out=r, cfg=self.clean)
+        self.eng.sync_copies(self.rs, out=self.r, scrub=True)
+
+    def config(self, world):
+        return {"workload": "matrixMultiply %dx%d uint32 TMR, memory replicated x3 (default mode), batch %d matrices/GPU" % (self.n, self.n, self.batch),
+                "side": self.n, "batch_per_gpu": self.batch, "replicas": 3, "engine": "mfma x3 + exit vote",
+                "parallelism": "dp%d (independent matrices)" % world}
+
+    def roofline(self, kern_ms):
+        n, batch = self.n, self.batch
+        bytes_alg = float(batch) * n * n * 4 * (3 * 3 + 3 + 1)  # three launches x (f, s, r) + the vote: three products read, one written
+        t = kern_ms * 1e-3
+        return {"bound": "hbm", "kernel": "3 x mm_mfma_blk3_kernel<1, false> + sync_copies_kernel", "kernel_ms": kern_ms,
+                "achieved": bytes_alg / t * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_alg / t * 1e-9 / HBM_PEAK_GBS,
+                "algorithmic_bytes": bytes_alg,
+                "note": "kernel_ms = the four kernels of a step together (HIP events of the C ABI); algorithmic bytes = 3 x 12 n^2 (each replica's "
+                        "own f, s, r) + 16 n^2 (exit vote: three products read, the voted one written; repairs of a disagreeing copy are not counted)"}
 
 
 class CRC16(Workload):
@@ -621,7 +672,9 @@ class ChSha(Workload):
         g = torch.Generator(device=dev).manual_seed(21 + rank)
         self.msgs = torch.randint(0, 256, (self.nm, self.len), dtype=torch.uint8, device=dev, generator=g)
         self.out = torch.empty((self.nm, 5), dtype=torch.int32, device=dev)
-        self.cfg = coast_amd.XmrConfig(coast_amd.TMR)
+        # --clone-staging: COAST_F_CLONE_STAGING, the global -> LDS staging loads cloned and compared (+ 10 % kernel time for 94.7 -> 97.2 % coverage)
+        self.clone = bool(getattr(a, "clone_staging", False))
+        self.cfg = coast_amd.XmrConfig(coast_amd.TMR, 0, coast_amd.F_CLONE_STAGING if self.clone else 0)
         self.eng, self.ca = eng, coast_amd
         rng = np.random.default_rng(5 + rank)
         items = rng.choice(self.nm, a.faults, replace=False)
@@ -774,6 +827,9 @@ def result_fields(wl, run, a, world, steps, warmup, with_cpu):
         # tiles / workgroups of the lean kernel that owned an armed upset and applied, voted and counted it themselves
         "hooked_blocks_last_launch": run["launch_info"]["hooked_blocks"],
         "roofline": roof,
+        # what a timed step contains (not like-for-like with rounds 2-3, whose steps uploaded the table every time)
+        "timed_step": "inject (the step's upset table equals the previous step's: it stays resident on the device -- a host compare, no upload; the "
+                      "kernel still applies every upset) + launch + fold of the per-workgroup counter slots into the totals",
     }
     if getattr(wl, "checked", None):
         out["outputs_checked"] = wl.checked
@@ -809,6 +865,32 @@ def extra_legs(a, eng, dist, dev, rank, world, coast_amd):
         if rank == 0:
             legs[name] = result_fields(wl, run, b, world, steps, warm, with_cpu=(world == 1 and not a.no_cpu_baseline))
         wl.free()
+    if world == 1:
+        # the headline's variants: the armed upsets as REAL register flips (the kernel's PHYS instantiation), north_star's
+        # replica layout (three adjacent lanes, cross-lane voter: COAST_MM_TILE=lanes), and COAST's default mode (memory replicated)
+        for name, cls, over, env in (("mm_cloned_staging", MM, {"batch": 8192, "clone_staging": True}, {}),
+                                     ("mm_physical_upsets", MM, {"mm_phys": True, "batch": 8192}, {}),
+                                     ("mm_lane_replicas", MM, {"batch": 8192}, {"COAST_MM_TILE": "lanes"}),
+                                     ("mm_default_mode", MMDefaultMode, {"batch": 8192}, {})):
+            torch.cuda.synchronize()
+            time.sleep(1.0)
+            b = copy.copy(a)
+            b.batch, b.faults = 0, 4096
+            for k, v in over.items():
+                setattr(b, k, v)
+            saved = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                wl = cls(b, eng, dev, rank, coast_amd)
+                run = timed_run(wl, eng, dist, dev, 10, 3, world)
+                legs[name] = result_fields(wl, run, b, world, 10, 3, with_cpu=False)
+                wl.free()
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
         legs["config1_mm32_cpu_tmr"] = cpu_baseline_config1_mm32(eng, coast_amd)
     return legs

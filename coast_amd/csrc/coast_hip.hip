@@ -502,6 +502,9 @@ extern "C" int coast_set_stream(coast_ctx *c, void *hip_stream)
 {
     if (!c)
         return COAST_EINVAL;
+    if (c->stream != (hipStream_t)hip_stream)
+        for (auto &b : c->fb) // a resident fault table is ordered before the launches of the stream it was armed for: a new stream
+            b.residentK = 0;  // has no dependency on it -- the next armed launch uploads and orders its table again
     c->stream = (hipStream_t)hip_stream;
     return COAST_OK;
 }
@@ -667,8 +670,10 @@ bool decode_mm_mfma(const coast_fault &f, const void *gp, DevFault &d)
     const uint64_t nn = (uint64_t)h.g.n * h.g.n;
     if (f.item >= nn * h.batch || f.replica >= h.replicas)
         return false;
-    if (f.site != COAST_SITE_MM_VGPR && (f.site > COAST_SITE_MM_OPB || f.step > (uint32_t)h.g.n))
+    if (f.site != COAST_SITE_MM_VGPR && f.site != COAST_SITE_MM_PREG && (f.site > COAST_SITE_MM_OPB || f.step > (uint32_t)h.g.n))
         return false;
+    if (f.site == COAST_SITE_MM_PREG && ((f.step & 63u) >= 60u || (((f.step >> 19) & 1u) ? ((f.step >> 20) & 511u) >= 102u : ((f.step >> 20) & 511u) >= 256u)))
+        return false; // slot 0..59; v0..v255 / s0..s101
     const uint64_t mat = f.item / nn, e = f.item % nn;
     const uint32_t i = (uint32_t)(e / h.g.n), j = (uint32_t)(e % h.g.n);
     d.block = (uint32_t)(mat * (uint64_t)(h.g.n / 64) + i / 64u);
@@ -705,8 +710,18 @@ bool decode_mm_indexed(const coast_fault &f, const void *gp, DevFault &d)
 } // namespace
 
 extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t *d_s, uint32_t *d_r, int n,
-                              size_t batch, const coast_cfg *cfg, uint8_t *d_detected)
+                              size_t batch, const coast_cfg *cfgIn, uint8_t *d_detected)
 {
+    // COAST_F_CLONE_STAGING is a property of the matrix-core kernel's staging path, not a sync-point rule: it selects no stepwise kernel and
+    // the rule checks below do not see it
+    coast_cfg cfgRules{};
+    bool cloneStaging = false;
+    if (cfgIn) {
+        cfgRules = *cfgIn;
+        cloneStaging = (cfgIn->flags & COAST_F_CLONE_STAGING) != 0 && cfgIn->replicas > 1;
+        cfgRules.flags &= ~(uint32_t)COAST_F_CLONE_STAGING;
+    }
+    const coast_cfg *cfg = cfgIn ? &cfgRules : nullptr;
     int rc = check_cfg(c, cfg, true);
     if (rc)
         return rc;
@@ -807,7 +822,7 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     // COAST_SITE_MM_VGPR: a physical upset of a named vector register of the register-block matrix-core kernel (its PHYS instantiation)
     bool havePhys = false;
     for (const coast_fault &af : c->armed)
-        havePhys = havePhys || af.site == COAST_SITE_MM_VGPR;
+        havePhys = havePhys || af.site == COAST_SITE_MM_VGPR || af.site == COAST_SITE_MM_PREG;
     if (havePhys && !(mfma && mmBlocks && mmBlocks2 && mmBlocks3))
         return fail(c, COAST_EINVAL, "coast_mm_batch: COAST_SITE_MM_VGPR names a register of mm_mfma_blk3_kernel: side 256, no sync_every / "
                                      "flags, COAST_MM_ENGINE / COAST_MM_TILE at their defaults");
@@ -846,6 +861,34 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
         else                                                                                                    \
             LAUNCH_FAST(R, V, 1);                                                                               \
     } while (0)
+    /* mm_mfma_blk3_kernel<R, FLAGS, PHYS, CLONE>: FLAGS = per-item flags wanted (the physical-upset instantiation always carries them; the   \
+     * unprotected mode has none), CLONE = COAST_F_CLONE_STAGING (replicas > 1) */                                                        \
+#define LAUNCH_BLK3_ONE(R, FL, PH, CL)                                                                          \
+    do {                                                                                                        \
+        using G3 = MmBlk2<R>;                                                                                   \
+        HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<R, FL, PH, CL>,                        \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3::LDS_BYTES));        \
+        hipLaunchKernelGGL((mm_mfma_blk3_kernel<R, FL, PH, CL>), dim3(gridB), dim3(G3::NTHR), G3::LDS_BYTES,    \
+                           c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);                    \
+    } while (0)
+#define LAUNCH_BLK3(R)                                                                                          \
+    do {                                                                                                        \
+        constexpr bool canClone = (R) > 1;                                                                      \
+        const bool wantFlags = d_detected != nullptr && (R) > 1;                                                \
+        if (cloneStaging && canClone) {                                                                         \
+            if (havePhys)                                                                                       \
+                LAUNCH_BLK3_ONE(R, true, true, canClone);                                                       \
+            else if (wantFlags)                                                                                 \
+                LAUNCH_BLK3_ONE(R, true, false, canClone);                                                      \
+            else                                                                                                \
+                LAUNCH_BLK3_ONE(R, false, false, canClone);                                                     \
+        } else if (havePhys)                                                                                    \
+            LAUNCH_BLK3_ONE(R, true, true, false);                                                              \
+        else if (wantFlags)                                                                                     \
+            LAUNCH_BLK3_ONE(R, true, false, false);                                                             \
+        else                                                                                                    \
+            LAUNCH_BLK3_ONE(R, false, false, false);                                                            \
+    } while (0)
 #define LAUNCH_MM(R)                                                                                            \
     do {                                                                                                        \
         if (mfma && R == 3 && mmBlocks) { /* TMR: replicas in register blocks */              \
@@ -858,23 +901,7 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
             if (have) /* the armed upsets are applied inside the matrix-core kernels: the panels that do it */    \
                 hookedBlocks = nFaultBlocks;                                                                    \
             if (mmBlocks2 && mmBlocks3) {                                                                       \
-                using G2 = MmBlk2<3>;                                                                           \
-                if (havePhys) {                                                                                 \
-                    HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<3, true, true>,            \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
-                    hipLaunchKernelGGL((mm_mfma_blk3_kernel<3, true, true>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
-                                       c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);        \
-                } else if (d_detected) {                                                                               \
-                    HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<3, true>,                  \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
-                    hipLaunchKernelGGL((mm_mfma_blk3_kernel<3, true>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
-                                       c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);        \
-                } else {                                                                                        \
-                    HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<3, false>,                 \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
-                    hipLaunchKernelGGL((mm_mfma_blk3_kernel<3, false>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
-                                       c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);        \
-                }                                                                                               \
+                LAUNCH_BLK3(3);                                                                                 \
             } else if (mmBlocks2) {                                                                             \
                 using G2 = MmBlk2<3>;                                                                           \
                 if (d_detected) {                                                                               \
@@ -911,22 +938,7 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
             const uint32_t gridB = 4u * (uint32_t)std::min<uint64_t>((uint64_t)batch, (uint64_t)std::max(1, c->numCUs / 4)); \
             if (have)                                                                                           \
                 hookedBlocks = nFaultBlocks;                                                                    \
-            if (havePhys) {                                                                                     \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<R, true, true>,                \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
-                hipLaunchKernelGGL((mm_mfma_blk3_kernel<R, true, true>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
-                                   c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);            \
-            } else if (d_detected && R == 2) {                                                                  \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<R, true>,                      \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
-                hipLaunchKernelGGL((mm_mfma_blk3_kernel<R, true>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES,  \
-                                   c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);            \
-            } else {                                                                                            \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk3_kernel<R, false>,                     \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2::LDS_BYTES)); \
-                hipLaunchKernelGGL((mm_mfma_blk3_kernel<R, false>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
-                                   c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);            \
-            }                                                                                                   \
+            LAUNCH_BLK3(R);                                                                                     \
             engine = COAST_ENGINE_MATRIX_CORE;                                                                  \
             fastBlocks = nbm;                                                                                   \
             break;                                                                                              \

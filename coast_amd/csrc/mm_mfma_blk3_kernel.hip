@@ -50,9 +50,24 @@
 #endif
 // two A fragment sets: a set's four A fragments are requested a whole set (ten MFMAs) ahead, into the other buffer (0: one set, re-read behind
 // each fragment's last use).  1.4 % faster (7.10 -> 7.00 ms, profiles/r04_mm_ab.txt) and the allocator fits it: 256 VGPRs, 1 spill outside the steps.
+// (Round 5 measured a ring of six fragment registers with the same leads -- eight registers fewer -- at + 1.7 %: profiles/r05_mm_clone_ab.txt.)
 #ifndef COAST_MM3_ABUF
 #define COAST_MM3_ABUF 1
 #endif
+
+// CLONE (round 5, COAST_F_CLONE_STAGING): THE STAGING PATH AS A CLONED LOAD.  The kernel loads every raw word of s and f once, converts it once
+// and writes the byte planes into the LDS image every replica reads: an upset of a staging register (pbs, bgRaw: 20 of 256 VGPRs, alive for
+// more than a pipeline step) is common-mode -- 233 of 501 / 76 of 79 real flips there stored wrong matrices with TMR_ERROR_CNT unchanged
+// (profiles/r05_campaign_physical_real_all_seed0_5000.txt).  The pass clones the load (cloning.cpp:2187-2209; one address under
+// -noMemReplication, :2247-2255).  With CLONE every raw word is loaded a SECOND time (an L2 hit) half a step before its conversion and compared
+// with the staged copy in front of the first instruction that consumes it.  TMR: a mismatch loads the word a third time through a freshly
+// computed address and keeps select(a == b, a, c) (synchronization.cpp:934-938, the third copy evaluated lazily), TMR_ERROR_CNT + 1 per word;
+// DWC: the compare that fails counts a detected item and flags the first element the word reaches.  What stays single: the five conversion
+// stages' temporaries (digits -> byte planes, alive for three to six slots each).
+// PRICE: the register file is full (256 VGPRs, two waves per SIMD) -- the twelve clone registers push address registers into scratch, whose
+// reloads drain the whole VMEM queue, and sixteen more buffer loads and four compare-and-branch sequences per slab cost what they cost at this
+// chip's power limit: + 30 % (6.77 -> 8.82 ms; the loads alone + 12.6 %, the f clone alone + 5 %: profiles/r05_mm_clone_ab.txt), for 94.4 -> 96.6 %
+// coverage in the uniform register-file campaign (profiles/r05_campaign_uniform_*.txt).  Hence a flag, not the default.
 
 namespace coast {
 
@@ -62,8 +77,12 @@ namespace coast {
 // step, used by the replica's sets of both row blocks, re-read for the next step), or a limb-sum accumulator (flipped at the start of a
 // step that is not the tile's first; it stays until the tile's vote).  The hooks sit in front of the MFMAs they precede; the clean
 // instantiations do not contain them.
-enum { SITE_MM_VGPR = 6 };
-template <int NREP, bool FLAGS, bool PHYS = false>
+// SITE_MM_PREG (round 5): the same kind of upset, but of ANY register of the wave, named by its PHYSICAL number -- v0 .. v255 through the
+// VGPR index mode (s_set_gpr_idx_on), s0 .. s101 through s_movrels / s_movreld -- in front of any of a step's MFMA slots, the compiler knowing
+// nothing of it: what the reference's injector does when it draws a register of the core (simulation/platform/resources/injector.py:70-72,
+// 237-260).  Address registers, lane constants, loop counters, descriptors, the staging clones, whatever the allocator put there.
+enum { SITE_MM_VGPR = 6, SITE_MM_PREG = 7 };
+template <int NREP, bool FLAGS, bool PHYS = false, bool CLONE = false>
 __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(const uint32_t *__restrict__ F,
                                                                             const uint32_t *__restrict__ S,
                                                                             uint32_t *__restrict__ R, uint32_t nblocks, Counters ctr,
@@ -74,6 +93,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
     // DWC and the unprotected mode (round 4) run the same kernel with four / two sets per step: NS = 20 NREP slots, the conversion and
     // background stages at the same relative places (one per NREP slots), the barrier in the middle, the tile end set by set.
     constexpr int NS = 20 * NREP, HALF = NS / 2, NSET = 2 * NREP;
+    constexpr bool DUP = CLONE && NREP > 1; // (the unprotected mode has nothing to compare with)
     extern __shared__ __attribute__((aligned(16))) uint8_t smemP[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,12 +136,47 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         const int d0 = wv * G::N + (((l >> 2) ^ wv) * 16) + (l & 3) * 4;
         return (d0 ^ ((j & 1) * 128)) + j * 8 * G::N;
     };
+    // a staging compare that failed (cold path).  TMR: third copy, select(a == b, a, c), one corrected error per word; DWC: replica 0's word
+    // stays, one detected item per word
+    uint32_t stageMiss = 0; // this lane's words whose two staged copies differed
+    auto launder = [](int v) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(v)); // the clone's address register is its own: not to be merged with the original's
+        return v;
+    };
     {
         const __amdgpu_buffer_rsrc_t rsF = rsFof(0);
         u32x4_t pa[G::A_PER_THR];
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u)
             pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, voffFof(), soffFw + (pnl * G::BM + u * 8) * G::N * 4, COAST_MM_AUX_F);
+        if constexpr (DUP) { // the first panel is staged in one go: its clone too
+            u32x4_t pd[G::A_PER_THR];
+#pragma unroll
+            for (int u = 0; u < G::A_PER_THR; ++u)
+                pd[u] = __builtin_amdgcn_raw_buffer_load_b128(rsF, launder(voffFof()), soffFw + (pnl * G::BM + u * 8) * G::N * 4, COAST_MM_AUX_F);
+            bool mis = false;
+#pragma unroll
+            for (int u = 0; u < G::A_PER_THR; ++u)
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    mis = mis || pa[u][d] != pd[u][d];
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(mis) != 0, 0)) {
+#pragma unroll
+                for (int u = 0; u < G::A_PER_THR; ++u) {
+                    const u32x4_t pc = __builtin_amdgcn_raw_buffer_load_b128(rsF, launder(voffFof()), soffFw + (pnl * G::BM + u * 8) * G::N * 4, COAST_MM_AUX_F);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const bool e = pa[u][d] == pd[u][d];
+                        stageMiss += e ? 0u : 1u;
+                        if constexpr (NREP == 3)
+                            pa[u][d] = e ? pa[u][d] : pc[d];
+                        if constexpr (FLAGS)
+                            if (!e && detected != nullptr && mat0 < nblocks) // (row of the word, column 0: the first element it reaches)
+                                detected[mat0 * nn + (size_t)(pnl * G::BM + u * 8 + wv) * G::N] = 1;
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < G::A_PER_THR; ++u) {
             const uint32_t y[4] = {mm_digits(pa[u][0]), mm_digits(pa[u][1]), mm_digits(pa[u][2]), mm_digits(pa[u][3])};
@@ -137,6 +192,9 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
     auto bgPiece = [](int g) { return 2 * ((g >> 2) & 3) + ((g & 3) - 1); };
     auto bgLoad = [&](int g) __attribute__((always_inline)) {
         return __builtin_amdgcn_raw_buffer_load_b128(rsFof((g >> 4) + 1), voffFof(), soffFw + (pnl * G::BM + 8 * bgPiece(g)) * G::N * 4, COAST_MM_AUX_F);
+    };
+    auto bgLoadDup = [&](int g) __attribute__((always_inline)) { // the clone's load: its own address register
+        return __builtin_amdgcn_raw_buffer_load_b128(rsFof((g >> 4) + 1), launder(voffFof()), soffFw + (pnl * G::BM + 8 * bgPiece(g)) * G::N * 4, COAST_MM_AUX_F);
     };
 
     auto tileCol0 = [&](int g) __attribute__((always_inline)) { return (wave + G::NLANE * ((g >> 2) & 3)) * G::CT; };
@@ -196,21 +254,101 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         };
         using U0 = std::integral_constant<int, 0>;
         using U1 = std::integral_constant<int, 1>;
+        // ---- the clones of the staged words (CLONE).  dupS[kk]: the second copy of pbs[u][kk] (two adjacent words of one row of s) of the
+        // round u that is converted next -- requested behind the compare of the round before, 26-29 slots ahead of its own.  dupF: the second
+        // copy of bgRaw.
+        u32x2_t dupS[4] = {};
+        u32x4_t dupF = {0u, 0u, 0u, 0u};
+        auto dupLoadS = [&](auto uTag, auto kkTag, const __amdgpu_buffer_rsrc_t rs, int so) __attribute__((always_inline)) {
+            constexpr int u = decltype(uTag)::value, kk = decltype(kkTag)::value;
+            dupS[kk] = __builtin_amdgcn_raw_buffer_load_b64(rs, voffB + kk * G::N * 4, so + u * kRoundOff, 0);
+        };
+        auto flagElem = [&](uint32_t mat, int row, int col) __attribute__((always_inline)) {
+            if constexpr (FLAGS)
+                if (detected != nullptr && mat < nblocks)
+                    detected[mat * nn + (size_t)row * G::N + col] = 1;
+        };
+        // in front of the first instruction that consumes a word of the round; gs = the slab it belongs to.  (The round's second column is
+        // converted fifteen slots later: for those slots its words are single again -- a sixth of the time they spend in a register.)
+        auto verifyS = [&](auto uTag, int gs) __attribute__((always_inline)) {
+            constexpr int u = decltype(uTag)::value;
+            bool mis = false;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                mis = mis || pbs[u][kk][0] != dupS[kk][0] || pbs[u][kk][1] != dupS[kk][1];
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(mis) != 0, 0)) {
+                const __amdgpu_buffer_rsrc_t rs = rsSof(gs >> 4);
+                const int so = slabOff(gs) + u * kRoundOff, l = freshLane();
+                const int vo = ((4 * (l >> 3)) * G::N + 2 * (l & 7)) * 4;
+                const bool exists = matOf(gs >> 4) < nblocks; // (a slab staged ahead for a matrix behind the batch's last: zeros, and no vote of anybody's)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const u32x2_t c = __builtin_amdgcn_raw_buffer_load_b64(rs, vo + kk * G::N * 4, so, 0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const bool e = pbs[u][kk][h] == dupS[kk][h] || !exists;
+                        stageMiss += e ? 0u : 1u;
+                        if constexpr (NREP == 3)
+                            pbs[u][kk][h] = e ? pbs[u][kk][h] : c[h];
+                        if (!e) // (first row of the panel, the word's column: the first element it reaches)
+                            flagElem(matOf(gs >> 4), pnl * G::BM, tileCol0(gs) + 2 * (l & 7) + h);
+                    }
+                }
+            }
+        };
+        auto verifyF = [&](int gc) __attribute__((always_inline)) { // gc = the bg step that consumes bgRaw
+            bool mis = false;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                mis = mis || bgRaw[d] != dupF[d];
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(mis) != 0, 0)) {
+                const u32x4_t c = bgLoad(gc);
+                const bool exists = matOf((gc >> 4) + 1) < nblocks;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const bool e = bgRaw[d] == dupF[d] || !exists;
+                    stageMiss += e ? 0u : 1u;
+                    if constexpr (NREP == 3)
+                        bgRaw[d] = e ? bgRaw[d] : c[d];
+                    if (!e)
+                        flagElem(matOf((gc >> 4) + 1), pnl * G::BM + 8 * bgPiece(gc) + wv, 0);
+                }
+            }
+        };
+        auto verifyRoundNow = [&](int gs, auto uTag) __attribute__((always_inline)) { // prologue: a round that is converted at once
+            if constexpr (DUP) {
+                const __amdgpu_buffer_rsrc_t rs = rsSof(gs >> 4);
+                const int so = slabOff(gs);
+                for_each_index(std::make_integer_sequence<int, 4>{}, [&](auto kkTag) __attribute__((always_inline)) { dupLoadS(uTag, kkTag, rs, so); });
+                verifyS(uTag, gs);
+            }
+        };
         // prologue.  Wave 1 of the pair owns the even slabs: slab 0 whole, slab 2 in its registers.  Wave 0 owns the odd ones: slab
         // 1's first round converted here, its second round in the registers for step 0 (its duty step).
         if (H == 1) {
             loadRound(0, U0{});
             loadRound(0, U1{});
+            verifyRoundNow(0, U0{});
             convRound(U0{}, wbufOff);
+            verifyRoundNow(0, U1{});
             convRound(U1{}, wbufOff);
             loadRound(2, U0{});
             loadRound(2, U1{});
         } else {
             loadRound(1, U0{});
             loadRound(1, U1{});
+            verifyRoundNow(1, U0{});
             convRound(U0{}, wbufOff + G::B_BUF);
+            if constexpr (DUP) { // step 0 is this wave's duty step: the clones of slab 1's second round
+                const __amdgpu_buffer_rsrc_t rs = rsSof(0);
+                const int so = slabOff(1);
+                for_each_index(std::make_integer_sequence<int, 4>{}, [&](auto kkTag) __attribute__((always_inline)) { dupLoadS(U1{}, kkTag, rs, so); });
+            }
         }
-        bgRaw = bgLoad(1); // the first bg step
+        if constexpr (DUP)
+            bgRaw = u32x4_t{0u, 0u, 0u, 0u}; // (the first bg step's piece is requested in step 0)
+        else
+            bgRaw = bgLoad(1); // the first bg step
         __syncthreads(); // panel 0 and the pairs' slab 0 are complete
 
         // ---- tile end, set by set.  A set's sums are final ten slots after it started in the tile's LAST step; the sets that are through
@@ -282,6 +420,59 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         constexpr int kNextStride = NREP == 1 ? 2 : 6; // slots between the stages of the next step
 
         uint32_t fFirst = 0, fCount = 0;
+        // COAST_SITE_MM_PREG (PHYS): the upset of this wave in the current item, if any: key = step of the item << 6 | slot; sel = register file
+        // << 9 | register number; lane | bit << 8
+        uint32_t pregKey = 0xffffffffu, pregSel = 0u, pregLaneBit = 0u;
+        // word w of entry q of the upset table (1: .local, 2: .step, 3: .replica | .site << 8 | .bit << 16 | .index << 24).  PHYS: through a
+        // descriptor that ends with the panel's entries, no vector register in the address -- an upset of any VGPR cannot send this read anywhere
+        auto ftWord = [&](uint32_t q, int w) __attribute__((always_inline)) {
+            if constexpr (PHYS) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<DevFault *>(ft.list), 0, (int)((fFirst + fCount) * 16u), 0x00020000);
+                return __builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(rs, 0, (int)(q * 16u) + 4 * w, 0));
+            } else {
+                return __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(ft.list + q)[w]);
+            }
+        };
+        // (PHYS: the end of the panel's entries, with a bound of its own -- an upset of the count must not walk the table for minutes)
+        auto fEnd = [&]() __attribute__((always_inline)) {
+            if constexpr (PHYS)
+                return fFirst + (fCount > 256u ? 256u : fCount);
+            else
+                return fFirst + fCount;
+        };
+        auto pregScan = [&]() __attribute__((always_inline)) {
+            pregKey = 0xffffffffu;
+#pragma unroll 1
+            for (uint32_t q = fFirst, nq = 0; q < fFirst + fCount && nq < 64u; ++q, ++nq) { // (nq: a flipped count must not walk the table for ever)
+                const uint32_t sw = ftWord(q, 2), packed = ftWord(q, 3);
+                if (((packed >> 8) & 0xffu) == (uint32_t)SITE_MM_PREG && ((sw >> 16) & 7u) == (uint32_t)wv) {
+                    pregKey = sw & 0x3ffu;
+                    pregSel = (sw >> 19) & 0x3ffu;
+                    pregLaneBit = ((sw >> 10) & 63u) | (((packed >> 16) & 31u) << 8);
+                }
+            }
+        };
+        auto pregFlip = [&]() __attribute__((always_inline)) {
+            const uint32_t idx = pregSel & 511u, bitMask = 1u << (pregLaneBit >> 8);
+            if ((pregSel >> 9) == 0u) {
+                const uint32_t vm = freshLane() == (int)(pregLaneBit & 63u) ? bitMask : 0u;
+                // (the wait states a matrix-core result needs before a VALU may touch its register are the compiler's business everywhere
+                // else; m0 carries the index and is put back)
+                uint32_t m0save;
+                asm volatile("s_mov_b32 %0, m0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_set_gpr_idx_on %1, 0x9\n\ts_nop 1\n\tv_xor_b32 v0, v0, %2\n\ts_nop 1\n\t"
+                             "s_set_gpr_idx_off\n\ts_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 1"
+                             : "=&s"(m0save)
+                             : "s"(idx), "v"(vm)
+                             : "memory");
+            } else {
+                uint32_t tmp, m0save;
+                asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\ts_movrels_b32 %0, s0\n\ts_xor_b32 %0, %0, %3\n\ts_nop 0\n\ts_movreld_b32 s0, %0\n\t"
+                             "s_nop 2\n\ts_mov_b32 m0, %1\n\ts_nop 1"
+                             : "=&s"(tmp), "=&s"(m0save)
+                             : "s"(idx), "s"(bitMask)
+                             : "scc", "memory");
+            }
+        };
         // ---- injector hook: the consequence of an armed upset on the replica's word is an additive constant (everything downstream
         // is linear mod 2^32), written on the replica's limb-0 sums before the tile's last step -- see mm_mfma_blk_kernel.hip.  OPA
         // names replica r's loaded f[i][k]: here that register exists per replica (the A fragment of the replica's set).
@@ -289,8 +480,8 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             const int col0 = tileCol0(g), prow0 = pnl * G::BM;
             bool hooked = false;
 #pragma unroll 1
-            for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
-                const int fcol = (int)(__builtin_amdgcn_readfirstlane(ft.list[q].local) & 255u);
+            for (uint32_t q = fFirst; q < fEnd(); ++q) {
+                const int fcol = (int)(ftWord(q, 1) & 255u);
                 hooked = hooked || (fcol >= col0 && fcol < col0 + G::CT);
             }
             if (!hooked)
@@ -298,14 +489,12 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             uint32_t curKey = 0xffffffffu, curStep = 0xffffffffu;
             uint32_t dsum[3] = {0u, 0u, 0u}, am[3] = {0u, 0u, 0u}, bm[3] = {0u, 0u, 0u};
 #pragma unroll 1
-            for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
-                const DevFault *fp = ft.list + q;
-                const uint32_t local = __builtin_amdgcn_readfirstlane(fp->local);
+            for (uint32_t q = fFirst; q < fEnd(); ++q) {
+                const uint32_t local = ftWord(q, 1);
                 const int frow = (int)(local >> 8), fcol = (int)(local & 255u);
                 if (fcol < col0 || fcol >= col0 + G::CT)
                     continue;
-                const uint32_t fstep = __builtin_amdgcn_readfirstlane(fp->step);
-                const uint32_t packed = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(&fp->replica));
+                const uint32_t fstep = ftWord(q, 2), packed = ftWord(q, 3);
                 const uint32_t frep = packed & 0xffu, fsite = (packed >> 8) & 0xffu, m = 1u << ((packed >> 16) & 31u);
                 if constexpr (PHYS)
                     if (fsite > (uint32_t)SITE_MM_OPB)
@@ -367,18 +556,20 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         // (same row block and address for the next replica: the load is the replicated instruction); b[rr][q] is re-read behind its
         // last use in the second row block, from the other slab buffer.
         constexpr bool ABUF = COAST_MM3_ABUF != 0;
-        v4i_t a[ABUF ? 2 : 1][4], b[NREP][4];
+        constexpr int NA = ABUF ? 8 : 4;
+        constexpr auto aIdx = [](int set, int p) { return ABUF ? 4 * (set & 1) + p : p; }; // register of fragment p of a set
+        v4i_t a[NA], b[NREP][4];
         int offA = panelOff(0), offB = bOff;
-        auto loadA = [&](auto pTag, int rbl, int off) __attribute__((always_inline)) {
+        auto loadA = [&](auto pTag, int rbl, int off) __attribute__((always_inline)) { // (one set: register p)
             constexpr int p = decltype(pTag)::value;
             if constexpr (COAST_MM3_KNOCK & 512) // timing: the read is issued and awaited, but always of the same 16 bytes per lane
-                a[0][p] = *reinterpret_cast<const v4i_t *>(smemP + (off & 0) + aOff + p * G::PLANE_A);
+                a[p] = *reinterpret_cast<const v4i_t *>(smemP + (off & 0) + aOff + p * G::PLANE_A);
             else
-                a[0][p] = *reinterpret_cast<const v4i_t *>(smemP + off + p * G::PLANE_A + (2 * H + rbl) * 16 * G::N);
+                a[p] = *reinterpret_cast<const v4i_t *>(smemP + off + p * G::PLANE_A + (2 * H + rbl) * 16 * G::N);
         };
-        auto loadA2 = [&](auto bufTag, auto pTag, int rbl, int off) __attribute__((always_inline)) {
-            constexpr int p = decltype(pTag)::value, bf = decltype(bufTag)::value;
-            a[ABUF ? bf : 0][p] = *reinterpret_cast<const v4i_t *>(smemP + off + p * G::PLANE_A + (2 * H + rbl) * 16 * G::N);
+        auto loadAi = [&](auto idxTag, auto pTag, int rbl, int off) __attribute__((always_inline)) { // plane p of row block rbl into register idx
+            constexpr int p = decltype(pTag)::value, idx = decltype(idxTag)::value;
+            a[idx] = *reinterpret_cast<const v4i_t *>(smemP + off + p * G::PLANE_A + (2 * H + rbl) * 16 * G::N);
         };
         auto loadB = [&](auto rrTag, auto qTag, int bufOff) __attribute__((always_inline)) {
             constexpr int rr = decltype(rrTag)::value, q = decltype(qTag)::value;
@@ -396,10 +587,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         // tile (column / 16); .replica the replica; .step = k-slab of the tile (bits 1:0) | lane << 8 | dword of the 4-dword fragment << 16 |
         // register << 24 (0-3: A fragment of byte plane p; 4-7: B fragment of plane q; 8-11: limb-sum accumulator t); .bit the bit.
         auto physFields = [&](uint32_t q, int g, uint32_t &frep, uint32_t &reg, uint32_t &dword, uint32_t &frb, uint32_t &mask) __attribute__((always_inline)) {
-            const DevFault *fp = ft.list + q;
-            const uint32_t local = __builtin_amdgcn_readfirstlane(fp->local);
-            const uint32_t sw = __builtin_amdgcn_readfirstlane(fp->step);
-            const uint32_t packed = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(&fp->replica));
+            const uint32_t local = ftWord(q, 1), sw = ftWord(q, 2), packed = ftWord(q, 3);
             const uint32_t frow = local >> 8, fcol = local & 255u;
             frep = packed & 0xffu;
             reg = (sw >> 24) & 31u;
@@ -412,7 +600,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         auto physA = [&](int g, auto setTag) __attribute__((always_inline)) { // in front of the first MFMA of set `set`
             constexpr int set = decltype(setTag)::value;
 #pragma unroll 1
-            for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
+            for (uint32_t q = fFirst; q < fEnd(); ++q) {
                 uint32_t frep, reg, dword, frb, mask;
                 if (!physFields(q, g, frep, reg, dword, frb, mask) || reg > 3u || frb != (uint32_t)(set / NREP) || frep != (uint32_t)(set % NREP))
                     continue;
@@ -420,12 +608,12 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
                     for (int d = 0; d < 4; ++d)
-                        a[ABUF ? set & 1 : 0][pp][d] ^= (int)((reg == (uint32_t)pp && dword == (uint32_t)d) ? mask : 0u);
+                        a[aIdx(set, pp)][d] ^= (int)((reg == (uint32_t)pp && dword == (uint32_t)d) ? mask : 0u);
             }
         };
         auto physStart = [&](int g, bool accLive) __attribute__((always_inline)) { // at the start of a step: B fragments, accumulators
 #pragma unroll 1
-            for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
+            for (uint32_t q = fFirst; q < fEnd(); ++q) {
                 uint32_t frep, reg, dword, frb, mask;
                 if (!physFields(q, g, frep, reg, dword, frb, mask) || reg < 4u)
                     continue;
@@ -464,8 +652,9 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             constexpr int POS = decltype(posTag)::value;     // g % 4
             constexpr bool DUTY = (POS & 1) == H;            // first half: second staging round of slab g + 1; otherwise second half: first round of slab g + 2
             constexpr bool BG = POS == 1 || POS == 2;        // a background f piece, in the half without conversion
-            const int soffLoad = slabOff(g + 3);
-            const __amdgpu_buffer_rsrc_t rsLoad = rsSof((g + 3) >> 4);
+            const int gLoad = (DUP && !DUTY) ? g + 2 : g + 3; // duty step: the staged copies of slab g + 3; off duty: the clones of slab g + 2
+            const int soffLoad = slabOff(gLoad);
+            const __amdgpu_buffer_rsrc_t rsLoad = rsSof(gLoad >> 4);
             const int bufNext = wbufOff + ((g + 1) & 1) * G::B_BUF;
             const int bufConv = DUTY ? bufNext : wbufOff + (g & 1) * G::B_BUF;
             int offAnext = panelOff(g + 1);
@@ -498,6 +687,8 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             };
             auto convStage = [&](auto kTag) __attribute__((always_inline)) {
                 constexpr int k = decltype(kTag)::value, u = k / 10, h = (k / 5) % 2, sub = k % 5;
+                if constexpr (sub == 0 && h == 0 && DUP)
+                    verifyS(std::integral_constant<int, u>{}, DUTY ? g + 1 : g + 2);
                 if constexpr (sub == 0)
                     digits4(pbs[u][0][h], pbs[u][1][h], std::integral_constant<int, 0>{});
                 else if constexpr (sub == 1)
@@ -514,11 +705,14 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             };
             auto bgStage = [&](auto subTag) __attribute__((always_inline)) {
                 constexpr int sub = decltype(subTag)::value;
+                if constexpr (sub == 0 && DUP)
+                    verifyF(g);
                 if constexpr (sub == 0)
                     digits4(bgRaw[0], bgRaw[1], std::integral_constant<int, 0>{});
                 else if constexpr (sub == 1) {
                     digits4(bgRaw[2], bgRaw[3], std::integral_constant<int, 1>{});
-                    bgRaw = bgLoad(POS == 1 ? g + 1 : g + 3); // the next bg step: this tile's third step, or the next tile's second
+                    if constexpr (POS == 1 || !DUP)
+                        bgRaw = bgLoad(POS == 1 ? g + 1 : g + 3); // the next bg step: this tile's third step, or the next tile's second
                 } else if constexpr (sub == 2)
                     perm1();
                 else if constexpr (sub == 3)
@@ -533,6 +727,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             if constexpr (PHYS)
                 if (fCount != 0u)
                     physStart(g, FIRST == 0);
+            const uint32_t pregSlot = PHYS ? pregKey - ((uint32_t)(g & 15) << 6) : 0xffffffffu; // the slot of THIS step the upset sits in front of, if any
             auto slot = [&](auto mTag) __attribute__((always_inline)) {
                 constexpr int m = decltype(mTag)::value;
                 constexpr int set = m / 10, j = m % 10, rb = set / NREP, rr = set % NREP;
@@ -542,20 +737,23 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 constexpr bool fromZero = FIRST != 0 && p == 0;
                 if constexpr (j == 0 && set != 0)
                     asm volatile("" : "+v"(offA)); // this set's A fragments are its own loads
+                if constexpr (PHYS)
+                    if (pregSlot == (uint32_t)m)
+                        pregFlip();
                 if constexpr (PHYS && j == 0)
                     if (fCount != 0u)
                         physA(g, std::integral_constant<int, set>{});
                 if constexpr (!(COAST_MM3_KNOCK & 32))
-                    acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ABUF ? set & 1 : 0][p], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
+                    acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[aIdx(set, p)], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
                 if constexpr (ABUF && j < 4) { // the NEXT set's fragment j, into the other buffer: a whole set ahead of its first use
                     if constexpr (set == NSET - 1) {
                         if constexpr (j == 0)
                             asm volatile("" : "+v"(offAnext));
-                        loadA2(std::integral_constant<int, (set + 1) & 1>{}, std::integral_constant<int, j>{}, 0, offAnext);
+                        loadAi(std::integral_constant<int, aIdx(set + 1, j)>{}, std::integral_constant<int, j>{}, 0, offAnext);
                     } else {
                         if constexpr (j == 0)
                             asm volatile("" : "+v"(offA));
-                        loadA2(std::integral_constant<int, (set + 1) & 1>{}, std::integral_constant<int, j>{}, (set + 1) / NREP, offA);
+                        loadAi(std::integral_constant<int, aIdx(set + 1, j)>{}, std::integral_constant<int, j>{}, (set + 1) / NREP, offA);
                     }
                 }
                 if constexpr (!ABUF && jj == 3 - p && !((COAST_MM3_KNOCK & 1) && set % NREP != NREP - 1) && !(COAST_MM3_KNOCK & (256 | 2048))) { // last use of a[p] in this set: the next set's (the next step's first set behind the last)
@@ -585,6 +783,27 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                     pbs[1][(m - HALF) / (2 * NREP)] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + ((m - HALF) / (2 * NREP)) * G::N * 4, soffLoad + kRoundOff, 0);
                 if constexpr (BG && (m / HALF == (DUTY ? 1 : 0)) && (m % HALF) % (2 * NREP) == (NREP == 1 ? 0 : 2) && !(COAST_MM3_KNOCK & 64))
                     bgStage(std::integral_constant<int, (m % HALF) / (2 * NREP)>{});
+                // CLONE: the f piece of the tile's second step is requested one step ahead, not three (in the previous tile's third step): the
+                // staged word and its clone sit in registers for a step instead of two on average -- and with four registers free for most of
+                // the tile the clone registers fit without a reload inside the MFMA blocks.  (Measured for the default too: - 1.1 % for
+                // 94.4 -> 94.7 % coverage, not taken: profiles/r05_mm_clone_ab.txt.)
+                if constexpr (DUP && POS == 0 && m == (H == 0 ? 1 : HALF + 1) && !(COAST_MM3_KNOCK & 64))
+                    bgRaw = bgLoad(g + 1);
+                if constexpr (DUP && !DUTY) {
+                    // the clones of slab g + 2, off duty: those of its first round in the first slots of the step (compared in the second half), those
+                    // of its second round behind that compare (compared in the next step's first slot)
+                    constexpr int u = m / HALF, mh = m % HALF;
+                    if constexpr (mh >= 1 && mh < 5)
+                        dupLoadS(std::integral_constant<int, u>{}, std::integral_constant<int, mh - 1>{}, rsLoad, soffLoad);
+                }
+                if constexpr (DUP) {
+                    // bgRaw's clone: a step whose bg stages run in its second half requests it in slot 1; for a next step whose stages run in its
+                    // first half it is requested here, behind this step's own compare
+                    if constexpr (BG && DUTY && m == 1)
+                        dupF = bgLoadDup(g);
+                    if constexpr ((POS == 0 || POS == 1) && (((POS + 1) & 1) != H) && m == HALF + 4)
+                        dupF = bgLoadDup(g + 1);
+                }
                 if constexpr (POS == 3 && !(COAST_MM3_KNOCK & 8))
                     teLast(g, voffR, mTag);
                 if constexpr (FIRST != 0 && m % kNextStride == 1 && m / kNextStride < 4 * NNEXT && !(COAST_MM3_KNOCK & 8))
@@ -605,22 +824,30 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         using T3 = std::integral_constant<int, 3>;
         int gLast = 3;
         uint32_t anyTile = 0u;
+        // (PHYS: a second, independent bound -- an upset of the loop's registers must not turn a campaign run into a walk through memory)
+        const uint32_t itemCap = PHYS ? (nblocks + stride - 1u) / stride : 0xffffffffu;
 #pragma unroll 1
-        for (int item = 0; matOf(item) < nblocks; ++item) {
+        for (int item = 0; matOf(item) < nblocks && (uint32_t)item < itemCap; ++item) {
             const uint32_t mat = matOf(item);
             if (ft.range) {
                 const uint2 rg = ft.range[mat * (uint32_t)G::NPANEL + (uint32_t)pnl];
                 fFirst = __builtin_amdgcn_readfirstlane(rg.x);
                 fCount = __builtin_amdgcn_readfirstlane(rg.y);
             }
+            if constexpr (PHYS)
+                pregScan();
             if (item > 0) { // hand-over: the panel is complete behind the barrier of the previous item's last step
                 f = F + mat * nn;
                 s = S + mat * nn;
                 rsR = rsrcOf(R + mat * nn, true, (int)(nn * 4));
                 rsD = flagsOf(mat);
             }
+            [[maybe_unused]] uint32_t tileGuard = 0u; // (PHYS: the same for the tile counter)
 #pragma unroll 1
             for (int tile = 0; tile < G::TPW; ++tile) {
+                if constexpr (PHYS)
+                    if (tileGuard++ >= (uint32_t)G::TPW)
+                        break;
                 const int g0 = item * G::SPP + tile * G::NSLAB;
                 step(g0, T1{}, T0{}); // + the previous tile's last eight stages (the previous item's resources at a hand-over)
                 rsRp = rsR;
@@ -646,7 +873,8 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         __syncthreads();
         // TMR: TMR_ERROR_CNT = the votes whose copies were not all equal; DWC: every element is an item with one compare -- a failed one is
         // a detected item; __SYNC_COUNT = the votes of tiles that exist (none in the unprotected mode)
-        block_tally(NREP == 3 ? nExec - agree : 0u, nReal, NREP == 2 ? detItems + (nExec - agree) : 0u, sCnt, ctr, blockIdx.x);
+        // (+ the staging compares that failed: a corrected word under TMR, a detected one under DWC)
+        block_tally(NREP == 3 ? nExec - agree + stageMiss : 0u, nReal, NREP == 2 ? detItems + (nExec - agree) + stageMiss : 0u, sCnt, ctr, blockIdx.x);
     };
     if (wv >= G::NLANE)
         run(std::integral_constant<int, 1>{});

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define COAST_HIP_ABI_VERSION 6 /* 6: COAST_F_LOCAL_STORE_SYNC, COAST_F_O0_SHAPE; 2: coast_cfg.flags; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info, new flags/sites;
+#define COAST_HIP_ABI_VERSION 7 /* 7: COAST_F_CLONE_STAGING, COAST_SITE_MM_PREG; 6: COAST_F_LOCAL_STORE_SYNC, COAST_F_O0_SHAPE; 2: coast_cfg.flags; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info, new flags/sites;
                                  * 4: control-flow signatures (coast_cfcss_assign, coast_crazycf_*), additive;
                                  * 5: COAST_REPLICA_ALL, COAST_ETIMEOUT, coast_launch_info.hooked_blocks, additive */
 
@@ -118,7 +118,18 @@ enum {
     /* single-call host shims only (the batch entry points reject it): run the region in the reference's DEFAULT mode,
      * memory replicated as well -- one unprotected launch per memory copy + the exit vote of coast_sync_copies(scrub).
      * Without it the shims use the lane-replicated -noMemReplication engine. */
-    COAST_F_HOST_MEMORY_REPLICATED = 0x100u
+    COAST_F_HOST_MEMORY_REPLICATED = 0x100u,
+    /* coast_mm_batch, side 256 on the matrix cores (the default engine and tile), TMR / DWC: the global -> LDS staging loads are CLONED
+     * (cloning.cpp:2187-2209; one address for the copies under -noMemReplication, :2247-2255).  Without it every raw word of f and s is
+     * loaded once into a staging register, converted once and written into the LDS image all replicas read: an upset of that register is
+     * common-mode, the wrong words come out with TMR_ERROR_CNT unchanged.  With it every word is loaded a second time half a pipeline step
+     * ahead of its conversion and compared in front of its first use; TMR takes select(a == b, a, c) with a third load and counts one
+     * corrected error per word, DWC counts a detected item and flags the first element the word reaches.  sync_count is unchanged (a cloned
+     * load is not a sync point of the reference either; the votes stay where the stores are).  Price on an MI355X: + 30 % kernel time (the
+     * register file is full; profiles/r05_mm_clone_ab.txt), for 94.4 -> 96.6 % coverage of single-bit upsets drawn uniformly from the wave's
+     * register state (tools/campaign.py --reg-model uniform).  Ignored where it has no meaning: other sides and engines (the lane-replicated
+     * kernels issue one load per replica lane already), unprotected runs.  Does not select the stepwise kernels the other flags select. */
+    COAST_F_CLONE_STAGING = 0x200u
 };
 
 /* Counters.  errors_corrected is TMR_ERROR_CNT (synchronization.cpp:269-294,1391-1443: +1 per voted value whose
@@ -176,6 +187,16 @@ enum {
      * hardware computes from the flipped register: TMR out-votes it, DWC flags the items it reaches, an unprotected run returns the wrong
      * words (tests/test_gpu_parity.py::test_mm_physical_register_upsets).  Rejected by every other mm engine. */
     COAST_SITE_MM_VGPR = 6,
+    /* A physical upset of ANY register of a wave of the same kernel, named by its physical number (round 5): what the reference's injector does
+     * when it draws a register of the core (simulation/platform/resources/injector.py:70-72, 237-260).  item = b n^2 + i n names the matrix and
+     * the 64-row panel (i / 64: the workgroup); step = slot (bits 5:0: the upset sits in front of MFMA slot 0..59 of the step) | step of the
+     * panel's 16 (bits 9:6: column tile * 4 + k-slab) | lane << 10 (6 bits, vector registers) | wave of the workgroup << 16 (3 bits) | register
+     * file << 19 (0: vector, v0..v255; 1: scalar, s0..s101) | register number << 20 (9 bits); bit = the bit.  The compiler knows nothing of the
+     * exclusive-or: accumulators, operand fragments, staging words and their clones, address registers, lane constants, loop counters,
+     * descriptors -- whatever the allocator put there at that moment.  One upset per (wave, matrix).  Scalar upsets can send a descriptor or a
+     * kernel-argument pointer anywhere in the address space: a memory fault ends the process (tools/campaign.py runs them in children).
+     * mm_mfma_blk3_kernel only (side 256, no sync_every / flags); replica is ignored. */
+    COAST_SITE_MM_PREG = 7,
     COAST_SITE_SHA_M = 8,  /* schedule word m[step%64] of compression step/64, right after it is produced */
     COAST_SITE_SHA_WV = 9, /* working variable index 0..7 (a..h) before round step%64 of compression step/64 */
     COAST_SITE_SHA_STATE = 10, /* ctx_state[index] before compression `step` (== ncompress: before the digest) */

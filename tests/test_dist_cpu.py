@@ -113,3 +113,70 @@ def test_bench_rejects_mismatched_world():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env,
                        timeout=600)
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def _race_builder(root, q):
+    """one of the eight ranks of a multi-GPU launch on a stale tree: import the package's build module and build()"""
+    sys.path.insert(0, root)
+    try:
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("race_build", os.path.join(root, "coast_amd", "build.py"))
+        b = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(b)
+        b._build_examples = lambda *a, **k: None  # (the C demos link against ROCm: not what this test is about)
+        lib = b.build()
+        q.put(("ok", b._stamp_ok(b.source_hash()), os.path.getsize(lib)))
+    except Exception as e:  # noqa: BLE001
+        q.put(("fail", repr(e), 0))
+
+
+def test_eight_ranks_racing_build_compile_once(tmp_path):
+    """the eight ranks of `bench.py --gpus 8` all come through coast_amd.build.build(); on a stale tree (sources edited,
+    library from before) exactly ONE of them may compile, the others must wait on the lock and then find a current library -- never two
+    compilers writing the same file, never a rank loading a half-written one.  A stand-in `hipcc` (slow, counts its invocations, writes the
+    hash it was given) keeps the test at seconds; the locking and stamping logic is the real one."""
+    import shutil
+    import stat
+
+    root = tmp_path / "tree"
+    (root / "coast_amd" / "csrc").mkdir(parents=True)
+    (root / "include").mkdir()
+    shutil.copy(os.path.join(ROOT, "coast_amd", "build.py"), root / "coast_amd" / "build.py")
+    (root / "include" / "coast_hip.h").write_text("/* header */\n")
+    (root / "coast_amd" / "csrc" / "coast_hip.hip").write_text("// kernel source, edited\n")
+    fake = tmp_path / "bin"
+    fake.mkdir()
+    count = tmp_path / "compiles.txt"
+    script = fake / "hipcc"
+    script.write_text("""#!/bin/bash
+# stand-in compiler: one line per invocation, then a slow, non-atomic write of the output (what a real link is)
+echo x >> %s
+out=""; hash=""
+while [ $# -gt 0 ]; do
+  case "$1" in -o) out="$2"; shift;; -DCOAST_SOURCE_HASH=*) hash="${1#-DCOAST_SOURCE_HASH=}";; esac
+  shift
+done
+printf 'partial' > "$out"; sleep 1.5; printf 'library %%s' "$hash" > "$out"
+""" % count)
+    script.chmod(script.stat().st_mode | stat.S_IEXEC)
+    lib = root / "coast_amd" / "lib"
+    lib.mkdir()
+    (lib / "libcoast_hip.so").write_text("library \"0000000000000000\" stale")  # the tree was edited after this was built
+    old_path = os.environ["PATH"]
+    os.environ["PATH"] = str(fake) + os.pathsep + old_path
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_race_builder, args=(str(root), q)) for _ in range(8)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=120) for _ in range(8)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        os.environ["PATH"] = old_path
+    assert all(r[0] == "ok" and r[1] for r in res), res
+    assert count.read_text().count("x") == 1, count.read_text()  # one compile for eight ranks
+    assert len({r[2] for r in res}) == 1  # everybody saw the finished file

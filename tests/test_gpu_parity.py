@@ -1612,6 +1612,28 @@ def test_bench_two_ranks_real_engines_counters_all_reduced():
     assert "gloo" in two["collective"] and "2 ranks" in two["collective"]
 
 
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """De-risk the driver's first 8-GPU run on the hardware there is (VERDICT r4 item 7): `bench.py --gpus 8` starts eight ranks itself;
+    with COAST_BENCH_BACKEND=gloo they share the one GPU and the collective is host-staged -- rank logic, sharding of the upset seeds,
+    per-rank rows and the summed counters are exactly what the RCCL run executes per rank.  mm: the grid mapping of the register-block kernel
+    at small batches, eight contexts on one device; crc16 at 255 bytes: the reference's block length on the sharded stream (north_star's 8-GPU
+    config; the N > 1 extra leg runs 256 bytes only)."""
+    args = ["--steps", "2", "--warmup", "1", "--batch", "64", "--faults", "40", "--no-extra", "--no-cpu-baseline"]
+    one = _run_bench(["--gpus", "1"] + args)
+    eight = _run_bench(["--gpus", "8"] + args, {"COAST_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert eight["n_gpus"] == 8 and "8 ranks" in eight["collective"]
+    rk = eight["ranks"]
+    assert sorted(r["rank"] for r in rk["per_rank"]) == list(range(8)) and rk["slowest_rank"] in range(8)
+    assert all(r["kernel_ms"] > 0 and r["step_ms"] > 0 for r in rk["per_rank"])
+    assert eight["corrected_faults"] == 8 * one["corrected_faults"] == 8 * 2 * 40
+    assert eight["sync_count"] == 8 * one["sync_count"] and eight["injected_faults"] == 8 * one["injected_faults"]
+    assert eight["outputs_match_unprotected"] and eight["voted_by"] == "matrix_core"
+    crc = _run_bench(["--gpus", "8", "--workload", "crc16", "--block-len", "255", "--batch", "32768", "--steps", "2", "--warmup", "1",
+                      "--faults", "32", "--no-cpu-baseline"], {"COAST_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert crc["n_gpus"] == 8 and crc["corrected_faults"] == 8 * 2 * 32 and crc["sync_count"] == 8 * 2 * 32768
+    assert crc["outputs_match_unprotected"] and len(crc["ranks"]["per_rank"]) == 8
+
+
 def test_bench_two_ranks_crc16_stream_sharded():
     """the 8-GPU config's shape at two ranks: every rank streams its own shard, counters all-reduced"""
     two = _run_bench(["--gpus", "2", "--workload", "crc16", "--block-len", "255", "--batch", "65536", "--steps", "2", "--warmup", "1",
@@ -2844,11 +2866,16 @@ def test_mm_physical_register_upsets(eng, cls):
     eng.mm_batch(df, ds, cfg=ca.XmrConfig(1))  # (a rejected launch leaves the upsets armed: this one consumes them)
 
 
-def test_mm_physical_upsets_of_the_shared_staging_registers_are_silent(eng):
+@pytest.mark.parametrize("clone", [True, False])
+def test_mm_physical_upsets_of_the_staging_registers(eng, clone):
     """COAST_SITE_MM_VGPR registers 12-20: a raw word of s / of the next f panel in the wave's staging registers, on its way into the LDS
-    image every replica (and, for s, both waves of the pair) reads -- the analogue of a memory upset under -noMemReplication.  A real flip
-    there is common-mode: under TMR the wrong words come out with TMR_ERROR_CNT == 0 (every vote agrees), and they have the structure of
-    one corrupted word of s (a column of one 64-row panel moved by +-2^bit f[i][k]) or of f (a row moved by +-2^bit s[k][j])."""
+    image every replica (and, for s, both waves of the pair) reads.  DEFAULT: every word is staged once -- a real flip there is common-mode,
+    the analogue of a memory upset under -noMemReplication: the wrong words come out with TMR_ERROR_CNT == 0 (233 of 501 / 76 of 79 runs,
+    profiles/r05_campaign_physical_real_all_seed0_5000.txt).  COAST_F_CLONE_STAGING (round 5): the staging load is cloned
+    (cloning.cpp:2187-2209, 2247-2255) -- a second load half a step ahead of the conversion, compared in front of the first instruction that
+    consumes the word; TMR takes select(a == b, a, c) with a third load (TMR_ERROR_CNT + 1, every word of the product the clean one), DWC
+    counts a detected item and flags the first element the word reaches.  The unprotected run shows what the flip does when nobody looks
+    (one column of a 64-row panel / one row moved by +-2^bit times the other operand)."""
     import coast_amd as ca
 
     n, batch = 256, 66  # 66 matrices on 64 workgroup groups: workgroups 0 and 1 own a second matrix, whose f panel they stage ahead
@@ -2856,41 +2883,67 @@ def test_mm_physical_upsets_of_the_shared_staging_registers_are_silent(eng):
     f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
     s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
     df, ds = _dev(f), _dev(s)
+    flag = ca.F_CLONE_STAGING if clone else 0
     eng.reset_stats()
-    clean = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(3)), np.uint32)
+    clean = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(3, 0, flag)), np.uint32)
     syncs = eng.stats()["sync_count"]
-    hits = {"s": 0, "f": 0}
+    assert syncs == batch * n * n and (clean == _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(1)), np.uint32)).all()
+    hits, caught = {"s": 0, "f": 0}, {"s": 0, "f": 0}
     for trial in range(24):
         fcls = trial % 3 == 2
         b, i, j = int(rng.integers(0, 2)) if fcls else int(rng.integers(0, batch)), int(rng.integers(0, n)), int(rng.integers(0, n))
         reg, dword = (20, int(rng.integers(0, 4))) if fcls else (12 + int(rng.integers(0, 8)), int(rng.integers(0, 2)))
-        bit = int(rng.integers(0, 32))
+        bit, rep = int(rng.integers(0, 32)), int(rng.integers(0, 3))
         step = int(rng.integers(0, 4)) | (int(rng.integers(0, 64)) << 8) | (dword << 16) | (reg << 24)
+        fault = lambda r: ca.make_faults([(b * n * n + i * n + j, r, ca.SITE_MM_VGPR, step, bit)])
+        # TMR without the clones: the flip's own consequence (nothing compares the staged word with anything), no vote sees it
         eng.reset_stats()
-        eng.inject_faults(ca.make_faults([(b * n * n + i * n + j, int(rng.integers(0, 3)), ca.SITE_MM_VGPR, step, bit)]))
-        out = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(3)), np.uint32)
+        eng.inject_faults(fault(rep))
+        raw = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(3)), np.uint32)
         st = eng.stats()
-        assert st["errors_corrected"] == 0 and st["dwc_detected"] == 0 and st["sync_count"] == syncs, (trial, st)  # nothing to see for a voter
-        diff = np.argwhere(out != clean)
-        if not len(diff):
-            continue  # (the register held no live word at that moment, or the word's consequence was a multiple of 2^32)
-        m = int(diff[0, 0])
-        assert (diff[:, 0] == m).all()
-        delta = (out[m].astype(np.int64) - clean[m].astype(np.int64)) % 2**32
-        cands = [(1 << bit) % 2**32, (-(1 << bit)) % 2**32]
-        if fcls:    # one row of the staged panel, all columns
-            rows = np.unique(diff[:, 1])
-            assert len(rows) == 1
-            d = delta[rows[0]]
-            assert any(((c * s[m, k].astype(np.uint64)) % 2**32 == d).all() for k in range(n) for c in cands), trial
-            hits["f"] += 1
-        else:       # one column, the rows of one 64-row panel
-            cols, p0 = np.unique(diff[:, 2]), (int(diff[0, 1]) // 64) * 64
-            assert len(cols) == 1 and all(p0 <= r < p0 + 64 for r in diff[:, 1])
-            d = delta[p0:p0 + 64, cols[0]]
-            assert any(((c * f[m, p0:p0 + 64, k].astype(np.uint64)) % 2**32 == d).all() for k in range(n) for c in cands), trial
-            hits["s"] += 1
+        assert st["errors_corrected"] == 0 and st["dwc_detected"] == 0 and st["sync_count"] == syncs, (trial, st)
+        diff = np.argwhere(raw != clean)
+        live = len(diff) > 0  # (else: the register held no live word at that moment, or the word's consequence was a multiple of 2^32)
+        m = None
+        if live:
+            m = int(diff[0, 0])
+            assert (diff[:, 0] == m).all()
+            delta = (raw[m].astype(np.int64) - clean[m].astype(np.int64)) % 2**32
+            cands = [(1 << bit) % 2**32, (-(1 << bit)) % 2**32]
+            if fcls:    # one row of the staged panel, all columns
+                rows = np.unique(diff[:, 1])
+                assert len(rows) == 1
+                d = delta[rows[0]]
+                assert any(((c * s[m, k].astype(np.uint64)) % 2**32 == d).all() for k in range(n) for c in cands), trial
+            else:       # one column, the rows of one 64-row panel
+                cols, p0 = np.unique(diff[:, 2]), (int(diff[0, 1]) // 64) * 64
+                assert len(cols) == 1 and all(p0 <= r < p0 + 64 for r in diff[:, 1])
+                d = delta[p0:p0 + 64, cols[0]]
+                assert any(((c * f[m, p0:p0 + 64, k].astype(np.uint64)) % 2**32 == d).all() for k in range(n) for c in cands), trial
+            hits["f" if fcls else "s"] += 1
+        if not clone:
+            continue
+        # TMR with the clones: the copies disagree, the third one decides: the clean product, one corrected error, no extra sync point.
+        # (The s words are staged in the same slots by both kernels: a word that was live there is live here.  The f pieces are not: the
+        # cloning kernel requests them one step ahead instead of up to three, its register is dead at two of a tile's four step starts.)
+        eng.reset_stats()
+        eng.inject_faults(fault(rep))
+        out = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(3, 0, flag)), np.uint32)
+        st = eng.stats()
+        assert (out == clean).all(), trial
+        assert st["errors_corrected"] in ((1,) if live and not fcls else (0, 1)) and st["dwc_detected"] == 0 and st["sync_count"] == syncs, (trial, live, st)
+        caught["f" if fcls else "s"] += st["errors_corrected"]
+        # DWC with the clones: detected, and flagged in the matrix the word belongs to
+        det = _dev(np.zeros(batch * n * n, dtype=np.uint8))
+        eng.reset_stats()
+        eng.inject_faults(fault(int(rng.integers(0, 2))))
+        eng.mm_batch(df, ds, cfg=ca.XmrConfig(2, 0, flag), detected=det)
+        st2 = eng.stats()
+        flagged = np.flatnonzero(_host(det, np.uint8).reshape(batch, -1).any(axis=1))
+        assert st2["errors_corrected"] == 0 and st2["dwc_detected"] in ((1,) if live and not fcls else (0, 1)), (trial, live, st2)
+        assert len(flagged) == st2["dwc_detected"] and (not st2["dwc_detected"] or m is None or flagged[0] == m), (trial, flagged, m)
     assert hits["s"] >= 3 and hits["f"] >= 1, hits
+    assert not clone or (caught["s"] >= 3 and caught["f"] >= 1), caught
 
 
 @pytest.mark.parametrize("replicas", [2, 1])
@@ -2979,6 +3032,36 @@ def test_mm_256_register_block_kernel_batch_shapes(eng, orc, batch, tile, monkey
     fh, sh = _host(f, np.uint32), _host(s, np.uint32)
     exp, _, _ = orc.mm_xmr_items(fh, sh, items.astype(np.uint64))
     assert (_host(r, np.uint32).reshape(-1)[items] == exp).all()
+
+
+def _uniform_campaign(argv):
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("coast_campaign", os.path.join(root, "tools", "campaign.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.run_uniform_campaign(mod.parse(["-b", "mm", "--side", "256", "--reg-model", "uniform", "-n"] + argv))
+
+
+def test_campaign_uniform_register_file_mm256():
+    """`campaign.py --reg-model uniform` (round 5): ONE coverage figure for the matrix-core kernel -- an exclusive-or on one bit of ANY
+    physical register of a wave (COAST_SITE_MM_PREG: v0..v255 through the VGPR index mode, s0..s101 through s_movrels / s_movreld), drawn
+    uniformly from the register state the kernel's code object allocates, in front of a uniformly random MFMA slot; the launches run in
+    child processes (an upset of a pointer is a memory fault), the scalar class counts as errors unless --sgpr run.  5000 runs
+    (profiles/r05_campaign_uniform_*.txt): TMR 94.7 %, with COAST_F_CLONE_STAGING 97.2 %, DWC 92.1 / 95.8 %, unprotected: see there; the
+    reference's MSP430 table (docs/source/results/msp430.rst:14): unmitigated 84.0 %, -TMR 99.6 %, -TMR -countErrors 95.0 %."""
+    recs, t = _uniform_campaign(["-m", "TMR", "-t", "1280"])
+    _, c = _uniform_campaign(["-m", "TMR", "-t", "1280", "--clone-staging"])
+    _, u = _uniform_campaign(["-m", "NONE", "-t", "1280"])
+    for s in (t, c, u):
+        assert s["runs"] == 1280 == s["success"] + s["errors"] + s["faults"] + s["invalids"] and s["invalids"] <= 3, s
+        assert s["scalar_upsets_not_executed_counted_as_errors"] >= 1  # (s0..s101 and the spill registers' lanes: ~1.4 % of the state)
+    assert {r["class"] for r in recs} <= {"success", "fault", "error", "invalid"} and all(0 <= r["target"]["reg"] < 256 for r in recs)
+    assert t["coverage_pct"] > 91.0 and t["faults"] > 350          # (94.7 % at 5000 runs; 37 % of the upsets are out-voted and counted)
+    assert c["coverage_pct"] > 94.0 and c["coverage_pct"] > t["coverage_pct"] and c["clone_staging"]
+    assert u["faults"] == 0 and u["coverage_pct"] < t["coverage_pct"] - 3.0, (u["coverage_pct"], t["coverage_pct"])
 
 
 def test_campaign_physical_real_all_registers_mm256(eng, tmp_path, monkeypatch):

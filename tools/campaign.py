@@ -38,6 +38,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import coast_amd as ca  # noqa: E402
 
+def cu_count():
+    """compute units of the device (the matrix-core kernel runs one workgroup per CU, four per matrix); 256 = an MI355X, for the CPU-side tests"""
+    return torch.cuda.get_device_properties(0).multi_processor_count if torch.cuda.is_available() else 256
+
+
 MODES = {"TMR": ca.TMR, "DWC": ca.DWC, "NONE": ca.UNPROTECTED, "CFCSS": ca.UNPROTECTED}  # CFCSS: -b crazycf only
 
 
@@ -411,6 +416,8 @@ def run_campaign(a, eng=None):
                 targets.append({"replica": row[1], "site": row[2], "step": row[3], "bit": row[4]})
         eng.inject_faults(ca.make_faults(rows))
         flags = (ca.F_BRANCH_SYNC if a.benchmark == "crc16" else ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC) if a.counters_in_sor else 0
+        if getattr(a, "clone_staging", False):
+            flags |= ca.F_CLONE_STAGING
         out = bench.run(inp, ca.XmrConfig(rep, 0, flags), det)
         engine = eng.last_launch()
         if physical and bench.real_staging:
@@ -478,7 +485,8 @@ def run_campaign(a, eng=None):
         # steps stage the next matrix's first slabs, and all of them its f panel), or of run m - 2 * stride (the f piece requested in a
         # matrix's last step is the first piece of the panel after the next: probe of round 4, run 287 -> matrix 415).
         # stride = one matrix per workgroup group = min(runs, CUs / 4).
-        stride, staging = min(runs, 64), ("s_raw", "f_raw")
+        # (the kernel's stride between a workgroup's matrices: gridDim.x / 4 = min(batch, CUs / 4))
+        stride, staging = min(runs, max(1, cu_count() // 4)), ("s_raw", "f_raw")
         cls_of = lambda r: classes[r] if r >= 0 else None
         for m in np.flatnonzero(bad_staged):
             if cls_of(m - stride) == "f_raw":
@@ -561,6 +569,221 @@ def run_campaign(a, eng=None):
     return records, summary
 
 
+# ------------------------------------------------------------------------------------------------ the uniform register-file campaign
+def uniform_draw(rng, n_vgpr=256, n_sgpr=102):
+    """one bit of the register state of one wave of the kernel, uniformly: n_vgpr VGPRs x 64 lanes x 32 bits + n_sgpr SGPRs x 32 bits (the
+    registers the kernel's code object allocates; the reference's injector draws a register of the core uniformly: injector.py:70-72,
+    237-260), at a uniformly random MFMA slot of the panel's 16 steps (60 slots each under TMR, 40 under DWC, 20 unprotected)"""
+    vbits, sbits = n_vgpr * 64 * 32, n_sgpr * 32
+    file = int(rng.random() < sbits / (vbits + sbits))
+    return {"file": file, "reg": int(rng.integers(0, n_sgpr if file else n_vgpr)), "lane": 0 if file else int(rng.integers(0, 64)),
+            "bit": int(rng.integers(0, 32)), "wave": int(rng.integers(0, 8)), "panel": int(rng.integers(0, 4)),
+            "step": int(rng.integers(0, 16)), "slot": int(rng.integers(0, 60))}
+
+
+PHYS_KERNEL = "_ZN5coast19mm_mfma_blk3_kernelILi%dELb1ELb1ELb%dEEEvPKjS2_PjjNS_8CountersENS_8FaultTabEPh"  # mm_mfma_blk3_kernel<replicas, true, true, clone>
+
+
+def kernel_registers(replicas, clone=False):
+    """(VGPRs, SGPRs the kernel allocates, the VGPRs it spills scalar registers into) of mm_mfma_blk3_kernel<replicas, true, true, clone>, read
+    from the code object inside the very library that runs (the bundle in its .hip_fatbin) with the image's llvm-readelf / llvm-objdump: no
+    allocation map to keep in step with the compiler.  The spill registers (v_writelane_b32 / v_readlane_b32): a lane of such a register IS a
+    scalar register -- a descriptor word, a kernel-argument pointer, a loop counter -- and an upset there belongs to the scalar class (it can
+    send an access anywhere in the address space)."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+
+    from coast_amd import _lib as libmod
+
+    path = os.environ.get("COAST_LIB_OVERRIDE") or libmod.lib_path()
+    data = open(path, "rb").read()
+    pos = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    if pos < 0:
+        raise SystemExit("campaign: no offload bundle in %s" % path)
+    n = struct.unpack_from("<Q", data, pos + 24)[0]
+    off, co = pos + 32, None
+    for _ in range(n):
+        o, sz, ts = struct.unpack_from("<QQQ", data, off)
+        triple = data[off + 24:off + 24 + ts].decode()
+        off += 24 + ts
+        if "gfx950" in triple:
+            co = data[pos + o:pos + o + sz]
+    if co is None:
+        raise SystemExit("campaign: no gfx950 code object in %s" % path)
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    sym = PHYS_KERNEL % (replicas, int(bool(clone)))
+    with tempfile.NamedTemporaryFile(suffix=".co") as fh:
+        fh.write(co)
+        fh.flush()
+        text = subprocess.run([llvm + "llvm-objdump", "-d", "--no-show-raw-insn", "--disassemble-symbols=" + sym, fh.name],
+                              capture_output=True, text=True, check=True).stdout
+        notes = subprocess.run([llvm + "llvm-readelf", "--notes", fh.name], capture_output=True, text=True, check=True).stdout
+    if "v_mfma" not in text:
+        raise SystemExit("campaign: %s not found in the code object" % sym)
+    rec = [blk for blk in notes.split("  - .agpr_count:") if ".name:           " + sym + "\n" in blk]
+    if len(rec) != 1:
+        raise SystemExit("campaign: no metadata record of %s" % sym)
+    nv, ns = int(re.search(r"\.vgpr_count:\s+(\d+)", rec[0]).group(1)), int(re.search(r"\.sgpr_count:\s+(\d+)", rec[0]).group(1))
+    return nv, min(ns, 102), sorted({int(m) for m in re.findall(r"v_writelane_b32\s+v(\d+)", text)})
+
+
+def preg_row(item, d):
+    step = d["slot"] | (d["step"] << 6) | (d["lane"] << 10) | (d["wave"] << 16) | (d["file"] << 19) | (d["reg"] << 20)
+    return (item, 0, ca.SITE_MM_PREG, step, d["bit"])
+
+
+def run_uniform_campaign(a, eng=None):
+    """--reg-model uniform (-b mm --side 256): ONE coverage figure for the matrix-core kernel, no census, no model.  A run = one workgroup
+    group (four 64-row panels) that multiplies three matrices in a row; the upset -- COAST_SITE_MM_PREG: an exclusive-or on one bit of a
+    physical register, v0..v255 of one lane or s0..s101, of one wave of one of the four workgroups -- falls in front of a uniformly random
+    MFMA slot of the MIDDLE matrix; the run is an error when ANY word of the group's three products is wrong (a staged word, an address
+    register or a loop counter can carry the damage into the next matrix; nothing carries it into another workgroup).  64 runs per launch
+    (one per workgroup group of a 256-CU part), so a run's outcome is its own.
+    The launches run in CHILD processes (as every run of the reference's campaign is a QEMU process of its own): an upset can turn a pointer
+    into a wild address -- a scalar register, or a lane of the vector registers the compiler spills scalar registers into -- and the memory
+    fault that follows takes the process with it.  A launch whose child dies is split until the run that kills it is alone: that run is
+    `invalid` (supervisor.py files a crashed run the same way) and counts against the coverage.  Scalar-class upsets (s0..s101 and the spill
+    registers' lanes): --sgpr count (default) does not execute them and counts every one as an error; --sgpr run executes them, one per launch."""
+    import subprocess
+
+    rng = np.random.default_rng(a.seed)
+    rep = MODES[a.mode]
+    if a.benchmark != "mm" or a.side != 256 or a.mode == "CFCSS":
+        raise SystemExit("--reg-model uniform: the register file is that of the matrix-core kernel (-b mm --side 256 -m TMR | DWC | NONE)")
+    quads = max(1, cu_count() // 4)  # workgroup groups of a launch = its stride between a workgroup's matrices
+    runs = a.runs
+    nv, ns, spill = kernel_registers(max(rep, 1), a.clone_staging and rep > 1)
+    spill = set(spill)  # vector registers whose lanes hold spilled scalar registers: the scalar class too
+    nslots = 20 * max(rep, 1)  # MFMA slots of a pipeline step
+    draws = [uniform_draw(rng, nv, ns) for _ in range(runs)]
+    for d in draws:
+        d["slot"] %= nslots
+    scalar = lambda d: d["file"] == 1 or d["reg"] in spill
+    executed = np.array([not scalar(d) or a.sgpr == "run" for d in draws])
+    vec = [r for r in range(runs) if not scalar(draws[r])]
+    if os.environ.get("COAST_CAMPAIGN_ONLY"):  # development: arm the runs lo <= r < hi only
+        lo, hi = (int(x) for x in os.environ["COAST_CAMPAIGN_ONLY"].split(":"))
+        vec = [r for r in vec if lo <= r < hi]
+    todo = [vec[k:k + quads] for k in range(0, len(vec), quads)]
+    if a.sgpr == "run":
+        todo += [[r] for r in range(runs) if scalar(draws[r])]
+    results, invalid, stats = {}, set(), {"errors_corrected": 0, "sync_count": 0, "dwc_detected": 0}
+    t0 = time.perf_counter()
+    children = 0
+    while todo:
+        spec = json.dumps({"mode": a.mode, "seed": a.seed, "clone": bool(a.clone_staging), "launches": [[[r, draws[r]] for r in grp] for grp in todo]})
+        children += 1
+        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--preg-child", "-"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        try:
+            out, _ = proc.communicate(spec, timeout=120 + 2 * len(todo))
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            out, _ = proc.communicate()
+        started, done = None, set()
+        for line in out.splitlines():
+            w = line.split(" ", 2)
+            if w[0] == "start":
+                started = int(w[1])
+            elif w[0] == "done":
+                k = int(w[1])
+                res = json.loads(w[2])
+                for r, bd, fl in res["runs"]:
+                    results[r] = (bool(bd), bool(fl))
+                for key in stats:
+                    stats[key] += res["stats"][key]
+                done.add(k)
+                started = None
+        rest = [grp for k, grp in enumerate(todo) if k not in done]
+        if started is not None and started not in done:  # the child died inside launch `started`: halve it until the killer is alone
+            grp = todo[started]
+            rest = [g for g in rest if g is not grp]
+            if len(grp) == 1:
+                invalid.add(grp[0])
+            else:
+                rest = [grp[:len(grp) // 2], grp[len(grp) // 2:]] + rest
+        elif proc.returncode != 0 and len(rest) == len(todo):
+            raise SystemExit("campaign: the child made no progress (exit %s):\n%s" % (proc.returncode, out[-2000:]))
+        todo = rest
+    wall = time.perf_counter() - t0
+    aborting = rep == ca.DWC
+    records, counts = [], {"success": 0, "errors": 0, "faults": 0, "timeouts": 0, "invalids": 0, "aborts": 0, "not_executed": 0}
+    by_reg = {}
+    for r, d in enumerate(draws):
+        bad, flagged = results.get(r, (False, False))
+        if r in invalid:
+            cls = "invalid"
+            counts["invalids"] += 1
+        elif not executed[r] or r not in results:
+            cls = "error"  # not executed, counted against the coverage
+            counts["errors"] += 1
+            counts["not_executed"] += 1
+        elif aborting and flagged:
+            cls = "abort"
+            counts["timeouts"] += 1
+            counts["aborts"] += 1
+        elif bad:
+            cls = "error"
+            counts["errors"] += 1
+        elif flagged:
+            cls = "fault"
+            counts["faults"] += 1
+        else:
+            cls = "success"
+            counts["success"] += 1
+        key = ("s%d" if d["file"] else "v%d") % d["reg"]
+        e = by_reg.setdefault(key, [0, 0])
+        e[0] += 1
+        e[1] += cls in ("error", "invalid")
+        records.append({"run": r, "section": "registers", "target": d, "class": cls,
+                        "result": {"core": 0, "errors": int(cls == "error"), "faults": int(bool(flagged)), "runtime_us": wall * 1e6 / runs}})
+    nbad = counts["errors"] + counts["invalids"]
+    summary = {
+        "name": "mm_%s_registers_uniform%s" % (a.mode, "_clone_staging" if a.clone_staging else ""), "clone_staging": bool(a.clone_staging), "benchmark": "mm", "mode": a.mode, "section": "registers", "mem_mode": None, "runs": runs,
+        "success": counts["success"], "errors": counts["errors"], "faults": counts["faults"], "timeouts": counts["timeouts"],
+        "invalids": counts["invalids"], "aborts": counts["aborts"], "scalar_upsets_not_executed_counted_as_errors": counts["not_executed"],
+        "coverage_pct": 100.0 * (runs - nbad) / runs,
+        # (an upset of a tally register -- agree, the vote counts -- lands in these sums as whatever the flipped bit weighs)
+        "TMR_ERROR_CNT": stats["errors_corrected"], "__SYNC_COUNT": stats["sync_count"], "dwc_detected": stats["dwc_detected"],
+        "engine": "matrix_core", "stepwise_blocks": 0, "hooked_blocks": 0, "child_processes": children,
+        "wall_s": wall, "seconds_per_injection": wall / runs,
+        "fault_model": "one single-bit flip of a 32-bit register per run (FaultInjector.flipOneBit, injector.py:202-207); the register is drawn uniformly "
+                       "from the wave's register state (injector.py:70-72, 237-260): v0..v%d x 64 lanes, s0..s%d (what the kernel's code object allocates)" % (nv - 1, ns - 1),
+        "reg_model": "uniform: COAST_SITE_MM_PREG, a real exclusive-or on a PHYSICAL register of the running kernel in front of a uniformly random MFMA slot "
+                     "of the middle one of the three matrices a workgroup group multiplies; error = any wrong word in the three products; invalid = "
+                     "the process died (memory fault)",
+        "registers_with_errors": {k: v for k, v in sorted(by_reg.items(), key=lambda kv: -kv[1][1]) if v[1]},
+        "scalar_class": "s0..s101 and the lanes of %s (the vector registers the compiler spills scalar registers into: v_writelane_b32 in the "
+                        "kernel's code object)" % ", ".join("v%d" % r for r in sorted(spill)),
+        "counters_in_sor": False,
+    }
+    return records, summary
+
+
+def preg_child(_):
+    """one child of the uniform campaign: the launches of the spec on stdin, `start k` before and `done k {...}` behind each"""
+    spec = json.loads(sys.stdin.read())
+    eng = ca.Engine(0)
+    n, nn, items = 256, 256 * 256, 3
+    quads = max(1, cu_count() // 4)
+    g = torch.Generator(device="cuda").manual_seed(spec["seed"])
+    f, s = [torch.randint(-2**31, 2**31, (items * quads, n, n), dtype=torch.int32, device="cuda", generator=g) for _ in range(2)]
+    gold = eng.mm_batch(f, s, cfg=ca.XmrConfig(ca.UNPROTECTED)).clone()
+    cfg = ca.XmrConfig(MODES[spec["mode"]], 0, ca.F_CLONE_STAGING if spec.get("clone") else 0)
+    for k, grp in enumerate(spec["launches"]):
+        print("start %d" % k, flush=True)
+        eng.reset_stats()
+        eng.inject_faults(ca.make_faults([preg_row((quads + q) * nn + 64 * d["panel"] * n, d) for q, (r, d) in enumerate(grp)]))
+        det = torch.zeros(items * quads * nn, dtype=torch.uint8, device="cuda")
+        out = eng.mm_batch(f, s, cfg=cfg, detected=det)
+        wrong = (out != gold).reshape(items, quads, -1).any(dim=2).any(dim=0).cpu().numpy()
+        seen = det.reshape(items, quads, -1).any(dim=2).any(dim=0).cpu().numpy()
+        st = eng.stats()
+        print("done %d %s" % (k, json.dumps({"runs": [[r, int(wrong[q]), int(seen[q])] for q, (r, d) in enumerate(grp)],
+                                             "stats": {key: st[key] for key in ("errors_corrected", "sync_count", "dwc_detected")}})), flush=True)
+
+
 def format_summary(s):
     """FileSummary.__str__ (jsonParser.py:46-75)"""
     n = s["runs"]
@@ -576,6 +799,11 @@ def format_summary(s):
              " (%3.6f seconds per injection)" % s["seconds_per_injection"]]
     if s["aborts"]:
         lines += ["Additional Data:", "Aborts:     %d (%3.2f%%)" % (s["aborts"], 100.0 * s["aborts"] / n)]
+    if "registers_with_errors" in s:
+        top = list(s["registers_with_errors"].items())[:24]
+        lines += ["Scalar upsets not executed (counted as errors): %d" % s["scalar_upsets_not_executed_counted_as_errors"],
+                  "Coverage:   %3.2f%% (uniform draw over the wave's register state; one figure)" % s["coverage_pct"],
+                  "Registers with errors (runs, errors): " + ", ".join("%s %d/%d" % (k, v[1], v[0]) for k, v in top)]
     if s.get("by_class"):
         lines += ["Register classes (physical model):"]
         for c in s["census"]:
@@ -610,11 +838,18 @@ def parse(argv=None):
     ap.add_argument("-t", "--runs", type=int, default=5000)
     ap.add_argument("-s", "--section", default="registers", choices=["registers", "memory"])
     ap.add_argument("--mem-mode", default="nomemrep", choices=["nomemrep", "default", "storesync"])
-    ap.add_argument("--reg-model", default="sites", choices=["sites", "physical", "physical-real", "physical-real-all"],
+    ap.add_argument("--reg-model", default="sites", choices=["sites", "physical", "physical-real", "physical-real-all", "uniform"],
                     help="registers: `sites` = a replica-private injector site per run; `physical` (-b mm --side 256 -m TMR) = any "
                          "register of the matrix-core kernel's wave, weighted by its register census, shared state included; "
                          "`physical-real` = the replica-private classes as real flips of the running kernel's VGPRs; "
-                         "`physical-real-all` = the staging registers as real flips too (an error can land in the workgroup's next matrix)")
+                         "`physical-real-all` = the staging registers as real flips too (an error can land in the workgroup's next matrix); "
+                         "`uniform` = one bit of ANY physical register of a wave (COAST_SITE_MM_PREG), drawn uniformly: one coverage figure")
+    ap.add_argument("--sgpr", default="count", choices=["count", "run"],
+                    help="--reg-model uniform: scalar-register upsets are not executed and count as errors (count), or run one per launch in "
+                         "child processes (run: a wild descriptor is a memory fault that ends the child)")
+    ap.add_argument("--clone-staging", action="store_true",
+                    help="-b mm --side 256: run with COAST_F_CLONE_STAGING (the global -> LDS staging loads cloned and compared)")
+    ap.add_argument("--preg-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--counters-in-sor", action="store_true",
                     help="registers: run with COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC (the loop counters replica-private, their branch conditions "
                          "and GEP offsets voted) and aim every upset at a loop counter")
@@ -628,7 +863,9 @@ def parse(argv=None):
 
 def main():
     a = parse()
-    records, summary = run_campaign(a)
+    if a.preg_child:
+        return preg_child(a.preg_child)
+    records, summary = run_uniform_campaign(a) if a.reg_model == "uniform" else run_campaign(a)
     if not a.no_logging:
         summary["log_prefix"] = write_logs(a, records, summary)
     print(format_summary(summary))
