@@ -309,9 +309,9 @@ class MM(Workload):
     def tile():
         """blocks3 (default): mm_mfma_blk3_kernel (replica = accumulator block, in-lane vote, two waves per SIMD, every loaded operand
         replicated: a replica's MFMAs read their own A and B fragments); blocks2: mm_mfma_blk2_kernel (one A fragment set for the three
-        replicas, COAST_MM_TILE=blocks2); blocks: mm_mfma_blk_kernel (blocks2 with one wave per SIMD); lanes: mm_mfma_panel_kernel"""
+        replicas, COAST_MM_TILE=blocks2); lanes: mm_mfma_panel_kernel (the replicas in adjacent lanes, north_star's layout)"""
         t = os.environ.get("COAST_MM_TILE")
-        return t if t in ("lanes", "blocks", "blocks2") else "blocks3"
+        return t if t in ("lanes", "blocks2") else "blocks3"
 
     def roofline(self, kern_ms):
         n, batch = self.n, self.batch
@@ -325,9 +325,8 @@ class MM(Workload):
             # computation needs on the matrix core (lane padding 32/30 and ragged tiles are NOT counted)
             ops = 2.0 * macs * 10 * 3
             if self.tile() != "lanes":
-                two = self.tile() in ("blocks2", "blocks3")
-                kern = {"blocks3": "mm_mfma_blk3_kernel<3, false>", "blocks2": "mm_mfma_blk2_kernel<3, false>",
-                        "blocks": "mm_mfma_blk_kernel<3, false>"}[self.tile()]
+                two = True
+                kern = {"blocks3": "mm_mfma_blk3_kernel<3, false>", "blocks2": "mm_mfma_blk2_kernel<3, false>"}[self.tile()]
                 return dict(hbm, **{
                     "bound": "mfma", "kernel": kern,
                     "achieved": ops / t * 1e-12, "peak": I8_MFMA_PEAK * 1e-12, "unit": "TOP/s (int8)",

@@ -20,7 +20,6 @@
 #include "injector.hip"
 #include "mm_kernel.hip"
 #include "mm_mfma_kernel.hip"
-#include "mm_mfma_blk_kernel.hip"
 #include "mm_mfma_blk2_kernel.hip"
 #include "mm_mfma_blk3_kernel.hip"
 #include "sha256_kernel.hip"
@@ -806,9 +805,9 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     // side 256: the int8-MFMA limb kernel, injector hooks included; COAST_MM_ENGINE=valu selects the v_mad_u64_u32 kernels
     const char *eng = getenv("COAST_MM_ENGINE");
     const bool mfma = n == 256 && !allGeneral && !(eng && !strcmp(eng, "valu"));
-    // TMR: replicas in register blocks, two waves per SIMD (mm_mfma_blk3_kernel); COAST_MM_TILE=blocks selects the one-wave-per-SIMD
-    // predecessor (mm_mfma_blk_kernel), COAST_MM_TILE=lanes the lane-replica kernel (mm_mfma_panel_kernel), which also serves DWC and
-    // the unprotected mode
+    // TMR: replicas in register blocks, two waves per SIMD (mm_mfma_blk3_kernel); COAST_MM_TILE=lanes selects the lane-replica kernel
+    // (mm_mfma_panel_kernel: north_star's layout, three adjacent lanes and a cross-lane voter), which also serves DWC and the unprotected
+    // mode there; COAST_MM_TILE=blocks (the one-wave-per-SIMD predecessor) was retired in round 5
     const char *tileEnv = getenv("COAST_MM_TILE");
     const bool mmBlocks = !(tileEnv && !strcmp(tileEnv, "lanes"));
     const bool mmBlocks2 = !(tileEnv && !strcmp(tileEnv, "blocks"));
@@ -823,6 +822,9 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     bool havePhys = false;
     for (const coast_fault &af : c->armed)
         havePhys = havePhys || af.site == COAST_SITE_MM_VGPR || af.site == COAST_SITE_MM_PREG;
+    bool havePreg = false; // ... of ANY register, by physical number: the instantiation with a hook in front of every MFMA slot
+    for (const coast_fault &af : c->armed)
+        havePreg = havePreg || af.site == COAST_SITE_MM_PREG;
     if (havePhys && !(mfma && mmBlocks && mmBlocks2 && mmBlocks3))
         return fail(c, COAST_EINVAL, "coast_mm_batch: COAST_SITE_MM_VGPR names a register of mm_mfma_blk3_kernel: side 256, no sync_every / "
                                      "flags, COAST_MM_ENGINE / COAST_MM_TILE at their defaults");
@@ -861,8 +863,8 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
         else                                                                                                    \
             LAUNCH_FAST(R, V, 1);                                                                               \
     } while (0)
-    /* mm_mfma_blk3_kernel<R, FLAGS, PHYS, CLONE>: FLAGS = per-item flags wanted (the physical-upset instantiation always carries them; the   \
-     * unprotected mode has none), CLONE = COAST_F_CLONE_STAGING (replicas > 1) */                                                        \
+    /* mm_mfma_blk3_kernel<R, FLAGS, PHYS, CLONE>: FLAGS = per-item flags wanted (the physical-upset instantiations always carry them; the  \
+     * unprotected mode has none), PHYS = 1: COAST_SITE_MM_VGPR hooks, 2: + COAST_SITE_MM_PREG, CLONE = COAST_F_CLONE_STAGING (replicas > 1) */ \
 #define LAUNCH_BLK3_ONE(R, FL, PH, CL)                                                                          \
     do {                                                                                                        \
         using G3 = MmBlk2<R>;                                                                                   \
@@ -876,23 +878,26 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
         constexpr bool canClone = (R) > 1;                                                                      \
         const bool wantFlags = d_detected != nullptr && (R) > 1;                                                \
         if (cloneStaging && canClone) {                                                                         \
-            if (havePhys)                                                                                       \
-                LAUNCH_BLK3_ONE(R, true, true, canClone);                                                       \
+            if (havePreg)                                                                                       \
+                LAUNCH_BLK3_ONE(R, true, 2, canClone);                                                          \
+            else if (havePhys)                                                                                  \
+                LAUNCH_BLK3_ONE(R, true, 1, canClone);                                                          \
             else if (wantFlags)                                                                                 \
-                LAUNCH_BLK3_ONE(R, true, false, canClone);                                                      \
+                LAUNCH_BLK3_ONE(R, true, 0, canClone);                                                          \
             else                                                                                                \
-                LAUNCH_BLK3_ONE(R, false, false, canClone);                                                     \
-        } else if (havePhys)                                                                                    \
-            LAUNCH_BLK3_ONE(R, true, true, false);                                                              \
+                LAUNCH_BLK3_ONE(R, false, 0, canClone);                                                         \
+        } else if (havePreg)                                                                                    \
+            LAUNCH_BLK3_ONE(R, true, 2, false);                                                                 \
+        else if (havePhys)                                                                                      \
+            LAUNCH_BLK3_ONE(R, true, 1, false);                                                                 \
         else if (wantFlags)                                                                                     \
-            LAUNCH_BLK3_ONE(R, true, false, false);                                                             \
+            LAUNCH_BLK3_ONE(R, true, 0, false);                                                                 \
         else                                                                                                    \
-            LAUNCH_BLK3_ONE(R, false, false, false);                                                            \
+            LAUNCH_BLK3_ONE(R, false, 0, false);                                                                \
     } while (0)
 #define LAUNCH_MM(R)                                                                                            \
     do {                                                                                                        \
         if (mfma && R == 3 && mmBlocks) { /* TMR: replicas in register blocks */              \
-            using GB = MmBlk<3>;                                                                                \
             FaultTab ftm = ft;                                                                                  \
             if (!have)                                                                                          \
                 ftm.list = nullptr, ftm.range = nullptr;                                                        \
@@ -915,16 +920,9 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
                     hipLaunchKernelGGL((mm_mfma_blk2_kernel<3, false>), dim3(gridB), dim3(G2::NTHR), G2::LDS_BYTES, \
                                        c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);        \
                 }                                                                                               \
-            } else if (d_detected) {                                                                            \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk_kernel<3, true>,                       \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB::LDS_BYTES)); \
-                hipLaunchKernelGGL((mm_mfma_blk_kernel<3, true>), dim3(gridB), dim3(GB::NTHR), GB::LDS_BYTES,   \
-                                   c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);            \
             } else {                                                                                            \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk_kernel<3, false>,                      \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB::LDS_BYTES)); \
-                hipLaunchKernelGGL((mm_mfma_blk_kernel<3, false>), dim3(gridB), dim3(GB::NTHR), GB::LDS_BYTES,  \
-                                   c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);            \
+                return fail(c, COAST_EINVAL, "coast_mm_batch: COAST_MM_TILE=blocks (mm_mfma_blk_kernel, one wave per SIMD) was retired in round 5: " \
+                                             "blocks3 (default), blocks2 or lanes");                          \
             }                                                                                                   \
             engine = COAST_ENGINE_MATRIX_CORE;                                                                  \
             fastBlocks = nbm;                                                                                   \

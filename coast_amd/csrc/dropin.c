@@ -253,6 +253,11 @@ void coast_dropin_matrix_multiply(const void *f, const void *s, void *r, int sid
     coast_cfg cfg = dropin_cfg_counters(); /* COAST_COUNTERS_IN_SOR=1: i, j, k, sum replica-private, loop conditions + GEP offsets voted */
     if (cfg.flags & (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC))
         cfg.sync_every = 0u; /* every loop condition is a sync point already */
+    {
+        const char *cl = getenv("COAST_CLONE_STAGING"); /* side 256 on the matrix cores: the staging loads cloned and compared (COAST_F_CLONE_STAGING) */
+        if (cl && *cl && *cl != '0' && cfg.replicas > 1u)
+            cfg.flags |= COAST_F_CLONE_STAGING;
+    }
     dropin_maybe_inject();
     const int rc = coast_matrix_multiply_host((const uint32_t *)f, (const uint32_t *)s, (uint32_t *)r, side, &cfg);
     if (rc)

@@ -1,5 +1,15 @@
-// mm_mfma_blk2_kernel.hip -- the register-block TMR matrix_multiply kernel (mm_mfma_blk_kernel.hip: read that file's header first)
-// with TWO waves per SIMD.
+// mm_mfma_blk2_kernel.hip -- the register-block TMR matrix_multiply kernel with TWO waves per SIMD (its one-wave-per-SIMD predecessor,
+// mm_mfma_blk_kernel -- the replicas of an output element in three accumulator blocks of one lane, 192 accumulator registers in AGPRs --
+// was retired in round 5: docs/design/mm.md section 4.1a has its design, git history its source).
+//
+// Replicas in REGISTER BLOCKS: replica r of r[i][j] is accumulator block r of ONE lane, fed by its own B-operand registers (read from the
+// single LDS copy once per replica: the load is part of the replicated computation, the memory is not) and accumulated by its own MFMAs -- no
+// idle lane-columns and no ragged last tile (16 tiles of 16 logical columns per 64-row panel), the converted s slab (16 columns x 64 k) keeps
+// all 64 conversion lanes busy, the voter compares registers of one lane and the voted tile is stored straight from the registers.  A
+// workgroup is persistent (one per CU) and takes one 64-row panel position of a sequence of matrices: the next matrix's rows of f are fetched
+// and converted into a second LDS panel buffer in the background of the current panel's steps, and the s pipeline runs straight across the
+// matrix boundary.  Injector hooks: everything downstream of an upset is linear mod 2^32, so its exact consequence on the replica's
+// recombined word is an additive constant (mm_mfma_kernel.hip, file header), placed on the replica's limb-0 accumulator.
 //
 // With one wave per SIMD every non-MFMA instruction of the step costs matrix-core issue time (~6.6 cycles each, ~200 of them
 // per 120 MFMAs: profiles/microbench_r02.txt).  Two waves per SIMD hide one wave's VALU / LDS / VMEM instructions behind the other
@@ -37,6 +47,13 @@
 #endif
 
 namespace coast {
+
+// f(integral_constant<int, 0>), f(<1>), ...: a loop whose index is a constant in every iteration's own instantiation (the step's
+// slots are too big for `#pragma unroll` to take -- its cost estimate runs before the slot tests fold away)
+template <class Fn, int... Is> __device__ __forceinline__ void for_each_index(std::integer_sequence<int, Is...>, Fn &&fn)
+{
+    (fn(std::integral_constant<int, Is>{}), ...);
+}
 
 template <int NREP> struct MmBlk2 {
     static constexpr int N = 256, KS = 64, NSLAB = N / KS;
@@ -133,7 +150,13 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
 
     auto tileCol0 = [&](int g) __attribute__((always_inline)) { return (wave + G::NLANE * ((g >> 2) & 3)) * G::CT; };
 
-    // s staging and the slab layout: as in mm_mfma_blk_kernel (conflict-free fragment reads and conversion stores)
+    // s staging: one conversion item = four consecutive k of one column -> one word in each of the four planes; a lane owns the two
+    // columns of a pair, lane -> (pair l % 8, k-quad l / 8 + 8 * round): a dwordx2 load instruction fetches eight full tile rows
+    // (64 B each).  A plane holds one 64-byte row per column, column c in row (c % 8) * 2 + c / 8, its four 16-byte slots (slot =
+    // k / 16) at slot ^ ((c / 2) % 4): the fragment reads (ds_read_b128: lane = column, k group; 64 banks, lane groups of 16) and
+    // the conversion stores (ds_write_b32: the eight columns of one parity x four k-quads per 32 lanes; 32 banks) are both
+    // conflict-free -- checked by enumeration (tests/test_lds_layouts_cpu.py), SQ_LDS_BANK_CONFLICT agrees.
+    // Fragment addresses: A row block rb, plane p, slab sl: (aOff ^ (sl * 64)) + rb * 16 * N + p * PLANE_A (slot 4 sl + kg, swizzled).
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     auto colRow = [](int c) { return ((c & 7) << 1) | (c >> 3); };
     auto colSwz = [](int c) { return (c >> 1) & 3; };
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
         bgRaw = bgLoad(H == 1 ? 0 : 1); // this wave's first background step
         __syncthreads(); // panel 0 and the pairs' slab 0 are complete
 
-        // ---- tile end (branch-free, see mm_mfma_blk_kernel): this wave's two row blocks
+        // ---- tile end (branch-free): this wave's two row blocks
         uint32_t teV[3], teVoted = 0u, teMiss = 0u;
         __amdgpu_buffer_rsrc_t rsRp = rsrcOf(R, false, 0), rsDp = rsRp; // where the previous tile's second row block goes (nowhere before the first tile)
         auto teStage = [&](int g, int voffR, uint32_t real, auto rbTag, auto kTag) __attribute__((always_inline)) {
@@ -309,7 +332,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk2_kernel(con
 
 
         // ---- one pipeline step of this wave = the 60 MFMAs of slab `g` on its two row blocks (buffer g & 1 of the pair).  Order and
-        // operand refresh as in mm_mfma_blk_kernel (a[p] behind its block; b[rr][q] in the second row block, A plane 3 - q, from the
+        // operand refresh (a[p] behind its block; b[rr][q] in the second row block, A plane 3 - q, from the
         // other slab buffer).  After slot 29 every wave of the workgroup meets at a barrier: the converters are through (stage 19
         // stores at slot 28), the fragments of slab g + 1 may be read.
         v4i_t a[4], b[NREP][4];

@@ -1,5 +1,5 @@
 // mm_mfma_blk3_kernel.hip -- the register-block TMR matrix_multiply kernel of round 4: mm_mfma_blk2_kernel's geometry (read that
-// file's and mm_mfma_blk_kernel.hip's headers first) with two changes.
+// file's header first) with two changes.
 //
 // 1. EVERY LOADED OPERAND IS REPLICATED.  The pass clones every load of the protected region and its users (cloning.cpp:2187-2209;
 //    under -noMemReplication the three loads keep one address, :2247-2255): an upset in a loaded f[i][k] or s[k][j] register is
@@ -77,12 +77,13 @@ namespace coast {
 // step, used by the replica's sets of both row blocks, re-read for the next step), or a limb-sum accumulator (flipped at the start of a
 // step that is not the tile's first; it stays until the tile's vote).  The hooks sit in front of the MFMAs they precede; the clean
 // instantiations do not contain them.
-// SITE_MM_PREG (round 5): the same kind of upset, but of ANY register of the wave, named by its PHYSICAL number -- v0 .. v255 through the
+// PHYS == 2, SITE_MM_PREG (round 5; an instantiation of its own: its 60 hook points per step body cost the named-register instantiation a
+// factor in speed): the same kind of upset, but of ANY register of the wave, named by its PHYSICAL number -- v0 .. v255 through the
 // VGPR index mode (s_set_gpr_idx_on), s0 .. s101 through s_movrels / s_movreld -- in front of any of a step's MFMA slots, the compiler knowing
 // nothing of it: what the reference's injector does when it draws a register of the core (simulation/platform/resources/injector.py:70-72,
 // 237-260).  Address registers, lane constants, loop counters, descriptors, the staging clones, whatever the allocator put there.
 enum { SITE_MM_VGPR = 6, SITE_MM_PREG = 7 };
-template <int NREP, bool FLAGS, bool PHYS = false, bool CLONE = false>
+template <int NREP, bool FLAGS, int PHYS = 0, bool CLONE = false>
 __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(const uint32_t *__restrict__ F,
                                                                             const uint32_t *__restrict__ S,
                                                                             uint32_t *__restrict__ R, uint32_t nblocks, Counters ctr,
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
 
     auto tileCol0 = [&](int g) __attribute__((always_inline)) { return (wave + G::NLANE * ((g >> 2) & 3)) * G::CT; };
 
-    // s staging and the slab layout: as in mm_mfma_blk_kernel (conflict-free fragment reads and conversion stores)
+    // s staging and the slab layout: as in mm_mfma_blk2_kernel.hip (conflict-free fragment reads and conversion stores)
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     auto colRow = [](int c) { return ((c & 7) << 1) | (c >> 3); };
     auto colSwz = [](int c) { return (c >> 1) & 3; };
@@ -426,19 +427,13 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         // word w of entry q of the upset table (1: .local, 2: .step, 3: .replica | .site << 8 | .bit << 16 | .index << 24).  PHYS: through a
         // descriptor that ends with the panel's entries, no vector register in the address -- an upset of any VGPR cannot send this read anywhere
         auto ftWord = [&](uint32_t q, int w) __attribute__((always_inline)) {
-            if constexpr (PHYS) {
+            if constexpr (PHYS == 2) {
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<DevFault *>(ft.list), 0, (int)((fFirst + fCount) * 16u), 0x00020000);
                 return __builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(rs, 0, (int)(q * 16u) + 4 * w, 0));
             } else {
-                return __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(ft.list + q)[w]);
+                const DevFault *fp = ft.list + q;
+                return __builtin_amdgcn_readfirstlane(w == 1 ? fp->local : w == 2 ? fp->step : *reinterpret_cast<const uint32_t *>(&fp->replica));
             }
-        };
-        // (PHYS: the end of the panel's entries, with a bound of its own -- an upset of the count must not walk the table for minutes)
-        auto fEnd = [&]() __attribute__((always_inline)) {
-            if constexpr (PHYS)
-                return fFirst + (fCount > 256u ? 256u : fCount);
-            else
-                return fFirst + fCount;
         };
         auto pregScan = [&]() __attribute__((always_inline)) {
             pregKey = 0xffffffffu;
@@ -474,13 +469,13 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             }
         };
         // ---- injector hook: the consequence of an armed upset on the replica's word is an additive constant (everything downstream
-        // is linear mod 2^32), written on the replica's limb-0 sums before the tile's last step -- see mm_mfma_blk_kernel.hip.  OPA
+        // is linear mod 2^32), written on the replica's limb-0 sums before the tile's last step -- see mm_mfma_kernel.hip, file header.  OPA
         // names replica r's loaded f[i][k]: here that register exists per replica (the A fragment of the replica's set).
         auto tileHook = [&](int g) __attribute__((always_inline)) {
             const int col0 = tileCol0(g), prow0 = pnl * G::BM;
             bool hooked = false;
 #pragma unroll 1
-            for (uint32_t q = fFirst; q < fEnd(); ++q) {
+            for (uint32_t q = fFirst; q < fFirst + (PHYS == 2 && fCount > 256u ? 256u : fCount); ++q) { // (PHYS: a bound of its own -- an upset of the count must not walk the table for minutes)
                 const int fcol = (int)(ftWord(q, 1) & 255u);
                 hooked = hooked || (fcol >= col0 && fcol < col0 + G::CT);
             }
@@ -489,7 +484,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             uint32_t curKey = 0xffffffffu, curStep = 0xffffffffu;
             uint32_t dsum[3] = {0u, 0u, 0u}, am[3] = {0u, 0u, 0u}, bm[3] = {0u, 0u, 0u};
 #pragma unroll 1
-            for (uint32_t q = fFirst; q < fEnd(); ++q) {
+            for (uint32_t q = fFirst; q < fFirst + (PHYS == 2 && fCount > 256u ? 256u : fCount); ++q) { // (PHYS: a bound of its own -- an upset of the count must not walk the table for minutes)
                 const uint32_t local = ftWord(q, 1);
                 const int frow = (int)(local >> 8), fcol = (int)(local & 255u);
                 if (fcol < col0 || fcol >= col0 + G::CT)
@@ -600,7 +595,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         auto physA = [&](int g, auto setTag) __attribute__((always_inline)) { // in front of the first MFMA of set `set`
             constexpr int set = decltype(setTag)::value;
 #pragma unroll 1
-            for (uint32_t q = fFirst; q < fEnd(); ++q) {
+            for (uint32_t q = fFirst; q < fFirst + (PHYS == 2 && fCount > 256u ? 256u : fCount); ++q) { // (PHYS: a bound of its own -- an upset of the count must not walk the table for minutes)
                 uint32_t frep, reg, dword, frb, mask;
                 if (!physFields(q, g, frep, reg, dword, frb, mask) || reg > 3u || frb != (uint32_t)(set / NREP) || frep != (uint32_t)(set % NREP))
                     continue;
@@ -613,7 +608,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         };
         auto physStart = [&](int g, bool accLive) __attribute__((always_inline)) { // at the start of a step: B fragments, accumulators
 #pragma unroll 1
-            for (uint32_t q = fFirst; q < fEnd(); ++q) {
+            for (uint32_t q = fFirst; q < fFirst + (PHYS == 2 && fCount > 256u ? 256u : fCount); ++q) { // (PHYS: a bound of its own -- an upset of the count must not walk the table for minutes)
                 uint32_t frep, reg, dword, frb, mask;
                 if (!physFields(q, g, frep, reg, dword, frb, mask) || reg < 4u)
                     continue;
@@ -727,7 +722,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             if constexpr (PHYS)
                 if (fCount != 0u)
                     physStart(g, FIRST == 0);
-            const uint32_t pregSlot = PHYS ? pregKey - ((uint32_t)(g & 15) << 6) : 0xffffffffu; // the slot of THIS step the upset sits in front of, if any
+            const uint32_t pregSlot = PHYS == 2 ? pregKey - ((uint32_t)(g & 15) << 6) : 0xffffffffu; // the slot of THIS step the upset sits in front of, if any
             auto slot = [&](auto mTag) __attribute__((always_inline)) {
                 constexpr int m = decltype(mTag)::value;
                 constexpr int set = m / 10, j = m % 10, rb = set / NREP, rr = set % NREP;
@@ -737,7 +732,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 constexpr bool fromZero = FIRST != 0 && p == 0;
                 if constexpr (j == 0 && set != 0)
                     asm volatile("" : "+v"(offA)); // this set's A fragments are its own loads
-                if constexpr (PHYS)
+                if constexpr (PHYS == 2)
                     if (pregSlot == (uint32_t)m)
                         pregFlip();
                 if constexpr (PHYS && j == 0)
@@ -825,7 +820,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         int gLast = 3;
         uint32_t anyTile = 0u;
         // (PHYS: a second, independent bound -- an upset of the loop's registers must not turn a campaign run into a walk through memory)
-        const uint32_t itemCap = PHYS ? (nblocks + stride - 1u) / stride : 0xffffffffu;
+        const uint32_t itemCap = PHYS == 2 ? (nblocks + stride - 1u) / stride : 0xffffffffu;
 #pragma unroll 1
         for (int item = 0; matOf(item) < nblocks && (uint32_t)item < itemCap; ++item) {
             const uint32_t mat = matOf(item);
@@ -834,7 +829,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 fFirst = __builtin_amdgcn_readfirstlane(rg.x);
                 fCount = __builtin_amdgcn_readfirstlane(rg.y);
             }
-            if constexpr (PHYS)
+            if constexpr (PHYS == 2)
                 pregScan();
             if (item > 0) { // hand-over: the panel is complete behind the barrier of the previous item's last step
                 f = F + mat * nn;
@@ -845,7 +840,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             [[maybe_unused]] uint32_t tileGuard = 0u; // (PHYS: the same for the tile counter)
 #pragma unroll 1
             for (int tile = 0; tile < G::TPW; ++tile) {
-                if constexpr (PHYS)
+                if constexpr (PHYS == 2)
                     if (tileGuard++ >= (uint32_t)G::TPW)
                         break;
                 const int g0 = item * G::SPP + tile * G::NSLAB;

@@ -487,7 +487,7 @@ def test_crc16_faults_vs_oracle(eng, orc, block_len, replicas, sync_every):
 
 
 # ------------------------------------------------------------------------------------------------ common-mode upsets (COAST_REPLICA_ALL)
-@pytest.mark.parametrize("tile", ["blocks3", "blocks2", "blocks", "lanes"])
+@pytest.mark.parametrize("tile", ["blocks3", "blocks2", "lanes"])
 def test_mm_256_common_mode_upsets_are_silent_data_corruption(eng, orc, tile, monkeypatch):
     """the matrix-core kernels share the A operand (and the s words on their way into LDS) between the
     replicas.  COAST_REPLICA_ALL arms the same flip in every replica's copy: all copies agree, the voter passes the wrong word,
@@ -2986,11 +2986,11 @@ def test_mm_256_register_block_kernel_dwc_and_unprotected(eng, orc, batch, repli
     assert (out["default"][0].cpu().numpy().view(np.uint32).reshape(-1)[items.astype(np.int64)] == want).all()
 
 
-@pytest.mark.parametrize("tile", ["blocks3", "blocks2", "blocks"])
+@pytest.mark.parametrize("tile", ["blocks3", "blocks2"])
 @pytest.mark.parametrize("batch", [1, 2, 5, 63, 64, 65, 130, 200])
 def test_mm_256_register_block_kernel_batch_shapes(eng, orc, batch, tile, monkeypatch):
     """the persistent TMR kernels (two waves per SIMD: blocks3 -- the default, every loaded operand replicated -- and blocks2, one A
-    fragment set for the three replicas; one wave per SIMD: COAST_MM_TILE=blocks; a workgroup =
+    fragment set for the three replicas; a workgroup =
     one panel position of matrices m, m + 64, ...): batches that leave panel groups
     empty, end in the middle of a stride, or give every workgroup several items -- outputs equal the lane-replica kernel's
     (COAST_MM_TILE=lanes) word for word, upsets in first and later items are out-voted, flagged per item and counted, and a sparse

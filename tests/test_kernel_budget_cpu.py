@@ -24,7 +24,6 @@ TU = r'''
 #include "injector.hip"
 #include "mm_kernel.hip"
 #include "mm_mfma_kernel.hip"
-#include "mm_mfma_blk_kernel.hip"
 #include "mm_mfma_blk2_kernel.hip"
 #include "mm_mfma_blk3_kernel.hip"
 #include "sha256_kernel.hip"
@@ -34,11 +33,9 @@ namespace coast {
 #define MMARGS const uint32_t *, const uint32_t *, uint32_t *, uint32_t, Counters, FaultTab, uint8_t *
 template __global__ void mm_mfma_blk3_kernel<3, true>(MMARGS);
 template __global__ void mm_mfma_blk3_kernel<3, false>(MMARGS);
-template __global__ void mm_mfma_blk3_kernel<3, false, false, true>(MMARGS);
+template __global__ void mm_mfma_blk3_kernel<3, false, 0, true>(MMARGS);
 template __global__ void mm_mfma_blk2_kernel<3, true>(MMARGS);
 template __global__ void mm_mfma_blk2_kernel<3, false>(MMARGS);
-template __global__ void mm_mfma_blk_kernel<3, true>(MMARGS);
-template __global__ void mm_mfma_blk_kernel<3, false>(MMARGS);
 #define AESARGS uint8_t *, uint8_t *, uint64_t, uint64_t, Counters, FaultTab, uint8_t *, size_t
 template __global__ void aes128_enc_rep_kernel<2>(AESARGS);
 template __global__ void aes128_dec_rep_kernel<2>(AESARGS);
@@ -95,7 +92,7 @@ def test_mm_register_block_kernels_fit_their_register_files(compiled, flags):
     # two waves per SIMD: 256 VGPRs, no AGPRs; the default TMR kernel (blk3) and its predecessor (blk2)
     # per-kernel limits: blk2 at its round-3 values, blk3 at the ones measured with it
     for kern, spill_cap, hot_loads in (("mm_mfma_blk3_kernel", 10, 2), ("mm_mfma_blk2_kernel", 8, 1)):
-        tail = ", false, false>" if kern == "mm_mfma_blk3_kernel" else ">"  # (blk3's third / fourth parameters: physical-upset hooks, cloned staging)
+        tail = ", 0, false>" if kern == "mm_mfma_blk3_kernel" else ">"  # (blk3's third / fourth parameters: physical-upset hooks, cloned staging)
         u2 = _find(usage, "void coast::%s<3, %s%s" % (kern, flags, tail))
         assert u2["VGPRs"] <= 256 and u2["AGPRs"] == 0 and u2["Occupancy [waves/SIMD]"] == 2
         # the armed-upset hook (cold, wave-uniform branch) may park a few registers; the step bodies must not
@@ -109,23 +106,20 @@ def test_mm_register_block_kernels_fit_their_register_files(compiled, flags):
             if len(re.findall(r"v_mfma_i32_16x16x64_i8", blk)) >= 60:
                 assert len(re.findall(r"scratch_load", blk)) <= hot_loads and not re.search(r"scratch_store", blk), kern
     # blk3: every set of ten MFMAs reads its own four A fragments (24 + 12 B fragment reads per step and wave)
-    b3 = _find(bodies, "void coast::mm_mfma_blk3_kernel<3, %s, false, false>" % flags)
+    b3 = _find(bodies, "void coast::mm_mfma_blk3_kernel<3, %s, 0, false>" % flags)
     assert len(re.findall(r"ds_read_b128", b3)) >= 8 * 36
     if flags == "false":
         # COAST_F_CLONE_STAGING: the register file is full -- the twelve clone registers must not cost a reload inside the MFMA blocks (a
         # scratch reload drains the VMEM queue: builds that had them ran + 30 % instead of + 15 %, profiles/r05_mm_clone_ab.txt).  Held here:
         # two waves per SIMD, the MFMA count, the clone loads, no scratch traffic in the blocks that hold MFMAs
-        uc = _find(usage, "void coast::mm_mfma_blk3_kernel<3, false, false, true>")
-        bc = _find(bodies, "void coast::mm_mfma_blk3_kernel<3, false, false, true>")
+        uc = _find(usage, "void coast::mm_mfma_blk3_kernel<3, false, 0, true>")
+        bc = _find(bodies, "void coast::mm_mfma_blk3_kernel<3, false, 0, true>")
         assert uc["VGPRs"] <= 256 and uc["Occupancy [waves/SIMD]"] == 2 and len(re.findall(r"v_mfma_i32_16x16x64_i8", bc)) == 480
         # eight more two-word loads per converted slab (one slab per wave and two steps: the off-duty variants of the 4 x 2 step bodies)
         assert len(re.findall(r"buffer_load_dwordx2", bc)) - len(re.findall(r"buffer_load_dwordx2", b3)) >= 8 * 4
         for blk in re.split(r"\n\.LBB\d+_\d+:", bc):
             if len(re.findall(r"v_mfma_i32_16x16x64_i8", blk)) >= 10:
                 assert not re.search(r"scratch_(load|store)", blk)
-    # one wave per SIMD: accumulators in AGPRs, nothing spilled
-    u1 = _find(usage, "void coast::mm_mfma_blk_kernel<3, %s>" % flags)
-    assert u1["VGPRs Spill"] == 0 and u1["Occupancy [waves/SIMD]"] == 1 and u1["VGPRs"] <= 256 and u1["AGPRs"] <= 256
 
 
 def test_lds_table_kernels_keep_their_occupancy(compiled):
@@ -153,8 +147,8 @@ def test_kernels_that_address_lds_from_zero_have_no_static_lds(compiled):
     the dynamic segment starts at LDS offset 0; they guard it with a run-time trap.  A static `__shared__` added to one of them would
     move the dynamic segment up -- this holds the layout at build time so that the trap can never be what reports it."""
     usage, _ = compiled
-    for name in ("aes128_enc_rep_kernel<2>", "aes128_dec_rep_kernel<2>", "mm_mfma_blk3_kernel<3, true, false, false>",
-                 "mm_mfma_blk3_kernel<3, false, false, false>", "mm_mfma_blk3_kernel<3, false, false, true>", "mm_mfma_blk2_kernel<3, true>", "mm_mfma_blk2_kernel<3, false>"):
+    for name in ("aes128_enc_rep_kernel<2>", "aes128_dec_rep_kernel<2>", "mm_mfma_blk3_kernel<3, true, 0, false>",
+                 "mm_mfma_blk3_kernel<3, false, 0, false>", "mm_mfma_blk3_kernel<3, false, 0, true>", "mm_mfma_blk2_kernel<3, true>", "mm_mfma_blk2_kernel<3, false>"):
         assert _find(usage, "void coast::" + name)["LDS Size [bytes/block]"] == 0, name
 
 

@@ -45,7 +45,7 @@ def col_swz(c):
 
 
 def test_mm_fragment_reads_are_conflict_free():
-    """mm_mfma_blk2_kernel.hip / mm_mfma_blk_kernel.hip: aOff, panelA (f panel, 256-byte rows, 16-byte slots XORed with the row) and
+    """mm_mfma_blk2_kernel.hip / mm_mfma_blk3_kernel.hip: aOff, panelA (f panel, 256-byte rows, 16-byte slots XORed with the row) and
     bOff (s slab: plane[q][row(c)][64 B], slots XORed with (c / 2) % 4), every k-slab position, every row block"""
     for slab in range(4):
         for rb in range(4):

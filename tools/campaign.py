@@ -581,11 +581,11 @@ def uniform_draw(rng, n_vgpr=256, n_sgpr=102):
             "step": int(rng.integers(0, 16)), "slot": int(rng.integers(0, 60))}
 
 
-PHYS_KERNEL = "_ZN5coast19mm_mfma_blk3_kernelILi%dELb1ELb1ELb%dEEEvPKjS2_PjjNS_8CountersENS_8FaultTabEPh"  # mm_mfma_blk3_kernel<replicas, true, true, clone>
+PHYS_KERNEL = "_ZN5coast19mm_mfma_blk3_kernelILi%dELb1ELi2ELb%dEEEvPKjS2_PjjNS_8CountersENS_8FaultTabEPh"  # mm_mfma_blk3_kernel<replicas, true, 2, clone>
 
 
 def kernel_registers(replicas, clone=False):
-    """(VGPRs, SGPRs the kernel allocates, the VGPRs it spills scalar registers into) of mm_mfma_blk3_kernel<replicas, true, true, clone>, read
+    """(VGPRs, SGPRs the kernel allocates, the VGPRs it spills scalar registers into) of mm_mfma_blk3_kernel<replicas, true, 2, clone>, read
     from the code object inside the very library that runs (the bundle in its .hip_fatbin) with the image's llvm-readelf / llvm-objdump: no
     allocation map to keep in step with the compiler.  The spill registers (v_writelane_b32 / v_readlane_b32): a lane of such a register IS a
     scalar register -- a descriptor word, a kernel-argument pointer, a loop counter -- and an upset there belongs to the scalar class (it can

@@ -6,7 +6,10 @@ feeds (a load: -noLoadSync drops it; a store: -noStoreAddrSync).  The IR is what
 under /root/reference (the reference's flow compiles at -O0 before opt, tests/makefiles/Makefile.common); the instrumentation is a call
 in front of each such instruction of the chosen functions, the counts come from RUNNING the instrumented code on the benchmark's own kind
 of input.  tests/test_ir_counts_cpu.py compares them with the oracle's schedules (coast_oracle.c: mm_call_indexed, aes_item_indexed,
-ct_item_indexed, chsha_item_indexed).  Needs the reference checkout: a container-side pin, like oracle/_ref."""
+ct_item_indexed, chsha_item_indexed).  Needs the reference checkout: a container-side pin, like oracle/_ref.
+CAVEAT: CLANG below is the image's LLVM 22; the pass runs on clang-7's -O0 IR (tests/makefiles/Makefile.compile:3-10) and LLVM 7 is not
+available here.  The statement classes counted (one conditional branch per evaluated condition, one GEP per variable subscript, one store
+per assignment at -O0) are what -O0 lowering has produced for C like this across those versions, but nothing here checks it."""
 import os
 import re
 import subprocess
