@@ -847,9 +847,11 @@ def extra_legs(a, eng, dist, dev, rank, world, coast_amd):
     import copy
 
     legs = {}
-    plan = [("crc16_256B", CRC16, {"block_len": 256}, 20, 5)]
+    # (both crc16 legs at every N: 255 bytes is the reference's own block length -- `unsigned char length` -- and the shape north_star's
+    # 8-GPU stream has to hold its 40 % of the HBM roofline in)
+    plan = [("crc16_256B", CRC16, {"block_len": 256}, 20, 5), ("crc16_255B", CRC16, {"block_len": 255}, 20, 5)]
     if world == 1:
-        plan += [("crc16_255B", CRC16, {"block_len": 255}, 20, 5), ("sha256", SHA256, {}, 20, 5), ("aes", AES, {}, 40, 8),
+        plan += [("sha256", SHA256, {}, 20, 5), ("aes", AES, {}, 40, 8),
                  # the BASELINE batch (1 Mi blocks) is a 50-80 us launch; the same kernels on 16 Mi blocks show what they sustain
                  ("aes_16Mi_blocks", AES, {"batch": 1 << 24}, 12, 4)]
     for name, cls, over, steps, warm in plan:
