@@ -69,6 +69,17 @@
 // chip's power limit: + 30 % (6.77 -> 8.82 ms; the loads alone + 12.6 %, the f clone alone + 5 %: profiles/r05_mm_clone_ab.txt), for 94.4 -> 96.6 %
 // coverage in the uniform register-file campaign (profiles/r05_campaign_uniform_*.txt).  Hence a flag, not the default.
 
+// round 5: WIDE staging loads of s.  A buffer load costs this kernel about what seven LDS reads cost (profiles/r05_mm_clone_ab.txt), and the
+// s staging issued eight two-word loads per slab and wave (a lane: two adjacent columns x eight k).  1: four four-word loads -- a lane owns
+// four adjacent columns x four k (lane -> column quad l % 4, k-quad l / 4), one load instruction fetches sixteen full tile rows -- into the
+// same LDS image through the same conflict-free stores (tests/test_lds_layouts_cpu.py); the four loads are requested in the duty step behind
+// the last read of the registers they replace (slots 21 - 48), 42 - 69 slots ahead of their first use.  - 0.55 % (6.785 -> 6.747 ms; with one
+// more load per slab, a dword per row two steps ahead so that the four find their lines in L2: + 1.0 %, not kept).  The clone form keeps
+// the two-word loads (its compare is per staging round).  0: round 4's loads (A/B builds).
+#ifndef COAST_MM3_WIDE
+#define COAST_MM3_WIDE 1
+#endif
+
 namespace coast {
 
 // PHYS (round 4): the instantiation that runs when a COAST_SITE_MM_VGPR upset is armed -- a REAL exclusive-or on one bit of one lane of a
@@ -95,6 +106,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
     // background stages at the same relative places (one per NREP slots), the barrier in the middle, the tile end set by set.
     constexpr int NS = 20 * NREP, HALF = NS / 2, NSET = 2 * NREP;
     constexpr bool DUP = CLONE && NREP > 1; // (the unprotected mode has nothing to compare with)
+    constexpr bool WIDE = COAST_MM3_WIDE != 0 && !DUP;
     extern __shared__ __attribute__((aligned(16))) uint8_t smemP[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -208,6 +220,11 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
     const int dstB0 = colRow(2 * (lane & 7)) * G::KS + ((((lane >> 3) >> 2) ^ colSwz(2 * (lane & 7))) * 16) + ((lane >> 3) & 3) * 4;
     auto dstB = [&](int u, int h) __attribute__((always_inline)) { return (dstB0 ^ (u * 32)) + h * 2 * G::KS; };
     constexpr int kRoundOff = 8 * 4 * G::N * 4;
+    // WIDE: lane -> (column quad cq = l % 4: columns 4 cq .. + 3; k-quad l / 4: rows 4 (l / 4) .. + 3 of the slab).  Column c = 4 cq + h sits in
+    // row colRow(c) = 8 (cq % 2) + 2 h + cq / 2 of a plane, its slots XORed with colSwz(c) = 2 (cq % 2) ^ (h / 2)
+    const int voffW = ((4 * (lane >> 2)) * G::N + 4 * (lane & 3)) * 4;
+    const int dstW0 = (8 * (lane & 1) + ((lane & 3) >> 1)) * G::KS + (((lane >> 4) ^ (2 * (lane & 1))) * 16) + ((lane >> 2) & 3) * 4;
+    auto dstW = [&](int h) __attribute__((always_inline)) { return (dstW0 ^ ((h >> 1) * 16)) + h * 2 * G::KS; };
     auto slabOff = [&](int g) __attribute__((always_inline)) { return ((g & 3) * G::KS * G::N + tileCol0(g)) * 4; };
 
     const int aOff = l16 * G::N + ((kg ^ l16) * 16);
@@ -231,7 +248,34 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         // step g in which the wave is off duty, round 1 in the first half of step g + 1 (duty); each register set is reloaded in
         // the duty step with the slab two further on
         u32x2_t pbs[G::B_ROUNDS][4];
+        u32x4_t pw[4]; // WIDE: row 4 (l / 4) + kk of the slab, columns 4 (l % 4) .. + 3
         u32x4_t bgRaw;
+        // conversion group grp = 0..3 of a slab: four consecutive k of one column.  Two-word loads: staging round grp / 2, column grp % 2 of the
+        // lane's pair; WIDE: column grp of the lane's quad
+        auto rawWord = [&](auto grpTag, auto kkTag) __attribute__((always_inline)) {
+            constexpr int grp = decltype(grpTag)::value, kk = decltype(kkTag)::value;
+            if constexpr (WIDE)
+                return pw[kk][grp];
+            else
+                return pbs[grp / 2][kk][grp % 2];
+        };
+        auto dstGrp = [&](int grp) __attribute__((always_inline)) { return WIDE ? dstW(grp) : dstB(grp / 2, grp % 2); };
+        auto loadSlabW = [&](int gs) __attribute__((always_inline)) {
+            const int so = slabOff(gs);
+            const __amdgpu_buffer_rsrc_t rs = rsSof(gs >> 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                pw[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffW + kk * G::N * 4, so, 0);
+        };
+        auto convGroupNowW = [&](auto grpTag, int bufOff) __attribute__((always_inline)) {
+            constexpr int grp = decltype(grpTag)::value;
+            const uint32_t y[4] = {mm_digits(pw[0][grp]), mm_digits(pw[1][grp]), mm_digits(pw[2][grp]), mm_digits(pw[3][grp])};
+            uint32_t w[4];
+            mm_transpose4(y, w);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint32_t *>(smemP + bufOff + q * G::PLANE_B + dstW(grp)) = w[q];
+        };
 
         auto loadRound = [&](int gs, auto uTag) __attribute__((always_inline)) {
             constexpr int u = decltype(uTag)::value;
@@ -326,7 +370,22 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         };
         // prologue.  Wave 1 of the pair owns the even slabs: slab 0 whole, slab 2 in its registers.  Wave 0 owns the odd ones: slab
         // 1's first round converted here, its second round in the registers for step 0 (its duty step).
-        if (H == 1) {
+        if constexpr (WIDE) {
+            using T2 = std::integral_constant<int, 2>;
+            using T3 = std::integral_constant<int, 3>;
+            if (H == 1) {
+                loadSlabW(0);
+                convGroupNowW(U0{}, wbufOff);
+                convGroupNowW(U1{}, wbufOff);
+                convGroupNowW(T2{}, wbufOff);
+                convGroupNowW(T3{}, wbufOff);
+                loadSlabW(2);
+            } else {
+                loadSlabW(1);
+                convGroupNowW(U0{}, wbufOff + G::B_BUF);
+                convGroupNowW(U1{}, wbufOff + G::B_BUF);
+            }
+        } else if (H == 1) {
             loadRound(0, U0{});
             loadRound(0, U1{});
             verifyRoundNow(0, U0{});
@@ -620,7 +679,10 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                             for (int h = 0; h < 2; ++h)
-                                pbs[u][kk][h] ^= (reg == (uint32_t)(12 + 4 * u + kk) && dword == (uint32_t)h) ? mask : 0u;
+                                if constexpr (WIDE) // (the same sixteen words: register 12 + 4 u + kk, dword h = row kk's word 2 u + h)
+                                    pw[kk][2 * u + h] ^= (reg == (uint32_t)(12 + 4 * u + kk) && dword == (uint32_t)h) ? mask : 0u;
+                                else
+                                    pbs[u][kk][h] ^= (reg == (uint32_t)(12 + 4 * u + kk) && dword == (uint32_t)h) ? mask : 0u;
 #pragma unroll
                     for (int d = 0; d < 4; ++d)
                         bgRaw[d] ^= (reg == 20u && dword == (uint32_t)d) ? mask : 0u;
@@ -684,10 +746,15 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 constexpr int k = decltype(kTag)::value, u = k / 10, h = (k / 5) % 2, sub = k % 5;
                 if constexpr (sub == 0 && h == 0 && DUP)
                     verifyS(std::integral_constant<int, u>{}, DUTY ? g + 1 : g + 2);
+                using GRP = std::integral_constant<int, k / 5>; // (two-word loads: round u, column h of the pair; WIDE: column k / 5 of the quad)
+                using K0 = std::integral_constant<int, 0>;
+                using K1 = std::integral_constant<int, 1>;
+                using K2 = std::integral_constant<int, 2>;
+                using K3 = std::integral_constant<int, 3>;
                 if constexpr (sub == 0)
-                    digits4(pbs[u][0][h], pbs[u][1][h], std::integral_constant<int, 0>{});
+                    digits4(rawWord(GRP{}, K0{}), rawWord(GRP{}, K1{}), std::integral_constant<int, 0>{});
                 else if constexpr (sub == 1)
-                    digits4(pbs[u][2][h], pbs[u][3][h], std::integral_constant<int, 1>{});
+                    digits4(rawWord(GRP{}, K2{}), rawWord(GRP{}, K3{}), std::integral_constant<int, 1>{});
                 else if constexpr (sub == 2)
                     perm1();
                 else if constexpr (sub == 3)
@@ -695,7 +762,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<uint32_t *>(smemP + bufConv + q * G::PLANE_B + dstB(u, h)) = w[q];
+                        *reinterpret_cast<uint32_t *>(smemP + bufConv + q * G::PLANE_B + dstGrp(k / 5)) = w[q];
                 }
             };
             auto bgStage = [&](auto subTag) __attribute__((always_inline)) {
@@ -772,9 +839,16 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                     convStage(std::integral_constant<int, 10 + m / NREP>{});
                 if constexpr (!DUTY && m >= HALF && (m - HALF) % NREP == 0 && !(COAST_MM3_KNOCK & 16)) // first staging round (stages 0..9) of slab g + 2
                     convStage(std::integral_constant<int, (m - HALF) / NREP>{});
-                if constexpr (DUTY && m % (2 * NREP) == 2 * NREP - 1 && m < 8 * NREP && !(COAST_MM3_KNOCK & 128)) // round 0's registers: free since the previous step's second half
+                if constexpr (WIDE) {
+                    // the slab two further on: four four-word loads, behind the last read of the registers they replace (the fourth group's
+                    // second digits stage: slot 6 NREP of this duty step)
+                    constexpr int W0 = 7 * NREP, WS = 3 * NREP; // (requested right behind the registers' last read instead, slots 19 - 28: the same time)
+                    if constexpr (DUTY && m >= W0 && (m - W0) % WS == 0 && (m - W0) / WS < 4 && !(COAST_MM3_KNOCK & 128))
+                        pw[(m - W0) / WS] = __builtin_amdgcn_raw_buffer_load_b128(rsLoad, voffW + ((m - W0) / WS) * G::N * 4, soffLoad, 0);
+                }
+                if constexpr (!WIDE && DUTY && m % (2 * NREP) == 2 * NREP - 1 && m < 8 * NREP && !(COAST_MM3_KNOCK & 128)) // round 0's registers: free since the previous step's second half
                     pbs[0][m / (2 * NREP)] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + (m / (2 * NREP)) * G::N * 4, soffLoad, 0);
-                if constexpr (DUTY && m % (2 * NREP) == 2 * NREP - 1 && m >= HALF && m < HALF + 8 * NREP && !(COAST_MM3_KNOCK & 128)) // round 1's: free after stage 16
+                if constexpr (!WIDE && DUTY && m % (2 * NREP) == 2 * NREP - 1 && m >= HALF && m < HALF + 8 * NREP && !(COAST_MM3_KNOCK & 128)) // round 1's: free after stage 16
                     pbs[1][(m - HALF) / (2 * NREP)] = __builtin_amdgcn_raw_buffer_load_b64(rsLoad, voffB + ((m - HALF) / (2 * NREP)) * G::N * 4, soffLoad + kRoundOff, 0);
                 if constexpr (BG && (m / HALF == (DUTY ? 1 : 0)) && (m % HALF) % (2 * NREP) == (NREP == 1 ? 0 : 2) && !(COAST_MM3_KNOCK & 64))
                     bgStage(std::integral_constant<int, (m % HALF) / (2 * NREP)>{});

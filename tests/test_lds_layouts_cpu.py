@@ -71,6 +71,32 @@ def test_mm_conversion_stores_stay_within_two_way():
         assert worst_multiplicity(a, 4, G32, 32) <= 2, ("f", wv, j, p)
 
 
+def test_mm_wide_staging_writes_the_same_image_without_conflicts():
+    """mm_mfma_blk3_kernel.hip, round 5 (COAST_MM3_WIDE): a lane owns four adjacent columns x four k of a slab (lane -> column quad l % 4,
+    k-quad l / 4; four buffer_load_dwordx4 per slab).  Its conversion stores must hit exactly the bytes the fragment reads expect -- column c,
+    k..k+3 at colRow(c) * 64 + ((k / 16) ^ colSwz(c)) * 16 + k % 16 of a plane -- every (column, k-quad) once, and stay conflict-free."""
+    cq, kquad = LANE & 3, LANE >> 2
+    dst0 = (8 * (LANE & 1) + ((LANE & 3) >> 1)) * KS + (((LANE >> 4) ^ (2 * (LANE & 1))) * 16) + ((LANE >> 2) & 3) * 4
+    seen = set()
+    for h in range(4):
+        a = (dst0 ^ ((h >> 1) * 16)) + h * 2 * KS
+        c, k = 4 * cq + h, 4 * kquad
+        want = col_row(c) * KS + (((k >> 4) ^ col_swz(c)) * 16) + (k & 15)
+        assert (a == want).all(), h
+        seen.update((int(x), int(y)) for x, y in zip(c, k))
+        for q in range(4):
+            assert worst_multiplicity(a + q * 16 * KS, 4, G32, 32) == 1, ("wide", h, q)
+    assert len(seen) == 16 * 16  # 16 columns x 16 k-quads: the whole slab
+    # the loads: row 4 (l / 4) + kk, columns 4 (l % 4) .. + 3 -> one instruction = 16 rows x 64 contiguous bytes
+    voff = ((4 * kquad) * N + 4 * cq) * 4
+    for kk in range(4):
+        rows = (voff + kk * N * 4) // (N * 4)
+        assert sorted(set(rows.tolist())) == [4 * r + kk for r in range(16)]
+        for r in set(rows.tolist()):
+            cols = sorted(((voff + kk * N * 4) % (N * 4))[rows == r].tolist())
+            assert cols == [0, 16, 32, 48]
+
+
 @pytest.mark.parametrize("nrep", [1, 2, 3])
 def test_aes_replicated_tables_never_conflict(nrep):
     """aes_kernel.hip aes_rep_addr (round 3): entry value v owns a 256-byte row of a 64 KiB table block -- four slots of 16 copies x 4
