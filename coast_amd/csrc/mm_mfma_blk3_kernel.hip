@@ -1,9 +1,10 @@
 // mm_mfma_blk3_kernel.hip -- the register-block TMR matrix_multiply kernel of round 4: mm_mfma_blk2_kernel's geometry (read that
 // file's header first) with two changes.
 //
-// 1. EVERY LOADED OPERAND IS REPLICATED.  The pass clones every load of the protected region and its users (cloning.cpp:2187-2209;
-//    under -noMemReplication the three loads keep one address, :2247-2255): an upset in a loaded f[i][k] or s[k][j] register is
-//    out-voted (tests/mm_common/mm_common_tmr.c:13).  mm_mfma_blk2_kernel had replica-private B fragments but ONE A fragment set
+// 1. EVERY OPERAND LOAD FROM LDS IS REPLICATED.  (Not the global -> LDS staging loads in front of them: by default those fill ONE register
+//    set whose upsets are common-mode; COAST_F_CLONE_STAGING -- the CLONE instantiation below -- clones them too.  ADVICE r4.)  The pass
+//    clones every load of the protected region and its users (cloning.cpp:2187-2209; under -noMemReplication the three loads keep one
+//    address, :2247-2255): an upset in a loaded f[i][k] or s[k][j] operand register is out-voted (tests/mm_common/mm_common_tmr.c:13).  mm_mfma_blk2_kernel had replica-private B fragments but ONE A fragment set
 //    for the three replicas.  Here a step's 60 MFMAs run as six sets of ten -- set = (row block, replica) -- and a set reads ITS
 //    OWN four A fragments from the LDS panel (the load is replicated, the memory is not): an A register is live for one replica's
 //    1-4 MFMAs, 24 instead of 8 ds_read_b128 per step and wave.
