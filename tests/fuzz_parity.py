@@ -41,14 +41,19 @@ def main():
     eng = coast_amd.Engine(0)
     t0 = time.time()
     cases = {"mm": 0, "sha256": 0, "aes": 0, "crc16": 0, "cache_test": 0, "chsha": 0, "chaes_walk": 0, "crazycf_xmr": 0, "walks": 0}
+    kinds = [k for k in os.environ.get("FUZZ_KINDS", "").split(",") if k in cases] or list(cases)  # e.g. FUZZ_KINDS=mm: one family only
     while time.time() - t0 < budget:
-        kind = str(rng.choice(list(cases)))
+        kind = str(rng.choice(kinds))
         rep = int(rng.choice([1, 2, 3]))
         nrep = rep
         if kind == "mm":
             n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 19, 31, 32, 33, 48, 64, 65, 96, 128, 256]))
             batch = int(rng.integers(1, max(2, 20000 // (n * n)) + 1)) if n < 128 else 1
             sync_every = int(rng.choice([0, 0, 1, 2, 7, n]))
+            clone = 0
+            if n == 256:  # the matrix-core kernels: several matrices per workgroup group, with and without the cloned staging loads (round 5)
+                batch, sync_every = int(rng.integers(1, 7)) if rng.random() < 0.8 else int(rng.integers(60, 70)), int(rng.choice([0, 0, 0, 16]))
+                clone = coast_amd.F_CLONE_STAGING if sync_every == 0 and rng.random() < 0.5 else 0
             f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
             s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
             nit = batch * n * n
@@ -58,9 +63,9 @@ def main():
             det = torch.zeros(nit, dtype=torch.uint8, device="cuda")
             eng.reset_stats()
             eng.inject_faults(fl)
-            got = eng.mm_batch(dev(f), dev(s), cfg=coast_amd.XmrConfig(rep, sync_every), detected=det).cpu().numpy().view(np.uint32)
+            got = eng.mm_batch(dev(f), dev(s), cfg=coast_amd.XmrConfig(rep, sync_every, clone), detected=det).cpu().numpy().view(np.uint32)
             ok = (got == exp).all() and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all()
-            desc = "mm n=%d batch=%d rep=%d V=%d k=%d" % (n, batch, rep, sync_every, len(fl))
+            desc = "mm n=%d batch=%d rep=%d V=%d k=%d clone=%d" % (n, batch, rep, sync_every, len(fl), int(bool(clone)))
         elif kind == "sha256":
             ln = int(rng.choice([0, 1, 3, 8, 55, 56, 57, 63, 64, 65, 100, 119, 120, 128, 200, 300]))
             stride = ln + int(rng.choice([0, 0, 1, 3, 4])) if rng.random() < 0.5 else ((ln + 15) // 16) * 16 + 16 * int(rng.integers(0, 2))
