@@ -226,6 +226,9 @@ def cpu_baseline_config1_mm32(eng, coast_amd):
 class Workload:
     """setup() allocates device-resident synthetic inputs; launch() enqueues one protected pass."""
     kernels_per_step = 1
+    # HIP timing events around every launch (1), or around every n-th one, its time counted n times (coast_set_profiling(ctx, n)): a pair
+    # of event packets costs the stream ~15 us per step next to a 60 us kernel (profiles/r05_aes_step.txt)
+    profile_every = 1
 
     def free(self):
         for k in list(self.__dict__):
@@ -573,6 +576,8 @@ class AES(Workload):
                                              for it in items])
         self.units_per_step = self.n
         self.dir = 0
+        # a 50-70 us launch: bracket every 5th one (odd: the steps alternate encrypt / decrypt, both directions are sampled alike)
+        self.profile_every = 5 if self.n <= (1 << 21) else 1
 
     def launch(self):
         """alternate encrypt / decrypt in place, ONE launch per step.  The reference contract (TI_aes_128.c:107-231): encryption leaves
@@ -738,6 +743,7 @@ def timed_run(wl, eng, dist, dev, steps, warmup, world):
         eng.reduce_counters()
         return allreduce_counters(eng, dist, snapshot=False)  # (one rank, no process group: the live totals, no copy kernel)
 
+    eng.set_profiling(wl.profile_every)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -760,6 +766,7 @@ def timed_run(wl, eng, dist, dev, steps, warmup, world):
     tot = [int(x) for x in tot.cpu().tolist()]
     st = eng.stats()
     kern_ms = st["kernel_ms"] / max(steps, 1)
+    eng.set_profiling(1)
     out = {"dt": dt, "totals": tot, "kernel_ms": kern_ms, "launch_info": eng.last_launch(),
            "hbm_bytes_per_step": st["hbm_bytes"] / max(steps, 1)}
     if dist:
@@ -809,6 +816,8 @@ def result_fields(wl, run, a, world, steps, warmup, with_cpu):
     roof = wl.roofline(run["kernel_ms"])
     traffic, src = pmc_traffic(wl.name, cfg)
     roof["traffic"] = traffic
+    roof["kernel_ms_from"] = ("HIP events around every launch of the timed region" if wl.profile_every == 1 else
+                              "HIP events around every %dth launch of the timed region, each counted %d times" % (wl.profile_every, wl.profile_every))
     if src:
         # a committed measurement of this same command, looked up by configuration -- NOT a counter pass of this very run (PMC
         # collection serialises the kernels and needs rocprofv3 around the process: tools/profile.sh)
@@ -851,7 +860,7 @@ def extra_legs(a, eng, dist, dev, rank, world, coast_amd):
     # 8-GPU stream has to hold its 40 % of the HBM roofline in)
     plan = [("crc16_256B", CRC16, {"block_len": 256}, 20, 5), ("crc16_255B", CRC16, {"block_len": 255}, 20, 5)]
     if world == 1:
-        plan += [("sha256", SHA256, {}, 20, 5), ("aes", AES, {}, 40, 8),
+        plan += [("sha256", SHA256, {}, 20, 5), ("aes", AES, {}, 60, 10),
                  # the BASELINE batch (1 Mi blocks) is a 50-80 us launch; the same kernels on 16 Mi blocks show what they sustain
                  ("aes_16Mi_blocks", AES, {"batch": 1 << 24}, 12, 4)]
     for name, cls, over, steps, warm in plan:

@@ -84,8 +84,10 @@ struct coast_ctx {
     // Optional kernel timing (coast_set_profiling): a pair of timing events around every protected launch on the
     // context's stream, folded into kernelMs whenever the stream is known to be idle.
     bool profiling = false;
+    unsigned profEvery = 1, profSeen = 0; // coast_set_profiling(ctx, n > 1): every n-th launch is bracketed, its time counted n times
     struct EvPair {
         hipEvent_t a, b;
+        unsigned weight;
     };
     std::vector<EvPair> evPending, evFree;
     double kernelMs = 0.0;
@@ -321,7 +323,7 @@ int profile_fold(coast_ctx *c, bool wait)
         float ms = 0.f;
         const hipError_t q = hipEventElapsedTime(&ms, e.a, e.b);
         if (q == hipSuccess) {
-            c->kernelMs += (double)ms;
+            c->kernelMs += (double)ms * (double)e.weight;
             c->evFree.push_back(e);
         } else if (q == hipErrorNotReady) {
             (void)hipGetLastError();
@@ -347,12 +349,14 @@ int profile_begin(coast_ctx *c)
     c->evOpen = false;
     if (!c->profiling)
         return COAST_OK;
+    if (c->profEvery > 1 && (c->profSeen++ % c->profEvery) != 0)
+        return COAST_OK; // (a sampled bracket: this launch runs without timing events in front of and behind it)
     if (c->evPending.size() >= 1024) {
         int rc = profile_fold(c, true);
         if (rc)
             return rc;
     }
-    coast_ctx::EvPair e;
+    coast_ctx::EvPair e{};
     if (!c->evFree.empty()) {
         e = c->evFree.back();
         c->evFree.pop_back();
@@ -367,6 +371,7 @@ int profile_begin(coast_ctx *c)
         c->evFree.push_back(e);
         return fail(c, COAST_EHIP, "hipEventRecord failed on a timing event");
     }
+    e.weight = c->profEvery > 1 ? c->profEvery : 1u;
     c->evPending.push_back(e);
     c->evOpen = true;
     return COAST_OK;
@@ -593,6 +598,8 @@ extern "C" int coast_set_profiling(coast_ctx *c, int enable)
     if (!c)
         return COAST_EINVAL;
     c->profiling = enable != 0;
+    c->profEvery = enable > 1 ? (unsigned)enable : 1u;
+    c->profSeen = 0;
     return COAST_OK;
 }
 

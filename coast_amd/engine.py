@@ -109,7 +109,7 @@ class Engine:
 
     def set_profiling(self, on: bool = True):
         """HIP timing events around every protected launch on the engine's stream -> stats()['kernel_ms']."""
-        self._check(self._lib.coast_set_profiling(self._h, int(bool(on))))
+        self._check(self._lib.coast_set_profiling(self._h, int(on)))  # True / 1: every launch; n > 1: every n-th launch, counted n times
 
     def last_launch(self) -> dict:
         """What the most recent protected launch dispatched to (coast_last_launch_info)."""

@@ -292,7 +292,9 @@ int coast_reduce_counters(coast_ctx *ctx);
 int coast_allreduce_counters(coast_ctx *ctx, void *rccl_comm);
 int coast_read_stats(coast_ctx *ctx, coast_stats *out); /* synchronises the stream */
 int coast_reset_stats(coast_ctx *ctx);
-/* bracket every protected launch with HIP timing events on the context's stream -> coast_stats.kernel_ms */
+/* bracket every protected launch with HIP timing events on the context's stream -> coast_stats.kernel_ms.  enable = n > 1 (ABI 7): only
+ * every n-th launch is bracketed and its time counted n times -- for launches of tens of microseconds, whose pair of event packets costs the
+ * stream a fifth of the launch (profiles/r05_aes_step.txt); kernel_ms is then an estimate that is exact when the launches are alike. */
 int coast_set_profiling(coast_ctx *ctx, int enable);
 int coast_last_launch_info(const coast_ctx *ctx, coast_launch_info *out);
 
