@@ -1,4 +1,6 @@
-import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+"""tools/aes_step_split.py -- where the time of an aes-128 DWC step of 1 Mi blocks goes: kernels back to back, + counter fold, + armed upsets,
++ timing events (profiles/r05_aes_step.txt).  Run on the GPU box."""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time, torch, numpy as np, coast_amd as ca
 eng = ca.Engine(0)
 n = 1 << 20
