@@ -18,14 +18,9 @@ class _FakeEngine:  # stands in for coast_amd.Engine where there is no device: o
 
 
 def _engine_with(vals):
-    """the engine whose totals are `vals`: on a GPU box the REAL coast_amd.Engine, its device-resident counters tensor (the one
-    coast_bind_counters gave the C side) set to the values -- the collective then runs on exactly what the product all-reduces"""
-    if torch.cuda.is_available():
-        import coast_amd
-
-        eng = coast_amd.Engine(0)
-        eng.counters.copy_(torch.tensor(vals, dtype=eng.counters.dtype))
-        return eng
+    """the engine whose totals are `vals`.  Always the stand-in here (the not-gpu suite must not behave differently on a box
+    that happens to have a GPU); the real coast_amd.Engine -- its device-resident counters tensor, the one coast_bind_counters gave the C
+    side -- goes through the same collective in tests/test_gpu_parity.py::test_bench_two_ranks_real_engines_counters_all_reduced."""
     return _FakeEngine(vals)
 
 
