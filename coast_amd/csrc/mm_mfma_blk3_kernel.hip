@@ -70,15 +70,16 @@
 // chip's power limit: + 30 % (6.77 -> 8.82 ms; the loads alone + 12.6 %, the f clone alone + 5 %: profiles/r05_mm_clone_ab.txt), for 94.4 -> 96.6 %
 // coverage in the uniform register-file campaign (profiles/r05_campaign_uniform_*.txt).  Hence a flag, not the default.
 
-// round 5: WIDE staging loads of s.  A buffer load costs this kernel about what seven LDS reads cost (profiles/r05_mm_clone_ab.txt), and the
-// s staging issued eight two-word loads per slab and wave (a lane: two adjacent columns x eight k).  1: four four-word loads -- a lane owns
-// four adjacent columns x four k (lane -> column quad l % 4, k-quad l / 4), one load instruction fetches sixteen full tile rows -- into the
-// same LDS image through the same conflict-free stores (tests/test_lds_layouts_cpu.py); the four loads are requested in the duty step behind
-// the last read of the registers they replace (slots 21 - 48), 42 - 69 slots ahead of their first use.  - 0.55 % (6.785 -> 6.747 ms; with one
-// more load per slab, a dword per row two steps ahead so that the four find their lines in L2: + 1.0 %, not kept).  The clone form keeps
-// the two-word loads (its compare is per staging round).  0: round 4's loads (A/B builds).
+// round 5, measured and NOT the default: WIDE staging loads of s.  A buffer load costs this kernel about what seven LDS reads cost
+// (profiles/r05_mm_clone_ab.txt), and the s staging issues eight two-word loads per slab and wave (a lane: two adjacent columns x eight k).
+// 1: four four-word loads -- a lane owns four adjacent columns x four k (lane -> column quad l % 4, k-quad l / 4), one load instruction
+// fetches sixteen full tile rows -- into the same LDS image through the same conflict-free stores (tests/test_lds_layouts_cpu.py), requested
+// in the duty step behind the last read of the registers they replace (slots 21 - 48).  - 0.5 % kernel time on two boxes -- and 1.7 points
+// of coverage: all sixteen raw words of a lane now sit in registers from one request to the last group's conversion, and the uniform
+// register-file campaign (same 5000 draws) went from 223 wrong products to 308 (95.5 -> 93.8 %; the sixteen registers: 60 - 75 % of their
+// hits silent against 35 - 50 % for the two-word form).  Half a percent of time is not worth a third more silent corruptions.
 #ifndef COAST_MM3_WIDE
-#define COAST_MM3_WIDE 1
+#define COAST_MM3_WIDE 0
 #endif
 
 namespace coast {

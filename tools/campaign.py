@@ -677,7 +677,9 @@ def run_uniform_campaign(a, eng=None):
         children += 1
         proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--preg-child", "-"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
         try:
-            out, _ = proc.communicate(spec, timeout=120 + 2 * len(todo))
+            # (a launch takes a tenth of a second; the first child of a fresh box pages torch in for a minute or two.  A child that hangs --
+            # an upset that turns a loop bound into a long walk -- is cut and its launch halved like a crashed one's)
+            out, _ = proc.communicate(spec, timeout=(240 if children == 1 else 75) + len(todo))
         except subprocess.TimeoutExpired:
             proc.kill()
             out, _ = proc.communicate()
