@@ -99,3 +99,62 @@ def test_physical_real_campaign_bookkeeping(monkeypatch, model):
         if t["class"] == "f_raw":
             lands = r["run"] + (128 if (t["step"] & 3) == 3 else 64)
             assert (r["class"] == "error") == (lands < 600), (r["run"], t)
+
+
+def test_uniform_campaign_isolates_the_runs_that_take_the_process_down(monkeypatch):
+    """`--reg-model uniform` without a GPU: stand-in children that die (memory fault) or hang inside the launch that contains a `killer` run.
+    The campaign must halve such a launch until the killer is alone, file exactly the killers as `invalid`, keep every other run's outcome,
+    count the scalar class (s0..s101 and the spill registers' lanes) as errors without executing it, and cut a hanging child."""
+    import json
+    import subprocess
+
+    mod = _load(monkeypatch)
+    monkeypatch.setattr(mod, "kernel_registers", lambda replicas, clone=False: (256, 102, [254, 255]))
+    a = mod.parse(["-b", "mm", "--side", "256", "-m", "TMR", "-t", "700", "--reg-model", "uniform", "-n"])
+    rng = np.random.default_rng(a.seed)
+    draws = [mod.uniform_draw(rng, 256, 102) for _ in range(700)]
+    scalar = {r for r, d in enumerate(draws) if d["file"] == 1 or d["reg"] in (254, 255)}
+    vector = [r for r in range(700) if r not in scalar]
+    crashers, hanger = {vector[5], vector[6], vector[300]}, vector[100]   # two in one launch, one elsewhere; and one that hangs
+    wrong = {r for r in vector if r % 7 == 0} - crashers - {hanger}
+    spawned = []
+
+    class _Child:
+        def __init__(self, argv, **kw):
+            assert "--preg-child" in argv
+            self.returncode = 0
+            spawned.append(self)
+
+        def communicate(self, spec=None, timeout=None):
+            if spec is None:   # (after kill(): whatever was printed before)
+                return self.out, None
+            lines = []
+            for k, grp in enumerate(json.loads(spec)["launches"]):
+                runs = [r for r, _ in grp]
+                lines.append("start %d" % k)
+                if crashers & set(runs):
+                    self.returncode = -6
+                    break
+                if hanger in runs:
+                    self.out = "\n".join(lines) + "\n"
+                    raise subprocess.TimeoutExpired("child", timeout)
+                lines.append("done %d %s" % (k, json.dumps({"runs": [[r, int(r in wrong), int(r % 3 == 0)] for r in runs],
+                                                           "stats": {"errors_corrected": len(runs), "sync_count": 1, "dwc_detected": 0}})))
+            return "\n".join(lines) + "\n", None
+
+        def kill(self):
+            self.returncode = -9
+
+    monkeypatch.setattr(subprocess, "Popen", _Child)
+    recs, summ = mod.run_uniform_campaign(a)
+    cls = {r["run"]: r["class"] for r in recs}
+    assert {r for r, c in cls.items() if c == "invalid"} == crashers | {hanger}
+    assert summ["invalids"] == 4 and summ["scalar_upsets_not_executed_counted_as_errors"] == len(scalar) > 0
+    for r in range(700):
+        if r in scalar:
+            assert cls[r] == "error"
+        elif r not in crashers and r != hanger:
+            assert cls[r] == ("error" if r in wrong else "fault" if r % 3 == 0 else "success"), r
+    assert summ["errors"] == len(scalar) + len(wrong) and summ["success"] + summ["faults"] + summ["errors"] + summ["invalids"] == 700
+    assert abs(summ["coverage_pct"] - 100.0 * (700 - summ["errors"] - 4) / 700) < 1e-9
+    assert 10 < len(spawned) < 40   # halving: about log2(64) children per killer, not one per run
