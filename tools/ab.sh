@@ -1,6 +1,7 @@
 #!/bin/bash
 # [BENCH_ARGS="--workload crc16 --block-len 255"] [REPS="1 2"] tools/ab.sh libA.so libB.so ... -- development: bench the mm headline with differently built libraries back to back on ONE box
 # (boxes differ in sustained clock by several percent, so A/B numbers from different gpurun calls do not compare)
+# (round 5: bench.py quotes the headline with COAST_F_CLONE_STAGING; BENCH_ARGS="--single-staging" benches the unflagged kernel)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for rep in ${REPS:-1 2}; do
   for lib in "$@"; do
