@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--block-len", type=int, default=256, help="crc16 block length in bytes (the reference's maximum is 255)")
     ap.add_argument("--faults", type=int, default=-1,
                     help="single-bit flips injected per GPU per step (default: 4096 for mm, 1024 otherwise)")
+    ap.add_argument("--profile-every", type=int, default=0,
+                    help="bracket every n-th launch with HIP timing events (its time counted n times) instead of the workload's own period")
     ap.add_argument("--single-staging", action="store_true",
                     help="mm: run WITHOUT COAST_F_CLONE_STAGING -- the matrix-core kernel's global -> LDS staging loads not cloned (10 %% faster, "
                          "95.7 instead of 98.3 %% coverage of register upsets); the headline is quoted on the cloned form (VERDICT r4 item 1)")
@@ -985,6 +987,8 @@ def main():
     eng = coast_amd.Engine(dev.index)
     eng.set_profiling(True)
     wl = WORKLOADS[a.workload](a, eng, dev, rank, coast_amd)
+    if a.profile_every > 0:
+        wl.profile_every = a.profile_every
     run = timed_run(wl, eng, dist, dev, a.steps, a.warmup, world)
     out = None
     if rank == 0:
