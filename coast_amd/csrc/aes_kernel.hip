@@ -800,6 +800,7 @@ __global__ __launch_bounds__(kAesRepThreads) __attribute__((amdgpu_waves_per_eu(
     }
 #undef TE
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+    block_fold(ctr, blockIdx.x, sCnt + 3);
 }
 
 template <int NREP>
@@ -969,6 +970,7 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
 #undef SUBROT
 #undef TDCOL
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+    block_fold(ctr, blockIdx.x, sCnt + 3);
 }
 
 #undef AES_DEC_HOOK

@@ -49,6 +49,7 @@ struct coast_ctx {
     unsigned long long *dTotals = nullptr; // internal totals
     unsigned long long *dBound = nullptr;  // caller-owned totals (optional)
     unsigned long long pendingLaunches = 0;
+    bool slotsDirty = false; // a launch since the last fold left its counts in the slots (a kernel that folds in its own exit path does not)
 
     std::vector<coast_fault> armed; // host copy of the faults waiting for the next launch
     // Fault tables are double-buffered: launch i uploads into buffer i & 1 while launch i-1 may still be reading the
@@ -118,6 +119,9 @@ int fail(coast_ctx *ctx, int code, const char *fmt, ...)
                         __LINE__);                                                                            \
     } while (0)
 
+// the counter slots, and behind them the ticket word of the kernels that fold the slots themselves (Counters::ticket)
+constexpr size_t kSlotBytes = sizeof(unsigned long long) * ((size_t)kCounterSlots * kSlotStride + 8);
+uint32_t *ticket_of(coast_ctx *c) { return reinterpret_cast<uint32_t *>(c->dSlots + (size_t)kCounterSlots * kSlotStride); }
 unsigned long long *totals_of(coast_ctx *c) { return c->dBound ? c->dBound : c->dTotals; }
 
 // `indexedOk`: this kernel implements the index-in-the-sphere-of-replication flags (mm, sha256, crc16)
@@ -396,6 +400,7 @@ int after_launch(coast_ctx *c, int haveFaults, uint32_t engine = COAST_ENGINE_NO
 {
     HIP_TRY(c, hipGetLastError());
     c->pendingLaunches += 1;
+    c->slotsDirty = true;
     if (c->evOpen) {
         HIP_TRY(c, hipEventRecord(c->evPending.back().b, c->stream));
         c->evOpen = false;
@@ -447,9 +452,9 @@ extern "C" int coast_create(coast_ctx **out, int device)
         bail(hipEventCreateWithFlags(&c->fb[1].evUploaded, hipEventDisableTiming)) ||
         bail(hipEventCreateWithFlags(&c->evMainReady, hipEventDisableTiming)) ||
         bail(hipEventCreateWithFlags(&c->evSideDone, hipEventDisableTiming)) ||
-        bail(hipMalloc((void **)&c->dSlots, sizeof(unsigned long long) * kCounterSlots * kSlotStride)) ||
+        bail(hipMalloc((void **)&c->dSlots, kSlotBytes)) ||
         bail(hipMalloc((void **)&c->dTotals, sizeof(unsigned long long) * 4)) ||
-        bail(hipMemset(c->dSlots, 0, sizeof(unsigned long long) * kCounterSlots * kSlotStride)) ||
+        bail(hipMemset(c->dSlots, 0, kSlotBytes)) ||
         bail(hipMemset(c->dTotals, 0, sizeof(unsigned long long) * 4)))
         return COAST_EHIP;
     hipDeviceProp_t prop;
@@ -525,11 +530,14 @@ extern "C" int coast_reduce_counters(coast_ctx *c)
 {
     if (!c)
         return COAST_EINVAL;
+    if (!c->slotsDirty && c->pendingLaunches == 0)
+        return COAST_OK; // nothing launched since the last fold, or the last launch folded in its own exit path (block_fold)
     HIP_TRY(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(kCounterSlots), 0, c->stream, c->dSlots, totals_of(c),
                        c->pendingLaunches);
     HIP_TRY(c, hipGetLastError());
     c->pendingLaunches = 0;
+    c->slotsDirty = false;
     return COAST_OK;
 }
 
@@ -616,9 +624,10 @@ extern "C" int coast_reset_stats(coast_ctx *c)
     if (!c)
         return COAST_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemsetAsync(c->dSlots, 0, sizeof(unsigned long long) * kCounterSlots * kSlotStride, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dSlots, 0, kSlotBytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(totals_of(c), 0, sizeof(unsigned long long) * 4, c->stream));
     c->pendingLaunches = 0;
+    c->slotsDirty = false;
     // timing brackets still in flight belong to the period being discarded
     for (coast_ctx::EvPair &e : c->evPending)
         c->evFree.push_back(e);

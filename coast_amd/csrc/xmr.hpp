@@ -30,6 +30,11 @@ struct FaultTab {
 struct Counters {
     unsigned long long *slots; // [kCounterSlots][kSlotStride]
     uint32_t flags;            // coast_cfg.flags of the launch (kFlagNoStoreDataSync), read by the general kernels
+    // In-kernel fold (block_fold; aes-128's persistent kernels): with `totals` set, the last workgroup to leave folds the slots into the
+    // totals itself -- no reduce_counters_kernel behind the launch, one dependent dispatch less per step.  Null everywhere else.
+    uint32_t foldLaunches;      // what the fold adds to totals[3]: the launches since the last fold, this one included
+    unsigned long long *totals; // {errors, syncs, dwc_items, launches}
+    uint32_t *ticket;           // workgroups that have left; the last one sets it back to 0
 };
 constexpr uint32_t kFlagNoStoreDataSync = 1u; // == COAST_F_NO_STORE_DATA_SYNC
 constexpr uint32_t kFlagBranchSync = 2u;      // == COAST_F_BRANCH_SYNC: loop / byte counters are replica-private, their branch conditions voted
@@ -236,6 +241,53 @@ __device__ __forceinline__ void block_tally(uint32_t miss, uint32_t syncs, uint3
             atomicAdd(slot + 1, (unsigned long long)s_cnt[1]);
         if (s_cnt[2])
             atomicAdd(slot + 2, (unsigned long long)s_cnt[2]);
+    }
+}
+
+// The counter fold inside the protected kernel (Counters::totals set): every workgroup calls this behind block_tally, all threads.  The
+// workgroup's slot atomics are released in front of its ticket; the workgroup that draws the last ticket reads and clears every slot with
+// atomics (the slots were written with atomics from every XCD: the exchange runs where they ran), sums them per wave and adds the sums to
+// the totals.  `slotKey`: block_tally's; `s_flag`: one uint32 of LDS nobody else writes between block_tally's barrier and the kernel's end.
+__device__ __forceinline__ void block_fold(const Counters &ctr, uint32_t slotKey, uint32_t *s_flag)
+{
+    if (!ctr.totals)
+        return;
+    if (threadIdx.x == 0) {
+        // (no __threadfence: on gfx950 that is a write-back of the XCD's L2, full of the launch's own dirty output -- measured + 8 us per
+        // launch.  Slots, ticket and totals are only ever touched by device-scope atomics, which execute past the L2s: it is enough that
+        // this thread's slot atomics have been acknowledged before its ticket is drawn.)
+        // Acknowledged is taken literally: a RETURNING read-modify-write on the slot's own 64-byte line (its first pad word; the line's
+        // atomics execute in one L2 channel, in order) has its value back before the ticket is drawn.  (+ 0 on the counter words themselves
+        // would do, but the compiler turns an idempotent atomic into a load.)
+        unsigned long long *mine = ctr.slots + (size_t)(slotKey % kCounterSlots) * kSlotStride;
+        const unsigned long long r = atomicAdd(mine + 3, 1ull);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(r) : "memory");
+        *s_flag = atomicAdd(ctr.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*s_flag == 0u)
+        return;
+    unsigned long long v[3] = {0ull, 0ull, 0ull};
+    for (uint32_t t = threadIdx.x; t < (uint32_t)kCounterSlots; t += blockDim.x) {
+        unsigned long long *slot = ctr.slots + (size_t)t * kSlotStride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            v[c] += atomicExch(slot + c, 0ull);
+    }
+    if (threadIdx.x < (uint32_t)kCounterSlots) { // (waves past the slots hold zeros)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                v[c] += (unsigned long long)__shfl_xor((long long)v[c], o, kWave);
+            if ((threadIdx.x & (kWave - 1)) == 0 && v[c])
+                atomicAdd(&ctr.totals[c], v[c]);
+        }
+    }
+    if (threadIdx.x == 0) {
+        atomicExch(ctr.ticket, 0u);
+        if (ctr.foldLaunches)
+            atomicAdd(&ctr.totals[3], (unsigned long long)ctr.foldLaunches);
     }
 }
 
