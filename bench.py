@@ -629,9 +629,10 @@ class AES(Workload):
                 "hbm_achieved_GBs": self.n * 64 / t * 1e-9, "algorithmic_bytes": float(self.n) * 64,
                 "note": "bank-replicated tables: the lookups are conflict-free and their address is one v_perm_b32; the kernels are "
                         "bound by their VALU instruction count (466 / 717 per block and lane); 1 Mi blocks are a 46-64 us launch clean, the "
-                        "armed upsets are applied inside it (+ ~12 us: profiles/r04_aes_step.txt); one launch per step, no harness copy; the counter "
-                        "fold runs in the kernel's exit path (the last workgroup out), so kernel_ms contains it and no fold kernel follows "
-                        "the launch (profiles/r05_aes_step.txt)"}
+                        "armed upsets are applied inside it (+ ~12 us: profiles/r04_aes_step.txt); one launch per step, no harness copy"
+                        + ("; COAST_AES_FOLD=1: the counter fold runs in the kernel's exit path (the last workgroup out), kernel_ms contains "
+                           "it and no fold kernel follows the launch (profiles/r05_aes_step.txt)"
+                           if os.environ.get("COAST_AES_FOLD", "") == "1" else "")}
 
     def cpu(self):
         return cpu_baseline_items("aes")

@@ -283,7 +283,8 @@ int coast_set_stream(coast_ctx *ctx, void *hip_stream);
  * replacing the single global TMR_ERROR_CNT of synchronization.cpp:1428-1431).  NULL restores the internal one. */
 int coast_bind_counters(coast_ctx *ctx, uint64_t *d_totals);
 /* fold the per-workgroup counter slots into the totals (async; coast_read_stats does it implicitly).  Launches nothing when no
- * protected launch has left counts in the slots since the last fold -- the persistent aes-128 kernels fold in their own exit path. */
+ * protected launch has left counts in the slots since the last fold (with COAST_AES_FOLD=1 the persistent aes-128 kernels fold in
+ * their own exit path). */
 int coast_reduce_counters(coast_ctx *ctx);
 /* Multi-GPU, C hosts: coast_reduce_counters + ncclAllReduce(SUM, 4 x uint64, in place) of the totals over `rccl_comm` (an
  * ncclComm_t the host created for this context's device: one rank per GPU), on the context's stream.  Afterwards every
