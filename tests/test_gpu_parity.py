@@ -436,46 +436,6 @@ def test_aes_bank_replicated_table_kernels(eng, orc, golden, replicas, direction
         assert (stt.cpu().numpy() == pt).all() and (k2.cpu().numpy() == key2).all()
 
 
-@pytest.mark.parametrize("replicas", [2, 3])
-def test_aes_persistent_kernels_fold_their_own_counters(eng, replicas, monkeypatch):
-    """the persistent aes kernels fold the counter slots in their exit path (block_fold: the last workgroup to leave; no fold kernel
-    behind the launch).  Same totals -- errors, syncs, detected items, LAUNCHES -- as the separate fold (COAST_AES_FOLD=0), over steps that
-    alternate directions, with launches of other kernels (whose counts sit in the slots when the aes kernel folds) in between, with and
-    without an explicit reduce_counters after every launch, and the ticket back at zero for the next launch every time"""
-    import torch
-
-    import coast_amd
-
-    rng = np.random.default_rng(4242 + replicas)
-    n = 70001
-    st0 = rng.integers(0, 256, (n, 16), dtype=np.uint8)
-    key0 = rng.integers(0, 256, (n, 16), dtype=np.uint8)
-    data = torch.from_numpy(rng.integers(0, 256, (4096, 64), dtype=np.uint8)).cuda()
-    monkeypatch.setenv("COAST_AES_TABLES", "replicated")
-    got = {}
-    for fold in ("1", "0"):
-        monkeypatch.setenv("COAST_AES_FOLD", fold)
-        for explicit in (False, True):
-            ds, dk = torch.from_numpy(st0.copy()).cuda(), torch.from_numpy(key0.copy()).cuda()
-            eng.reset_stats()
-            seen = []
-            for step in range(6):
-                fl = _rand_faults(np.random.default_rng(step), 40, n, replicas, [16, 17], 10, max_index=4)
-                if step % 3 == 2:  # another kernel's counts in the slots, its launch pending
-                    eng.crc16_batch(data, 64, cfg=coast_amd.XmrConfig(3))
-                eng.inject_faults(fl)
-                eng.aes128_batch(ds, dk, step & 1, cfg=coast_amd.XmrConfig(replicas))
-                if explicit:
-                    eng.reduce_counters()
-                if step % 2:
-                    seen.append(tuple(eng.stats()[k] for k in ("errors_corrected", "sync_count", "dwc_detected", "launches")))
-            got[(fold, explicit)] = (ds.cpu().numpy(), dk.cpu().numpy(), seen)
-    ref = got[("0", True)]
-    assert ref[2][-1][-1] == 8 and ref[2][0][0] + ref[2][0][2] > 0
-    for k, v in got.items():
-        assert (v[0] == ref[0]).all() and (v[1] == ref[1]).all() and v[2] == ref[2], k
-
-
 def test_aes_roundtrip_1M(eng):
     """BASELINE config 3 size: 2^20 blocks with per-block keys, encrypt then decrypt must round-trip."""
     import torch
@@ -3111,3 +3071,19 @@ def test_campaign_physical_real_all_registers_mm256(eng, tmp_path, monkeypatch):
     the file: its attribution rule for f pieces requested in a matrix's last tile was deduced from that run's record after the round's last
     GPU second.)"""
     test_campaign_physical_register_model_mm256(eng, tmp_path, "blocks3-real-all", monkeypatch)
+
+
+@pytest.mark.parametrize("replicas", [2, 3])
+def test_aes_persistent_kernels_fold_their_own_counters(replicas):
+    """COAST_AES_FOLD=1 (opt-in): the persistent aes kernels fold the counter slots in their exit path (block_fold: the last workgroup to
+    leave; no fold kernel behind the launch) -- same states, keys, totals and launch counts as the separate fold.  tests/aes_fold_check.py in
+    a process of its own, at the end of the suite: a GPU memory fault seen once on this path's kernels is unexplained, and
+    a fault here must cost this test, not the suite."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "aes_fold_check.py"), str(replicas)], capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0 and "aes fold ok" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
