@@ -23,7 +23,7 @@ def rand_faults(rng, k, nitems, nrep):
 
 def main():
     replicas = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    eng = coast_amd.Engine()
+    eng = coast_amd.Engine(0)
     rng = np.random.default_rng(4242 + replicas)
     n = 70001
     st0 = rng.integers(0, 256, (n, 16), dtype=np.uint8)
