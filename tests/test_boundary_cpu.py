@@ -99,3 +99,21 @@ def test_make_faults_layout():
     assert len(raw) == 16
     assert int.from_bytes(raw[0:8], "little") == 0x1122334455 and int.from_bytes(raw[8:12], "little") == 77
     assert list(raw[12:16]) == [2, coast_amd.SITE_MM_OPB, 31, 5]
+
+
+def test_c_abi_soak_tool_builds_against_the_header(tmp_path):
+    """tools/dev/aes_soak.cpp (the crash soak behind DESIGN.md 8.6: coast_aes128_batch from a C host, no Python) compiles and links
+    against include/coast_hip.h and the in-tree library -- no GPU is touched."""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    lib = os.path.join(root, "coast_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libcoast_hip.so")):
+        pytest.skip("library not built")
+    p = subprocess.run([hipcc, "-O2", "-std=c++17", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "dev", "aes_soak.cpp"),
+                        "-o", str(tmp_path / "aes_soak"), "-L", lib, "-lcoast_hip"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
