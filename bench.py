@@ -322,7 +322,7 @@ class MM(Workload):
         replicated: a replica's MFMAs read their own A and B fragments); blocks2: mm_mfma_blk2_kernel (one A fragment set for the three
         replicas, COAST_MM_TILE=blocks2); lanes: mm_mfma_panel_kernel (the replicas in adjacent lanes, north_star's layout)"""
         t = os.environ.get("COAST_MM_TILE")
-        return t if t in ("lanes", "blocks2") else "blocks3"
+        return t if t in ("lanes", "blocks2", "panel128") else "blocks3"
 
     def roofline(self, kern_ms):
         n, batch = self.n, self.batch
@@ -338,6 +338,7 @@ class MM(Workload):
             if self.tile() != "lanes":
                 two = True
                 kern = {"blocks3": "mm_mfma_blk3_kernel<3, false, 0, %s>" % ("true" if self.clone else "false"),
+                        "panel128": "mm_mfma_blk4_kernel<false, %s>" % ("true" if self.clone else "false"),
                         "blocks2": "mm_mfma_blk2_kernel<3, false>"}[self.tile()]
                 return dict(hbm, **{
                     "bound": "mfma", "kernel": kern,
@@ -355,7 +356,7 @@ class MM(Workload):
                             + ("every replica's MFMAs read their own A and B fragments from LDS (the loads are replicated, the memory is "
                                "not: cloning.cpp:2187-2209, 2247-2255); " + ("the global -> LDS staging loads are cloned too and compared "
                                "in front of their first use (COAST_F_CLONE_STAGING; + 10 % kernel time); " if self.clone else
-                               "ONE staging register set on the way into LDS (no COAST_F_CLONE_STAGING); ") if self.tile() == "blocks3" else
+                               "ONE staging register set on the way into LDS (no COAST_F_CLONE_STAGING); ") if self.tile() in ("blocks3", "panel128") else
                                "own B-operand registers and MFMAs per replica, ONE A fragment set for the three; ")
                             + ("two waves per SIMD, each with half the tile's rows (96 accumulator registers)" if two else
                                "one wave per SIMD (192 accumulator registers)") +
@@ -629,9 +630,9 @@ class AES(Workload):
                 "note": "bank-replicated tables: the lookups are conflict-free and their address is one v_perm_b32; the kernels are "
                         "bound by their VALU instruction count (466 / 717 per block and lane); 1 Mi blocks are a 46-64 us launch clean, the "
                         "armed upsets are applied inside it (+ ~12 us: profiles/r04_aes_step.txt); one launch per step, no harness copy"
-                        + ("; COAST_AES_FOLD=1: the counter fold runs in the kernel's exit path (the last workgroup out), kernel_ms contains "
-                           "it and no fold kernel follows the launch (profiles/r05_aes_step.txt)"
-                           if os.environ.get("COAST_AES_FOLD", "") == "1" else "")}
+                        + ("; the counter fold runs in the kernel's exit path (the last workgroup out), kernel_ms contains it and no fold kernel "
+                           "follows the launch (profiles/r05_aes_step.txt; COAST_AES_FOLD=0 takes it out)"
+                           if os.environ.get("COAST_AES_FOLD", "") != "0" else "; COAST_AES_FOLD=0: a separate fold kernel behind every launch")}
 
     def cpu(self):
         return cpu_baseline_items("aes")

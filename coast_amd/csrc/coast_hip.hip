@@ -22,6 +22,7 @@
 #include "mm_mfma_kernel.hip"
 #include "mm_mfma_blk2_kernel.hip"
 #include "mm_mfma_blk3_kernel.hip"
+#include "mm_mfma_blk4_kernel.hip"
 #include "sha256_kernel.hip"
 #include "aes_kernel.hip"
 #include "crc16_kernel.hip"
@@ -654,6 +655,7 @@ struct MmHostGeom {
     size_t batch;
     int replicas;
     int tpb;
+    int panelRows = 64; // matrix-core kernels: rows of a matrix per workgroup (mm_mfma_blk4_kernel: 128)
 };
 
 bool decode_mm(const coast_fault &f, const void *gp, DevFault &d)
@@ -678,7 +680,7 @@ bool decode_mm(const coast_fault &f, const void *gp, DevFault &d)
     return true;
 }
 
-// side 256 on the matrix cores: workgroup = 64 rows of one matrix, element = (row in the panel, column)
+// side 256 on the matrix cores: workgroup = 64 (mm_mfma_blk4_kernel: 128) rows of one matrix, element = (row in the panel, column)
 bool decode_mm_mfma(const coast_fault &f, const void *gp, DevFault &d)
 {
     const MmHostGeom &h = *(const MmHostGeom *)gp;
@@ -691,8 +693,9 @@ bool decode_mm_mfma(const coast_fault &f, const void *gp, DevFault &d)
         return false; // slot 0..59; v0..v255 / s0..s101
     const uint64_t mat = f.item / nn, e = f.item % nn;
     const uint32_t i = (uint32_t)(e / h.g.n), j = (uint32_t)(e % h.g.n);
-    d.block = (uint32_t)(mat * (uint64_t)(h.g.n / 64) + i / 64u);
-    d.local = ((i % 64u) << 8) | j;
+    const uint32_t pr = (uint32_t)h.panelRows;
+    d.block = (uint32_t)(mat * (uint64_t)((uint32_t)h.g.n / pr) + i / pr);
+    d.local = ((i % pr) << 8) | j;
     d.step = f.step;
     d.replica = f.replica;
     d.site = f.site;
@@ -830,7 +833,15 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     // default (round 4): mm_mfma_blk3_kernel -- blocks2's geometry with every loaded operand replicated (a replica's MFMAs read their
     // own A fragments); COAST_MM_TILE=blocks2 selects mm_mfma_blk2_kernel (one A fragment set for the three replicas)
     const bool mmBlocks3 = !(tileEnv && !strcmp(tileEnv, "blocks2"));
-    const uint64_t nbm = (uint64_t)(n / 64) * batch; // workgroups of the panel kernel: 64 rows of one matrix each
+    // COAST_MM_TILE=panel128 (round 6): mm_mfma_blk4_kernel -- a workgroup owns 128 rows (two column-tile lanes x four row quarters), s is
+    // converted twice per matrix instead of four times.  TMR without physical-register upsets (those name mm_mfma_blk3_kernel's registers)
+    bool havePhysEarly = false;
+    for (const coast_fault &af : c->armed)
+        havePhysEarly = havePhysEarly || af.site == COAST_SITE_MM_VGPR || af.site == COAST_SITE_MM_PREG;
+    const bool mmPanel128 = mfma && cfg->replicas == 3 && tileEnv && !strcmp(tileEnv, "panel128") && !havePhysEarly;
+    if (mmPanel128)
+        h.panelRows = MmBlk4::BM;
+    const uint64_t nbm = (uint64_t)(n / h.panelRows) * batch; // workgroups' panels: 64 (128) rows of one matrix each
     if (mfma && nbm > 0x7fffffffull)
         return fail(c, COAST_EINVAL, "coast_mm_batch: %llu workgroups exceed the grid limit", (unsigned long long)nbm);
 
@@ -911,8 +922,35 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
         else                                                                                                    \
             LAUNCH_BLK3_ONE(R, false, 0, false);                                                                \
     } while (0)
+#define LAUNCH_BLK4_ONE(FL, CL)                                                                                 \
+    do {                                                                                                        \
+        HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk4_kernel<FL, CL>,                               \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)MmBlk4::LDS_BYTES));    \
+        hipLaunchKernelGGL((mm_mfma_blk4_kernel<FL, CL>), dim3(gridP), dim3(MmBlk4::NTHR), MmBlk4::LDS_BYTES,   \
+                           c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);                    \
+    } while (0)
 #define LAUNCH_MM(R)                                                                                            \
     do {                                                                                                        \
+        if (mmPanel128 && R == 3) { /* TMR on a 128-row panel: two workgroups (one XCD) share a matrix */       \
+            FaultTab ftm = ft;                                                                                  \
+            if (!have)                                                                                          \
+                ftm.list = nullptr, ftm.range = nullptr;                                                        \
+            const uint32_t gridP = 2u * (uint32_t)std::min<uint64_t>((uint64_t)batch, (uint64_t)std::max(1, c->numCUs / 2)); \
+            if (have)                                                                                           \
+                hookedBlocks = nFaultBlocks;                                                                    \
+            if (cloneStaging) {                                                                                 \
+                if (d_detected)                                                                                 \
+                    LAUNCH_BLK4_ONE(true, true);                                                                \
+                else                                                                                            \
+                    LAUNCH_BLK4_ONE(false, true);                                                               \
+            } else if (d_detected)                                                                              \
+                LAUNCH_BLK4_ONE(true, false);                                                                   \
+            else                                                                                                \
+                LAUNCH_BLK4_ONE(false, false);                                                                  \
+            engine = COAST_ENGINE_MATRIX_CORE;                                                                  \
+            fastBlocks = nbm;                                                                                   \
+            break;                                                                                              \
+        }                                                                                                       \
         if (mfma && R == 3 && mmBlocks) { /* TMR: replicas in register blocks */              \
             FaultTab ftm = ft;                                                                                  \
             if (!have)                                                                                          \

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 const uint32_t sw = ftWord(q, 2), packed = ftWord(q, 3);
                 if (((packed >> 8) & 0xffu) == (uint32_t)SITE_MM_PREG && ((sw >> 16) & 7u) == (uint32_t)wv) {
                     pregKey = sw & 0x3ffu;
-                    pregSel = (sw >> 19) & 0x3ffu;
+                    pregSel = (((sw >> 19) & 1u) << 9) | ((sw >> 20) & 511u); // file << 9 | register (the step word packs file << 19 | register << 20)
                     pregLaneBit = ((sw >> 10) & 63u) | (((packed >> 16) & 31u) << 8);
                 }
             }

@@ -260,7 +260,10 @@ __device__ __forceinline__ void block_fold(const Counters &ctr, uint32_t slotKey
         // atomics execute in one L2 channel, in order) has its value back before the ticket is drawn.  (+ 0 on the counter words themselves
         // would do, but the compiler turns an idempotent atomic into a load.)
         unsigned long long *mine = ctr.slots + (size_t)(slotKey % kCounterSlots) * kSlotStride;
-        const unsigned long long r = atomicAdd(mine + 3, 1ull);
+        // (an exchange with 0: returning, not idempotent for the compiler, and the pad word stays 0 -- ADVICE r5: an add of 1 accumulated there.
+        // On gfx9 the s_waitcnt vmcnt(0) behind it also covers the non-returning slot atomics by itself -- they count in vmcnt until the L2
+        // acknowledges them --, so the order holds twice over.)
+        const unsigned long long r = atomicExch(mine + 3, 0ull);
         asm volatile("s_waitcnt vmcnt(0)" ::"v"(r) : "memory");
         *s_flag = atomicAdd(ctr.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
     }

@@ -487,7 +487,7 @@ def test_crc16_faults_vs_oracle(eng, orc, block_len, replicas, sync_every):
 
 
 # ------------------------------------------------------------------------------------------------ common-mode upsets (COAST_REPLICA_ALL)
-@pytest.mark.parametrize("tile", ["blocks3", "blocks2", "lanes"])
+@pytest.mark.parametrize("tile", ["blocks3", "blocks2", "lanes", "panel128"])
 def test_mm_256_common_mode_upsets_are_silent_data_corruption(eng, orc, tile, monkeypatch):
     """the matrix-core kernels share the A operand (and the s words on their way into LDS) between the
     replicas.  COAST_REPLICA_ALL arms the same flip in every replica's copy: all copies agree, the voter passes the wrong word,
@@ -2997,8 +2997,8 @@ def test_mm_256_register_block_kernel_dwc_and_unprotected(eng, orc, batch, repli
     assert (out["default"][0].cpu().numpy().view(np.uint32).reshape(-1)[items.astype(np.int64)] == want).all()
 
 
-@pytest.mark.parametrize("tile", ["blocks3", "blocks2"])
-@pytest.mark.parametrize("batch", [1, 2, 5, 63, 64, 65, 130, 200])
+@pytest.mark.parametrize("tile", ["blocks3", "blocks2", "panel128", "panel128+clones"])
+@pytest.mark.parametrize("batch", [1, 2, 5, 63, 64, 65, 127, 128, 129, 130, 200, 300])
 def test_mm_256_register_block_kernel_batch_shapes(eng, orc, batch, tile, monkeypatch):
     """the persistent TMR kernels (two waves per SIMD: blocks3 -- the default, every loaded operand replicated -- and blocks2, one A
     fragment set for the three replicas; a workgroup =
@@ -3020,16 +3020,19 @@ def test_mm_256_register_block_kernel_batch_shapes(eng, orc, batch, tile, monkey
             for it in items]
     fl = ca.make_faults(rows)
     det = torch.zeros(batch * n * n, dtype=torch.uint8, device="cuda")
-    monkeypatch.setenv("COAST_MM_TILE", tile)
+    # round 6: panel128 = mm_mfma_blk4_kernel (a workgroup owns 128 rows: panel position of matrices m, m + 128, ...; the f panel is replaced
+    # region by region across an item hand-over -- batches above 128 give workgroups several items), with and without its cloned staging loads
+    monkeypatch.setenv("COAST_MM_TILE", tile.split("+")[0])
+    cfg = ca.XmrConfig(ca.TMR, 0, ca.F_CLONE_STAGING if tile.endswith("+clones") else 0)
     eng.reset_stats()
     eng.inject_faults(fl)
-    r = eng.mm_batch(f, s, detected=det)
+    r = eng.mm_batch(f, s, detected=det, cfg=cfg)
     st = eng.stats()
     assert eng.last_launch()["engine"] == "matrix_core" and eng.last_launch()["general_blocks"] == 0
     # the same launch without the per-item flag array (the other template instance: no flag stores)
     eng.reset_stats()
     eng.inject_faults(fl)
-    r0 = eng.mm_batch(f, s)
+    r0 = eng.mm_batch(f, s, cfg=cfg)
     assert torch.equal(r, r0) and _stats3(eng.stats()) == _stats3(st)
     monkeypatch.setenv("COAST_MM_TILE", "lanes")
     det2 = torch.zeros_like(det)
@@ -3054,6 +3057,57 @@ def _uniform_campaign(argv):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod.run_uniform_campaign(mod.parse(["-b", "mm", "--side", "256", "--reg-model", "uniform", "-n"] + argv))
+
+
+def test_mm_preg_upset_lands_on_the_register_it_names(eng):
+    """COAST_SITE_MM_PREG packs `file << 19 | register << 20` into coast_fault.step; round 5's kernel read the selector
+    from bit 19 on and used (register << 1 | file) & 511 as the VGPR index -- a draw of vR flipped v[2R mod 256] and the scalar path never ran.
+    Pinned on registers whose effect is known without a model: the ACCUMULATORS of the kernel, read out of the running library's own code
+    object (tools/campaign.py:kernel_accumulator_vgprs).  One lane of one accumulator register, flipped in the middle of a tile, moves
+    exactly ONE output word by +-2^(bit + 8 t) (t = the limb the register sums) in the unprotected kernel, and is exactly ONE out-voted,
+    counted vote under TMR -- for odd and even register numbers alike, and for registers whose double is NOT an accumulator (the old decode
+    would have flipped that one)."""
+    import importlib.util
+    import os
+
+    import torch
+
+    import coast_amd as ca
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("coast_campaign_preg", os.path.join(root, "tools", "campaign.py"))
+    camp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(camp)
+    n, nn = 256, 256 * 256
+    g = torch.Generator(device="cuda").manual_seed(606)
+    f = torch.randint(-2**31, 2**31, (1, n, n), dtype=torch.int32, device="cuda", generator=g)
+    s = torch.randint(-2**31, 2**31, (1, n, n), dtype=torch.int32, device="cuda", generator=g)
+    gold = eng.mm_batch(f, s, cfg=ca.XmrConfig(ca.UNPROTECTED)).clone()
+    for mode, clone in ((ca.UNPROTECTED, False), (ca.TMR, False), (ca.TMR, True)):
+        acc = camp.kernel_accumulator_vgprs(mode, clone)
+        assert len(acc) >= 16 * mode, (mode, clone, acc)
+        accs = set(acc)
+        # registers whose alias under the old decode -- v[2R mod 256] -- is no accumulator, odd and even ones, low and high numbers
+        tell = [r for r in acc if (2 * r) % 256 not in accs]
+        picks = sorted(set(tell[:3] + tell[-3:] + [r for r in acc if r % 2][:2] + [r for r in acc if r % 2 == 0][-2:]))
+        assert len(picks) >= 4 and any(r % 2 for r in picks) and any(r % 2 == 0 for r in picks)
+        for k, reg in enumerate(picks):
+            bit, lane, wave, panel = (3 + 5 * k) % 8, (7 * k + 1) % 64, k % 8, k % 4  # (bit < 8: bit + 8 t < 32 for every limb t -- the flip is visible mod 2^32)
+            d = {"file": 0, "reg": reg, "lane": lane, "bit": bit, "wave": wave, "panel": panel, "step": 6, "slot": 30 % (20 * mode)}
+            eng.reset_stats()
+            eng.inject_faults(ca.make_faults([camp.preg_row(64 * panel * n, d)]))
+            det = torch.zeros(nn, dtype=torch.uint8, device="cuda")
+            out = eng.mm_batch(f, s, cfg=ca.XmrConfig(mode, 0, ca.F_CLONE_STAGING if clone else 0), detected=det)
+            st = eng.stats()
+            wrong = (out != gold).nonzero()
+            if mode == ca.UNPROTECTED:
+                assert wrong.shape[0] == 1, (reg, wrong.shape)
+                _, i, j = (int(x) for x in wrong[0])
+                delta = (int(out[0, i, j]) - int(gold[0, i, j])) % 2**32
+                assert delta in {(sgn * (1 << (bit + 8 * t))) % 2**32 for t in range(4) for sgn in (1, -1) if bit + 8 * t < 32} | {0x80000000}, (reg, bit, hex(delta))
+                assert 64 * panel <= i < 64 * panel + 64  # the panel the upset named
+            else:
+                assert wrong.shape[0] == 0 and st["errors_corrected"] == 1 and int(det.sum()) == 1, (reg, wrong.shape, st)
 
 
 def test_campaign_uniform_register_file_mm256():

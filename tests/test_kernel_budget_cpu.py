@@ -166,18 +166,21 @@ def test_injector_hooks_cost_the_lean_kernels_nothing(compiled):
 
 
 def test_in_kernel_counter_fold_orders_by_atomics_not_by_an_l2_write_back(compiled):
-    """round 5, block_fold (xmr.hpp; COAST_AES_FOLD=1): the last workgroup out of a persistent aes kernel folds the counter slots.  Its
+    """round 5, block_fold (xmr.hpp; the default since round 6, COAST_AES_FOLD=0 takes it out): the last workgroup out of a persistent aes kernel folds the counter slots.  Its
     ordering is a returning atomic on the slot's own line in front of the ticket -- a `__threadfence()` there is `buffer_wbl2` on gfx950,
     a write-back of an L2 full of the launch's own output: + 8 us on a 60 us kernel (profiles/r05_aes_step.txt).  Holds that at build
     time: the fold is compiled into both kernels (three read-and-clear exchanges), and no L2 write-back is."""
     _, bodies = compiled
     for name in ("void coast::aes128_enc_rep_kernel<2>", "void coast::aes128_dec_rep_kernel<2>"):
         b = _find(bodies, name)
-        assert len(re.findall(r"global_atomic_swap_x2", b)) == 3, name
+        # three read-and-clear exchanges of the fold + the returning exchange on the slot line's pad word (round 6: an exchange with 0 -- the
+        # pad stays 0 -- where round 5 added 1)
+        assert len(re.findall(r"global_atomic_swap_x2", b)) == 4, name
         assert "buffer_wbl2" not in b and "buffer_inv" not in b, name
-        # the slot line's returning add (sc0) sits in front of the ticket's returning add
-        i_line, i_ticket = b.find("global_atomic_add_x2 v["), b.find("global_atomic_add v")
+        # the slot line's returning exchange (sc0) sits in front of the ticket's returning add, an s_waitcnt vmcnt(0) between them
+        i_line, i_ticket = b.find("global_atomic_swap_x2 v["), b.find("global_atomic_add v")
         assert 0 < i_line < i_ticket and "sc0" in b[i_line:b.find("\n", i_line)] and "sc0" in b[i_ticket:b.find("\n", i_ticket)], name
+        assert "s_waitcnt vmcnt(0)" in b[i_line:i_ticket], name
 
 
 def test_bench_lookup_counts_match_the_compiled_kernels():

@@ -584,13 +584,9 @@ def uniform_draw(rng, n_vgpr=256, n_sgpr=102):
 PHYS_KERNEL = "_ZN5coast19mm_mfma_blk3_kernelILi%dELb1ELi2ELb%dEEEvPKjS2_PjjNS_8CountersENS_8FaultTabEPh"  # mm_mfma_blk3_kernel<replicas, true, 2, clone>
 
 
-def kernel_registers(replicas, clone=False):
-    """(VGPRs, SGPRs the kernel allocates, the VGPRs it spills scalar registers into) of mm_mfma_blk3_kernel<replicas, true, 2, clone>, read
-    from the code object inside the very library that runs (the bundle in its .hip_fatbin) with the image's llvm-readelf / llvm-objdump: no
-    allocation map to keep in step with the compiler.  The spill registers (v_writelane_b32 / v_readlane_b32): a lane of such a register IS a
-    scalar register -- a descriptor word, a kernel-argument pointer, a loop counter -- and an upset there belongs to the scalar class (it can
-    send an access anywhere in the address space)."""
-    import re
+def _kernel_text(sym):
+    """(disassembly, metadata notes) of one kernel of the library that runs: the gfx950 code object out of the bundle in its .hip_fatbin,
+    through the image's llvm-objdump / llvm-readelf"""
     import struct
     import subprocess
     import tempfile
@@ -613,7 +609,6 @@ def kernel_registers(replicas, clone=False):
     if co is None:
         raise SystemExit("campaign: no gfx950 code object in %s" % path)
     llvm = "/opt/rocm/lib/llvm/bin/"
-    sym = PHYS_KERNEL % (replicas, int(bool(clone)))
     with tempfile.NamedTemporaryFile(suffix=".co") as fh:
         fh.write(co)
         fh.flush()
@@ -622,11 +617,38 @@ def kernel_registers(replicas, clone=False):
         notes = subprocess.run([llvm + "llvm-readelf", "--notes", fh.name], capture_output=True, text=True, check=True).stdout
     if "v_mfma" not in text:
         raise SystemExit("campaign: %s not found in the code object" % sym)
+    return text, notes
+
+
+def kernel_registers(replicas, clone=False):
+    """(VGPRs, SGPRs the kernel allocates, the VGPRs it spills scalar registers into) of mm_mfma_blk3_kernel<replicas, true, 2, clone>, read
+    from the code object inside the very library that runs (the bundle in its .hip_fatbin) with the image's llvm-readelf / llvm-objdump: no
+    allocation map to keep in step with the compiler.  The spill registers (v_writelane_b32 / v_readlane_b32): a lane of such a register IS a
+    scalar register -- a descriptor word, a kernel-argument pointer, a loop counter -- and an upset there belongs to the scalar class (it can
+    send an access anywhere in the address space)."""
+    import re
+
+    sym = PHYS_KERNEL % (replicas, int(bool(clone)))
+    text, notes = _kernel_text(sym)
     rec = [blk for blk in notes.split("  - .agpr_count:") if ".name:           " + sym + "\n" in blk]
     if len(rec) != 1:
         raise SystemExit("campaign: no metadata record of %s" % sym)
     nv, ns = int(re.search(r"\.vgpr_count:\s+(\d+)", rec[0]).group(1)), int(re.search(r"\.sgpr_count:\s+(\d+)", rec[0]).group(1))
     return nv, min(ns, 102), sorted({int(m) for m in re.findall(r"v_writelane_b32\s+v(\d+)", text)})
+
+
+def kernel_accumulator_vgprs(replicas, clone=False):
+    """the vector registers mm_mfma_blk3_kernel<replicas, true, 2, clone> accumulates its limb sums in: every register of a v_mfma's
+    destination tuple that is also its addend tuple (`v_mfma_i32_16x16x64_i8 v[a:b], ., ., v[a:b]`), read from the running library's own
+    code object.  An upset of one lane of one of them in the middle of a tile moves exactly one output word (tests: the PREG decode)."""
+    import re
+
+    text, _ = _kernel_text(PHYS_KERNEL % (replicas, int(bool(clone))))
+    acc = set()
+    for m in re.finditer(r"v_mfma_i32_16x16x64_i8\s+v\[(\d+):(\d+)\],\s*v\[\d+:\d+\],\s*v\[\d+:\d+\],\s*v\[(\d+):(\d+)\]", text):
+        if m.group(1) == m.group(3) and m.group(2) == m.group(4):
+            acc.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return sorted(acc)
 
 
 def preg_row(item, d):
