@@ -74,8 +74,8 @@ def parse():
     ap.add_argument("--profile-every", type=int, default=0,
                     help="bracket every n-th launch with HIP timing events (its time counted n times) instead of the workload's own period")
     ap.add_argument("--single-staging", action="store_true",
-                    help="mm: run WITHOUT COAST_F_CLONE_STAGING -- the matrix-core kernel's global -> LDS staging loads not cloned (10 %% faster, "
-                         "95.7 instead of 98.3 %% coverage of register upsets); the headline is quoted on the cloned form (VERDICT r4 item 1)")
+                    help="mm: run with COAST_F_SINGLE_STAGING -- the matrix-core kernel's global -> LDS staging loads not cloned (6 %% faster, lower "
+                         "coverage of register upsets: docs/design/campaign.md); the headline is quoted on the cloned form, the library's default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline workload only")
     return ap.parse_args()
@@ -254,12 +254,13 @@ class MM(Workload):
         self.f = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device=dev, generator=g)
         self.s = torch.randint(-2**31, 2**31, (batch, n, n), dtype=torch.int32, device=dev, generator=g)
         self.r = torch.empty_like(self.f)
-        # The headline is quoted on the PROTECTED form: COAST_F_CLONE_STAGING, the matrix-core kernel's global -> LDS
-        # staging loads cloned, compared, a third load deciding -- what the pass does to every load (cloning.cpp:2187-2209, 2247-2255).  It
-        # costs 10 % kernel time and takes the coverage of single-bit register upsets from 95.7 to 98.3 % (tools/campaign.py --reg-model
-        # uniform, 2 x 5000 runs).  --single-staging / extra.mm_single_staging: the library's unflagged default, one staging register set.
+        # The headline is quoted on the PROTECTED form -- the library's default since ABI 8: the
+        # matrix-core kernel's global -> LDS staging loads cloned, compared, a third load deciding -- what the pass does to every load
+        # (cloning.cpp:2187-2209, 2247-2255).  It costs 6 % kernel time in mm_mfma_blk4_kernel (profiles/r06_mm_blk4_ab.txt); the coverage of
+        # single-bit register upsets with and without it: docs/design/campaign.md.  --single-staging / extra.mm_single_staging:
+        # COAST_F_SINGLE_STAGING, one staging register set.
         self.clone = not bool(getattr(a, "single_staging", False)) and self.n == 256
-        self.cfg = coast_amd.XmrConfig(coast_amd.TMR, 0, coast_amd.F_CLONE_STAGING if self.clone else 0)
+        self.cfg = coast_amd.XmrConfig(coast_amd.TMR, 0, 0 if self.clone else coast_amd.F_SINGLE_STAGING)
         self.eng, self.ca = eng, coast_amd
         # one accumulator upset in one replica of K distinct output elements: each must be out-voted and counted once
         rng = np.random.default_rng(99 + rank)
@@ -318,11 +319,12 @@ class MM(Workload):
 
     @staticmethod
     def tile():
-        """blocks3 (default): mm_mfma_blk3_kernel (replica = accumulator block, in-lane vote, two waves per SIMD, every loaded operand
-        replicated: a replica's MFMAs read their own A and B fragments); blocks2: mm_mfma_blk2_kernel (one A fragment set for the three
-        replicas, COAST_MM_TILE=blocks2); lanes: mm_mfma_panel_kernel (the replicas in adjacent lanes, north_star's layout)"""
+        """panel128 (default since round 6): mm_mfma_blk4_kernel (a workgroup owns 128 rows: two column-tile lanes x four row quarters, s
+        converted twice per matrix; replica = accumulator block, in-lane vote, two waves per SIMD, every loaded operand replicated);
+        blocks3: mm_mfma_blk3_kernel (the same on a 64-row panel, rounds 4-5's default); blocks2: mm_mfma_blk2_kernel (one A fragment set
+        for the three replicas); lanes: mm_mfma_panel_kernel (the replicas in adjacent lanes, north_star's layout)"""
         t = os.environ.get("COAST_MM_TILE")
-        return t if t in ("lanes", "blocks2", "panel128") else "blocks3"
+        return t if t in ("lanes", "blocks2", "blocks3") else "panel128"
 
     def roofline(self, kern_ms):
         n, batch = self.n, self.batch
@@ -355,8 +357,8 @@ class MM(Workload):
                             "in three accumulator blocks of the same lane, voted in-lane; "
                             + ("every replica's MFMAs read their own A and B fragments from LDS (the loads are replicated, the memory is "
                                "not: cloning.cpp:2187-2209, 2247-2255); " + ("the global -> LDS staging loads are cloned too and compared "
-                               "in front of their first use (COAST_F_CLONE_STAGING; + 10 % kernel time); " if self.clone else
-                               "ONE staging register set on the way into LDS (no COAST_F_CLONE_STAGING); ") if self.tile() in ("blocks3", "panel128") else
+                               "in front of their first use (the default; + 6 % kernel time); " if self.clone else
+                               "ONE staging register set on the way into LDS (COAST_F_SINGLE_STAGING); ") if self.tile() in ("blocks3", "panel128") else
                                "own B-operand registers and MFMAs per replica, ONE A fragment set for the three; ")
                             + ("two waves per SIMD, each with half the tile's rows (96 accumulator registers)" if two else
                                "one wave per SIMD (192 accumulator registers)") +
@@ -902,10 +904,12 @@ def extra_legs(a, eng, dist, dev, rank, world, coast_amd):
             legs[name] = result_fields(wl, run, b, world, steps, warm, with_cpu=(world == 1 and not a.no_cpu_baseline))
         wl.free()
     if world == 1:
-        # the headline's variants: one staging register set (the library's unflagged default: no clones), the armed
+        # the headline's variants: one staging register set (COAST_F_SINGLE_STAGING: no clones), the armed
         # upsets as REAL register flips (the kernel's PHYS instantiation), north_star's replica layout (three adjacent lanes, cross-lane voter:
         # COAST_MM_TILE=lanes), and COAST's default mode (memory replicated)
         for name, cls, over, env in (("mm_single_staging", MM, {"batch": 8192, "single_staging": True}, {}),
+                                     # rounds 4-5's kernel (64-row panel) in the form the round-5 line was quoted on
+                                     ("mm_blocks3_clones", MM, {"batch": 8192}, {"COAST_MM_TILE": "blocks3"}),
                                      ("mm_physical_upsets", MM, {"mm_phys": True, "batch": 8192, "single_staging": True}, {}),
                                      ("mm_lane_replicas", MM, {"batch": 8192, "single_staging": True}, {"COAST_MM_TILE": "lanes"}),
                                      ("mm_default_mode", MMDefaultMode, {"batch": 8192}, {})):

@@ -5,7 +5,7 @@ the thin host-side mirror of the reference's interface for that path: the protec
 names (matrix_multiply, sha256_hash, aes_enc_dec, crc16), the batch engine, the fault injector and the multi-GPU
 counter reduction.  Nothing here computes on the CPU.
 """
-from .engine import (DWC, F_ADDR_SYNC, F_BRANCH_SYNC, F_CLONE_STAGING, F_LOCAL_STORE_SYNC, F_MEMORY_COPIES, F_NO_LOAD_SYNC, F_NO_STORE_ADDR_SYNC, F_O0_SHAPE,  # noqa: F401
+from .engine import (DWC, F_ADDR_SYNC, F_BRANCH_SYNC, F_CLONE_STAGING, F_SINGLE_STAGING, F_LOCAL_STORE_SYNC, F_MEMORY_COPIES, F_NO_LOAD_SYNC, F_NO_STORE_ADDR_SYNC, F_O0_SHAPE,  # noqa: F401
                      F_NO_STORE_DATA_SYNC, TMR, UNPROTECTED, Engine, XmrConfig, make_faults)
 from .hostapi import (FaultDetectedDWC, aes_enc_dec, crc16, host_stats, matrix_multiply,  # noqa: F401
                       sha256_hash)

@@ -730,14 +730,15 @@ bool decode_mm_indexed(const coast_fault &f, const void *gp, DevFault &d)
 extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t *d_s, uint32_t *d_r, int n,
                               size_t batch, const coast_cfg *cfgIn, uint8_t *d_detected)
 {
-    // COAST_F_CLONE_STAGING is a property of the matrix-core kernel's staging path, not a sync-point rule: it selects no stepwise kernel and
-    // the rule checks below do not see it
+    // COAST_F_CLONE_STAGING / COAST_F_SINGLE_STAGING are properties of the matrix-core kernels' staging path, not sync-point rules: they
+    // select no stepwise kernel and the rule checks below do not see them.  Cloned is the default for replicas >= 2 (ABI 8): the pass clones
+    // every load (cloning.cpp:2187-2209, 2247-2255)
     coast_cfg cfgRules{};
     bool cloneStaging = false;
     if (cfgIn) {
         cfgRules = *cfgIn;
-        cloneStaging = (cfgIn->flags & COAST_F_CLONE_STAGING) != 0 && cfgIn->replicas > 1;
-        cfgRules.flags &= ~(uint32_t)COAST_F_CLONE_STAGING;
+        cloneStaging = cfgIn->replicas > 1 && (cfgIn->flags & COAST_F_SINGLE_STAGING) == 0;
+        cfgRules.flags &= ~(uint32_t)(COAST_F_CLONE_STAGING | COAST_F_SINGLE_STAGING);
     }
     const coast_cfg *cfg = cfgIn ? &cfgRules : nullptr;
     int rc = check_cfg(c, cfg, true);
@@ -833,12 +834,15 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     // default (round 4): mm_mfma_blk3_kernel -- blocks2's geometry with every loaded operand replicated (a replica's MFMAs read their
     // own A fragments); COAST_MM_TILE=blocks2 selects mm_mfma_blk2_kernel (one A fragment set for the three replicas)
     const bool mmBlocks3 = !(tileEnv && !strcmp(tileEnv, "blocks2"));
-    // COAST_MM_TILE=panel128 (round 6): mm_mfma_blk4_kernel -- a workgroup owns 128 rows (two column-tile lanes x four row quarters), s is
-    // converted twice per matrix instead of four times.  TMR without physical-register upsets (those name mm_mfma_blk3_kernel's registers)
-    bool havePhysEarly = false;
+    // mm_mfma_blk4_kernel (round 6): a workgroup owns 128 rows (two column-tile lanes x four row quarters), s is converted twice per matrix
+    // instead of four times.  TMR without physical-register upsets (those name mm_mfma_blk3_kernel's registers)
+    // (COAST_SITE_MM_VGPR names mm_mfma_blk3_kernel's registers: such a launch runs there; COAST_SITE_MM_PREG -- any physical register -- has
+    // an instantiation in both kernels)
+    bool haveVgprEarly = false;
     for (const coast_fault &af : c->armed)
-        havePhysEarly = havePhysEarly || af.site == COAST_SITE_MM_VGPR || af.site == COAST_SITE_MM_PREG;
-    const bool mmPanel128 = mfma && cfg->replicas == 3 && tileEnv && !strcmp(tileEnv, "panel128") && !havePhysEarly;
+        haveVgprEarly = haveVgprEarly || af.site == COAST_SITE_MM_VGPR;
+    // (the default TMR kernel since round 6; COAST_MM_TILE=blocks3 | blocks2 | lanes select the older ones)
+    const bool mmPanel128 = mfma && cfg->replicas == 3 && (!tileEnv || !*tileEnv || !strcmp(tileEnv, "panel128")) && !haveVgprEarly;
     if (mmPanel128)
         h.panelRows = MmBlk4::BM;
     const uint64_t nbm = (uint64_t)(n / h.panelRows) * batch; // workgroups' panels: 64 (128) rows of one matrix each
@@ -922,11 +926,11 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
         else                                                                                                    \
             LAUNCH_BLK3_ONE(R, false, 0, false);                                                                \
     } while (0)
-#define LAUNCH_BLK4_ONE(FL, CL)                                                                                 \
+#define LAUNCH_BLK4_ONE(FL, CL, PH)                                                                             \
     do {                                                                                                        \
-        HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk4_kernel<FL, CL>,                               \
+        HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_blk4_kernel<FL, CL, PH>,                           \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)MmBlk4::LDS_BYTES));    \
-        hipLaunchKernelGGL((mm_mfma_blk4_kernel<FL, CL>), dim3(gridP), dim3(MmBlk4::NTHR), MmBlk4::LDS_BYTES,   \
+        hipLaunchKernelGGL((mm_mfma_blk4_kernel<FL, CL, PH>), dim3(gridP), dim3(MmBlk4::NTHR), MmBlk4::LDS_BYTES, \
                            c->stream, d_f, d_s, d_r, (uint32_t)batch, ctr, ftm, d_detected);                    \
     } while (0)
 #define LAUNCH_MM(R)                                                                                            \
@@ -939,14 +943,18 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
             if (have)                                                                                           \
                 hookedBlocks = nFaultBlocks;                                                                    \
             if (cloneStaging) {                                                                                 \
-                if (d_detected)                                                                                 \
-                    LAUNCH_BLK4_ONE(true, true);                                                                \
+                if (havePreg) /* (the physical-upset instantiation always carries the per-item flags) */        \
+                    LAUNCH_BLK4_ONE(true, true, 2);                                                             \
+                else if (d_detected)                                                                            \
+                    LAUNCH_BLK4_ONE(true, true, 0);                                                             \
                 else                                                                                            \
-                    LAUNCH_BLK4_ONE(false, true);                                                               \
-            } else if (d_detected)                                                                              \
-                LAUNCH_BLK4_ONE(true, false);                                                                   \
+                    LAUNCH_BLK4_ONE(false, true, 0);                                                            \
+            } else if (havePreg)                                                                                \
+                LAUNCH_BLK4_ONE(true, false, 2);                                                                \
+            else if (d_detected)                                                                                \
+                LAUNCH_BLK4_ONE(true, false, 0);                                                                \
             else                                                                                                \
-                LAUNCH_BLK4_ONE(false, false);                                                                  \
+                LAUNCH_BLK4_ONE(false, false, 0);                                                               \
             engine = COAST_ENGINE_MATRIX_CORE;                                                                  \
             fastBlocks = nbm;                                                                                   \
             break;                                                                                              \

@@ -254,12 +254,11 @@ void coast_dropin_matrix_multiply(const void *f, const void *s, void *r, int sid
     if (cfg.flags & (COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC))
         cfg.sync_every = 0u; /* every loop condition is a sync point already */
     {
-        /* side 256 on the matrix cores: the staging loads cloned and compared (COAST_F_CLONE_STAGING) -- what the pass does to every load of the
-         * region (cloning.cpp:2187-2209), so the drop-in does it unless COAST_CLONE_STAGING=0 says otherwise (a single call is latency-bound: the
-         * flag's 10 % of kernel time do not show) */
+        /* side 256 on the matrix cores: the staging loads are cloned and compared -- what the pass does to every load of the region
+         * (cloning.cpp:2187-2209) and the library's default since ABI 8; COAST_CLONE_STAGING=0 opts out (COAST_F_SINGLE_STAGING) */
         const char *cl = getenv("COAST_CLONE_STAGING");
-        if (!(cl && *cl == '0') && cfg.replicas > 1u)
-            cfg.flags |= COAST_F_CLONE_STAGING;
+        if (cl && *cl == '0')
+            cfg.flags |= COAST_F_SINGLE_STAGING;
     }
     dropin_maybe_inject();
     const int rc = coast_matrix_multiply_host((const uint32_t *)f, (const uint32_t *)s, (uint32_t *)r, side, &cfg);

@@ -8,8 +8,8 @@
 //   * A slab (64 k x 16 columns) of a lane is converted by the lane's four waves TOGETHER, a quarter each (16 k x 16 columns: one group of
 //     four k of one column per thread), in the first half of the step in front of the one that multiplies it.  Every wave runs the same
 //     code: the row quarter and the lane are wave-uniform run-time values (one instruction stream for the eight waves; mm_mfma_blk3_kernel
-//     has two).  Per wave and step: 5 conversion stages instead of 10, four one-word raw loads (two register sets of four words, requested
-//     two steps ahead) instead of sixteen words in flight.
+//     has two).  Per wave and step: 5 conversion stages instead of 10, four one-word raw loads (one register set of four words, requested a
+//     step ahead) instead of sixteen words in flight.
 //   * The f panel is 128 rows x 256 k x 4 byte planes = 128 KB: single-buffered (160 KB of LDS hold it and the lanes' two slab buffers).
 //     The next matrix's panel replaces it REGION BY REGION -- region s = k-slab s of all 128 rows, 32 KB, four 16-byte pieces per thread --
 //     each region behind the barrier that follows its last read (step s of the matrix's last column tile) and in front of the barrier that
@@ -22,18 +22,27 @@
 //     wave-uniform `real` predicate.
 //   * CLONE (COAST_F_CLONE_STAGING; cloning.cpp:2187-2209, 2247-2255): every raw word of s and f is loaded a second time and compared in
 //     front of the first instruction that consumes it; a mismatch loads it a third time and keeps select(a == b, a, c).  The clone of an s
-//     word is requested half a step ahead of its compare, the clone of an f piece right behind the original.
+//     word and of an f piece is requested right behind the original (the line the original just fetched).
 //
-// TMR only: DWC and the unprotected mode stay on mm_mfma_blk3_kernel<2 / 1>; so do the physical-register upset sites
-// (COAST_SITE_MM_VGPR / _PREG), which name that kernel's registers.
+// TMR only: DWC and the unprotected mode stay on mm_mfma_blk3_kernel<2 / 1>; so does COAST_SITE_MM_VGPR, which names that kernel's registers.
+// PHYS == 2: COAST_SITE_MM_PREG as in mm_mfma_blk3_kernel -- a real exclusive-or on ANY physical register of a wave (v0..v255 through the VGPR
+// index mode, s0..s101 through s_movrels / s_movreld) in front of any MFMA slot of any of an item's 32 steps (coast_fault.step: slot | step % 16
+// << 6 | lane << 10 | wave << 16 | file << 19 | register << 20 | step / 16 << 29), the compiler knowing nothing of it: an instantiation of its
+// own (60 hook points per step body), the vehicle of tools/campaign.py --reg-model uniform --kernel panel128.
 #include <type_traits>
 #include <utility>
 
 #include "xmr.hpp"
 
-// development: 0 = clone loads of s half a step ahead of the compare (one clone set); 1 = right behind the original (two clone sets)
+// 0 = clone loads of s half a step ahead of the compare; 1 (shipped) = right behind the original: the clone hits the line the original just
+// fetched (profiles/r06_mm_blk4_ab.txt: 6.87 -> 6.84 ms)
 #ifndef COAST_MM4_DUP_ADJ
-#define COAST_MM4_DUP_ADJ 0
+#define COAST_MM4_DUP_ADJ 1
+#endif
+// register sets of raw s words per wave (2: requested two steps ahead of their conversion; 1 (shipped): one step ahead, four registers fewer --
+// the clone form 7.03 -> 6.87 ms, profiles/r06_mm_blk4_ab.txt)
+#ifndef COAST_MM4_SETS
+#define COAST_MM4_SETS 1
 #endif
 // development: conversion stage stride in the steps without f work (6: spread over the half step; 2: the first ten slots)
 #ifndef COAST_MM4_CONV_STRIDE
@@ -48,14 +57,16 @@ struct MmBlk4 {
     static constexpr int NLANE = 2, NQ = 4, NW = NLANE * NQ, NTHR = 64 * NW; // two column-tile lanes x four row quarters
     static constexpr int BM = 128, NPANEL = N / BM;
     static constexpr int NCT = N / CT, TPW = NCT / NLANE, SPP = TPW * NSLAB; // 8 tiles, 32 steps per panel
-    static constexpr int PLANE_A = BM * N, A_PANEL = 4 * PLANE_A;           // 128 KB, single-buffered
+    // f panel: [row][byte plane][256 B] -- a row's four planes side by side, so that every fragment address of a step is one register + a 16-bit
+    // instruction offset (plane-major planes of 32 KB put planes 2 and 3 beyond it: two v_add_u32 per set of ten MFMAs)
+    static constexpr int PLANE_A = N, ROW_A = 4 * N, A_PANEL = BM * ROW_A;   // 128 KB, single-buffered
     static constexpr int PLANE_B = CT * KS, B_BUF = 4 * PLANE_B;
     static constexpr int LANE_LDS = 2 * B_BUF;
     static constexpr size_t LDS_BYTES = (size_t)A_PANEL + NLANE * LANE_LDS; // 144 KB
     static constexpr int A_PER_THR = (BM * (N / 4)) / NTHR;                 // 16 pieces per thread and panel
 };
 
-template <bool FLAGS, bool CLONE>
+template <bool FLAGS, bool CLONE, int PHYS = 0>
 __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uint32_t *__restrict__ F, const uint32_t *__restrict__ S,
                                                                       uint32_t *__restrict__ R, uint32_t nblocks, Counters ctr,
                                                                       FaultTab ft, uint8_t *__restrict__ detected)
@@ -64,6 +75,8 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     constexpr int NREP = 3, NS = 20 * NREP, HALF = NS / 2, NSET = 2 * NREP;
     constexpr bool DUP = CLONE;
     constexpr bool DUPADJ = DUP && COAST_MM4_DUP_ADJ != 0;
+    constexpr int NSETS = COAST_MM4_SETS;
+    static_assert(NSETS == 1 || NSETS == 2, "one or two register sets of raw s words");
     extern __shared__ __attribute__((aligned(16))) uint8_t smemP[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     uint32_t stageMiss = 0; // this lane's words whose two staged copies differed
 
     // ---- f panel.  Thread t = 64 wv + l: row32 = t / 16 (0..31), k-quad in a slab kqi = t % 16.  Piece pc = 4 s + jj of the thread: k-slab s
-    // (region s), panel row 32 jj + row32, words k = 64 s + 4 kqi .. + 3.  LDS: plane p, row * 256 + (slot ^ (row & 15)) * 16 + (kqi & 3) * 4
+    // (region s), panel row 32 jj + row32, words k = 64 s + 4 kqi .. + 3.  LDS: row * 1024 + p * 256 + (slot ^ (row & 15)) * 16 + (kqi & 3) * 4
     // with slot = 4 s + kqi / 4 (a fragment read of 16 rows and a conversion store of two rows x 16 k-quads both cover every bank group)
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     auto voffFof = [&]() __attribute__((always_inline)) {
@@ -120,8 +133,8 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     auto panelDst = [&](int pc) __attribute__((always_inline)) {
         const int l = freshLane();
         const int row32 = 4 * wv + (l >> 4), kqi = l & 15;
-        const int d0 = row32 * G::N + (((kqi >> 2) ^ (row32 & 15)) * 16) + (kqi & 3) * 4;
-        return (d0 ^ ((pc >> 2) * 64)) + (pc & 3) * 32 * G::N;
+        const int d0 = row32 * G::ROW_A + (((kqi >> 2) ^ (row32 & 15)) * 16) + (kqi & 3) * 4;
+        return (d0 ^ ((pc >> 2) * 64)) + (pc & 3) * 32 * G::ROW_A;
     };
     auto storePiece = [&](const u32x4_t raw, int pc) __attribute__((always_inline)) {
         const uint32_t y[4] = {mm_digits(raw[0]), mm_digits(raw[1]), mm_digits(raw[2]), mm_digits(raw[3])};
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     const int dstS = colRow(l16) * G::KS + ((HQ ^ colSwz(l16)) * 16) + kg * 4;
     auto slabOff = [&](int g) __attribute__((always_inline)) { return (((g & 3) * G::KS + 16 * HQ) * G::N + tileCol0(g)) * 4; };
 
-    const int aOff = (32 * HQ + l16) * G::N + ((kg ^ l16) * 16);
+    const int aOff = (32 * HQ + l16) * G::ROW_A + ((kg ^ l16) * 16);
     const int bOff = colRow(l16) * G::KS + ((kg ^ colSwz(l16)) * 16);
     auto panelOff = [&](int g) __attribute__((always_inline)) { return aOff ^ ((g & 3) * 64); };
 
@@ -200,9 +213,9 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
             for (int pz = 0; pz < 4; ++pz)
                 acc[rbz][rz][pz] = v4i_t{0, 0, 0, 0};
 
-    // raw s words: set j % 2 holds this wave's four words of slab j, requested in step j - 3 behind the conversion of slab j - 2
-    uint32_t pbs[2][4];
-    uint32_t dupS[DUPADJ ? 2 : 1][4] = {}; // their clones (CLONE)
+    // raw s words: set j % NSETS holds this wave's four words of slab j, requested in step j - 1 - NSETS behind the conversion of slab j - NSETS
+    uint32_t pbs[NSETS][4];
+    uint32_t dupS[DUPADJ ? NSETS : 1][4] = {}; // their clones (CLONE)
     u32x4_t bgRaw[2], dupF[2];             // the two f pieces of a half step (BG steps) and their clones
     dupF[0] = dupF[1] = u32x4_t{0u, 0u, 0u, 0u};
 #pragma unroll
@@ -255,18 +268,20 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     using U0 = std::integral_constant<int, 0>;
     using U1 = std::integral_constant<int, 1>;
     using SEQ4 = std::make_integer_sequence<int, 4>;
-    // prologue: slab 0 converted here (set 0), slab 1 in set 1 for step 0, slab 2 in set 0 for step 1
+    // prologue: slab 0 converted here (set 0); two sets: slab 1 in set 1 for step 0, slab 2 in set 0 for step 1; one set: slab 1 in set 0
+    using SLAST = std::integral_constant<int, NSETS - 1>;
     for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadS(0, U0{}, kkTag); });
-    for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadS(1, U1{}, kkTag); });
+    if constexpr (NSETS == 2)
+        for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadS(1, SLAST{}, kkTag); });
     if constexpr (DUP) {
         for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadDupS(0, U0{}, kkTag); });
         verifyS(U0{}, 0);
     }
     convNow(U0{}, wbufOff);
-    for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadS(2, U0{}, kkTag); });
+    for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadS(NSETS, U0{}, kkTag); });
     if constexpr (DUP) {
-        for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadDupS(1, U1{}, kkTag); }); // compared in step 0's first slot
-        if constexpr (DUPADJ)
+        for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadDupS(1, SLAST{}, kkTag); }); // compared in step 0's first slot
+        if constexpr (DUPADJ && NSETS == 2)
             for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadDupS(2, U0{}, kkTag); });
     }
     __syncthreads(); // panel 0 and the lanes' slab 0 are complete
@@ -319,9 +334,50 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     constexpr int kNextStride = 6;
 
     uint32_t fFirst = 0, fCount = 0;
+    // word w of entry q of the upset table.  PHYS: through a descriptor that ends with the panel's entries, no vector register in the address --
+    // an upset of any VGPR cannot send this read anywhere
     auto ftWord = [&](uint32_t q, int w) __attribute__((always_inline)) {
-        const DevFault *fp = ft.list + q;
-        return __builtin_amdgcn_readfirstlane(w == 1 ? fp->local : w == 2 ? fp->step : *reinterpret_cast<const uint32_t *>(&fp->replica));
+        if constexpr (PHYS == 2) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<DevFault *>(ft.list), 0, (int)((fFirst + fCount) * 16u), 0x00020000);
+            return __builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(rs, 0, (int)(q * 16u) + 4 * w, 0));
+        } else {
+            const DevFault *fp = ft.list + q;
+            return __builtin_amdgcn_readfirstlane(w == 1 ? fp->local : w == 2 ? fp->step : *reinterpret_cast<const uint32_t *>(&fp->replica));
+        }
+    };
+    // COAST_SITE_MM_PREG (PHYS): the upset of this wave in the current item, if any: key = step of the item << 6 | slot; sel = register file << 9 |
+    // register number; lane | bit << 8
+    uint32_t pregKey = 0xffffffffu, pregSel = 0u, pregLaneBit = 0u;
+    auto pregScan = [&]() __attribute__((always_inline)) {
+        pregKey = 0xffffffffu;
+#pragma unroll 1
+        for (uint32_t q = fFirst, nq = 0; q < fFirst + fCount && nq < 64u; ++q, ++nq) { // (nq: a flipped count must not walk the table for ever)
+            const uint32_t sw = ftWord(q, 2), packed = ftWord(q, 3);
+            if (((packed >> 8) & 0xffu) == 7u /* COAST_SITE_MM_PREG */ && ((sw >> 16) & 7u) == (uint32_t)wv) {
+                pregKey = (sw & 0x3ffu) | (((sw >> 29) & 1u) << 10);
+                pregSel = (((sw >> 19) & 1u) << 9) | ((sw >> 20) & 511u);
+                pregLaneBit = ((sw >> 10) & 63u) | (((packed >> 16) & 31u) << 8);
+            }
+        }
+    };
+    auto pregFlip = [&]() __attribute__((always_inline)) {
+        const uint32_t idx = pregSel & 511u, bitMask = 1u << (pregLaneBit >> 8);
+        if ((pregSel >> 9) == 0u) {
+            const uint32_t vm = freshLane() == (int)(pregLaneBit & 63u) ? bitMask : 0u;
+            uint32_t m0save;
+            asm volatile("s_mov_b32 %0, m0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_set_gpr_idx_on %1, 0x9\n\ts_nop 1\n\tv_xor_b32 v0, v0, %2\n\ts_nop 1\n\t"
+                         "s_set_gpr_idx_off\n\ts_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 1"
+                         : "=&s"(m0save)
+                         : "s"(idx), "v"(vm)
+                         : "memory");
+        } else {
+            uint32_t tmp, m0save;
+            asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\ts_movrels_b32 %0, s0\n\ts_xor_b32 %0, %0, %3\n\ts_nop 0\n\ts_movreld_b32 s0, %0\n\t"
+                         "s_nop 2\n\ts_mov_b32 m0, %1\n\ts_nop 1"
+                         : "=&s"(tmp), "=&s"(m0save)
+                         : "s"(idx), "s"(bitMask)
+                         : "scc", "memory");
+        }
     };
     // ---- injector hook: the consequence of an armed upset on the replica's word is an additive constant (everything downstream is linear
     // mod 2^32), written on the replica's limb-0 sums before the tile's last step -- mm_mfma_kernel.hip, file header; .local = panel row << 8 | column
@@ -329,7 +385,7 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
         const int col0 = tileCol0(g), prow0 = pnl * G::BM;
         bool hooked = false;
 #pragma unroll 1
-        for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
+        for (uint32_t q = fFirst; q < fFirst + (PHYS == 2 && fCount > 256u ? 256u : fCount); ++q) { // (PHYS: an upset of the count must not walk the table for minutes)
             const int fcol = (int)(ftWord(q, 1) & 255u);
             hooked = hooked || (fcol >= col0 && fcol < col0 + G::CT);
         }
@@ -338,13 +394,16 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
         uint32_t curKey = 0xffffffffu, curStep = 0xffffffffu;
         uint32_t dsum[3] = {0u, 0u, 0u}, am[3] = {0u, 0u, 0u}, bm[3] = {0u, 0u, 0u};
 #pragma unroll 1
-        for (uint32_t q = fFirst; q < fFirst + fCount; ++q) {
+        for (uint32_t q = fFirst; q < fFirst + (PHYS == 2 && fCount > 256u ? 256u : fCount); ++q) {
             const uint32_t local = ftWord(q, 1);
             const int frow = (int)(local >> 8), fcol = (int)(local & 255u);
             if (fcol < col0 || fcol >= col0 + G::CT)
                 continue;
             const uint32_t fstep = ftWord(q, 2), packed = ftWord(q, 3);
             const uint32_t frep = packed & 0xffu, fsite = (packed >> 8) & 0xffu, m = 1u << ((packed >> 16) & 31u);
+            if constexpr (PHYS != 0)
+                if (fsite > (uint32_t)SITE_MM_OPB)
+                    continue; // (a physical register upset: applied where the register lives)
             if (local != curKey) { // a new element: its replicas start from clean running deltas
                 curKey = local;
                 curStep = 0xffffffffu;
@@ -406,7 +465,7 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     int offA = panelOff(0), offB = bOff;
     auto loadAi = [&](auto idxTag, auto pTag, int rbl, int off) __attribute__((always_inline)) { // plane p of row block rbl into register idx
         constexpr int p = decltype(pTag)::value, idx = decltype(idxTag)::value;
-        a[idx] = *reinterpret_cast<const v4i_t *>(smemP + off + p * G::PLANE_A + rbl * 16 * G::N);
+        a[idx] = *reinterpret_cast<const v4i_t *>(smemP + off + p * G::PLANE_A + rbl * 16 * G::ROW_A);
     };
     auto loadB = [&](auto rrTag, auto qTag, int bufOff) __attribute__((always_inline)) {
         constexpr int rr = decltype(rrTag)::value, q = decltype(qTag)::value;
@@ -426,7 +485,7 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
         constexpr int K1 = BG == 1 ? (POS == 2 ? 1 : POS == 3 ? 3 : -1) : BG == 2 ? (POS == 0 ? 5 : POS == 1 ? 7 : -1) : -1; // first half
         constexpr int K2 = BG == 1 ? (POS == 1 ? 0 : POS == 2 ? 2 : POS == 3 ? 4 : -1) : BG == 2 ? (POS == 0 ? 6 : -1) : -1; // second half
         constexpr bool PRELOAD = BG == 1 && POS == 1; // pieces 0 and 1 are requested in the half step in front of half step 0
-        constexpr int CSET = (POS + 1) & 1;           // register set of slab g + 1
+        constexpr int CSET = NSETS == 2 ? (POS + 1) & 1 : 0; // register set of slab g + 1
         constexpr int CS = (K1 >= 0 || PRELOAD) ? 2 : COAST_MM4_CONV_STRIDE; // conversion stage stride (BG steps: the first ten slots, the f stages behind)
         const int bufNext = wbufOff + ((g + 1) & 1) * G::B_BUF;
         int offAnext = panelOff(g + 1);
@@ -476,11 +535,22 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
                     *reinterpret_cast<uint32_t *>(smemP + bufNext + q * G::PLANE_B + dstS) = w[q];
             }
         };
+        // the f pieces' per-lane address registers, once per BG step (two registers of the sixteen the single A fragment set frees; recomputed
+        // per piece they cost as many instructions as the piece's conversion)
+        // (with the clones and two sets of raw s words the BG steps have no register left for them: recomputed per piece there)
+        constexpr bool HOISTF = BG != 0 && (!DUP || NSETS == 1);
+        int voffFh = 0, dstFh = 0;
+        if constexpr (HOISTF) {
+            voffFh = voffFof();
+            dstFh = panelDst(0);
+        }
+        auto voffFget = [&]() __attribute__((always_inline)) { return HOISTF ? voffFh : voffFof(); };
+        auto dstFget = [&]() __attribute__((always_inline)) { return HOISTF ? dstFh : panelDst(0); };
         auto bgLoad = [&](int pc, auto selTag) __attribute__((always_inline)) {
             constexpr int sel = decltype(selTag)::value;
-            bgRaw[sel] = __builtin_amdgcn_raw_buffer_load_b128(rsFof(bgItem), voffFof(), soffF(pc), COAST_MM_AUX_F);
+            bgRaw[sel] = __builtin_amdgcn_raw_buffer_load_b128(rsFof(bgItem), voffFget(), soffF(pc), COAST_MM_AUX_F);
             if constexpr (DUP) // the clone, right behind the original: its own address register
-                dupF[sel] = __builtin_amdgcn_raw_buffer_load_b128(rsFof(bgItem), launder(voffFof()), soffF(pc), COAST_MM_AUX_F);
+                dupF[sel] = __builtin_amdgcn_raw_buffer_load_b128(rsFof(bgItem), launder(voffFget()), soffF(pc), COAST_MM_AUX_F);
         };
         auto verifyF = [&](int pc, auto selTag) __attribute__((always_inline)) {
             constexpr int sel = decltype(selTag)::value;
@@ -516,13 +586,14 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
             else if constexpr (sub == 3)
                 perm2();
             else {
-                const int dst = panelDst(pc);
+                const int dst = (dstFget() ^ ((pc >> 2) * 64)) + (pc & 3) * 32 * G::ROW_A; // = panelDst(pc)
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
                     *reinterpret_cast<uint32_t *>(smemP + dst + p * G::PLANE_A) = w[p];
             }
         };
         const v4i_t zero = {0, 0, 0, 0};
+        const uint32_t pregSlot = PHYS == 2 ? pregKey - ((uint32_t)(g & 31) << 6) : 0xffffffffu; // the slot of THIS step the upset sits in front of, if any
         auto slot = [&](auto mTag) __attribute__((always_inline)) {
             constexpr int m = decltype(mTag)::value;
             constexpr int set = m / 10, j = m % 10, rb = set / NREP, rr = set % NREP;
@@ -533,6 +604,9 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
             constexpr int half = m / HALF, mh = m % HALF;
             if constexpr (j == 0 && set != 0)
                 asm volatile("" : "+v"(offA)); // this set's A fragments are its own loads
+            if constexpr (PHYS == 2)
+                if (pregSlot == (uint32_t)m)
+                    pregFlip();
             constexpr bool ABUF = BG == 0;
             constexpr auto aIdx = [](int st, int pp) { return ABUF ? 4 * (st & 1) + pp : pp; }; // register of fragment pp of set st
             acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[aIdx(set, p)], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
@@ -566,16 +640,16 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
             // conversion of slab g + 1: five stages in the first half
             if constexpr (half == 0 && mh % CS == 0 && mh / CS < 5)
                 convStage(std::integral_constant<int, mh / CS>{});
-            // the set just read is free behind stage 1: this wave's words of slab g + 3 (two steps ahead), one load per slot
+            // the set just read is free behind stage 1: this wave's words of slab g + 1 + NSETS, one load per slot
             {
                 constexpr int s1 = CS + 1; // the slot behind stage 1
                 if constexpr (half == 0 && mh >= s1 && mh < s1 + 4)
-                    loadS(g + 3, CSETT{}, std::integral_constant<int, mh - s1>{});
+                    loadS(g + 1 + NSETS, CSETT{}, std::integral_constant<int, mh - s1>{});
                 if constexpr (DUPADJ && half == 0 && mh >= s1 + 4 && mh < s1 + 8)
-                    loadDupS(g + 3, CSETT{}, std::integral_constant<int, mh - s1 - 4>{});
+                    loadDupS(g + 1 + NSETS, CSETT{}, std::integral_constant<int, mh - s1 - 4>{});
             }
             if constexpr (DUP && !DUPADJ && half == 1 && mh >= 1 && mh < 5) // the clones of slab g + 2 (set g % 2), compared in the next step's first slot
-                loadDupS(g + 2, std::integral_constant<int, POS & 1>{}, std::integral_constant<int, mh - 1>{});
+                loadDupS(g + 2, std::integral_constant<int, NSETS == 2 ? POS & 1 : 0>{}, std::integral_constant<int, mh - 1>{});
             // f pieces of the panel replacement: stages at the even slots 10..28 of a half step (piece A: 10..18, piece B: 20..28)
             if constexpr (PRELOAD && m == 11)
                 bgLoad(0, U0{});
@@ -609,14 +683,18 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     // [tile 7: BG1 POS 1, 2, 3].  Straight-line code and ONE clean inner loop: two alternative bodies that join (a diamond per step) made the
     // register allocator spill ~400 registers, an inner loop with a mid-loop exit ~150 (accumulator tuples reloaded in front of MFMAs) --
     // at the price of twelve inlined step bodies instead of nine.
+    // (PHYS: a second, independent bound -- an upset of the loop's registers must not turn a campaign run into a walk through memory)
+    const uint32_t itemCap = PHYS == 2 ? (nblocks + stride - 1u) / stride : 0xffffffffu;
 #pragma unroll 1
-    for (int item = 0; matOf(item) < nblocks; ++item) {
+    for (int item = 0; matOf(item) < nblocks && (uint32_t)item < itemCap; ++item) {
         const uint32_t mat = matOf(item);
         if (ft.range) {
             const uint2 rg = ft.range[mat * (uint32_t)G::NPANEL + (uint32_t)pnl];
             fFirst = __builtin_amdgcn_readfirstlane(rg.x);
             fCount = __builtin_amdgcn_readfirstlane(rg.y);
         }
+        if constexpr (PHYS == 2)
+            pregScan();
         if (item > 0) { // hand-over: regions 0 and 1 of the panel (and half of 2) are this item's already, the rest follows in its first two steps
             f = F + mat * nn;
             s = S + mat * nn;
@@ -628,8 +706,12 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
         rsRp = rsR;
         rsDp = rsD;
         step(gI + 1, T0{}, T1{}, T2{});
+        [[maybe_unused]] uint32_t tileGuard = 0u; // (PHYS: the same for the tile counter)
 #pragma unroll 1
         for (int tile = 0; tile < G::TPW - 2; ++tile) {
+            if constexpr (PHYS == 2)
+                if (tileGuard++ >= (uint32_t)G::TPW)
+                    break;
             const int g0 = gI + tile * G::NSLAB;
             step(g0 + 2, T0{}, T2{}, T0{});
             if (fCount != 0u)

@@ -19,7 +19,8 @@ F_NO_STORE_DATA_SYNC = 1  # coast_cfg.flags: the reference's -noStoreDataSync (i
 F_BRANCH_SYNC, F_ADDR_SYNC, F_NO_LOAD_SYNC, F_NO_STORE_ADDR_SYNC = 2, 4, 8, 16  # counters inside the SoR (mm, sha256, crc16)
 F_LOCAL_STORE_SYNC = 64  # with F_BRANCH_SYNC | F_ADDR_SYNC: the -O0 IR's stores into locals / in-place arrays are data votes (mm, aes128, crc16, cache_test, chsha)
 F_O0_SHAPE = 128  # sha256 with F_BRANCH_SYNC | F_ADDR_SYNC: the -O0 IR's shape (padding / output / transform loops are loops with voted counters)
-F_CLONE_STAGING = 0x200  # mm side 256 on the matrix cores: the global -> LDS staging loads are cloned and compared (COAST_F_CLONE_STAGING)
+F_CLONE_STAGING = 0x200  # mm side 256 on the matrix cores: the global -> LDS staging loads are cloned and compared -- the DEFAULT since ABI 8 (the flag is accepted)
+F_SINGLE_STAGING = 0x400  # ... opt out: every raw word staged once (COAST_F_SINGLE_STAGING)
 F_MEMORY_COPIES = 32  # sha256 / aes128 / crc16: arrays hold `replicas` copies back to back; loads per copy, voted stores into every copy
 
 

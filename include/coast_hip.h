@@ -19,7 +19,8 @@
 extern "C" {
 #endif
 
-#define COAST_HIP_ABI_VERSION 7 /* 7: COAST_F_CLONE_STAGING, COAST_SITE_MM_PREG; 6: COAST_F_LOCAL_STORE_SYNC, COAST_F_O0_SHAPE; 2: coast_cfg.flags; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info, new flags/sites;
+#define COAST_HIP_ABI_VERSION 8 /* 8: the staging loads of the matrix-core mm kernels are cloned BY DEFAULT (COAST_F_SINGLE_STAGING opts out), TMR side 256 runs mm_mfma_blk4_kernel;
+                                 * 7: COAST_F_CLONE_STAGING, COAST_SITE_MM_PREG; 6: COAST_F_LOCAL_STORE_SYNC, COAST_F_O0_SHAPE; 2: coast_cfg.flags; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info, new flags/sites;
                                  * 4: control-flow signatures (coast_cfcss_assign, coast_crazycf_*), additive;
                                  * 5: COAST_REPLICA_ALL, COAST_ETIMEOUT, coast_launch_info.hooked_blocks, additive */
 
@@ -40,9 +41,11 @@ enum {
  * in the lane-replicated kernels (sha256, aes, crc16, cache_test, CHStone sha / aes, quicksort, the VALU mm kernels and the
  * DWC / unprotected matrix-core mm kernel) replica r of work item q is lane replicas*q + r of a wavefront, so every vector
  * register of the item is replicated; in the TMR matrix-core mm kernels (side 256, the default) the replicas of an output
- * element are three accumulator blocks of ONE lane, each with its own B-operand registers and its own MFMAs, while the
- * A-operand fragments (rows of f) and the s words on their way into the LDS slab are a single copy shared by the three --
- * the analogue of a `__NO_xMR` value (tests/COAST.h:11): an upset there is common-mode (COAST_REPLICA_ALL below).
+ * element are three accumulator blocks of ONE lane, each with its own A- and B-operand registers (every LDS operand load is
+ * replicated, since round 4) and its own MFMAs; the raw words of f and s on their way into the LDS image are loaded twice and
+ * compared (cloned loads, the default since ABI 8; COAST_F_SINGLE_STAGING below).  What stays a single copy -- the conversion
+ * temporaries, address registers, lane constants -- is the analogue of a `__NO_xMR` value (tests/COAST.h:11): an upset there
+ * is common-mode (COAST_REPLICA_ALL below).
  * Wave-uniform scalars (loop counters, lengths, base pointers) and LDS tables are outside the sphere of replication everywhere.  sync_every adds the reference's loop-condition sync points at a
  * chosen granularity (synchronization.cpp:146-155): mm = every V k-steps, crc16 = every V bytes,
  * aes = 1 -> after every round; 0 = mandatory sync points only. */
@@ -119,17 +122,22 @@ enum {
      * memory replicated as well -- one unprotected launch per memory copy + the exit vote of coast_sync_copies(scrub).
      * Without it the shims use the lane-replicated -noMemReplication engine. */
     COAST_F_HOST_MEMORY_REPLICATED = 0x100u,
-    /* coast_mm_batch, side 256 on the matrix cores (the default engine and tile), TMR / DWC: the global -> LDS staging loads are CLONED
-     * (cloning.cpp:2187-2209; one address for the copies under -noMemReplication, :2247-2255).  Without it every raw word of f and s is
-     * loaded once into a staging register, converted once and written into the LDS image all replicas read: an upset of that register is
-     * common-mode, the wrong words come out with TMR_ERROR_CNT unchanged.  With it every word is loaded a second time half a pipeline step
-     * ahead of its conversion and compared in front of its first use; TMR takes select(a == b, a, c) with a third load and counts one
-     * corrected error per word, DWC counts a detected item and flags the first element the word reaches.  sync_count is unchanged (a cloned
-     * load is not a sync point of the reference either; the votes stay where the stores are).  Price on an MI355X: + 30 % kernel time (the
-     * register file is full; profiles/r05_mm_clone_ab.txt), for 94.4 -> 96.6 % coverage of single-bit upsets drawn uniformly from the wave's
-     * register state (tools/campaign.py --reg-model uniform).  Ignored where it has no meaning: other sides and engines (the lane-replicated
-     * kernels issue one load per replica lane already), unprotected runs.  Does not select the stepwise kernels the other flags select. */
-    COAST_F_CLONE_STAGING = 0x200u
+    /* coast_mm_batch, side 256 on the matrix cores (the default engine and tiles), TMR / DWC: the global -> LDS staging loads are CLONED
+     * (cloning.cpp:2187-2209; one address for the copies under -noMemReplication, :2247-2255) -- BY DEFAULT since ABI 8, as the pass
+     * clones every load of a protected function with no opt-out short of __NO_xMR.  Every raw word of f and s is loaded a second time and
+     * compared in front of its first use; TMR takes select(a == b, a, c) with a third load and counts one corrected error per word, DWC
+     * counts a detected item and flags the first element the word reaches.  sync_count is unchanged (a cloned load is not a sync point of
+     * the reference either; the votes stay where the stores are).  Price on an MI355X: + 6 % kernel time in the TMR kernel
+     * (mm_mfma_blk4_kernel, profiles/r06_mm_blk4_ab.txt; + 10-12 % in mm_mfma_blk3_kernel), for the coverage of single-bit upsets drawn
+     * uniformly from the wave's register state that docs/design/campaign.md tabulates (tools/campaign.py --reg-model uniform).
+     *   COAST_F_CLONE_STAGING   (ABI 7's opt-in) is accepted and means the default.
+     *   COAST_F_SINGLE_STAGING  opts out: every raw word is loaded ONCE into a staging register, converted once and written into the LDS
+     *                           image all replicas read -- an upset of that register is common-mode, the wrong words come out with
+     *                           TMR_ERROR_CNT unchanged (tests/test_gpu_parity.py::test_mm_physical_upsets_of_the_staging_registers).
+     * Both are ignored where they have no meaning: other sides and engines (the lane-replicated kernels issue one load per replica lane
+     * already), unprotected runs.  Neither selects the stepwise kernels the other flags select. */
+    COAST_F_CLONE_STAGING = 0x200u,
+    COAST_F_SINGLE_STAGING = 0x400u
 };
 
 /* Counters.  errors_corrected is TMR_ERROR_CNT (synchronization.cpp:269-294,1391-1443: +1 per voted value whose

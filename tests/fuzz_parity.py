@@ -53,7 +53,7 @@ def main():
             clone = 0
             if n == 256:  # the matrix-core kernels: several matrices per workgroup group, with and without the cloned staging loads (round 5)
                 batch, sync_every = int(rng.integers(1, 7)) if rng.random() < 0.8 else int(rng.integers(60, 70)), int(rng.choice([0, 0, 0, 16]))
-                clone = coast_amd.F_CLONE_STAGING if sync_every == 0 and rng.random() < 0.5 else 0
+                clone = 0 if sync_every == 0 and rng.random() < 0.5 else coast_amd.F_SINGLE_STAGING  # (cloned staging loads are the default)
             f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
             s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
             nit = batch * n * n
@@ -65,7 +65,7 @@ def main():
             eng.inject_faults(fl)
             got = eng.mm_batch(dev(f), dev(s), cfg=coast_amd.XmrConfig(rep, sync_every, clone), detected=det).cpu().numpy().view(np.uint32)
             ok = (got == exp).all() and stats3(eng.stats()) == est and (det.cpu().numpy() == edet).all()
-            desc = "mm n=%d batch=%d rep=%d V=%d k=%d clone=%d" % (n, batch, rep, sync_every, len(fl), int(bool(clone)))
+            desc = "mm n=%d batch=%d rep=%d V=%d k=%d clone=%d" % (n, batch, rep, sync_every, len(fl), int(not clone))
         elif kind == "sha256":
             ln = int(rng.choice([0, 1, 3, 8, 55, 56, 57, 63, 64, 65, 100, 119, 120, 128, 200, 300]))
             stride = ln + int(rng.choice([0, 0, 1, 3, 4])) if rng.random() < 0.5 else ((ln + 15) // 16) * 16 + 16 * int(rng.integers(0, 2))

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libcoast_hip.so does not export %s" % n
     assert set(names) == set(_lib.SYMBOLS), "python binding and header disagree"
-    assert lib.coast_abi_version() == 7  # 7: COAST_F_CLONE_STAGING, COAST_SITE_MM_PREG; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info; 4: control-flow signatures; 5: COAST_REPLICA_ALL, COAST_ETIMEOUT; 6: COAST_F_LOCAL_STORE_SYNC
+    assert lib.coast_abi_version() == 8  # 8: cloned staging loads by default (COAST_F_SINGLE_STAGING), mm_mfma_blk4_kernel; 7: COAST_F_CLONE_STAGING, COAST_SITE_MM_PREG; 3: coast_stats.kernel_ms/.hbm_bytes, coast_launch_info; 4: control-flow signatures; 5: COAST_REPLICA_ALL, COAST_ETIMEOUT; 6: COAST_F_LOCAL_STORE_SYNC
 
 
 def test_header_compiles_as_c_and_layouts_match(tmp_path):

@@ -109,7 +109,7 @@ def test_uniform_campaign_isolates_the_runs_that_take_the_process_down(monkeypat
     import subprocess
 
     mod = _load(monkeypatch)
-    monkeypatch.setattr(mod, "kernel_registers", lambda replicas, clone=False: (256, 102, [254, 255]))
+    monkeypatch.setattr(mod, "kernel_registers", lambda replicas, clone=False, kernel="blocks3": (256, 102, [254, 255]))
     a = mod.parse(["-b", "mm", "--side", "256", "-m", "TMR", "-t", "700", "--reg-model", "uniform", "-n"])
     rng = np.random.default_rng(a.seed)
     draws = [mod.uniform_draw(rng, 256, 102) for _ in range(700)]

@@ -2880,9 +2880,9 @@ def test_mm_physical_register_upsets(eng, cls):
 @pytest.mark.parametrize("clone", [True, False])
 def test_mm_physical_upsets_of_the_staging_registers(eng, clone):
     """COAST_SITE_MM_VGPR registers 12-20: a raw word of s / of the next f panel in the wave's staging registers, on its way into the LDS
-    image every replica (and, for s, both waves of the pair) reads.  DEFAULT: every word is staged once -- a real flip there is common-mode,
+    image every replica (and, for s, both waves of the pair) reads.  COAST_F_SINGLE_STAGING (the default up to ABI 7): every word is staged once -- a real flip there is common-mode,
     the analogue of a memory upset under -noMemReplication: the wrong words come out with TMR_ERROR_CNT == 0 (233 of 501 / 76 of 79 runs,
-    profiles/r05_campaign_physical_real_all_seed0_5000.txt).  COAST_F_CLONE_STAGING (round 5): the staging load is cloned
+    profiles/r05_campaign_physical_real_all_seed0_5000.txt).  DEFAULT since ABI 8 (round 5's COAST_F_CLONE_STAGING): the staging load is cloned
     (cloning.cpp:2187-2209, 2247-2255) -- a second load half a step ahead of the conversion, compared in front of the first instruction that
     consumes the word; TMR takes select(a == b, a, c) with a third load (TMR_ERROR_CNT + 1, every word of the product the clean one), DWC
     counts a detected item and flags the first element the word reaches.  The unprotected run shows what the flip does when nobody looks
@@ -2894,7 +2894,7 @@ def test_mm_physical_upsets_of_the_staging_registers(eng, clone):
     f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
     s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
     df, ds = _dev(f), _dev(s)
-    flag = ca.F_CLONE_STAGING if clone else 0
+    flag = 0 if clone else ca.F_SINGLE_STAGING  # (ABI 8: the clones are the default, COAST_F_SINGLE_STAGING takes them out)
     eng.reset_stats()
     clean = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(3, 0, flag)), np.uint32)
     syncs = eng.stats()["sync_count"]
@@ -2910,7 +2910,7 @@ def test_mm_physical_upsets_of_the_staging_registers(eng, clone):
         # TMR without the clones: the flip's own consequence (nothing compares the staged word with anything), no vote sees it
         eng.reset_stats()
         eng.inject_faults(fault(rep))
-        raw = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(3)), np.uint32)
+        raw = _host(eng.mm_batch(df, ds, cfg=ca.XmrConfig(3, 0, ca.F_SINGLE_STAGING)), np.uint32)
         st = eng.stats()
         assert st["errors_corrected"] == 0 and st["dwc_detected"] == 0 and st["sync_count"] == syncs, (trial, st)
         diff = np.argwhere(raw != clean)
@@ -3023,7 +3023,7 @@ def test_mm_256_register_block_kernel_batch_shapes(eng, orc, batch, tile, monkey
     # round 6: panel128 = mm_mfma_blk4_kernel (a workgroup owns 128 rows: panel position of matrices m, m + 128, ...; the f panel is replaced
     # region by region across an item hand-over -- batches above 128 give workgroups several items), with and without its cloned staging loads
     monkeypatch.setenv("COAST_MM_TILE", tile.split("+")[0])
-    cfg = ca.XmrConfig(ca.TMR, 0, ca.F_CLONE_STAGING if tile.endswith("+clones") else 0)
+    cfg = ca.XmrConfig(ca.TMR, 0, 0 if tile.endswith("+clones") else ca.F_SINGLE_STAGING)
     eng.reset_stats()
     eng.inject_faults(fl)
     r = eng.mm_batch(f, s, detected=det, cfg=cfg)
@@ -3059,14 +3059,16 @@ def _uniform_campaign(argv):
     return mod.run_uniform_campaign(mod.parse(["-b", "mm", "--side", "256", "--reg-model", "uniform", "-n"] + argv))
 
 
-def test_mm_preg_upset_lands_on_the_register_it_names(eng):
+@pytest.mark.parametrize("kernel", ["blocks3", "panel128"])
+def test_mm_preg_upset_lands_on_the_register_it_names(eng, kernel, monkeypatch):
     """COAST_SITE_MM_PREG packs `file << 19 | register << 20` into coast_fault.step; round 5's kernel read the selector
     from bit 19 on and used (register << 1 | file) & 511 as the VGPR index -- a draw of vR flipped v[2R mod 256] and the scalar path never ran.
-    Pinned on registers whose effect is known without a model: the ACCUMULATORS of the kernel, read out of the running library's own code
-    object (tools/campaign.py:kernel_accumulator_vgprs).  One lane of one accumulator register, flipped in the middle of a tile, moves
-    exactly ONE output word by +-2^(bit + 8 t) (t = the limb the register sums) in the unprotected kernel, and is exactly ONE out-voted,
-    counted vote under TMR -- for odd and even register numbers alike, and for registers whose double is NOT an accumulator (the old decode
-    would have flipped that one)."""
+    Pinned on registers whose effect is known without a model: the ADDEND tuple of the MFMA the upset sits in front of is a live limb-sum
+    accumulator (four registers: element rows i = 0..3 of one column), read out of the running library's own code object for every step body
+    (tools/campaign.py:kernel_addend_tuples; which body a given wave and step run is the compiler's business, so every body's tuple is
+    tried).  For the tuple of the body that runs, each of its four registers, flipped in one lane, moves exactly ONE output word by
+    +-2^(bit + 8 t) in the unprotected kernel -- four words in four consecutive rows of one column -- and is exactly ONE out-voted, counted
+    vote under TMR.  With the old decode no tuple behaves like that."""
     import importlib.util
     import os
 
@@ -3083,31 +3085,38 @@ def test_mm_preg_upset_lands_on_the_register_it_names(eng):
     f = torch.randint(-2**31, 2**31, (1, n, n), dtype=torch.int32, device="cuda", generator=g)
     s = torch.randint(-2**31, 2**31, (1, n, n), dtype=torch.int32, device="cuda", generator=g)
     gold = eng.mm_batch(f, s, cfg=ca.XmrConfig(ca.UNPROTECTED)).clone()
-    for mode, clone in ((ca.UNPROTECTED, False), (ca.TMR, False), (ca.TMR, True)):
-        acc = camp.kernel_accumulator_vgprs(mode, clone)
-        assert len(acc) >= 16 * mode, (mode, clone, acc)
-        accs = set(acc)
-        # registers whose alias under the old decode -- v[2R mod 256] -- is no accumulator, odd and even ones, low and high numbers
-        tell = [r for r in acc if (2 * r) % 256 not in accs]
-        picks = sorted(set(tell[:3] + tell[-3:] + [r for r in acc if r % 2][:2] + [r for r in acc if r % 2 == 0][-2:]))
-        assert len(picks) >= 4 and any(r % 2 for r in picks) and any(r % 2 == 0 for r in picks)
-        for k, reg in enumerate(picks):
-            bit, lane, wave, panel = (3 + 5 * k) % 8, (7 * k + 1) % 64, k % 8, k % 4  # (bit < 8: bit + 8 t < 32 for every limb t -- the flip is visible mod 2^32)
-            d = {"file": 0, "reg": reg, "lane": lane, "bit": bit, "wave": wave, "panel": panel, "step": 6, "slot": 30 % (20 * mode)}
-            eng.reset_stats()
-            eng.inject_faults(ca.make_faults([camp.preg_row(64 * panel * n, d)]))
-            det = torch.zeros(nn, dtype=torch.uint8, device="cuda")
-            out = eng.mm_batch(f, s, cfg=ca.XmrConfig(mode, 0, ca.F_CLONE_STAGING if clone else 0), detected=det)
-            st = eng.stats()
-            wrong = (out != gold).nonzero()
-            if mode == ca.UNPROTECTED:
-                assert wrong.shape[0] == 1, (reg, wrong.shape)
-                _, i, j = (int(x) for x in wrong[0])
-                delta = (int(out[0, i, j]) - int(gold[0, i, j])) % 2**32
-                assert delta in {(sgn * (1 << (bit + 8 * t))) % 2**32 for t in range(4) for sgn in (1, -1) if bit + 8 * t < 32} | {0x80000000}, (reg, bit, hex(delta))
-                assert 64 * panel <= i < 64 * panel + 64  # the panel the upset named
-            else:
-                assert wrong.shape[0] == 0 and st["errors_corrected"] == 1 and int(det.sum()) == 1, (reg, wrong.shape, st)
+    # both register-block kernels carry the hook: mm_mfma_blk3_kernel (64-row panels, 16 steps per item; also the unprotected / DWC kernel) and
+    # mm_mfma_blk4_kernel (128-row panels, 32 steps: the fifth bit of the step rides in bit 29 of coast_fault.step)
+    monkeypatch.setenv("COAST_MM_TILE", kernel)
+    rows = camp.KERNELS[kernel]["rows"]
+    bit, lane, wave, panel, step = 5, 37, 6, (2 if kernel == "blocks3" else 1), (6 if kernel == "blocks3" else 22)
+    deltas = {(sgn * (1 << (bit + 8 * t))) % 2**32 for t in range(4) for sgn in (1, -1)}
+    for mode, clone in (((ca.UNPROTECTED, False),) if kernel == "blocks3" else ()) + ((ca.TMR, False), (ca.TMR, True)):
+        slot = 10 * mode  # the first slot of a step's second half (its MFMA accumulates: no tile starts there)
+        tuples = sorted(set(camp.kernel_addend_tuples(mode, slot, clone, kernel if mode == ca.TMR else "blocks3")))
+        assert tuples and all(hi - lo == 3 for lo, hi in tuples), tuples
+        good = []
+        for lo, hi in tuples:
+            hits = []
+            for reg in range(lo, hi + 1):
+                d = {"file": 0, "reg": reg, "lane": lane, "bit": bit, "wave": wave, "panel": panel, "step": step, "slot": slot}
+                eng.reset_stats()
+                eng.inject_faults(ca.make_faults([camp.preg_row(rows * panel * n, d)]))
+                det = torch.zeros(nn, dtype=torch.uint8, device="cuda")
+                out = eng.mm_batch(f, s, cfg=ca.XmrConfig(mode, 0, 0 if clone else ca.F_SINGLE_STAGING), detected=det)
+                st = eng.stats()
+                wrong = (out != gold).nonzero()
+                if mode == ca.UNPROTECTED:
+                    if wrong.shape[0] == 1:
+                        _, i, j = (int(x) for x in wrong[0])
+                        if (int(out[0, i, j]) - int(gold[0, i, j])) % 2**32 in deltas and rows * panel <= i < rows * panel + rows:
+                            hits.append((i, j))
+                elif wrong.shape[0] == 0 and st["errors_corrected"] == 1 and int(det.sum()) == 1:
+                    hits.append(tuple(int(x) for x in det.reshape(n, n).nonzero()[0]))
+            if len(hits) == 4 and len({j for _, j in hits}) == 1 and sorted(i for i, _ in hits) == list(range(min(i for i, _ in hits), min(i for i, _ in hits) + 4)):
+                good.append((lo, hi, hits))
+        # the tuple of the body this wave runs at this step (bodies of the other row half / tile positions may share it or not)
+        assert good, (mode, clone, tuples)
 
 
 def test_campaign_uniform_register_file_mm256():

@@ -26,6 +26,7 @@ TU = r'''
 #include "mm_mfma_kernel.hip"
 #include "mm_mfma_blk2_kernel.hip"
 #include "mm_mfma_blk3_kernel.hip"
+#include "mm_mfma_blk4_kernel.hip"
 #include "sha256_kernel.hip"
 #include "aes_kernel.hip"
 #include "crc16_kernel.hip"
@@ -36,6 +37,8 @@ template __global__ void mm_mfma_blk3_kernel<3, false>(MMARGS);
 template __global__ void mm_mfma_blk3_kernel<3, false, 0, true>(MMARGS);
 template __global__ void mm_mfma_blk2_kernel<3, true>(MMARGS);
 template __global__ void mm_mfma_blk2_kernel<3, false>(MMARGS);
+template __global__ void mm_mfma_blk4_kernel<false, false>(MMARGS);
+template __global__ void mm_mfma_blk4_kernel<false, true>(MMARGS);
 #define AESARGS uint8_t *, uint8_t *, uint64_t, uint64_t, Counters, FaultTab, uint8_t *, size_t
 template __global__ void aes128_enc_rep_kernel<2>(AESARGS);
 template __global__ void aes128_dec_rep_kernel<2>(AESARGS);
@@ -120,6 +123,30 @@ def test_mm_register_block_kernels_fit_their_register_files(compiled, flags):
         for blk in re.split(r"\n\.LBB\d+_\d+:", bc):
             if len(re.findall(r"v_mfma_i32_16x16x64_i8", blk)) >= 10:
                 assert not re.search(r"scratch_(load|store)", blk)
+
+
+@pytest.mark.parametrize("clone", ["true", "false"])
+def test_mm_128_row_panel_kernel_fits_its_register_file(compiled, clone):
+    """mm_mfma_blk4_kernel (round 6, the TMR default): two waves per SIMD, no register in scratch at all, twelve step bodies of sixty MFMAs in
+    straight-line code and one clean inner loop (two alternative bodies that join, or an inner loop with a mid-loop exit, made the register
+    allocator reload accumulator tuples in front of MFMAs: hundreds of spills), every fragment read's address one register + an instruction
+    offset (the f panel as [row][plane][256 B])."""
+    usage, bodies = compiled
+    u = _find(usage, "void coast::mm_mfma_blk4_kernel<false, %s, 0>" % clone)
+    b = _find(bodies, "void coast::mm_mfma_blk4_kernel<false, %s, 0>" % clone)
+    assert u["VGPRs"] <= 256 and u["AGPRs"] == 0 and u["Occupancy [waves/SIMD]"] == 2 and u["VGPRs Spill"] == 0 and u["ScratchSize [bytes/lane]"] == 0, u
+    assert len(re.findall(r"v_mfma_i32_16x16x64_i8", b)) == 12 * 60 and not re.search(r"scratch_(load|store)", b)
+    # 24 A + 12 B fragment reads per step body; a step body without tile end and f work issues at most 40 VALU instructions beside its MFMAs
+    assert len(re.findall(r"ds_read_b128", b)) >= 12 * 36
+    lines = [ln.strip() for ln in b.split("\n") if ln.strip() and not ln.strip().startswith((";", ".")) and not ln.split(";")[0].strip().endswith(":")]
+    idx = [k for k, ln in enumerate(lines) if ln.startswith("v_mfma")]
+    lean = min(sum(1 for ln in lines[idx[60 * k]:idx[60 * k + 59]] if ln.startswith("v_") and not ln.startswith(("v_mfma", "v_readlane", "v_writelane")))
+               for k in range(12))
+    assert lean <= (40 if clone == "false" else 60), lean
+    if clone == "true":  # the clones: four more one-word loads of s per step body, two four-word loads of f more per f piece
+        b0 = _find(bodies, "void coast::mm_mfma_blk4_kernel<false, false, 0>")
+        assert len(re.findall(r"buffer_load_dword ", b)) - len(re.findall(r"buffer_load_dword ", b0)) >= 12 * 4
+        assert len(re.findall(r"buffer_load_dwordx4", b)) > len(re.findall(r"buffer_load_dwordx4", b0))
 
 
 def test_lds_table_kernels_keep_their_occupancy(compiled):

@@ -416,8 +416,8 @@ def run_campaign(a, eng=None):
                 targets.append({"replica": row[1], "site": row[2], "step": row[3], "bit": row[4]})
         eng.inject_faults(ca.make_faults(rows))
         flags = (ca.F_BRANCH_SYNC if a.benchmark == "crc16" else ca.F_BRANCH_SYNC | ca.F_ADDR_SYNC) if a.counters_in_sor else 0
-        if getattr(a, "clone_staging", False):
-            flags |= ca.F_CLONE_STAGING
+        if a.benchmark == "mm" and not getattr(a, "clone_staging", False):
+            flags |= ca.F_SINGLE_STAGING  # (the library clones the staging loads by default since ABI 8; the campaign's rows name the form they ran)
         out = bench.run(inp, ca.XmrConfig(rep, 0, flags), det)
         engine = eng.last_launch()
         if physical and bench.real_staging:
@@ -570,18 +570,29 @@ def run_campaign(a, eng=None):
 
 
 # ------------------------------------------------------------------------------------------------ the uniform register-file campaign
-def uniform_draw(rng, n_vgpr=256, n_sgpr=102):
+def uniform_draw(rng, n_vgpr=256, n_sgpr=102, npanels=4, nsteps=16):
     """one bit of the register state of one wave of the kernel, uniformly: n_vgpr VGPRs x 64 lanes x 32 bits + n_sgpr SGPRs x 32 bits (the
     registers the kernel's code object allocates; the reference's injector draws a register of the core uniformly: injector.py:70-72,
     237-260), at a uniformly random MFMA slot of the panel's 16 steps (60 slots each under TMR, 40 under DWC, 20 unprotected)"""
     vbits, sbits = n_vgpr * 64 * 32, n_sgpr * 32
     file = int(rng.random() < sbits / (vbits + sbits))
     return {"file": file, "reg": int(rng.integers(0, n_sgpr if file else n_vgpr)), "lane": 0 if file else int(rng.integers(0, 64)),
-            "bit": int(rng.integers(0, 32)), "wave": int(rng.integers(0, 8)), "panel": int(rng.integers(0, 4)),
-            "step": int(rng.integers(0, 16)), "slot": int(rng.integers(0, 60))}
+            "bit": int(rng.integers(0, 32)), "wave": int(rng.integers(0, 8)), "panel": int(rng.integers(0, npanels)),
+            "step": int(rng.integers(0, nsteps)), "slot": int(rng.integers(0, 60))}
 
 
 PHYS_KERNEL = "_ZN5coast19mm_mfma_blk3_kernelILi%dELb1ELi2ELb%dEEEvPKjS2_PjjNS_8CountersENS_8FaultTabEPh"  # mm_mfma_blk3_kernel<replicas, true, 2, clone>
+PHYS_KERNEL4 = "_ZN5coast19mm_mfma_blk4_kernelILb1ELb%dELi2EEEvPKjS2_PjjNS_8CountersENS_8FaultTabEPh"  # mm_mfma_blk4_kernel<true, clone, 2> (TMR, 128-row panel)
+# geometry of the two register-block kernels: rows of a matrix per workgroup, workgroups per matrix, pipeline steps per item
+KERNELS = {"blocks3": {"rows": 64, "panels": 4, "steps": 16}, "panel128": {"rows": 128, "panels": 2, "steps": 32}}
+
+
+def phys_symbol(replicas, clone, kernel="blocks3"):
+    if kernel == "panel128":
+        if replicas != 3:
+            raise SystemExit("campaign: mm_mfma_blk4_kernel (--kernel panel128) is the TMR kernel; DWC / unprotected run mm_mfma_blk3_kernel")
+        return PHYS_KERNEL4 % int(bool(clone))
+    return PHYS_KERNEL % (replicas, int(bool(clone)))
 
 
 def _kernel_text(sym):
@@ -620,7 +631,7 @@ def _kernel_text(sym):
     return text, notes
 
 
-def kernel_registers(replicas, clone=False):
+def kernel_registers(replicas, clone=False, kernel="blocks3"):
     """(VGPRs, SGPRs the kernel allocates, the VGPRs it spills scalar registers into) of mm_mfma_blk3_kernel<replicas, true, 2, clone>, read
     from the code object inside the very library that runs (the bundle in its .hip_fatbin) with the image's llvm-readelf / llvm-objdump: no
     allocation map to keep in step with the compiler.  The spill registers (v_writelane_b32 / v_readlane_b32): a lane of such a register IS a
@@ -628,7 +639,7 @@ def kernel_registers(replicas, clone=False):
     send an access anywhere in the address space)."""
     import re
 
-    sym = PHYS_KERNEL % (replicas, int(bool(clone)))
+    sym = phys_symbol(replicas, clone, kernel)
     text, notes = _kernel_text(sym)
     rec = [blk for blk in notes.split("  - .agpr_count:") if ".name:           " + sym + "\n" in blk]
     if len(rec) != 1:
@@ -637,22 +648,27 @@ def kernel_registers(replicas, clone=False):
     return nv, min(ns, 102), sorted({int(m) for m in re.findall(r"v_writelane_b32\s+v(\d+)", text)})
 
 
-def kernel_accumulator_vgprs(replicas, clone=False):
-    """the vector registers mm_mfma_blk3_kernel<replicas, true, 2, clone> accumulates its limb sums in: every register of a v_mfma's
-    destination tuple that is also its addend tuple (`v_mfma_i32_16x16x64_i8 v[a:b], ., ., v[a:b]`), read from the running library's own
-    code object.  An upset of one lane of one of them in the middle of a tile moves exactly one output word (tests: the PREG decode)."""
+def kernel_addend_tuples(replicas, slot, clone=False, kernel="blocks3"):
+    """for every step body of mm_mfma_blk3_kernel<replicas, true, 2, clone> (a body = 20 x replicas consecutive MFMAs of the disassembly): the
+    register tuple (first, last) the MFMA of slot `slot` takes as its addend -- a limb-sum accumulator that is LIVE in front of that slot,
+    whatever the allocator does with it afterwards (the accumulators migrate: a v_mfma's destination need not be its addend).  Read from the
+    running library's own code object.  (tests: the PREG decode)"""
     import re
 
-    text, _ = _kernel_text(PHYS_KERNEL % (replicas, int(bool(clone))))
-    acc = set()
-    for m in re.finditer(r"v_mfma_i32_16x16x64_i8\s+v\[(\d+):(\d+)\],\s*v\[\d+:\d+\],\s*v\[\d+:\d+\],\s*v\[(\d+):(\d+)\]", text):
-        if m.group(1) == m.group(3) and m.group(2) == m.group(4):
-            acc.update(range(int(m.group(1)), int(m.group(2)) + 1))
-    return sorted(acc)
+    text, _ = _kernel_text(phys_symbol(replicas, clone, kernel))
+    per = 20 * replicas
+    mf = re.findall(r"v_mfma_i32_16x16x64_i8\s+v\[\d+:\d+\],\s*v\[\d+:\d+\],\s*v\[\d+:\d+\],\s*(?:v\[(\d+):(\d+)\]|\S+)", text)
+    out = []
+    for b in range(len(mf) // per):
+        c0, c1 = mf[b * per + slot]
+        if c0:
+            out.append((int(c0), int(c1)))
+    return out
 
 
 def preg_row(item, d):
-    step = d["slot"] | (d["step"] << 6) | (d["lane"] << 10) | (d["wave"] << 16) | (d["file"] << 19) | (d["reg"] << 20)
+    # (steps 16..31 of mm_mfma_blk4_kernel's 32-step items: the fifth bit of the step rides in bit 29)
+    step = d["slot"] | ((d["step"] & 15) << 6) | (d["lane"] << 10) | (d["wave"] << 16) | (d["file"] << 19) | (d["reg"] << 20) | ((d["step"] >> 4) << 29)
     return (item, 0, ca.SITE_MM_PREG, step, d["bit"])
 
 
@@ -674,12 +690,14 @@ def run_uniform_campaign(a, eng=None):
     rep = MODES[a.mode]
     if a.benchmark != "mm" or a.side != 256 or a.mode == "CFCSS":
         raise SystemExit("--reg-model uniform: the register file is that of the matrix-core kernel (-b mm --side 256 -m TMR | DWC | NONE)")
-    quads = max(1, cu_count() // 4)  # workgroup groups of a launch = its stride between a workgroup's matrices
+    kern = a.kernel if rep == ca.TMR else "blocks3"  # (DWC and the unprotected mode run mm_mfma_blk3_kernel whatever the TMR kernel is)
+    geo = KERNELS[kern]
+    quads = max(1, cu_count() // geo["panels"])  # workgroup groups of a launch = its stride between a workgroup's matrices
     runs = a.runs
-    nv, ns, spill = kernel_registers(max(rep, 1), a.clone_staging and rep > 1)
+    nv, ns, spill = kernel_registers(max(rep, 1), a.clone_staging and rep > 1, kern)
     spill = set(spill)  # vector registers whose lanes hold spilled scalar registers: the scalar class too
     nslots = 20 * max(rep, 1)  # MFMA slots of a pipeline step
-    draws = [uniform_draw(rng, nv, ns) for _ in range(runs)]
+    draws = [uniform_draw(rng, nv, ns, geo["panels"], geo["steps"]) for _ in range(runs)]
     for d in draws:
         d["slot"] %= nslots
     scalar = lambda d: d["file"] == 1 or d["reg"] in spill
@@ -695,7 +713,7 @@ def run_uniform_campaign(a, eng=None):
     t0 = time.perf_counter()
     children = 0
     while todo:
-        spec = json.dumps({"mode": a.mode, "seed": a.seed, "clone": bool(a.clone_staging), "launches": [[[r, draws[r]] for r in grp] for grp in todo]})
+        spec = json.dumps({"mode": a.mode, "seed": a.seed, "clone": bool(a.clone_staging), "kernel": kern, "launches": [[[r, draws[r]] for r in grp] for grp in todo]})
         children += 1
         proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--preg-child", "-"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
         try:
@@ -764,7 +782,8 @@ def run_uniform_campaign(a, eng=None):
                         "result": {"core": 0, "errors": int(cls == "error"), "faults": int(bool(flagged)), "runtime_us": wall * 1e6 / runs}})
     nbad = counts["errors"] + counts["invalids"]
     summary = {
-        "name": "mm_%s_registers_uniform%s" % (a.mode, "_clone_staging" if a.clone_staging else ""), "clone_staging": bool(a.clone_staging), "benchmark": "mm", "mode": a.mode, "section": "registers", "mem_mode": None, "runs": runs,
+        "name": "mm_%s_registers_uniform%s%s" % (a.mode, "_clone_staging" if a.clone_staging else "", "_panel128" if kern == "panel128" else ""), "clone_staging": bool(a.clone_staging),
+        "kernel": "mm_mfma_blk4_kernel (128-row panel)" if kern == "panel128" else "mm_mfma_blk3_kernel (64-row panel)", "benchmark": "mm", "mode": a.mode, "section": "registers", "mem_mode": None, "runs": runs,
         "success": counts["success"], "errors": counts["errors"], "faults": counts["faults"], "timeouts": counts["timeouts"],
         "invalids": counts["invalids"], "aborts": counts["aborts"], "scalar_upsets_not_executed_counted_as_errors": counts["not_executed"],
         "coverage_pct": 100.0 * (runs - nbad) / runs,
@@ -790,15 +809,18 @@ def preg_child(_):
     spec = json.loads(sys.stdin.read())
     eng = ca.Engine(0)
     n, nn, items = 256, 256 * 256, 3
-    quads = max(1, cu_count() // 4)
+    kern = spec.get("kernel", "blocks3")
+    geo = KERNELS[kern]
+    os.environ["COAST_MM_TILE"] = kern  # (read by the library at every call)
+    quads = max(1, cu_count() // geo["panels"])
     g = torch.Generator(device="cuda").manual_seed(spec["seed"])
     f, s = [torch.randint(-2**31, 2**31, (items * quads, n, n), dtype=torch.int32, device="cuda", generator=g) for _ in range(2)]
     gold = eng.mm_batch(f, s, cfg=ca.XmrConfig(ca.UNPROTECTED)).clone()
-    cfg = ca.XmrConfig(MODES[spec["mode"]], 0, ca.F_CLONE_STAGING if spec.get("clone") else 0)
+    cfg = ca.XmrConfig(MODES[spec["mode"]], 0, 0 if spec.get("clone") else ca.F_SINGLE_STAGING)
     for k, grp in enumerate(spec["launches"]):
         print("start %d" % k, flush=True)
         eng.reset_stats()
-        eng.inject_faults(ca.make_faults([preg_row((quads + q) * nn + 64 * d["panel"] * n, d) for q, (r, d) in enumerate(grp)]))
+        eng.inject_faults(ca.make_faults([preg_row((quads + q) * nn + geo["rows"] * d["panel"] * n, d) for q, (r, d) in enumerate(grp)]))
         det = torch.zeros(items * quads * nn, dtype=torch.uint8, device="cuda")
         out = eng.mm_batch(f, s, cfg=cfg, detected=det)
         wrong = (out != gold).reshape(items, quads, -1).any(dim=2).any(dim=0).cpu().numpy()
@@ -872,7 +894,10 @@ def parse(argv=None):
                     help="--reg-model uniform: scalar-register upsets are not executed and count as errors (count), or run one per launch in "
                          "child processes (run: a wild descriptor is a memory fault that ends the child)")
     ap.add_argument("--clone-staging", action="store_true",
-                    help="-b mm --side 256: run with COAST_F_CLONE_STAGING (the global -> LDS staging loads cloned and compared)")
+                    help="-b mm --side 256: run with the staging loads cloned and compared (the library's default since ABI 8; without this option the campaign passes COAST_F_SINGLE_STAGING)")
+    ap.add_argument("--kernel", default="panel128", choices=["panel128", "blocks3"],
+                    help="--reg-model uniform -m TMR: the matrix-core kernel whose register file is drawn from -- mm_mfma_blk4_kernel (128-row panel, "
+                         "the library's TMR default since round 6) or mm_mfma_blk3_kernel (64-row panel, rounds 4-5; always the DWC / unprotected kernel)")
     ap.add_argument("--preg-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--counters-in-sor", action="store_true",
                     help="registers: run with COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC (the loop counters replica-private, their branch conditions "
