@@ -194,13 +194,20 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     // thread's four bytes: slot HQ, dword l / 16 (32 lanes = 16 columns x 2 dwords: 32 different banks)
     auto colRow = [](int c) { return ((c & 7) << 1) | (c >> 3); };
     auto colSwz = [](int c) { return (c >> 1) & 3; };
+    // ADDRESS REGISTERS (round 6, after the first uniform campaign of this kernel: profiles/r06_campaign_uniform_*): every LDS address of
+    // the steps is ONE per-lane base register + a compile-time instruction offset (the slab buffer's parity is the step's position in its
+    // tile).  Left to itself the compiler hoists `base + wave-uniform term` for every (plane, buffer) pair into registers that live for the
+    // whole kernel -- fifteen of them, each a single point of failure every replica depends on (every flip of any bit of any lane a
+    // silently wrong product: 91.2 % coverage against mm_mfma_blk3_kernel's 96.4 %).  Now: the fragment reads' bases are REPLICA-PRIVATE
+    // registers (aOffR[r], offBR[r]: a flip there corrupts one replica's operands and is out-voted at the tile's votes); the conversion's
+    // store base and the staging loads' offset exist twice under CLONE and are compared where they are used (a mismatch recomputes both
+    // from a fresh lane id and counts one corrected error -- select(a == b, a, c) with the third copy evaluated lazily).
     const int voffS = ((4 * kg) * G::N + l16) * 4;
-    const int dstS = colRow(l16) * G::KS + ((HQ ^ colSwz(l16)) * 16) + kg * 4;
+    const int dstS = wbufOff + colRow(l16) * G::KS + ((HQ ^ colSwz(l16)) * 16) + kg * 4; // (the lane's slab buffers included)
     auto slabOff = [&](int g) __attribute__((always_inline)) { return (((g & 3) * G::KS + 16 * HQ) * G::N + tileCol0(g)) * 4; };
 
     const int aOff = (32 * HQ + l16) * G::ROW_A + ((kg ^ l16) * 16);
-    const int bOff = colRow(l16) * G::KS + ((kg ^ colSwz(l16)) * 16);
-    auto panelOff = [&](int g) __attribute__((always_inline)) { return aOff ^ ((g & 3) * 64); };
+    const int bOff = wbufOff + colRow(l16) * G::KS + ((kg ^ colSwz(l16)) * 16); // (the lane's slab buffers included)
 
     uint32_t agree = 0;            // votes of this lane whose three copies were equal (phantom votes included)
     uint32_t nExec = 0, nReal = 0; // wave-uniform: votes executed / votes of tiles that exist (= the lane's __SYNC_COUNT)
@@ -228,9 +235,23 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
         constexpr int set = decltype(setTag)::value, kk = decltype(kkTag)::value;
         pbs[set][kk] = __builtin_amdgcn_raw_buffer_load_b32(rsSof(gs >> 5), voffS + kk * G::N * 4, slabOff(gs), 0);
     };
+    int voffS2 = launder(voffS), dstS2 = launder(dstS); // the clones' own address registers (CLONE)
     auto loadDupS = [&](int gs, auto setTag, auto kkTag) __attribute__((always_inline)) {
         constexpr int set = decltype(setTag)::value, kk = decltype(kkTag)::value;
-        dupS[DUPADJ ? set : 0][kk] = __builtin_amdgcn_raw_buffer_load_b32(rsSof(gs >> 5), launder(voffS) + kk * G::N * 4, slabOff(gs), 0);
+        dupS[DUPADJ ? set : 0][kk] = __builtin_amdgcn_raw_buffer_load_b32(rsSof(gs >> 5), voffS2 + kk * G::N * 4, slabOff(gs), 0);
+    };
+    // the conversion's store base against its clone, in front of the stores (cold path: both from a fresh lane id)
+    int dstSv = dstS;
+    auto verifyDst = [&]() __attribute__((always_inline)) {
+        if constexpr (DUP) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(dstSv != dstS2) != 0, 0)) {
+                const int l = freshLane(), c = l & 15;
+                const int fresh = wbufOff + (((c & 7) << 1) | (c >> 3)) * G::KS + ((HQ ^ ((c >> 1) & 3)) * 16) + (l >> 4) * 4;
+                stageMiss += (dstSv != dstS2) ? 1u : 0u;
+                dstSv = fresh;
+                dstS2 = launder(fresh);
+            }
+        }
     };
     // in front of the first instruction that consumes a word of the set; gs = the slab it belongs to
     auto verifyS = [&](auto setTag, int gs) __attribute__((always_inline)) {
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
         mm_transpose4(y, w);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<uint32_t *>(smemP + bufOff + q * G::PLANE_B + dstS) = w[q];
+            *reinterpret_cast<uint32_t *>(smemP + dstSv + bufOff + q * G::PLANE_B) = w[q];
     };
     using U0 = std::integral_constant<int, 0>;
     using U1 = std::integral_constant<int, 1>;
@@ -277,7 +298,7 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
         for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadDupS(0, U0{}, kkTag); });
         verifyS(U0{}, 0);
     }
-    convNow(U0{}, wbufOff);
+    convNow(U0{}, 0);
     for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadS(NSETS, U0{}, kkTag); });
     if constexpr (DUP) {
         for_each_index(SEQ4{}, [&](auto kkTag) __attribute__((always_inline)) { loadDupS(1, SLAST{}, kkTag); }); // compared in step 0's first slot
@@ -462,19 +483,24 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     // use): the sixteen registers that frees are where the two f pieces in flight and their clones live.  Both forms enter and leave a
     // step with a[0..3] = the first set's fragments.
     v4i_t a[8], b[NREP][4];
-    int offA = panelOff(0), offB = bOff;
+    int aOffR[NREP], offBR[NREP]; // replica-private fragment bases
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) {
+        aOffR[r] = launder(aOff);
+        offBR[r] = launder(bOff);
+    }
+    int offAset = aOffR[0]; // the A base of the set whose fragments are being read: aOffR[replica] ^ 64 * (g % 4), a temporary of a few slots
     auto loadAi = [&](auto idxTag, auto pTag, int rbl, int off) __attribute__((always_inline)) { // plane p of row block rbl into register idx
         constexpr int p = decltype(pTag)::value, idx = decltype(idxTag)::value;
         a[idx] = *reinterpret_cast<const v4i_t *>(smemP + off + p * G::PLANE_A + rbl * 16 * G::ROW_A);
     };
-    auto loadB = [&](auto rrTag, auto qTag, int bufOff) __attribute__((always_inline)) {
-        constexpr int rr = decltype(rrTag)::value, q = decltype(qTag)::value;
-        b[rr][q] = *reinterpret_cast<const v4i_t *>(smemP + bufOff + offB + q * G::PLANE_B);
+    auto loadB = [&](auto rrTag, auto qTag, auto parTag) __attribute__((always_inline)) { // parTag: which of the lane's two slab buffers
+        constexpr int rr = decltype(rrTag)::value, q = decltype(qTag)::value, par = decltype(parTag)::value;
+        b[rr][q] = *reinterpret_cast<const v4i_t *>(smemP + offBR[rr] + par * G::B_BUF + q * G::PLANE_B);
     };
-    for_each_index(SEQ4{}, [&](auto pTag) __attribute__((always_inline)) { loadAi(pTag, pTag, 0, offA); });
+    for_each_index(SEQ4{}, [&](auto pTag) __attribute__((always_inline)) { loadAi(pTag, pTag, 0, offAset); });
     for_each_index(std::make_integer_sequence<int, NREP>{}, [&](auto rrTag) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(offB)); // one load per replica: not to be merged
-        for_each_index(SEQ4{}, [&](auto qTag) __attribute__((always_inline)) { loadB(rrTag, qTag, wbufOff); });
+        for_each_index(SEQ4{}, [&](auto qTag) __attribute__((always_inline)) { loadB(rrTag, qTag, U0{}); });
     });
 
     auto step = [&](int g, auto firstTag, auto posTag, auto bgTag) __attribute__((always_inline)) {
@@ -487,9 +513,16 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
         constexpr bool PRELOAD = BG == 1 && POS == 1; // pieces 0 and 1 are requested in the half step in front of half step 0
         constexpr int CSET = NSETS == 2 ? (POS + 1) & 1 : 0; // register set of slab g + 1
         constexpr int CS = (K1 >= 0 || PRELOAD) ? 2 : COAST_MM4_CONV_STRIDE; // conversion stage stride (BG steps: the first ten slots, the f stages behind)
-        const int bufNext = wbufOff + ((g + 1) & 1) * G::B_BUF;
-        int offAnext = panelOff(g + 1);
-        offA = panelOff(g);
+        constexpr int PARN = (POS + 1) & 1; // slab g + 1's buffer (an item has an even number of steps: the parity of g is that of POS)
+        using PARNT = std::integral_constant<int, PARN>;
+        // (the base of the next set's fragments: that set's own replica's register, XORed with the k-slab's swizzle where the reads start)
+        auto setBase = [&](auto setTag) __attribute__((always_inline)) {
+            constexpr int st = decltype(setTag)::value; // NSET = the next step's first set
+            if constexpr (st == NSET)
+                offAset = aOffR[0] ^ (((POS + 1) & 3) * 64);
+            else
+                offAset = aOffR[st % NREP] ^ (POS * 64);
+        };
         const int bgItem = BG == 1 ? (g >> 5) + 1 : (g >> 5); // the item whose panel is being staged
         const uint32_t realPrev = g != 0 ? 1u : 0u;
         int voffR = 0;
@@ -530,9 +563,10 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
             else if constexpr (sub == 3)
                 perm2();
             else {
+                verifyDst();
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<uint32_t *>(smemP + bufNext + q * G::PLANE_B + dstS) = w[q];
+                    *reinterpret_cast<uint32_t *>(smemP + dstSv + PARN * G::B_BUF + q * G::PLANE_B) = w[q];
             }
         };
         // the f pieces' per-lane address registers, once per BG step (two registers of the sixteen the single A fragment set frees; recomputed
@@ -602,8 +636,6 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
             constexpr int q = 3 - p - jj;
             constexpr bool fromZero = FIRST != 0 && p == 0;
             constexpr int half = m / HALF, mh = m % HALF;
-            if constexpr (j == 0 && set != 0)
-                asm volatile("" : "+v"(offA)); // this set's A fragments are its own loads
             if constexpr (PHYS == 2)
                 if (pregSlot == (uint32_t)m)
                     pregFlip();
@@ -611,31 +643,17 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
             constexpr auto aIdx = [](int st, int pp) { return ABUF ? 4 * (st & 1) + pp : pp; }; // register of fragment pp of set st
             acc[rb][rr][p + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[aIdx(set, p)], b[rr][q], fromZero ? zero : acc[rb][rr][p + q], 0, 0, 0);
             if constexpr (ABUF && j < 4) { // the NEXT set's fragment j, into the other register set: a whole set ahead of its first use
-                if constexpr (set == NSET - 1) {
-                    if constexpr (j == 0)
-                        asm volatile("" : "+v"(offAnext));
-                    loadAi(std::integral_constant<int, aIdx(set + 1, j)>{}, std::integral_constant<int, j>{}, 0, offAnext);
-                } else {
-                    if constexpr (j == 0)
-                        asm volatile("" : "+v"(offA));
-                    loadAi(std::integral_constant<int, aIdx(set + 1, j)>{}, std::integral_constant<int, j>{}, (set + 1) / NREP, offA);
-                }
+                if constexpr (j == 0)
+                    setBase(std::integral_constant<int, set + 1>{});
+                loadAi(std::integral_constant<int, aIdx(set + 1, j)>{}, std::integral_constant<int, j>{}, set == NSET - 1 ? 0 : (set + 1) / NREP, offAset);
             }
             if constexpr (!ABUF && jj == 3 - p) { // last use of a[p] in this set: the next set's (the next step's first set behind the last)
-                if constexpr (set == NSET - 1) {
-                    if constexpr (p == 0)
-                        asm volatile("" : "+v"(offAnext));
-                    loadAi(std::integral_constant<int, p>{}, std::integral_constant<int, p>{}, 0, offAnext);
-                } else {
-                    if constexpr (p == 0)
-                        asm volatile("" : "+v"(offA));
-                    loadAi(std::integral_constant<int, p>{}, std::integral_constant<int, p>{}, (set + 1) / NREP, offA);
-                }
+                if constexpr (p == 0)
+                    setBase(std::integral_constant<int, set + 1>{});
+                loadAi(std::integral_constant<int, p>{}, std::integral_constant<int, p>{}, set == NSET - 1 ? 0 : (set + 1) / NREP, offAset);
             }
             if constexpr (rb == 1 && jj == 0) { // last use of b[rr][3 - p] in this step
-                if constexpr (p == 0)
-                    asm volatile("" : "+v"(offB));
-                loadB(std::integral_constant<int, rr>{}, std::integral_constant<int, 3 - p>{}, bufNext);
+                loadB(std::integral_constant<int, rr>{}, std::integral_constant<int, 3 - p>{}, PARNT{});
             }
             // conversion of slab g + 1: five stages in the first half
             if constexpr (half == 0 && mh % CS == 0 && mh / CS < 5)
