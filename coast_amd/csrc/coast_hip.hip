@@ -856,9 +856,13 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
     bool havePreg = false; // ... of ANY register, by physical number: the instantiation with a hook in front of every MFMA slot
     for (const coast_fault &af : c->armed)
         havePreg = havePreg || af.site == COAST_SITE_MM_PREG;
-    if (havePhys && !(mfma && mmBlocks && mmBlocks2 && mmBlocks3))
+    if (haveVgprEarly && !(mfma && mmBlocks && mmBlocks2 && mmBlocks3))
         return fail(c, COAST_EINVAL, "coast_mm_batch: COAST_SITE_MM_VGPR names a register of mm_mfma_blk3_kernel: side 256, no sync_every / "
-                                     "flags, COAST_MM_ENGINE / COAST_MM_TILE at their defaults");
+                                     "flags, COAST_MM_ENGINE at its default, COAST_MM_TILE unset or blocks3");
+    if (havePreg && !(mfma && mmBlocks2 && mmBlocks3))
+        return fail(c, COAST_EINVAL, "coast_mm_batch: COAST_SITE_MM_PREG is hooked into mm_mfma_blk4_kernel, mm_mfma_blk3_kernel and "
+                                     "mm_mfma_panel_kernel: side 256, no sync_every / flags, COAST_MM_TILE unset, panel128, blocks3 or lanes");
+    (void)havePhys;
     FaultTab ft;
     int have = 0;
     const uint32_t *dBlockList = nullptr;
@@ -1006,13 +1010,20 @@ extern "C" int coast_mm_batch(coast_ctx *c, const uint32_t *d_f, const uint32_t 
         if (mfma) { /* armed upsets are applied and out-voted inside the panel kernel: no VALU workgroup runs */ \
             using GP = MmPanel<R>;                                                                              \
             static_assert(GP::BPM == 256 / 64, "panel geometry");                                               \
-            HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_panel_kernel<R>,                               \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)GP::LDS_BYTES));    \
             FaultTab ftm = ft;                                                                                  \
             if (!have)                                                                                          \
                 ftm.list = nullptr, ftm.range = nullptr;                                                        \
-            hipLaunchKernelGGL(mm_mfma_panel_kernel<R>, dim3((uint32_t)nbm), dim3(GP::NTHR), GP::LDS_BYTES,     \
-                               c->stream, d_f, d_s, d_r, (uint32_t)nbm, ctr, ftm, d_detected);                  \
+            if (havePreg) { /* the instantiation with a hook in front of every MFMA slot */                     \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_panel_kernel<R, 2>,                        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GP::LDS_BYTES)); \
+                hipLaunchKernelGGL((mm_mfma_panel_kernel<R, 2>), dim3((uint32_t)nbm), dim3(GP::NTHR), GP::LDS_BYTES, \
+                                   c->stream, d_f, d_s, d_r, (uint32_t)nbm, ctr, ftm, d_detected);              \
+            } else {                                                                                            \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mm_mfma_panel_kernel<R>,                           \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GP::LDS_BYTES)); \
+                hipLaunchKernelGGL(mm_mfma_panel_kernel<R>, dim3((uint32_t)nbm), dim3(GP::NTHR), GP::LDS_BYTES, \
+                                   c->stream, d_f, d_s, d_r, (uint32_t)nbm, ctr, ftm, d_detected);              \
+            }                                                                                                   \
             if (have)                                                                                           \
                 hookedBlocks = nFaultBlocks;                                                                    \
             engine = COAST_ENGINE_MATRIX_CORE;                                                                  \

@@ -66,9 +66,10 @@
 // DWC: the compare that fails counts a detected item and flags the first element the word reaches.  What stays single: the five conversion
 // stages' temporaries (digits -> byte planes, alive for three to six slots each).
 // PRICE: the register file is full (256 VGPRs, two waves per SIMD) -- the twelve clone registers push address registers into scratch, whose
-// reloads drain the whole VMEM queue, and sixteen more buffer loads and four compare-and-branch sequences per slab cost what they cost at this
-// chip's power limit: + 30 % (6.77 -> 8.82 ms; the loads alone + 12.6 %, the f clone alone + 5 %: profiles/r05_mm_clone_ab.txt), for 94.4 -> 96.6 %
-// coverage in the uniform register-file campaign (profiles/r05_campaign_uniform_*.txt).  Hence a flag, not the default.
+// reloads drain the whole VMEM queue: first forms ran + 30 %; the shipped form (two-word clones, one compare per round, the f piece requested one
+// step ahead) + 10-12 % (profiles/r05_mm_clone_ab.txt, profiles/r06_mm_blk4_ab.txt).  Coverage with and without: docs/design/campaign.md (the
+// one table; round 5's own figures came from a broken register-selector decode).  Round 6: the clones are the library's default (ABI 8,
+// COAST_F_SINGLE_STAGING opts out) and the TMR default kernel is mm_mfma_blk4_kernel, where they cost + 6 %.
 
 // round 5, measured and NOT the default: WIDE staging loads of s.  A buffer load costs this kernel about what seven LDS reads cost
 // (profiles/r05_mm_clone_ab.txt), and the s staging issues eight two-word loads per slab and wave (a lane: two adjacent columns x eight k).
@@ -218,19 +219,31 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     auto colRow = [](int c) { return ((c & 7) << 1) | (c >> 3); };
     auto colSwz = [](int c) { return (c >> 1) & 3; };
+    // ADDRESS REGISTERS (round 6; mm_mfma_blk4_kernel.hip has the story): every LDS address of the slab buffers is ONE per-lane base register
+    // (the pair's buffer offset folded in) + a compile-time instruction offset -- the buffer's parity is the step's position in its tile.
+    // With `base + wave-uniform term` computed per use, the DWC and unprotected instantiations (which have registers to spare) kept some twenty
+    // hoisted sums alive for the whole kernel, each a single point of failure both replicas depend on: uniform-campaign coverage of DWC 88.4 %
+    // (profiles/r06_campaign_uniform_DWC_single_5000.txt).  PRIV (DWC): the fragment reads' bases are replica-private registers too, and
+    // under CLONE the conversion's store base and the staging loads' offset exist twice (compared / used by the clone loads).  The TMR
+    // instantiation keeps its single base registers: its register file is full (and mm_mfma_blk4_kernel is the TMR default).
+    constexpr bool PRIV = NREP == 2;
+    constexpr bool FOLD = NREP < 3; // (TMR: byte-identical to round 5's kernel)
+    const int wbufFold = FOLD ? wbufOff : 0, wbufRest = FOLD ? 0 : wbufOff;
     const int voffB = ((4 * (lane >> 3)) * G::N + 2 * (lane & 7)) * 4;
-    const int dstB0 = colRow(2 * (lane & 7)) * G::KS + ((((lane >> 3) >> 2) ^ colSwz(2 * (lane & 7))) * 16) + ((lane >> 3) & 3) * 4;
-    auto dstB = [&](int u, int h) __attribute__((always_inline)) { return (dstB0 ^ (u * 32)) + h * 2 * G::KS; };
+    const int dstB0c = wbufFold + colRow(2 * (lane & 7)) * G::KS + ((((lane >> 3) >> 2) ^ colSwz(2 * (lane & 7))) * 16) + ((lane >> 3) & 3) * 4;
+    int dstB0v = dstB0c; // (PRIV + CLONE: replaced by a fresh value when its clone disagrees.  The low 13 bits of the pair's buffer offset are
+                         // zero: the XOR / adds below stay inside the lane's own bits)
+    auto dstB = [&](int u, int h) __attribute__((always_inline)) { return ((PRIV ? dstB0v : dstB0c) ^ (u * 32)) + h * 2 * G::KS; };
     constexpr int kRoundOff = 8 * 4 * G::N * 4;
     // WIDE: lane -> (column quad cq = l % 4: columns 4 cq .. + 3; k-quad l / 4: rows 4 (l / 4) .. + 3 of the slab).  Column c = 4 cq + h sits in
     // row colRow(c) = 8 (cq % 2) + 2 h + cq / 2 of a plane, its slots XORed with colSwz(c) = 2 (cq % 2) ^ (h / 2)
     const int voffW = ((4 * (lane >> 2)) * G::N + 4 * (lane & 3)) * 4;
-    const int dstW0 = (8 * (lane & 1) + ((lane & 3) >> 1)) * G::KS + (((lane >> 4) ^ (2 * (lane & 1))) * 16) + ((lane >> 2) & 3) * 4;
+    const int dstW0 = wbufFold + (8 * (lane & 1) + ((lane & 3) >> 1)) * G::KS + (((lane >> 4) ^ (2 * (lane & 1))) * 16) + ((lane >> 2) & 3) * 4;
     auto dstW = [&](int h) __attribute__((always_inline)) { return (dstW0 ^ ((h >> 1) * 16)) + h * 2 * G::KS; };
     auto slabOff = [&](int g) __attribute__((always_inline)) { return ((g & 3) * G::KS * G::N + tileCol0(g)) * 4; };
 
     const int aOff = l16 * G::N + ((kg ^ l16) * 16);
-    const int bOff = colRow(l16) * G::KS + ((kg ^ colSwz(l16)) * 16);
+    const int bOff = wbufFold + colRow(l16) * G::KS + ((kg ^ colSwz(l16)) * 16);
     auto panelOff = [&](int g) __attribute__((always_inline)) { return ((g >> 4) & 1) * G::A_PANEL + (aOff ^ ((g & 3) * 64)); };
 
     auto run = [&](auto hTag) __attribute__((always_inline)) {
@@ -306,9 +319,27 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         // copy of bgRaw.
         u32x2_t dupS[4] = {};
         u32x4_t dupF = {0u, 0u, 0u, 0u};
+        int voffB2 = voffB, dstB02 = dstB0c; // PRIV: the clones' own offset register, the store base's clone
+        if constexpr (PRIV && DUP) {
+            voffB2 = launder(voffB);
+            dstB02 = launder(dstB0c);
+        }
         auto dupLoadS = [&](auto uTag, auto kkTag, const __amdgpu_buffer_rsrc_t rs, int so) __attribute__((always_inline)) {
             constexpr int u = decltype(uTag)::value, kk = decltype(kkTag)::value;
-            dupS[kk] = __builtin_amdgcn_raw_buffer_load_b64(rs, voffB + kk * G::N * 4, so + u * kRoundOff, 0);
+            dupS[kk] = __builtin_amdgcn_raw_buffer_load_b64(rs, (PRIV ? voffB2 : voffB) + kk * G::N * 4, so + u * kRoundOff, 0);
+        };
+        // PRIV + CLONE: the conversion's store base against its clone, in front of a group's stores (cold path: both from a fresh lane id; one
+        // detected / corrected word)
+        auto verifyDst = [&]() __attribute__((always_inline)) {
+            if constexpr (PRIV && DUP) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(dstB0v != dstB02) != 0, 0)) {
+                    const int l = freshLane();
+                    const int fresh = wbufFold + colRow(2 * (l & 7)) * G::KS + ((((l >> 3) >> 2) ^ colSwz(2 * (l & 7))) * 16) + ((l >> 3) & 3) * 4;
+                    stageMiss += (dstB0v != dstB02) ? 1u : 0u;
+                    dstB0v = fresh;
+                    dstB02 = launder(fresh);
+                }
+            }
         };
         auto flagElem = [&](uint32_t mat, int row, int col) __attribute__((always_inline)) {
             if constexpr (FLAGS)
@@ -377,30 +408,30 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             using T3 = std::integral_constant<int, 3>;
             if (H == 1) {
                 loadSlabW(0);
-                convGroupNowW(U0{}, wbufOff);
-                convGroupNowW(U1{}, wbufOff);
-                convGroupNowW(T2{}, wbufOff);
-                convGroupNowW(T3{}, wbufOff);
+                convGroupNowW(U0{}, wbufRest);
+                convGroupNowW(U1{}, wbufRest);
+                convGroupNowW(T2{}, wbufRest);
+                convGroupNowW(T3{}, wbufRest);
                 loadSlabW(2);
             } else {
                 loadSlabW(1);
-                convGroupNowW(U0{}, wbufOff + G::B_BUF);
-                convGroupNowW(U1{}, wbufOff + G::B_BUF);
+                convGroupNowW(U0{}, wbufRest + G::B_BUF);
+                convGroupNowW(U1{}, wbufRest + G::B_BUF);
             }
         } else if (H == 1) {
             loadRound(0, U0{});
             loadRound(0, U1{});
             verifyRoundNow(0, U0{});
-            convRound(U0{}, wbufOff);
+            convRound(U0{}, wbufRest);
             verifyRoundNow(0, U1{});
-            convRound(U1{}, wbufOff);
+            convRound(U1{}, wbufRest);
             loadRound(2, U0{});
             loadRound(2, U1{});
         } else {
             loadRound(1, U0{});
             loadRound(1, U1{});
             verifyRoundNow(1, U0{});
-            convRound(U0{}, wbufOff + G::B_BUF);
+            convRound(U0{}, wbufRest + G::B_BUF);
             if constexpr (DUP) { // step 0 is this wave's duty step: the clones of slab 1's second round
                 const __amdgpu_buffer_rsrc_t rs = rsSof(0);
                 const int so = slabOff(1);
@@ -616,6 +647,14 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         constexpr auto aIdx = [](int set, int p) { return ABUF ? 4 * (set & 1) + p : p; }; // register of fragment p of a set
         v4i_t a[NA], b[NREP][4];
         int offA = panelOff(0), offB = bOff;
+        // PRIV: replica-private fragment bases (a flip there corrupts one replica's operands: the compare at the tile's end sees it)
+        int aOffR[NREP], offBR[NREP];
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            aOffR[r] = PRIV ? launder(aOff) : aOff;
+            offBR[r] = PRIV ? launder(bOff) : bOff;
+        }
+        auto panelOffR = [&](int g, int r) __attribute__((always_inline)) { return ((g >> 4) & 1) * G::A_PANEL + (aOffR[r] ^ ((g & 3) * 64)); };
         auto loadA = [&](auto pTag, int rbl, int off) __attribute__((always_inline)) { // (one set: register p)
             constexpr int p = decltype(pTag)::value;
             if constexpr (COAST_MM3_KNOCK & 512) // timing: the read is issued and awaited, but always of the same 16 bytes per lane
@@ -630,14 +669,14 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
         auto loadB = [&](auto rrTag, auto qTag, int bufOff) __attribute__((always_inline)) {
             constexpr int rr = decltype(rrTag)::value, q = decltype(qTag)::value;
             if constexpr (COAST_MM3_KNOCK & 512)
-                b[rr][q] = *reinterpret_cast<const v4i_t *>(smemP + (bufOff & 0) + kSlabBase + offB + q * G::PLANE_B);
+                b[rr][q] = *reinterpret_cast<const v4i_t *>(smemP + (bufOff & 0) + (FOLD ? 0 : kSlabBase) + offB + q * G::PLANE_B);
             else
-                b[rr][q] = *reinterpret_cast<const v4i_t *>(smemP + bufOff + offB + q * G::PLANE_B);
+                b[rr][q] = *reinterpret_cast<const v4i_t *>(smemP + bufOff + (PRIV ? offBR[rr] : offB) + q * G::PLANE_B);
         };
         for_each_index(std::make_integer_sequence<int, 4>{}, [&](auto pTag) __attribute__((always_inline)) { loadA(pTag, 0, offA); });
         for_each_index(std::make_integer_sequence<int, NREP>{}, [&](auto rrTag) __attribute__((always_inline)) {
             asm volatile("" : "+v"(offB)); // one load per replica: not to be merged
-            for_each_index(std::make_integer_sequence<int, 4>{}, [&](auto qTag) __attribute__((always_inline)) { loadB(rrTag, qTag, wbufOff); });
+            for_each_index(std::make_integer_sequence<int, 4>{}, [&](auto qTag) __attribute__((always_inline)) { loadB(rrTag, qTag, wbufRest); });
         });
         // ---- COAST_SITE_MM_VGPR (PHYS): coast_fault.item names the panel, the row half (row / 32), the row block (row / 16) and the column
         // tile (column / 16); .replica the replica; .step = k-slab of the tile (bits 1:0) | lane << 8 | dword of the 4-dword fragment << 16 |
@@ -714,9 +753,16 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
             const int gLoad = (DUP && !DUTY) ? g + 2 : g + 3; // duty step: the staged copies of slab g + 3; off duty: the clones of slab g + 2
             const int soffLoad = slabOff(gLoad);
             const __amdgpu_buffer_rsrc_t rsLoad = rsSof(gLoad >> 4);
-            const int bufNext = wbufOff + ((g + 1) & 1) * G::B_BUF;
-            const int bufConv = DUTY ? bufNext : wbufOff + (g & 1) * G::B_BUF;
-            int offAnext = panelOff(g + 1);
+            // (an item has an even number of steps: the parity of g is that of POS -- the slab buffers' offsets are instruction offsets)
+            const int bufNext = FOLD ? ((POS + 1) & 1) * G::B_BUF : wbufOff + ((g + 1) & 1) * G::B_BUF;
+            const int bufConv = DUTY ? bufNext : (FOLD ? (POS & 1) * G::B_BUF : wbufOff + (g & 1) * G::B_BUF);
+            int offAnext = PRIV ? panelOffR(g + 1, 0) : panelOff(g + 1);
+            [[maybe_unused]] int offAR[NREP]; // PRIV: this step's A bases per replica
+            if constexpr (PRIV) {
+#pragma unroll
+                for (int r = 0; r < NREP; ++r)
+                    offAR[r] = panelOffR(g, r);
+            }
             offA = panelOff(g);
             const int bgDst = BG ? (((g >> 4) + 1) & 1) * G::A_PANEL + panelDst(bgPiece(g)) : 0;
             const uint32_t realPrev = g != 0 ? 1u : 0u;
@@ -762,6 +808,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                 else if constexpr (sub == 3)
                     perm2();
                 else {
+                    verifyDst();
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         *reinterpret_cast<uint32_t *>(smemP + bufConv + q * G::PLANE_B + dstGrp(k / 5)) = w[q];
@@ -817,7 +864,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                     } else {
                         if constexpr (j == 0)
                             asm volatile("" : "+v"(offA));
-                        loadAi(std::integral_constant<int, aIdx(set + 1, j)>{}, std::integral_constant<int, j>{}, (set + 1) / NREP, offA);
+                        loadAi(std::integral_constant<int, aIdx(set + 1, j)>{}, std::integral_constant<int, j>{}, (set + 1) / NREP, PRIV ? offAR[(set + 1) % NREP] : offA);
                     }
                 }
                 if constexpr (!ABUF && jj == 3 - p && !((COAST_MM3_KNOCK & 1) && set % NREP != NREP - 1) && !(COAST_MM3_KNOCK & (256 | 2048))) { // last use of a[p] in this set: the next set's (the next step's first set behind the last)
@@ -828,7 +875,7 @@ __global__ __launch_bounds__(MmBlk2<NREP>::NTHR, 1) void mm_mfma_blk3_kernel(con
                     } else {
                         if constexpr (p == 0)
                             asm volatile("" : "+v"(offA));
-                        loadA(std::integral_constant<int, p>{}, (set + 1) / NREP, offA);
+                        loadA(std::integral_constant<int, p>{}, (set + 1) / NREP, PRIV ? offAR[(set + 1) % NREP] : offA);
                     }
                 }
                 if constexpr (rb == 1 && jj == 0 && !(COAST_MM3_KNOCK & (256 | 1024))) { // last use of b[rr][3 - p] in this step

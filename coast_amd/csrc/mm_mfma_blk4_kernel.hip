@@ -121,18 +121,21 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     };
     uint32_t stageMiss = 0; // this lane's words whose two staged copies differed
 
-    // ---- f panel.  Thread t = 64 wv + l: row32 = t / 16 (0..31), k-quad in a slab kqi = t % 16.  Piece pc = 4 s + jj of the thread: k-slab s
+    // ---- f panel.  Thread (wave wv, lane l): row32 = 16 (wv / 4) + wv % 4 + 4 (l / 16) (0..31: a wave's four rows differ in bits 2-3, so that
+    // their conversion stores fall into four different bank groups -- rows 4 wv .. + 3 met on the same sixteen banks, SQ_LDS_BANK_CONFLICT
+    // 1.0e8 per launch, profiles/r06_mm_rocprofv3_summary.txt), k-quad in a slab kqi = l % 16.  Piece pc = 4 s + jj of the thread: k-slab s
     // (region s), panel row 32 jj + row32, words k = 64 s + 4 kqi .. + 3.  LDS: row * 1024 + p * 256 + (slot ^ (row & 15)) * 16 + (kqi & 3) * 4
     // with slot = 4 s + kqi / 4 (a fragment read of 16 rows and a conversion store of two rows x 16 k-quads both cover every bank group)
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const int wvRow = 16 * (wv >> 2) + (wv & 3); // the wave's first row of a 32-row piece group
     auto voffFof = [&]() __attribute__((always_inline)) {
         const int l = freshLane();
-        return (l >> 4) * (G::N * 4) + (l & 15) * 16;
+        return 4 * (l >> 4) * (G::N * 4) + (l & 15) * 16;
     };
-    auto soffF = [&](int pc) __attribute__((always_inline)) { return ((pnl * G::BM + 32 * (pc & 3) + 4 * wv) * G::N + 64 * (pc >> 2)) * 4; };
+    auto soffF = [&](int pc) __attribute__((always_inline)) { return ((pnl * G::BM + 32 * (pc & 3) + wvRow) * G::N + 64 * (pc >> 2)) * 4; };
     auto panelDst = [&](int pc) __attribute__((always_inline)) {
         const int l = freshLane();
-        const int row32 = 4 * wv + (l >> 4), kqi = l & 15;
+        const int row32 = wvRow + 4 * (l >> 4), kqi = l & 15;
         const int d0 = row32 * G::ROW_A + (((kqi >> 2) ^ (row32 & 15)) * 16) + (kqi & 3) * 4;
         return (d0 ^ ((pc >> 2) * 64)) + (pc & 3) * 32 * G::ROW_A;
     };
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
                         stageMiss += e ? 0u : 1u;
                         pa[u][d] = e ? pa[u][d] : pc[d];
                         if (!e) // (row of the word, column 0: the first element it reaches)
-                            flagElem(mat0, pnl * G::BM + 32 * ((pc0 + u) & 3) + 4 * wv + (freshLane() >> 4), 0);
+                            flagElem(mat0, pnl * G::BM + 32 * ((pc0 + u) & 3) + wvRow + 4 * (freshLane() >> 4), 0);
                     }
                 }
             }
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
                     stageMiss += e ? 0u : 1u;
                     bgRaw[sel][d] = e ? bgRaw[sel][d] : c[d];
                     if (!e)
-                        flagElem(matOf(bgItem), pnl * G::BM + 32 * (pc & 3) + 4 * wv + (freshLane() >> 4), 0);
+                        flagElem(matOf(bgItem), pnl * G::BM + 32 * (pc & 3) + wvRow + 4 * (freshLane() >> 4), 0);
                 }
             }
         };

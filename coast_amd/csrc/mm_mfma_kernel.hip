@@ -111,7 +111,11 @@ template <int NREP> struct MmPanel {
     static_assert(BM * CPW * 4 == WAVE_LDS, "output tile == slab double buffer");
 };
 
-template <int NREP>
+// PHYS == 2 (round 6): COAST_SITE_MM_PREG as in the register-block kernels -- a real exclusive-or on ANY physical register of a
+// wave in front of any of the 20 MFMA slots of any of the wave's pipeline steps (coast_fault.step: slot | step % 16 << 6 | lane << 10 | wave << 16 |
+// file << 19 | register << 20 | step / 16 << 29) -- so that tools/campaign.py --reg-model uniform --kernel lanes puts a coverage figure on the
+// replica layout north_star names: three adjacent lanes, every vector register of a work item replica-private by construction.
+template <int NREP, int PHYS = 0>
 __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void mm_mfma_panel_kernel(
     const uint32_t *__restrict__ F, const uint32_t *__restrict__ S, uint32_t *__restrict__ R, uint32_t nblocks, Counters ctr,
     FaultTab ft, uint8_t *__restrict__ detected)
@@ -162,6 +166,41 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
         fFirst = __builtin_amdgcn_readfirstlane(rg.x);
         fCount = __builtin_amdgcn_readfirstlane(rg.y);
     }
+
+    // COAST_SITE_MM_PREG (PHYS): this wave's upset, if any: key = step << 6 | slot; sel = register file << 9 | register; lane | bit << 8
+    uint32_t pregKey = 0xffffffffu, pregSel = 0u, pregLaneBit = 0u;
+    if constexpr (PHYS == 2) {
+#pragma unroll 1
+        for (uint32_t q = fFirst, nq = 0; q < fFirst + fCount && nq < 64u; ++q, ++nq) {
+            const DevFault *fp = ft.list + q;
+            const uint32_t sw = __builtin_amdgcn_readfirstlane(fp->step);
+            const uint32_t packed = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(&fp->replica));
+            if (((packed >> 8) & 0xffu) == 7u /* COAST_SITE_MM_PREG */ && ((sw >> 16) & 7u) == (uint32_t)wave) {
+                pregKey = (sw & 63u) | ((((sw >> 6) & 15u) | (((sw >> 29) & 3u) << 4)) << 6);
+                pregSel = (((sw >> 19) & 1u) << 9) | ((sw >> 20) & 511u);
+                pregLaneBit = ((sw >> 10) & 63u) | (((packed >> 16) & 31u) << 8);
+            }
+        }
+    }
+    auto pregFlip = [&]() __attribute__((always_inline)) {
+        const uint32_t idx = pregSel & 511u, bitMask = 1u << (pregLaneBit >> 8);
+        if ((pregSel >> 9) == 0u) {
+            const uint32_t vm = xmr_fresh_lane() == (int)(pregLaneBit & 63u) ? bitMask : 0u;
+            uint32_t m0save;
+            asm volatile("s_mov_b32 %0, m0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_set_gpr_idx_on %1, 0x9\n\ts_nop 1\n\tv_xor_b32 v0, v0, %2\n\ts_nop 1\n\t"
+                         "s_set_gpr_idx_off\n\ts_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 1"
+                         : "=&s"(m0save)
+                         : "s"(idx), "v"(vm)
+                         : "memory");
+        } else {
+            uint32_t tmp, m0save;
+            asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\ts_movrels_b32 %0, s0\n\ts_xor_b32 %0, %0, %3\n\ts_nop 0\n\ts_movreld_b32 s0, %0\n\t"
+                         "s_nop 2\n\ts_mov_b32 m0, %1\n\ts_nop 1"
+                         : "=&s"(tmp), "=&s"(m0save)
+                         : "s"(idx), "s"(bitMask)
+                         : "scc", "memory");
+        }
+    };
 
     // ---- this wave's work: column tiles wave, wave + NW, ... ; one pipeline step = one k slab of one tile
     const int tw = wave; // (dealing the tiles in reverse order in odd workgroups to even out the SIMDs was measured: slower --
@@ -288,6 +327,9 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
                 const uint32_t fstep = __builtin_amdgcn_readfirstlane(fp->step);
                 const uint32_t packed = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(&fp->replica));
                 const uint32_t frep = packed & 0xffu, fsite = (packed >> 8) & 0xffu, m = 1u << ((packed >> 16) & 31u);
+                if constexpr (PHYS != 0)
+                    if (fsite > 2u)
+                        continue; // (a physical register upset: applied where the register lives)
                 if (local != curKey) { // a new element: its replicas start from clean running deltas
                     curKey = local;
                     curStep = 0xffffffffu;
@@ -488,6 +530,9 @@ __global__ __launch_bounds__(MmPanel<NREP>::NTHR, MmPanel<NREP>::WG_PER_CU) void
                     // limb sums in the order t = 3 2 1 0 | 3 2 1 | 3 2 | 3: consecutive MFMAs never share an accumulator
                     // (measured: no difference to 0 1 2 3 | 1 2 3 | ..., the partner wave fills the dependency gap anyway)
                     const int q = 3 - p - qq;
+                    if constexpr (PHYS == 2)
+                        if (pregKey == (((uint32_t)it << 6) | (uint32_t)m))
+                            pregFlip();
                     acc[rb][p + q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rb][p], b[q],
                                                                            (FIRST && p == 0) ? zero : acc[rb][p + q], 0, 0, 0);
                     // behind the MFMAs: the 4 * B_ROUNDS loads for step it + NSETS (spread, so that the address unit never holds

@@ -3059,7 +3059,7 @@ def _uniform_campaign(argv):
     return mod.run_uniform_campaign(mod.parse(["-b", "mm", "--side", "256", "--reg-model", "uniform", "-n"] + argv))
 
 
-@pytest.mark.parametrize("kernel", ["blocks3", "panel128"])
+@pytest.mark.parametrize("kernel", ["blocks3", "panel128", "lanes"])
 def test_mm_preg_upset_lands_on_the_register_it_names(eng, kernel, monkeypatch):
     """COAST_SITE_MM_PREG packs `file << 19 | register << 20` into coast_fault.step; round 5's kernel read the selector
     from bit 19 on and used (register << 1 | file) & 511 as the VGPR index -- a draw of vR flipped v[2R mod 256] and the scalar path never ran.
@@ -3089,12 +3089,15 @@ def test_mm_preg_upset_lands_on_the_register_it_names(eng, kernel, monkeypatch):
     # mm_mfma_blk4_kernel (128-row panels, 32 steps: the fifth bit of the step rides in bit 29 of coast_fault.step)
     monkeypatch.setenv("COAST_MM_TILE", kernel)
     rows = camp.KERNELS[kernel]["rows"]
-    bit, lane, wave, panel, step = 5, 37, 6, (2 if kernel == "blocks3" else 1), (6 if kernel == "blocks3" else 22)
+    # (round 6, VERDICT r5 item 5a: the lane-replica kernel -- north_star's layout -- carries the hook too: 16-register tuples of
+    # v_mfma_i32_32x32x32_i8, four waves, a replica's element in its own lane)
+    bit, lane, wave, panel, step = 5, 37, (6 if kernel != "lanes" else 2), (1 if kernel == "panel128" else 2), {"blocks3": 6, "panel128": 22, "lanes": 21}[kernel]
     deltas = {(sgn * (1 << (bit + 8 * t))) % 2**32 for t in range(4) for sgn in (1, -1)}
     for mode, clone in (((ca.UNPROTECTED, False),) if kernel == "blocks3" else ()) + ((ca.TMR, False), (ca.TMR, True)):
-        slot = 10 * mode  # the first slot of a step's second half (its MFMA accumulates: no tile starts there)
+        slot = 10 * mode if kernel != "lanes" else 10  # the first slot of a step's second half (its MFMA accumulates: no tile starts there)
+        width = 16 if kernel == "lanes" else 4  # registers of an accumulator tuple = element rows of one column it holds per lane
         tuples = sorted(set(camp.kernel_addend_tuples(mode, slot, clone, kernel if mode == ca.TMR else "blocks3")))
-        assert tuples and all(hi - lo == 3 for lo, hi in tuples), tuples
+        assert tuples and all(hi - lo == width - 1 for lo, hi in tuples), tuples
         good = []
         for lo, hi in tuples:
             hits = []
@@ -3113,7 +3116,9 @@ def test_mm_preg_upset_lands_on_the_register_it_names(eng, kernel, monkeypatch):
                             hits.append((i, j))
                 elif wrong.shape[0] == 0 and st["errors_corrected"] == 1 and int(det.sum()) == 1:
                     hits.append(tuple(int(x) for x in det.reshape(n, n).nonzero()[0]))
-            if len(hits) == 4 and len({j for _, j in hits}) == 1 and sorted(i for i, _ in hits) == list(range(min(i for i, _ in hits), min(i for i, _ in hits) + 4)):
+            rows_hit = sorted(i for i, _ in hits)
+            if len(hits) == width and len({j for _, j in hits}) == 1 and len(set(rows_hit)) == width and (
+                    width == 16 or rows_hit == list(range(rows_hit[0], rows_hit[0] + 4))):
                 good.append((lo, hi, hits))
         # the tuple of the body this wave runs at this step (bodies of the other row half / tile positions may share it or not)
         assert good, (mode, clone, tuples)
@@ -3123,9 +3128,10 @@ def test_campaign_uniform_register_file_mm256():
     """`campaign.py --reg-model uniform` (round 5): ONE coverage figure for the matrix-core kernel -- an exclusive-or on one bit of ANY
     physical register of a wave (COAST_SITE_MM_PREG: v0..v255 through the VGPR index mode, s0..s101 through s_movrels / s_movreld), drawn
     uniformly from the register state the kernel's code object allocates, in front of a uniformly random MFMA slot; the launches run in
-    child processes (an upset of a pointer is a memory fault), the scalar class counts as errors unless --sgpr run.  5000 runs
-    (profiles/r05_campaign_uniform_*.txt): TMR 94.7 %, with COAST_F_CLONE_STAGING 97.2 %, DWC 92.1 / 95.8 %, unprotected: see there; the
-    reference's MSP430 table (docs/source/results/msp430.rst:14): unmitigated 84.0 %, -TMR 99.6 %, -TMR -countErrors 95.0 %."""
+    child processes (an upset of a pointer is a memory fault), the scalar class counts as errors unless --sgpr run.  The 5000-run figures
+    and how to read them: docs/design/campaign.md (ONE table; round 6: TMR on mm_mfma_blk4_kernel 97.5 % with the cloned staging loads -- the
+    default --, 93.4 % without, scalar class counted as errors; the reference's MSP430 table, docs/source/results/msp430.rst:14: unmitigated
+    84.0 %, -TMR 99.6 %, -TMR -countErrors 95.0 %)."""
     recs, t = _uniform_campaign(["-m", "TMR", "-t", "1280"])
     _, c = _uniform_campaign(["-m", "TMR", "-t", "1280", "--clone-staging"])
     _, u = _uniform_campaign(["-m", "NONE", "-t", "1280"])
@@ -3133,8 +3139,8 @@ def test_campaign_uniform_register_file_mm256():
         assert s["runs"] == 1280 == s["success"] + s["errors"] + s["faults"] + s["invalids"] and s["invalids"] <= 3, s
         assert s["scalar_upsets_not_executed_counted_as_errors"] >= 1  # (s0..s101 and the spill registers' lanes: ~1.4 % of the state)
     assert {r["class"] for r in recs} <= {"success", "fault", "error", "invalid"} and all(0 <= r["target"]["reg"] < 256 for r in recs)
-    assert t["coverage_pct"] > 91.0 and t["faults"] > 350          # (94.7 % at 5000 runs; 37 % of the upsets are out-voted and counted)
-    assert c["coverage_pct"] > 94.0 and c["coverage_pct"] > t["coverage_pct"] and c["clone_staging"]
+    assert t["coverage_pct"] > 90.0 and t["faults"] > 500          # (93.4 % at 5000 runs; 58 % of the upsets are out-voted and counted)
+    assert c["coverage_pct"] > 95.0 and c["coverage_pct"] > t["coverage_pct"] and c["clone_staging"]  # (97.5 % at 5000 runs)
     assert u["faults"] == 0 and u["coverage_pct"] < t["coverage_pct"] - 3.0, (u["coverage_pct"], t["coverage_pct"])
 
 

@@ -570,24 +570,32 @@ def run_campaign(a, eng=None):
 
 
 # ------------------------------------------------------------------------------------------------ the uniform register-file campaign
-def uniform_draw(rng, n_vgpr=256, n_sgpr=102, npanels=4, nsteps=16):
+def uniform_draw(rng, n_vgpr=256, n_sgpr=102, npanels=4, nsteps=16, nwaves=8, nsteps_short=None):
     """one bit of the register state of one wave of the kernel, uniformly: n_vgpr VGPRs x 64 lanes x 32 bits + n_sgpr SGPRs x 32 bits (the
     registers the kernel's code object allocates; the reference's injector draws a register of the core uniformly: injector.py:70-72,
     237-260), at a uniformly random MFMA slot of the panel's 16 steps (60 slots each under TMR, 40 under DWC, 20 unprotected)"""
     vbits, sbits = n_vgpr * 64 * 32, n_sgpr * 32
     file = int(rng.random() < sbits / (vbits + sbits))
     return {"file": file, "reg": int(rng.integers(0, n_sgpr if file else n_vgpr)), "lane": 0 if file else int(rng.integers(0, 64)),
-            "bit": int(rng.integers(0, 32)), "wave": int(rng.integers(0, 8)), "panel": int(rng.integers(0, npanels)),
-            "step": int(rng.integers(0, nsteps)), "slot": int(rng.integers(0, 60))}
+            "bit": int(rng.integers(0, 32)), "wave": (wave := int(rng.integers(0, nwaves))), "panel": int(rng.integers(0, npanels)),
+            # (the lane-replica kernel deals its 26 column tiles 7 / 7 / 6 / 6 to four waves: the second half of the waves has fewer steps)
+            "step": int(rng.integers(0, nsteps_short if nsteps_short and wave >= nwaves // 2 else nsteps)), "slot": int(rng.integers(0, 60))}
 
 
 PHYS_KERNEL = "_ZN5coast19mm_mfma_blk3_kernelILi%dELb1ELi2ELb%dEEEvPKjS2_PjjNS_8CountersENS_8FaultTabEPh"  # mm_mfma_blk3_kernel<replicas, true, 2, clone>
 PHYS_KERNEL4 = "_ZN5coast19mm_mfma_blk4_kernelILb1ELb%dELi2EEEvPKjS2_PjjNS_8CountersENS_8FaultTabEPh"  # mm_mfma_blk4_kernel<true, clone, 2> (TMR, 128-row panel)
 # geometry of the two register-block kernels: rows of a matrix per workgroup, workgroups per matrix, pipeline steps per item
-KERNELS = {"blocks3": {"rows": 64, "panels": 4, "steps": 16}, "panel128": {"rows": 128, "panels": 2, "steps": 32}}
+PHYS_KERNEL_LANES = "_ZN5coast20mm_mfma_panel_kernelILi%dELi2EEEvPKjS2_PjjNS_8CountersENS_8FaultTabEPh"  # mm_mfma_panel_kernel<replicas, 2> (replicas in adjacent lanes)
+KERNELS = {"blocks3": {"rows": 64, "panels": 4, "steps": 16, "waves": 8, "slots": None},
+           "panel128": {"rows": 128, "panels": 2, "steps": 32, "waves": 8, "slots": None},
+           # north_star's layout: a workgroup = one 64-row panel of one matrix (not persistent), four waves under TMR (7 / 7 / 6 / 6 column tiles
+           # of 8 k-slabs), 20 MFMAs (32 x 32 x 32) per step in every mode
+           "lanes": {"rows": 64, "panels": 4, "steps": 56, "steps_short": 48, "waves": 4, "slots": 20}}
 
 
 def phys_symbol(replicas, clone, kernel="blocks3"):
+    if kernel == "lanes":
+        return PHYS_KERNEL_LANES % replicas
     if kernel == "panel128":
         if replicas != 3:
             raise SystemExit("campaign: mm_mfma_blk4_kernel (--kernel panel128) is the TMR kernel; DWC / unprotected run mm_mfma_blk3_kernel")
@@ -656,8 +664,9 @@ def kernel_addend_tuples(replicas, slot, clone=False, kernel="blocks3"):
     import re
 
     text, _ = _kernel_text(phys_symbol(replicas, clone, kernel))
-    per = 20 * replicas
-    mf = re.findall(r"v_mfma_i32_16x16x64_i8\s+v\[\d+:\d+\],\s*v\[\d+:\d+\],\s*v\[\d+:\d+\],\s*(?:v\[(\d+):(\d+)\]|\S+)", text)
+    per = 20 if kernel == "lanes" else 20 * replicas  # (the lane-replica kernel: 20 MFMAs of 32 x 32 x 32 per step in every mode, 16-register tuples)
+    op = "v_mfma_i32_32x32x32_i8" if kernel == "lanes" else "v_mfma_i32_16x16x64_i8"
+    mf = re.findall(op + r"\s+v\[\d+:\d+\],\s*v\[\d+:\d+\],\s*v\[\d+:\d+\],\s*(?:v\[(\d+):(\d+)\]|\S+)", text)
     out = []
     for b in range(len(mf) // per):
         c0, c1 = mf[b * per + slot]
@@ -668,7 +677,7 @@ def kernel_addend_tuples(replicas, slot, clone=False, kernel="blocks3"):
 
 def preg_row(item, d):
     # (steps 16..31 of mm_mfma_blk4_kernel's 32-step items: the fifth bit of the step rides in bit 29)
-    step = d["slot"] | ((d["step"] & 15) << 6) | (d["lane"] << 10) | (d["wave"] << 16) | (d["file"] << 19) | (d["reg"] << 20) | ((d["step"] >> 4) << 29)
+    step = d["slot"] | ((d["step"] & 15) << 6) | (d["lane"] << 10) | (d["wave"] << 16) | (d["file"] << 19) | (d["reg"] << 20) | (((d["step"] >> 4) & 3) << 29)
     return (item, 0, ca.SITE_MM_PREG, step, d["bit"])
 
 
@@ -690,14 +699,17 @@ def run_uniform_campaign(a, eng=None):
     rep = MODES[a.mode]
     if a.benchmark != "mm" or a.side != 256 or a.mode == "CFCSS":
         raise SystemExit("--reg-model uniform: the register file is that of the matrix-core kernel (-b mm --side 256 -m TMR | DWC | NONE)")
-    kern = a.kernel if rep == ca.TMR else "blocks3"  # (DWC and the unprotected mode run mm_mfma_blk3_kernel whatever the TMR kernel is)
+    # (DWC and the unprotected mode run mm_mfma_blk3_kernel whatever the TMR register-block kernel is; the lane-replica kernel serves all three)
+    kern = a.kernel if (rep == ca.TMR or a.kernel == "lanes") else "blocks3"
+    if kern == "lanes" and rep != ca.TMR:
+        raise SystemExit("--kernel lanes: -m TMR (the DWC / unprotected wave counts and tile deals of mm_mfma_panel_kernel are not wired into the draw)")
     geo = KERNELS[kern]
     quads = max(1, cu_count() // geo["panels"])  # workgroup groups of a launch = its stride between a workgroup's matrices
     runs = a.runs
     nv, ns, spill = kernel_registers(max(rep, 1), a.clone_staging and rep > 1, kern)
     spill = set(spill)  # vector registers whose lanes hold spilled scalar registers: the scalar class too
-    nslots = 20 * max(rep, 1)  # MFMA slots of a pipeline step
-    draws = [uniform_draw(rng, nv, ns, geo["panels"], geo["steps"]) for _ in range(runs)]
+    nslots = geo["slots"] or 20 * max(rep, 1)  # MFMA slots of a pipeline step
+    draws = [uniform_draw(rng, nv, ns, geo["panels"], geo["steps"], geo["waves"], geo.get("steps_short")) for _ in range(runs)]
     for d in draws:
         d["slot"] %= nslots
     scalar = lambda d: d["file"] == 1 or d["reg"] in spill
@@ -782,8 +794,8 @@ def run_uniform_campaign(a, eng=None):
                         "result": {"core": 0, "errors": int(cls == "error"), "faults": int(bool(flagged)), "runtime_us": wall * 1e6 / runs}})
     nbad = counts["errors"] + counts["invalids"]
     summary = {
-        "name": "mm_%s_registers_uniform%s%s" % (a.mode, "_clone_staging" if a.clone_staging else "", "_panel128" if kern == "panel128" else ""), "clone_staging": bool(a.clone_staging),
-        "kernel": "mm_mfma_blk4_kernel (128-row panel)" if kern == "panel128" else "mm_mfma_blk3_kernel (64-row panel)", "benchmark": "mm", "mode": a.mode, "section": "registers", "mem_mode": None, "runs": runs,
+        "name": "mm_%s_registers_uniform%s%s" % (a.mode, "_clone_staging" if a.clone_staging else "", "_" + kern if kern != "blocks3" else ""), "clone_staging": bool(a.clone_staging),
+        "kernel": {"panel128": "mm_mfma_blk4_kernel (128-row panel)", "blocks3": "mm_mfma_blk3_kernel (64-row panel)", "lanes": "mm_mfma_panel_kernel (replicas in adjacent lanes)"}[kern], "benchmark": "mm", "mode": a.mode, "section": "registers", "mem_mode": None, "runs": runs,
         "success": counts["success"], "errors": counts["errors"], "faults": counts["faults"], "timeouts": counts["timeouts"],
         "invalids": counts["invalids"], "aborts": counts["aborts"], "scalar_upsets_not_executed_counted_as_errors": counts["not_executed"],
         "coverage_pct": 100.0 * (runs - nbad) / runs,
@@ -895,7 +907,7 @@ def parse(argv=None):
                          "child processes (run: a wild descriptor is a memory fault that ends the child)")
     ap.add_argument("--clone-staging", action="store_true",
                     help="-b mm --side 256: run with the staging loads cloned and compared (the library's default since ABI 8; without this option the campaign passes COAST_F_SINGLE_STAGING)")
-    ap.add_argument("--kernel", default="panel128", choices=["panel128", "blocks3"],
+    ap.add_argument("--kernel", default="panel128", choices=["panel128", "blocks3", "lanes"],
                     help="--reg-model uniform -m TMR: the matrix-core kernel whose register file is drawn from -- mm_mfma_blk4_kernel (128-row panel, "
                          "the library's TMR default since round 6) or mm_mfma_blk3_kernel (64-row panel, rounds 4-5; always the DWC / unprotected kernel)")
     ap.add_argument("--preg-child", default=None, help=argparse.SUPPRESS)
