@@ -16,6 +16,7 @@ LIB = os.path.join(LIBDIR, "libcoast_hip.so")
 DROPIN = os.path.join(LIBDIR, "libcoast_dropin.so")
 DROPIN_OBJ = os.path.join(LIBDIR, "coast_dropin.o")  # static object: link-time interposition needs a regular object
 ARCH = "gfx950"
+UNITS = ("coast_hip", "mm_phys_instances")  # translation units of libcoast_hip.so
 
 
 def _hipcc() -> str:
@@ -112,11 +113,29 @@ def _build_locked(force: bool, verbose: bool) -> str:
     want = source_hash()
     stale = force or not os.path.exists(LIB) or not _stamp_ok(want)
     if stale:
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
-               '-DCOAST_SOURCE_HASH="%s"' % want, "-o", LIB, os.path.join(CSRC, "coast_hip.hip")]
+        # two translation units, compiled side by side (mm_phys_instances.inc: the physical-upset instantiations of the matrix-core
+        # kernels are half of the compile time), linked into one library
+        base = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"]
+        objs, procs = [], []
+        for name in UNITS:
+            obj = os.path.join(LIBDIR, name + ".o")
+            cmd = base + ['-DCOAST_SOURCE_HASH="%s"' % want, "-c", os.path.join(CSRC, name + ".hip"), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            objs.append(obj)
+            procs.append((cmd, subprocess.Popen(cmd)))
+        for cmd, p in procs:
+            if p.wait() != 0:
+                for _, q in procs:
+                    if q.poll() is None:
+                        q.kill()
+                raise subprocess.CalledProcessError(p.returncode, cmd)
+        cmd = base + ['-DCOAST_SOURCE_HASH="%s"' % want, "-shared", "-o", LIB] + objs  # (the definition is unused by a link: it names the build in the process list)
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        for obj in objs:
+            os.remove(obj)
     dropin_src = os.path.join(CSRC, "dropin.c")
     if os.path.exists(dropin_src) and (stale or not os.path.exists(DROPIN) or not os.path.exists(DROPIN_OBJ)):
         cmd = ["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-I", os.path.join(HERE, "..", "include"), "-o", DROPIN,

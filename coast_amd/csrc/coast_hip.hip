@@ -23,6 +23,11 @@
 #include "mm_mfma_blk2_kernel.hip"
 #include "mm_mfma_blk3_kernel.hip"
 #include "mm_mfma_blk4_kernel.hip"
+namespace coast { // compiled in mm_phys_instances.hip
+#define X(...) extern template __global__ void __VA_ARGS__(COAST_MMARGS);
+#include "mm_phys_instances.inc"
+#undef X
+} // namespace coast
 #include "sha256_kernel.hip"
 #include "aes_kernel.hip"
 #include "crc16_kernel.hip"

@@ -140,6 +140,7 @@ def test_eight_ranks_racing_build_compile_once(tmp_path):
     shutil.copy(os.path.join(ROOT, "coast_amd", "build.py"), root / "coast_amd" / "build.py")
     (root / "include" / "coast_hip.h").write_text("/* header */\n")
     (root / "coast_amd" / "csrc" / "coast_hip.hip").write_text("// kernel source, edited\n")
+    (root / "coast_amd" / "csrc" / "mm_phys_instances.hip").write_text("// second translation unit\n")
     fake = tmp_path / "bin"
     fake.mkdir()
     count = tmp_path / "compiles.txt"
@@ -173,5 +174,5 @@ printf 'partial' > "$out"; sleep 1.5; printf 'library %%s' "$hash" > "$out"
     finally:
         os.environ["PATH"] = old_path
     assert all(r[0] == "ok" and r[1] for r in res), res
-    assert count.read_text().count("x") == 1, count.read_text()  # one compile for eight ranks
+    assert count.read_text().count("x") == 3, count.read_text()  # ONE build for eight ranks: two translation units side by side + the link
     assert len({r[2] for r in res}) == 1  # everybody saw the finished file
