@@ -44,6 +44,13 @@
 #ifndef COAST_MM4_SETS
 #define COAST_MM4_SETS 1
 #endif
+// A/B builds (profiles/r06_mm_blk4_ab.txt, fourth pass): bit 0 = under CLONE the original f piece is loaded with the default cache policy and only
+// its clone non-temporal (no effect: 6.78 ms either way); bit 1 (shipped) = the conversion's store-base compare rides in the staging compare's
+// branch at the step's first slot (- 1.0 %: one ballot and branch per step instead of two); bit 2 (shipped under CLONE) = the votes' agreement
+// tally through a scalar population count instead of a per-lane add (CLONE: - 0.6 % and no register left in scratch; single staging: + 0.8 %)
+#ifndef COAST_MM4_VAR
+#define COAST_MM4_VAR 6
+#endif
 // development: conversion stage stride in the steps without f work (6: spread over the half step; 2: the first ten slots)
 #ifndef COAST_MM4_CONV_STRIDE
 #define COAST_MM4_CONV_STRIDE 6
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     const int bOff = wbufOff + colRow(l16) * G::KS + ((kg ^ colSwz(l16)) * 16); // (the lane's slab buffers included)
 
     uint32_t agree = 0;            // votes of this lane whose three copies were equal (phantom votes included)
+    uint32_t agreeS = 0;           // (COAST_MM4_VAR & 4: the same, summed over the wave's lanes in a scalar register)
     uint32_t nExec = 0, nReal = 0; // wave-uniform: votes executed / votes of tiles that exist (= the lane's __SYNC_COUNT)
     v4i_t acc[2][NREP][4];         // row blocks 2 HQ and 2 HQ + 1
 #pragma unroll
@@ -245,15 +253,17 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     };
     // the conversion's store base against its clone, in front of the stores (cold path: both from a fresh lane id)
     int dstSv = dstS;
+    auto verifyDstCold = [&]() __attribute__((always_inline)) {
+        const int l = freshLane(), c = l & 15;
+        const int fresh = wbufOff + (((c & 7) << 1) | (c >> 3)) * G::KS + ((HQ ^ ((c >> 1) & 3)) * 16) + (l >> 4) * 4;
+        stageMiss += (dstSv != dstS2) ? 1u : 0u;
+        dstSv = fresh;
+        dstS2 = launder(fresh);
+    };
     auto verifyDst = [&]() __attribute__((always_inline)) {
-        if constexpr (DUP) {
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(dstSv != dstS2) != 0, 0)) {
-                const int l = freshLane(), c = l & 15;
-                const int fresh = wbufOff + (((c & 7) << 1) | (c >> 3)) * G::KS + ((HQ ^ ((c >> 1) & 3)) * 16) + (l >> 4) * 4;
-                stageMiss += (dstSv != dstS2) ? 1u : 0u;
-                dstSv = fresh;
-                dstS2 = launder(fresh);
-            }
+        if constexpr (DUP && (COAST_MM4_VAR & 2) == 0) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(dstSv != dstS2) != 0, 0))
+                verifyDstCold();
         }
     };
     // in front of the first instruction that consumes a word of the set; gs = the slab it belongs to
@@ -264,7 +274,11 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
             mis = mis || pbs[set][kk] != dupS[ds][kk];
+        if constexpr ((COAST_MM4_VAR & 2) != 0)
+            mis = mis || dstSv != dstS2;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(mis) != 0, 0)) {
+            if constexpr ((COAST_MM4_VAR & 2) != 0)
+                verifyDstCold();
             const __amdgpu_buffer_rsrc_t rs = rsSof(gs >> 5);
             const int so = slabOff(gs), l = freshLane();
             const int vo = ((4 * (l >> 4)) * G::N + (l & 15)) * 4;
@@ -329,7 +343,10 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
         const bool e01 = v0 == v1, e02 = v0 == vLast;
         const uint32_t voted = e01 ? v0 : vLast; // select(a == b, a, c), synchronization.cpp:934-938
         const bool same = e01 && e02;
-        agree += same ? 1u : 0u;
+        if constexpr ((COAST_MM4_VAR & 4) != 0 && DUP) // (the lanes' agreements counted once per wave: 64 lanes x this count = the per-lane tallies' sum)
+            agreeS += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(same));
+        else
+            agree += same ? 1u : 0u;
         nExec += 1u;
         nReal += real; // __SYNC_COUNT is counted where the vote happens
         const int erow = pnl * G::BM + (2 * HQ + rb) * 16 + i;
@@ -585,7 +602,7 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
         auto dstFget = [&]() __attribute__((always_inline)) { return HOISTF ? dstFh : panelDst(0); };
         auto bgLoad = [&](int pc, auto selTag) __attribute__((always_inline)) {
             constexpr int sel = decltype(selTag)::value;
-            bgRaw[sel] = __builtin_amdgcn_raw_buffer_load_b128(rsFof(bgItem), voffFget(), soffF(pc), COAST_MM_AUX_F);
+            bgRaw[sel] = __builtin_amdgcn_raw_buffer_load_b128(rsFof(bgItem), voffFget(), soffF(pc), (DUP && (COAST_MM4_VAR & 1)) ? 0 : COAST_MM_AUX_F);
             if constexpr (DUP) // the clone, right behind the original: its own address register
                 dupF[sel] = __builtin_amdgcn_raw_buffer_load_b128(rsFof(bgItem), launder(voffFget()), soffF(pc), COAST_MM_AUX_F);
         };
@@ -774,7 +791,11 @@ __global__ __launch_bounds__(MmBlk4::NTHR, 1) void mm_mfma_blk4_kernel(const uin
     __syncthreads();
     // TMR_ERROR_CNT = the votes whose copies were not all equal + the staging compares that failed (a corrected word each); __SYNC_COUNT =
     // the votes of tiles that exist
-    block_tally(nExec - agree + stageMiss, nReal, 0u, sCnt, ctr, blockIdx.x);
+    if constexpr ((COAST_MM4_VAR & 4) != 0 && DUP) { // lane 0 carries the wave's mismatches (64 nExec - agreeS), every lane its own staging misses
+        const uint32_t waveMiss = 64u * nExec - agreeS;
+        block_tally((lane == 0 ? waveMiss : 0u) + stageMiss, nReal, 0u, sCnt, ctr, blockIdx.x);
+    } else
+        block_tally(nExec - agree + stageMiss, nReal, 0u, sCnt, ctr, blockIdx.x);
 }
 
 } // namespace coast

@@ -1,5 +1,6 @@
 #!/bin/bash
-# development: bench the mm headline with different COAST_MM_TILE values back to back on ONE box: tools/ab_tile.sh blocks blocks2 blocks3 ...
+# development: bench the mm headline with different COAST_MM_TILE values back to back on ONE box: tools/ab_tile.sh panel128 blocks3 blocks2 lanes
+# (`blocks`, the one-wave-per-SIMD kernel of round 2, was retired in round 5 and is rejected by coast_mm_batch)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for rep in ${REPS:-1 2}; do
   for t in "$@"; do

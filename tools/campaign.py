@@ -614,26 +614,35 @@ def _kernel_text(sym):
 
     path = os.environ.get("COAST_LIB_OVERRIDE") or libmod.lib_path()
     data = open(path, "rb").read()
-    pos = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    # (the library is several translation units, each with an offload bundle of its own in .hip_fatbin: look for the kernel in every one)
+    cos, pos = [], data.find(b"__CLANG_OFFLOAD_BUNDLE__")
     if pos < 0:
         raise SystemExit("campaign: no offload bundle in %s" % path)
-    n = struct.unpack_from("<Q", data, pos + 24)[0]
-    off, co = pos + 32, None
-    for _ in range(n):
-        o, sz, ts = struct.unpack_from("<QQQ", data, off)
-        triple = data[off + 24:off + 24 + ts].decode()
-        off += 24 + ts
-        if "gfx950" in triple:
-            co = data[pos + o:pos + o + sz]
-    if co is None:
+    while pos >= 0:
+        n = struct.unpack_from("<Q", data, pos + 24)[0]
+        off = pos + 32
+        for _ in range(n):
+            o, sz, ts = struct.unpack_from("<QQQ", data, off)
+            triple = data[off + 24:off + 24 + ts].decode()
+            off += 24 + ts
+            if "gfx950" in triple:
+                cos.append(data[pos + o:pos + o + sz])
+        pos = data.find(b"__CLANG_OFFLOAD_BUNDLE__", pos + 1)
+    if not cos:
         raise SystemExit("campaign: no gfx950 code object in %s" % path)
     llvm = "/opt/rocm/lib/llvm/bin/"
-    with tempfile.NamedTemporaryFile(suffix=".co") as fh:
-        fh.write(co)
-        fh.flush()
-        text = subprocess.run([llvm + "llvm-objdump", "-d", "--no-show-raw-insn", "--disassemble-symbols=" + sym, fh.name],
-                              capture_output=True, text=True, check=True).stdout
-        notes = subprocess.run([llvm + "llvm-readelf", "--notes", fh.name], capture_output=True, text=True, check=True).stdout
+    text, notes = "", ""
+    for co in cos:
+        if sym.encode() not in co:
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".co") as fh:
+            fh.write(co)
+            fh.flush()
+            text = subprocess.run([llvm + "llvm-objdump", "-d", "--no-show-raw-insn", "--disassemble-symbols=" + sym, fh.name],
+                                  capture_output=True, text=True, check=True).stdout
+            notes = subprocess.run([llvm + "llvm-readelf", "--notes", fh.name], capture_output=True, text=True, check=True).stdout
+        if "v_mfma" in text:
+            break
     if "v_mfma" not in text:
         raise SystemExit("campaign: %s not found in the code object" % sym)
     return text, notes
