@@ -14,7 +14,7 @@ from ._lib import FAULT_DTYPE, CoastLibraryError  # noqa: F401
 REPLICA_ALL = 255  # COAST_REPLICA_ALL: a common-mode upset (state the replicas of a lane group share)
 SITE_MM_ACC, SITE_MM_OPA, SITE_MM_OPB = 0, 1, 2
 SITE_MM_VGPR = 6  # a physical register upset of the side-256 matrix-core kernel (step packs slab | lane << 8 | dword << 16 | register << 24)
-SITE_MM_PREG = 7  # ... of ANY register of a wave, by physical number (step packs slot | step << 6 | lane << 10 | wave << 16 | file << 19 | register << 20)
+SITE_MM_PREG = 7  # ... of ANY register of a wave, by physical number (step packs slot | step % 16 << 6 | lane << 10 | wave << 16 | file << 19 | register << 20 | step / 16 << 29)
 SITE_MM_I, SITE_MM_J, SITE_MM_K = 3, 4, 5  # COAST_F_BRANCH_SYNC / COAST_F_ADDR_SYNC: the loop counters, one item per call
 SITE_SHA_M, SITE_SHA_WV, SITE_SHA_STATE, SITE_SHA_DATALEN, SITE_SHA_I = 8, 9, 10, 11, 12
 SITE_AES_STATE, SITE_AES_KEY, SITE_AES_ROUND, SITE_AES_I = 16, 17, 18, 19

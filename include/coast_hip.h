@@ -182,7 +182,7 @@ enum {
                             * i of a replica, flipped right before loop condition number `step` of the call is evaluated */
     COAST_SITE_MM_J = 4,   /* ... j */
     COAST_SITE_MM_K = 5,   /* ... k; COAST_SITE_MM_ACC is `sum` with the same timing in that mode */
-    /* A PHYSICAL upset of the default side-256 matrix-core kernel (mm_mfma_blk3_kernel): one bit of one lane of a named vector register is
+    /* A PHYSICAL upset of the side-256 register-block kernel mm_mfma_blk3_kernel (rounds 4-5's TMR default; a launch that arms this site runs there): one bit of one lane of a named vector register is
      * flipped by a real exclusive-or while the kernel computes.  item = b n^2 + i n + j names the 64-row panel (i / 64), the wave's row half
      * (i / 32), the 16-row block (i / 16) and the 16-column tile (j / 16); replica the replica whose register it is; step = k-slab of the
      * tile (bits 1:0: k / 64) | lane << 8 | dword of the 4-dword fragment << 16 | register << 24 -- 0-3: the A-operand fragment of byte plane p
@@ -195,15 +195,18 @@ enum {
      * hardware computes from the flipped register: TMR out-votes it, DWC flags the items it reaches, an unprotected run returns the wrong
      * words (tests/test_gpu_parity.py::test_mm_physical_register_upsets).  Rejected by every other mm engine. */
     COAST_SITE_MM_VGPR = 6,
-    /* A physical upset of ANY register of a wave of the same kernel, named by its physical number (round 5): what the reference's injector does
-     * when it draws a register of the core (simulation/platform/resources/injector.py:70-72, 237-260).  item = b n^2 + i n names the matrix and
-     * the 64-row panel (i / 64: the workgroup); step = slot (bits 5:0: the upset sits in front of MFMA slot 0..59 of the step) | step of the
-     * panel's 16 (bits 9:6: column tile * 4 + k-slab) | lane << 10 (6 bits, vector registers) | wave of the workgroup << 16 (3 bits) | register
-     * file << 19 (0: vector, v0..v255; 1: scalar, s0..s101) | register number << 20 (9 bits); bit = the bit.  The compiler knows nothing of the
-     * exclusive-or: accumulators, operand fragments, staging words and their clones, address registers, lane constants, loop counters,
-     * descriptors -- whatever the allocator put there at that moment.  One upset per (wave, matrix).  Scalar upsets can send a descriptor or a
-     * kernel-argument pointer anywhere in the address space: a memory fault ends the process (tools/campaign.py runs them in children).
-     * mm_mfma_blk3_kernel only (side 256, no sync_every / flags); replica is ignored. */
+    /* A physical upset of ANY register of a wave of a matrix-core kernel, named by its physical number (round 5): what the reference's injector
+     * does when it draws a register of the core (simulation/platform/resources/injector.py:70-72, 237-260).  Hooked into the kernel the launch
+     * would run anyway: mm_mfma_blk4_kernel (TMR default: 128-row panels, 32 steps per item, 60 slots), mm_mfma_blk3_kernel (DWC, unprotected,
+     * COAST_MM_TILE=blocks3: 64-row panels, 16 steps, 20 x replicas slots) or mm_mfma_panel_kernel (COAST_MM_TILE=lanes: 64-row panels, a wave's
+     * 48 / 56 steps, 20 slots).  item = b n^2 + i n names the matrix and the panel (i / panel rows: the workgroup); step = slot (bits 5:0: the
+     * upset sits in front of that MFMA slot of the step) | step % 16 << 6 | lane << 10 (6 bits, vector registers) | wave of the workgroup << 16
+     * (3 bits) | register file << 19 (0: vector, v0..v255; 1: scalar, s0..s101) | register number << 20 (9 bits) | step / 16 << 29 (2 bits; round
+     * 6); bit = the bit.  The compiler knows nothing of the exclusive-or: accumulators, operand fragments, staging words and their clones, address
+     * registers, lane constants, loop counters, descriptors -- whatever the allocator put there at that moment.  One upset per (wave, matrix).
+     * Scalar upsets can send a descriptor or a kernel-argument pointer anywhere in the address space: a memory fault ends the process
+     * (tools/campaign.py runs them in children).  Side 256, no sync_every / flags; replica is ignored.  (Round 5's kernel read the selector from
+     * the wrong bits -- ADVICE r5; tests/test_gpu_parity.py::test_mm_preg_upset_lands_on_the_register_it_names pins the decode.) */
     COAST_SITE_MM_PREG = 7,
     COAST_SITE_SHA_M = 8,  /* schedule word m[step%64] of compression step/64, right after it is produced */
     COAST_SITE_SHA_WV = 9, /* working variable index 0..7 (a..h) before round step%64 of compression step/64 */
