@@ -45,11 +45,13 @@
 #define COAST_MM4_SETS 1
 #endif
 // A/B builds (profiles/r06_mm_blk4_ab.txt, fourth pass): bit 0 = under CLONE the original f piece is loaded with the default cache policy and only
-// its clone non-temporal (no effect: 6.78 ms either way); bit 1 (shipped) = the conversion's store-base compare rides in the staging compare's
-// branch at the step's first slot (- 1.0 %: one ballot and branch per step instead of two); bit 2 (shipped under CLONE) = the votes' agreement
-// tally through a scalar population count instead of a per-lane add (CLONE: - 0.6 % and no register left in scratch; single staging: + 0.8 %)
+// its clone non-temporal (no effect: 6.78 ms either way); bit 1 = the conversion's store-base compare rides in the staging compare's branch at
+// the step's first slot (- 1.0 %: one ballot and branch per step instead of two -- NOT shipped: the base register is then single for the 24 slots
+// between the compare and the stores, and three 5000-run campaigns of that build read 98.5 / 98.5 / 98.7 % against 98.9 % with the compare in
+// front of the stores); bit 2 (shipped under CLONE) = the votes' agreement tally through a scalar population count instead of a per-lane add
+// (CLONE: - 0.6 % and no register left in scratch; single staging: + 0.8 %)
 #ifndef COAST_MM4_VAR
-#define COAST_MM4_VAR 6
+#define COAST_MM4_VAR 4
 #endif
 // development: conversion stage stride in the steps without f work (6: spread over the half step; 2: the first ten slots)
 #ifndef COAST_MM4_CONV_STRIDE

@@ -53,6 +53,8 @@ def main():
             clone = 0
             if n == 256:  # the matrix-core kernels: several matrices per workgroup group, with and without the cloned staging loads (round 5)
                 batch, sync_every = int(rng.integers(1, 7)) if rng.random() < 0.8 else int(rng.integers(60, 70)), int(rng.choice([0, 0, 0, 16]))
+                if rng.random() < 0.04:  # round 6: more matrices than mm_mfma_blk4_kernel has panel pairs -- workgroups with a second item (the f
+                    batch = int(rng.integers(129, 136))  # panel replaced region by region across the hand-over), ~4 s of oracle each
                 clone = 0 if sync_every == 0 and rng.random() < 0.5 else coast_amd.F_SINGLE_STAGING  # (cloned staging loads are the default)
             f = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)
             s = rng.integers(0, 2**32, (batch, n, n), dtype=np.uint32)

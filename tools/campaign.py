@@ -690,6 +690,12 @@ def preg_row(item, d):
     return (item, 0, ca.SITE_MM_PREG, step, d["bit"])
 
 
+def _no_core_files():
+    import resource
+
+    resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
+
+
 def run_uniform_campaign(a, eng=None):
     """--reg-model uniform (-b mm --side 256): ONE coverage figure for the matrix-core kernel, no census, no model.  A run = one workgroup
     group (four 64-row panels) that multiplies three matrices in a row; the upset -- COAST_SITE_MM_PREG: an exclusive-or on one bit of a
@@ -736,7 +742,10 @@ def run_uniform_campaign(a, eng=None):
     while todo:
         spec = json.dumps({"mode": a.mode, "seed": a.seed, "clone": bool(a.clone_staging), "kernel": kern, "launches": [[[r, draws[r]] for r in grp] for grp in todo]})
         children += 1
-        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--preg-child", "-"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        # (a child that an upset takes down must not leave a core file behind: with 12 GB of device memory mapped each one is tens of GB, and
+        # the scalar-class runs of --sgpr run filled a 79 GB disk in one campaign)
+        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--preg-child", "-"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
+                                preexec_fn=_no_core_files, env=dict(os.environ, HSA_ENABLE_COREDUMP="0"))
         try:
             # (a launch takes a tenth of a second; the first child of a fresh box pages torch in for a minute or two.  A child that hangs --
             # an upset that turns a loop bound into a long walk -- is cut and its launch halved like a crashed one's)
