@@ -619,6 +619,10 @@ __global__ __launch_bounds__(256) void aes128_dec_fast_kernel(uint8_t *__restric
 // block {Te_0, Te_1, Te_2, Te_3}.  Decryption: block 0 = {Td_0, Td_1, Td_2, Td_3}, block 1 = {Tis_0 | S pairs (two slots),
 // rsbox, -}.  A copy still sits in bank 16 r + copy (dwords) / 2 copy + {0, 1} (pairs): the 16 distinct blocks of a 32-lane
 // group never meet on a bank.
+// 1 (shipped) = the exit votes of the persistent kernels in DPP form when only replica 0 stores; 0 = ds_bpermute everywhere (A/B: profiles/r06_aes_dpp_votes.txt)
+#ifndef COAST_AES_DPP_VOTES
+#define COAST_AES_DPP_VOTES 1
+#endif
 constexpr int kAesCopies = 16;
 constexpr int kAesRepThreads = 1024;
 constexpr int kAesRowBytes = 256;                      // one entry value: 4 slots x 16 copies x 4 bytes
@@ -768,14 +772,22 @@ __global__ __launch_bounds__(kAesRepThreads) __attribute__((amdgpu_waves_per_eu(
         const bool liveE = lmE.live && itemE < nblocksData, cntE = liveE && lmE.r == 0;
         Tally te = tl;
         te.det = 0;
-        s0 = xmr_sync<NREP>(s0, lmE, cntE, te);
-        s1 = xmr_sync<NREP>(s1, lmE, cntE, te);
-        s2 = xmr_sync<NREP>(s2, lmE, cntE, te);
-        s3 = xmr_sync<NREP>(s3, lmE, cntE, te);
-        k0 = xmr_sync<NREP>(k0, lmE, cntE, te);
-        k1 = xmr_sync<NREP>(k1, lmE, cntE, te);
-        k2 = xmr_sync<NREP>(k2, lmE, cntE, te);
-        k3 = xmr_sync<NREP>(k3, lmE, cntE, te);
+        if (COAST_AES_DPP_VOTES && copyBytes == 0) { // only replica 0 stores: the DPP form of the exit votes (its two neighbours; no trip through the LDS crossbar,
+                              // which the lookups of the other waves are using -- a ds_bpermute costs it three ds_read_b32)
+            s0 = xmr_final_vote_dpp<NREP>(s0, cntE, te), s1 = xmr_final_vote_dpp<NREP>(s1, cntE, te);
+            s2 = xmr_final_vote_dpp<NREP>(s2, cntE, te), s3 = xmr_final_vote_dpp<NREP>(s3, cntE, te);
+            k0 = xmr_final_vote_dpp<NREP>(k0, cntE, te), k1 = xmr_final_vote_dpp<NREP>(k1, cntE, te);
+            k2 = xmr_final_vote_dpp<NREP>(k2, cntE, te), k3 = xmr_final_vote_dpp<NREP>(k3, cntE, te);
+        } else { // memory copies: every replica stores the voted value into its own copy
+            s0 = xmr_sync<NREP>(s0, lmE, cntE, te);
+            s1 = xmr_sync<NREP>(s1, lmE, cntE, te);
+            s2 = xmr_sync<NREP>(s2, lmE, cntE, te);
+            s3 = xmr_sync<NREP>(s3, lmE, cntE, te);
+            k0 = xmr_sync<NREP>(k0, lmE, cntE, te);
+            k1 = xmr_sync<NREP>(k1, lmE, cntE, te);
+            k2 = xmr_sync<NREP>(k2, lmE, cntE, te);
+            k3 = xmr_sync<NREP>(k3, lmE, cntE, te);
+        }
         tl.miss = te.miss;
         tl.syncs = te.syncs;
         if (cntE || (liveE && copyBytes != 0)) {
@@ -940,14 +952,21 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
         uint32_t s0 = x0, s1 = x1, s2 = x2, s3 = x3;
         Tally te = tl;
         te.det = 0;
-        s0 = xmr_sync<NREP>(s0, lm, cnt, te);
-        s1 = xmr_sync<NREP>(s1, lm, cnt, te);
-        s2 = xmr_sync<NREP>(s2, lm, cnt, te);
-        s3 = xmr_sync<NREP>(s3, lm, cnt, te);
-        k0 = xmr_sync<NREP>(k0, lm, cnt, te);
-        k1 = xmr_sync<NREP>(k1, lm, cnt, te);
-        k2 = xmr_sync<NREP>(k2, lm, cnt, te);
-        k3 = xmr_sync<NREP>(k3, lm, cnt, te);
+        if (COAST_AES_DPP_VOTES && copyBytes == 0) { // only replica 0 stores: the DPP form of the exit votes (see aes128_enc_rep_kernel)
+            s0 = xmr_final_vote_dpp<NREP>(s0, cnt, te), s1 = xmr_final_vote_dpp<NREP>(s1, cnt, te);
+            s2 = xmr_final_vote_dpp<NREP>(s2, cnt, te), s3 = xmr_final_vote_dpp<NREP>(s3, cnt, te);
+            k0 = xmr_final_vote_dpp<NREP>(k0, cnt, te), k1 = xmr_final_vote_dpp<NREP>(k1, cnt, te);
+            k2 = xmr_final_vote_dpp<NREP>(k2, cnt, te), k3 = xmr_final_vote_dpp<NREP>(k3, cnt, te);
+        } else {
+            s0 = xmr_sync<NREP>(s0, lm, cnt, te);
+            s1 = xmr_sync<NREP>(s1, lm, cnt, te);
+            s2 = xmr_sync<NREP>(s2, lm, cnt, te);
+            s3 = xmr_sync<NREP>(s3, lm, cnt, te);
+            k0 = xmr_sync<NREP>(k0, lm, cnt, te);
+            k1 = xmr_sync<NREP>(k1, lm, cnt, te);
+            k2 = xmr_sync<NREP>(k2, lm, cnt, te);
+            k3 = xmr_sync<NREP>(k3, lm, cnt, te);
+        }
         tl.miss = te.miss;
         tl.syncs = te.syncs;
         if (cnt || (live && copyBytes != 0)) {

@@ -30,6 +30,10 @@
 //   crc16_general_kernel  byte-serial, exactly as written in crc16.c, with the injector hooks and the optional
 //                         per-V-bytes votes; one wave per tile; every tile when the launch asks for sync_every != 0 or
 //                         COAST_F_BRANCH_SYNC.
+//
+// Three more stream walks at the end of the file are round 6's measured-slower other formulation (no lookups: the recurrence on four
+// blocks per register; crc16_hybrid_kernel, crc16_packed_kernel, crc16_mixed_kernel<PW>).  The library does not instantiate them;
+// tools/crc_hyb_probe.hip does, and profiles/r06_crc16_hybrid.txt has their times.
 #include "xmr.hpp"
 
 namespace coast {
@@ -53,6 +57,10 @@ __global__ void crc16_table_kernel(uint16_t *__restrict__ t16)
     t16[idx] = (uint16_t)crc16_byte(crc16_byte(idx, 0u), 0u);
 }
 
+// 1 (shipped) = the stream kernel's return-value vote in DPP form when only replica 0 stores; 0 = ds_bpermute (A/B)
+#ifndef COAST_CRC_DPP_VOTE
+#define COAST_CRC_DPP_VOTE 1
+#endif
 constexpr int kCrcStreamThreads = 1024;
 constexpr int kCrcTableBytes = 65536 * 2;
 
@@ -474,7 +482,10 @@ __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
             }
             Tally te = tl;
             te.det = 0;
-            const uint32_t voted = xmr_sync<NREP>(crc[j], lm, cntT[j], te); // return-value sync
+            // return-value sync.  One memory copy: only replica 0 stores, so it votes on its two neighbours' values by DPP -- a ds_bpermute
+            // is three ds_read_b32 worth of the LDS crossbar this kernel is bound by (COAST_CRC_DPP_VOTE; profiles/r06_aes_dpp_votes.txt)
+            const uint32_t voted = (COAST_CRC_DPP_VOTE && copyOut == 0) ? xmr_final_vote_dpp<NREP>(crc[j], cntT[j], te)
+                                                                         : xmr_sync<NREP>(crc[j], lm, cntT[j], te);
             tl.miss = te.miss;
             tl.syncs = te.syncs;
             if (cntT[j] || (liveT[j] && copyOut != 0)) // memory copies: every replica stores the voted crc into its own result copy
@@ -487,6 +498,637 @@ __global__ __launch_bounds__(THREADS) void crc16_stream_kernel(
                         detected[itemT[j]] = 1;
                 }
             }
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------ hybrid walk (round 6)
+// crc16_hybrid_kernel: the lookup walk and a lookup-free walk side by side in one wave.  The pair-table walk above is bound by the
+// latency of its dependent, bank-conflicted ds_read_u16 chain (the LDS array ~68 % busy, the VALU ~37 %, the wave in s_waitcnt
+// 70 % of its cycles: profiles/r06_crc16_analysis.txt); round 3's hybrids put VALU steps INTO that chain and lengthened it.  Here
+// a wave owns NTL tiles that walk the table as before and four more tiles whose blocks are walked by the reference recurrence
+// itself (crc16.c:26-28), four blocks per instruction: lane NREP*q + r holds replica r of block q of EACH of the four tiles, their
+// crc high bytes packed in one register (H), their low bytes in another (L), and a byte step is 9 instructions for the four
+//     x = H ^ D;  y = x ^ ((x >> 4) & 0x0f0f0f0f);  H' = L ^ ((y << 4) & 0xf0f0f0f0) ^ ((y >> 3) & 0x1f1f1f1f);  L' = y ^ ((y << 5) & 0xe0e0e0e0)
+// (the 16-bit recurrence split into its bytes: the high byte of crc << 8 is the old low byte, x << 12 reaches the high byte as
+// x << 4, x << 5 as x >> 3; the masks stop a byte's bits at its neighbour's border).  D = the four blocks' data bytes, one
+// v_perm_b32 transposition (8 per 16 bytes) behind the funnel every row dword takes anyway.  The packed walk has no lookup and no
+// wait: it issues in the shadow of the table chains' LDS latency.  Same tiles, same lanes, same return-value sync, same armed /
+// tail tiles (walked byte by byte with the hooks) as crc16_stream_kernel; bit-identical results (tests: every alignment / tail).
+__device__ __forceinline__ void crc16_swar_step(uint32_t &H, uint32_t &L, uint32_t D)
+{
+    // a ^ (b & mask) is ONE v_bitop3_b32 (truth table 0x78); written out because the compiler splits two of the four into v_and + v_xor
+    const uint32_t x = H ^ D;
+    const uint32_t y = __builtin_amdgcn_bitop3_b32(x, x >> 4, 0x0f0f0f0fu, 0x78);
+    const uint32_t u = __builtin_amdgcn_bitop3_b32(L, y << 4, 0xf0f0f0f0u, 0x78);
+    H = __builtin_amdgcn_bitop3_b32(u, y >> 3, 0x1f1f1f1fu, 0x78);
+    L = __builtin_amdgcn_bitop3_b32(y, y << 5, 0xe0e0e0e0u, 0x78);
+}
+
+constexpr int kCrcSwarTiles = 4;
+
+template <int NREP, int NTL, bool ALIGNED, int BD = 8>
+__global__ __launch_bounds__(kCrcStreamThreads) void crc16_hybrid_kernel(
+    const uint8_t *__restrict__ data, uint32_t blockLen, uint64_t nblocksData, uint16_t *__restrict__ crcs,
+    const uint16_t *__restrict__ t16g, uint64_t ntiles, uint64_t ntilesWalk, Counters ctr, FaultTab ft,
+    uint8_t *__restrict__ detected, size_t copyIn = 0, size_t copyOut = 0)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smemRaw[];
+    uint16_t *T = reinterpret_cast<uint16_t *>(smemRaw);
+    uint32_t *sCnt = reinterpret_cast<uint32_t *>(smemRaw + kCrcTableBytes);
+    constexpr int THREADS = kCrcStreamThreads;
+    constexpr int IPW = LaneMap<NREP>::kItemsPerWave;
+    constexpr int NT = NTL + kCrcSwarTiles, CB = BD / 4; // tiles per wave and round; 16-byte chunks per batch
+    static_assert(BD == 4 || BD == 8 || BD == 16, "batch of 1, 2 or 4 chunks");
+    const LaneMap<NREP> lm;
+    const int tid = threadIdx.x;
+    if constexpr (NTL > 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(t16g);
+        uint4 *dst = reinterpret_cast<uint4 *>(T);
+        for (int e = tid; e < kCrcTableBytes / 16; e += THREADS)
+            dst[e] = src[e];
+    }
+    if (tid < 4)
+        sCnt[tid] = 0;
+    __syncthreads();
+
+    const uint64_t wavesTotal = (uint64_t)gridDim.x * (THREADS / kWave);
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (THREADS / kWave) + (tid >> 6);
+    Tally tl;
+    uint32_t detItems = 0;
+    // the row geometry of crc16_stream_kernel: nd full dwords, tb tail bytes; unaligned rows as the dword-aligned chunks that cover them
+    const uint32_t nd = blockLen >> 2, tb = blockLen & 3u;
+    const uint32_t nbFull = nd / BD, R = nd % BD;
+    const uint32_t nChunks = ALIGNED ? (blockLen >> 4) : ((nd + (tb ? 1u : 0u) + 1u + 3u) >> 2);
+
+    for (uint64_t tileBase = wave0 * NT; tileBase < ntiles; tileBase += wavesTotal * NT) {
+        const uint8_t *p[NT];
+        bool liveT[NT], cntT[NT], slowT[NT];
+        uint64_t itemT[NT];
+        uint32_t crc[NT], sel[NT];
+        uint32_t cur[NT][BD], nxt[NT][BD];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const uint64_t tile = tileBase + j;
+            const bool skip = tile >= ntiles;
+            slowT[j] = !skip && (tile >= ntilesWalk || (ft.range && __builtin_amdgcn_readfirstlane(ft.range[tile].y) != 0u));
+            itemT[j] = tile * IPW + (uint64_t)lm.q;
+            liveT[j] = !skip && lm.live && itemT[j] < nblocksData;
+            cntT[j] = liveT[j] && lm.r == 0;
+            const uint8_t *row = data + (size_t)lm.r * copyIn + ((liveT[j] && !slowT[j]) ? itemT[j] : 0) * (uint64_t)blockLen;
+            const uint32_t sh = ALIGNED ? 0u : (uint32_t)(reinterpret_cast<uintptr_t>(row) & 3u);
+            p[j] = row - sh;
+            // table tiles take their row dwords big-endian (b0 b1 | b2 b3 are the two pair indices), the packed tiles as they lie
+            sel[j] = j < NTL ? crc_perm_sel(sh) : 0x03020100u + 0x01010101u * sh;
+            crc[j] = 0xFFFFu;
+        }
+        bool anyWalk = false;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            anyWalk = anyWalk || (tileBase + j < ntiles && !slowT[j]);
+        if (anyWalk) {
+            uint32_t H = 0xffffffffu, L = 0xffffffffu;
+#define CRCH_LOAD_CHUNK(dst, j, bt, v)                                                                       \
+    do {                                                                                                     \
+        const uint4 q__ = *reinterpret_cast<const uint4 *>(p[j] + (size_t)(bt) * (4 * BD) + 16 * (v));       \
+        dst[j][4 * (v)] = q__.x, dst[j][4 * (v) + 1] = q__.y, dst[j][4 * (v) + 2] = q__.z, dst[j][4 * (v) + 3] = q__.w; \
+    } while (0)
+#define CRCH_LOAD_GUARDED(dst, bt)                                                                           \
+    _Pragma("unroll") for (int v = 0; v < CB; ++v) if ((uint32_t)CB * (bt) + (uint32_t)v < nChunks)         \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) CRCH_LOAD_CHUNK(dst, j, bt, v)
+#define CRCH_LOAD(dst, bt)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) _Pragma("unroll") for (int v = 0; v < CB; ++v) CRCH_LOAD_CHUNK(dst, j, bt, v)
+            // row dword i of the current batch: the table tiles' big-endian, the packed tiles' little-endian
+            auto rowDword = [&](int j, int i) __attribute__((always_inline)) {
+                if constexpr (ALIGNED)
+                    return j < NTL ? __builtin_bswap32(cur[j][i]) : cur[j][i];
+                else
+                    return __builtin_amdgcn_perm(i < BD - 1 ? cur[j][(i + 1) & (BD - 1)] : nxt[j][0], cur[j][i], sel[j]);
+            };
+            // one row dword of every tile: two pair lookups per table chain, four packed byte steps (`nbytes` of them at a row's tail)
+            auto step = [&](int i, uint32_t nbytes) __attribute__((always_inline)) {
+                uint32_t e[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    e[j] = rowDword(j, i);
+                const uint32_t a01 = __builtin_amdgcn_perm(e[NTL + 1], e[NTL], 0x05010400u); // {e0.0, e1.0, e0.1, e1.1}
+                const uint32_t a23 = __builtin_amdgcn_perm(e[NTL + 3], e[NTL + 2], 0x05010400u);
+                const uint32_t b01 = __builtin_amdgcn_perm(e[NTL + 1], e[NTL], 0x07030602u); // {e0.2, e1.2, e0.3, e1.3}
+                const uint32_t b23 = __builtin_amdgcn_perm(e[NTL + 3], e[NTL + 2], 0x07030602u);
+                if (nbytes == 4u) {
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        crc[j] = T[crc[j] ^ (e[j] >> 16)];
+                    crc16_swar_step(H, L, __builtin_amdgcn_perm(a23, a01, 0x05040100u));
+                    crc16_swar_step(H, L, __builtin_amdgcn_perm(a23, a01, 0x07060302u));
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        crc[j] = T[crc[j] ^ (e[j] & 0xffffu)];
+                    crc16_swar_step(H, L, __builtin_amdgcn_perm(b23, b01, 0x05040100u));
+                    crc16_swar_step(H, L, __builtin_amdgcn_perm(b23, b01, 0x07060302u));
+                } else { // b0 [b1 [b2]]: a pair lookup for two bytes and a byte-serial step for the odd one; nbytes packed steps
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) {
+                        if (nbytes >= 2u)
+                            crc[j] = T[crc[j] ^ (e[j] >> 16)];
+                        if (nbytes & 1u)
+                            crc[j] = crc16_byte(crc[j], nbytes == 1u ? e[j] >> 24 : (e[j] >> 8) & 0xffu);
+                    }
+                    crc16_swar_step(H, L, __builtin_amdgcn_perm(a23, a01, 0x05040100u));
+                    if (nbytes >= 2u)
+                        crc16_swar_step(H, L, __builtin_amdgcn_perm(a23, a01, 0x07060302u));
+                    if (nbytes == 3u)
+                        crc16_swar_step(H, L, __builtin_amdgcn_perm(b23, b01, 0x05040100u));
+                }
+            };
+            if (nbFull) {
+                CRCH_LOAD(cur, 0u);
+            } else {
+                CRCH_LOAD_GUARDED(cur, 0u);
+            }
+            for (uint32_t b = 0; b < nbFull; ++b) {
+                if (b + 1u < nbFull) {
+                    CRCH_LOAD(nxt, b + 1u);
+                } else {
+                    CRCH_LOAD_GUARDED(nxt, b + 1u);
+                }
+#pragma unroll
+                for (int i = 0; i < BD; ++i)
+                    step(i, 4u);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < BD; ++i)
+                        cur[j][i] = nxt[j][i];
+            }
+            if (R | tb) { // R < BD full dwords, then tb < 4 bytes: all of it in `cur`, except the dword the last funnel reaches into
+                if (!ALIGNED && (uint32_t)CB * (nbFull + 1u) < nChunks) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        nxt[j][0] = *reinterpret_cast<const uint32_t *>(p[j] + (size_t)(nbFull + 1u) * (4 * BD));
+                }
+#pragma unroll
+                for (int i = 0; i < BD; ++i) {
+                    if ((uint32_t)i < R)
+                        step(i, 4u);
+                    else if ((uint32_t)i == R && tb)
+                        step(i, tb);
+                }
+            }
+#undef CRCH_LOAD
+#undef CRCH_LOAD_GUARDED
+#undef CRCH_LOAD_CHUNK
+#pragma unroll
+            for (int k = 0; k < kCrcSwarTiles; ++k)
+                crc[NTL + k] = (((H >> (8 * k)) & 0xffu) << 8) | ((L >> (8 * k)) & 0xffu);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (slowT[j]) { // armed / tail tiles: byte by byte with the hooks, as in crc16_stream_kernel
+                uint2 fr = make_uint2(0u, 0u);
+                if (ft.range) {
+                    const uint2 rg = ft.range[tileBase + j];
+                    fr.x = __builtin_amdgcn_readfirstlane(rg.x);
+                    fr.y = __builtin_amdgcn_readfirstlane(rg.y);
+                }
+                crc[j] = crc16_bytes_hooked(data + (size_t)lm.r * copyIn + (liveT[j] ? itemT[j] : 0) * (uint64_t)blockLen,
+                                            liveT[j] ? blockLen : 0u, ft, fr, lm.q, lm.r, lm.live);
+            }
+            Tally te = tl;
+            te.det = 0;
+            const uint32_t voted = xmr_sync<NREP>(crc[j], lm, cntT[j], te); // return-value sync
+            tl.miss = te.miss;
+            tl.syncs = te.syncs;
+            if (cntT[j] || (liveT[j] && copyOut != 0))
+                crcs[(size_t)lm.r * copyOut + itemT[j]] = (uint16_t)(NREP == 3 ? voted : crc[j]);
+            if (cntT[j]) {
+                if (te.det) {
+                    if (NREP == 2)
+                        detItems += 1;
+                    if (detected)
+                        detected[itemT[j]] = 1;
+                }
+            }
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------ packed walk from LDS (round 6)
+// crc16_packed_kernel: the packed byte-step walk alone, its rows staged in LDS.  The probe of crc16_hybrid_kernel
+// (profiles/r06_crc16_hybrid.txt) showed what holds the packed walk back: not its instructions (0.75 per byte and lane against
+// the lookup walk's 1.4 + half a lookup) but its fetches -- four tiles per wave are four times the rows in flight per CU, every
+// 16-byte piece of a row is its own request at a 255-byte stride, and the lines fall out of L1 / L2 between two pieces.  Without
+// the 128 KiB table the LDS is free: a wave copies the 4 x IPW consecutive rows of its four tiles into its own LDS buffer with
+// LDS-DMA (global_load_lds_dwordx4: 1 KiB per instruction, every HBM line requested once, whole, in address order; no register
+// holds stream data outside the replicas -- the staged copy is memory, like the table it replaces) and every replica lane reads
+// its four rows from there (its own ds_read_b32 per dword: a cloned load).  Layout: row n of the wave's region at LDS byte
+// 272 n + (address of the row & 15): the 17 aligned 16-byte chunks that cover a row of <= 256 bytes, chunk j of row n fetched by
+// lane (17 n + j) % 64 of DMA instruction (17 n + j) / 64 -- the source address is per lane, the destination lane-linear.  272 B
+// = 68 dwords: the lanes of one ds_read_b32 (same dword of rows q, q + 1, ...) fall into banks 4 q + (0..3): conflict-free
+// within each half of the wave; the replicas of a block read the same address (broadcast).  One workgroup of 7 waves per CU
+// (7 x 84 x 272 B = 156 KiB); a wave's DMA phase runs under the other waves' walks.  Row lengths 160..256 bytes, TMR; armed /
+// tail tiles byte by byte from HBM with the hooks, as in crc16_stream_kernel.  The DMA's address arithmetic is not replicated
+// (neither is the persistent loop's tile counter); the walk, the crc registers and the return-value sync are.
+constexpr int kCrcPackPitch = 272;
+#ifndef CRC_PACK_KNOCK
+#define CRC_PACK_KNOCK 0 // tools/crc_hyb_probe: 1 = no staging copy, 2 = no walk (timing knock-outs; results are wrong)
+#endif
+template <int NREP> struct CrcPack {
+    static constexpr int kRows = kCrcSwarTiles * LaneMap<NREP>::kItemsPerWave;  // rows staged per wave and round
+    static constexpr int kBuf = kRows * kCrcPackPitch;                          // LDS bytes per wave
+    static constexpr int kWaves = (160 * 1024 - 512) / kBuf;                    // 7 (TMR), 4 (DWC), 2 (unprotected)
+    static constexpr int kThreads = kWaves * kWave;
+    static constexpr int kPieces = (kRows * 17 + 63) / 64;                      // DMA instructions per round
+    static constexpr size_t kLds = (size_t)kWaves * kBuf + kCrcPackPitch + 16;  // + the reach of the last batch past the last row, counters
+};
+
+template <int NREP, bool ALIGNED, int BD = 8>
+__global__ __launch_bounds__(CrcPack<NREP>::kThreads) void crc16_packed_kernel(
+    const uint8_t *__restrict__ data, uint32_t blockLen, uint64_t nblocksData, uint16_t *__restrict__ crcs, uint64_t ntiles,
+    uint64_t ntilesWalk, Counters ctr, FaultTab ft, uint8_t *__restrict__ detected)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smemRaw[];
+    using CP = CrcPack<NREP>;
+    constexpr int THREADS = CP::kThreads, IPW = LaneMap<NREP>::kItemsPerWave, NT = kCrcSwarTiles;
+    typedef __attribute__((address_space(3))) uint8_t *lds_u8p;
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32p;
+    typedef const __attribute__((address_space(1))) uint32_t *glb_u32p;
+    uint32_t *sCnt = reinterpret_cast<uint32_t *>(smemRaw + (size_t)CP::kWaves * CP::kBuf + kCrcPackPitch);
+    const LaneMap<NREP> lm;
+    const int tid = threadIdx.x;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    const lds_u8p wbuf = (lds_u8p)smemRaw + wv * (uint32_t)CP::kBuf;
+    if (tid < 4)
+        sCnt[tid] = 0;
+    __syncthreads();
+
+    const uint64_t wavesTotal = (uint64_t)gridDim.x * CP::kWaves;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * CP::kWaves + wv;
+    Tally tl;
+    uint32_t detItems = 0;
+    const uint32_t nd = blockLen >> 2, tb = blockLen & 3u;
+    const uint32_t nbFull = nd / BD, R = nd % BD;
+    const uint32_t qRow = lm.live ? (uint32_t)lm.q : 0u;
+
+    for (uint64_t tileBase = wave0 * NT; tileBase < ntiles; tileBase += wavesTotal * NT) {
+        bool liveT[NT], cntT[NT], slowT[NT];
+        uint64_t itemT[NT];
+        uint32_t crc[NT];
+        bool anyWalk = false; // wave-uniform: some tile of this round takes the packed walk
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const uint64_t tile = tileBase + j;
+            const bool skip = tile >= ntiles;
+            slowT[j] = !skip && (tile >= ntilesWalk || (ft.range && __builtin_amdgcn_readfirstlane(ft.range[tile].y) != 0u));
+            itemT[j] = tile * IPW + (uint64_t)lm.q;
+            liveT[j] = !skip && lm.live && itemT[j] < nblocksData;
+            cntT[j] = liveT[j] && lm.r == 0;
+            crc[j] = 0xFFFFu;
+            anyWalk = anyWalk || (!skip && !slowT[j]);
+        }
+        if (anyWalk) {
+            // the rows to stage: the round's tiles below ntilesWalk (the stream's last tiles are never read ahead of), the data's end
+            const uint64_t firstItem = tileBase * IPW;
+            const uint64_t endTile = tileBase + NT < ntilesWalk ? tileBase + NT : ntilesWalk;
+            const uint64_t endItem = endTile * IPW < nblocksData ? endTile * IPW : nblocksData;
+            const uint32_t rowsStage = (uint32_t)(endItem - firstItem); // anyWalk: tileBase < ntilesWalk
+            const uint8_t *region = data + firstItem * (uint64_t)blockLen;
+            const uint32_t regLow = (uint32_t)reinterpret_cast<uintptr_t>(region) & 15u;
+            if (CRC_PACK_KNOCK != 1) {
+                uint32_t n = (uint32_t)lm.lane / 17u, jc = (uint32_t)lm.lane - 17u * n; // piece 0: chunk jc of row n
+#pragma unroll
+                for (int m = 0; m < CP::kPieces; ++m) {
+                    const uint32_t rowOff = n * blockLen + regLow;  // the row's first byte, from the region's 16-byte floor
+                    const uint32_t src = (rowOff & ~15u) + 16u * jc; // this lane's chunk, same origin
+                    if (n < rowsStage && src < rowOff + blockLen)    // the chunk holds a byte of the row
+                        __builtin_amdgcn_global_load_lds((glb_u32p)(uintptr_t)(region - regLow + src),
+                                                         (__attribute__((address_space(3))) uint32_t *)(wbuf + m * 1024), 16, 0, 0);
+                    n += 3u, jc += 13u; // 64 = 3 * 17 + 13
+                    if (jc >= 17u)
+                        jc -= 17u, n += 1u;
+                }
+            }
+            lds_u32p lp[NT];
+            uint32_t sel[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const uint32_t nrow = (uint32_t)(IPW * k) + qRow;
+                const uint32_t b = nrow * (uint32_t)kCrcPackPitch + ((nrow * blockLen + regLow) & 15u);
+                lp[k] = (lds_u32p)(wbuf + (b & ~3u));
+                sel[k] = 0x03020100u + 0x01010101u * (b & 3u); // the funnel: row dword i = bytes s .. s + 3 of LDS dwords i, i + 1
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the staged rows have landed (this wave's own buffer: no barrier)
+            uint32_t H = 0xffffffffu, L = 0xffffffffu;
+            uint32_t cur[NT][BD], nxt[NT][BD];
+#define CRCP_LOAD(dst, bt)                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < NT; ++k) _Pragma("unroll") for (int i = 0; i < BD; ++i) dst[k][i] = lp[k][(bt) * BD + i]
+            auto step = [&](int i, uint32_t nbytes) __attribute__((always_inline)) {
+                uint32_t e[NT];
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    if constexpr (ALIGNED)
+                        e[k] = cur[k][i];
+                    else
+                        e[k] = __builtin_amdgcn_perm(i < BD - 1 ? cur[k][(i + 1) & (BD - 1)] : nxt[k][0], cur[k][i], sel[k]);
+                }
+                const uint32_t a01 = __builtin_amdgcn_perm(e[1], e[0], 0x05010400u), a23 = __builtin_amdgcn_perm(e[3], e[2], 0x05010400u);
+                crc16_swar_step(H, L, __builtin_amdgcn_perm(a23, a01, 0x05040100u));
+                if (nbytes >= 2u)
+                    crc16_swar_step(H, L, __builtin_amdgcn_perm(a23, a01, 0x07060302u));
+                if (nbytes >= 3u) {
+                    const uint32_t b01 = __builtin_amdgcn_perm(e[1], e[0], 0x07030602u), b23 = __builtin_amdgcn_perm(e[3], e[2], 0x07030602u);
+                    crc16_swar_step(H, L, __builtin_amdgcn_perm(b23, b01, 0x05040100u));
+                    if (nbytes == 4u)
+                        crc16_swar_step(H, L, __builtin_amdgcn_perm(b23, b01, 0x07060302u));
+                }
+            };
+            CRCP_LOAD(cur, 0u);
+            for (uint32_t b = 0; b < (CRC_PACK_KNOCK == 2 ? 1u : nbFull); ++b) {
+                CRCP_LOAD(nxt, b + 1u); // (LDS reads past a row's end stay inside the workgroup's allocation)
+#pragma unroll
+                for (int i = 0; i < BD; ++i)
+                    step(i, 4u);
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+#pragma unroll
+                    for (int i = 0; i < BD; ++i)
+                        cur[k][i] = nxt[k][i];
+            }
+            if (R | tb) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+                    nxt[k][0] = lp[k][(nbFull + 1u) * BD];
+#pragma unroll
+                for (int i = 0; i < BD; ++i) {
+                    if ((uint32_t)i < R)
+                        step(i, 4u);
+                    else if ((uint32_t)i == R && tb)
+                        step(i, tb);
+                }
+            }
+#undef CRCP_LOAD
+#pragma unroll
+            for (int k = 0; k < NT; ++k)
+                crc[k] = (((H >> (8 * k)) & 0xffu) << 8) | ((L >> (8 * k)) & 0xffu);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (slowT[j]) { // armed / tail tiles: byte by byte from HBM with the hooks, as in crc16_stream_kernel
+                uint2 fr = make_uint2(0u, 0u);
+                if (ft.range) {
+                    const uint2 rg = ft.range[tileBase + j];
+                    fr.x = __builtin_amdgcn_readfirstlane(rg.x);
+                    fr.y = __builtin_amdgcn_readfirstlane(rg.y);
+                }
+                crc[j] = crc16_bytes_hooked(data + (liveT[j] ? itemT[j] : 0) * (uint64_t)blockLen, liveT[j] ? blockLen : 0u, ft, fr, lm.q,
+                                            lm.r, lm.live);
+            }
+            Tally te = tl;
+            te.det = 0;
+            const uint32_t voted = xmr_sync<NREP>(crc[j], lm, cntT[j], te); // return-value sync
+            tl.miss = te.miss;
+            tl.syncs = te.syncs;
+            if (cntT[j])
+                crcs[itemT[j]] = (uint16_t)(NREP == 3 ? voted : crc[j]);
+            if (cntT[j]) {
+                if (te.det) {
+                    if (NREP == 2)
+                        detItems += 1;
+                    if (detected)
+                        detected[itemT[j]] = 1;
+                }
+            }
+        }
+    }
+    block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------ mixed walk (round 6)
+// crc16_mixed_kernel: both walks on one CU, each on the resource the other leaves idle.  The lookup walk is bound by the latency of
+// its conflicted ds_read_u16 chain and uses a third of the VALU; the packed walk uses the VALU alone, and what it needs from LDS is
+// a staging buffer.  Next to the 128 KiB table there are 32 KiB: one buffer of 84 rows x 96 bytes per packed wave -- a 64-byte
+// SEGMENT of each row (the six aligned 16-byte chunks that cover it and the dword its last funnel reaches into), four packed waves
+// (wave w of the workgroup runs on SIMD w % 4: one per SIMD), twelve lookup waves.  A packed wave reads a staged segment into
+// registers (17 dwords x 4 rows), has the NEXT segment (or the next round's first) copied into the same buffer by LDS-DMA, and walks
+// the 64 bytes from registers while the copy is in flight.  The stream is split statically: tiles [0, ntilesPacked) to the packed
+// waves (four consecutive tiles per wave and round), the rest to the lookup waves; the host picks the share (COAST_CRC_PACK_SHARE).
+constexpr int kCrcMixPackWaves = 4;
+constexpr int kCrcMixSegDwords = 16;
+constexpr int kCrcMixPitch = 96;                                         // LDS bytes per row segment
+constexpr int kCrcMixRows = kCrcSwarTiles * 21;                          // TMR
+constexpr int kCrcMixBuf = kCrcMixRows * kCrcMixPitch;                   // 8064 bytes per packed wave
+constexpr int kCrcMixPieces = (kCrcMixRows * 6 + 63) / 64;               // DMA instructions per segment
+// PW packed waves of the workgroup's 16: 4 = beside the table and 12 lookup waves; 16 = no table, no lookup waves
+template <int PW> constexpr size_t crc_mix_lds() { return 16 + (PW < 16 ? (size_t)kCrcTableBytes : 0) + (size_t)PW * kCrcMixBuf; }
+static_assert(crc_mix_lds<4>() <= 160 * 1024 && crc_mix_lds<16>() <= 160 * 1024, "table + staging buffers fit the CU's LDS");
+
+template <int PW>
+__global__ __launch_bounds__(kCrcStreamThreads) void crc16_mixed_kernel(
+    const uint8_t *__restrict__ data, uint32_t blockLen, uint64_t nblocksData, uint16_t *__restrict__ crcs,
+    const uint16_t *__restrict__ t16g, uint64_t ntiles, uint64_t ntilesWalk, uint64_t ntilesPacked, Counters ctr, FaultTab ft,
+    uint8_t *__restrict__ detected)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smemRaw[];
+    constexpr int NREP = 3, THREADS = kCrcStreamThreads, IPW = LaneMap<NREP>::kItemsPerWave, NP = kCrcSwarTiles;
+    constexpr int TW = THREADS / kWave - PW, SD = kCrcMixSegDwords;
+    constexpr uint32_t kBufBase = 16u + (TW ? (uint32_t)kCrcTableBytes : 0u);
+    typedef __attribute__((address_space(3))) uint8_t *lds_u8p;
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32p;
+    typedef const __attribute__((address_space(1))) uint32_t *glb_u32p;
+    uint16_t *T = reinterpret_cast<uint16_t *>(smemRaw + 16);
+    uint32_t *sCnt = reinterpret_cast<uint32_t *>(smemRaw);
+    const LaneMap<NREP> lm;
+    const int tid = threadIdx.x;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    if constexpr (TW > 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(t16g);
+        uint4 *dst = reinterpret_cast<uint4 *>(T);
+        for (int e = tid; e < kCrcTableBytes / 16; e += THREADS)
+            dst[e] = src[e];
+    }
+    if (tid < 4)
+        sCnt[tid] = 0;
+    __syncthreads();
+
+    Tally tl;
+    uint32_t detItems = 0;
+    const uint32_t nd = blockLen >> 2, tb = blockLen & 3u;
+
+    // what every tile ends with: armed / tail tiles byte by byte with the hooks, the return-value sync, the store
+    auto finishTile = [&](uint64_t tile, uint32_t crcWalk) __attribute__((always_inline)) {
+        const bool skip = tile >= ntiles;
+        const bool slow = !skip && (tile >= ntilesWalk || (ft.range && __builtin_amdgcn_readfirstlane(ft.range[tile].y) != 0u));
+        const uint64_t item = tile * IPW + (uint64_t)lm.q;
+        const bool live = !skip && lm.live && item < nblocksData, cnt = live && lm.r == 0;
+        uint32_t crc = crcWalk;
+        if (slow) {
+            const uint2 rg = ft.range ? ft.range[tile] : make_uint2(0u, 0u);
+            const uint2 fr = make_uint2(__builtin_amdgcn_readfirstlane(rg.x), __builtin_amdgcn_readfirstlane(rg.y));
+            crc = crc16_bytes_hooked(data + (live ? item : 0) * (uint64_t)blockLen, live ? blockLen : 0u, ft, fr, lm.q, lm.r, lm.live);
+        }
+        Tally te = tl;
+        te.det = 0;
+        const uint32_t voted = xmr_sync<NREP>(crc, lm, cnt, te);
+        tl.miss = te.miss;
+        tl.syncs = te.syncs;
+        if (cnt) {
+            crcs[item] = (uint16_t)voted;
+            if (te.det && detected)
+                detected[item] = 1;
+        }
+    };
+
+    if (wv < (uint32_t)PW) {
+        // ---- packed waves: tiles [0, ntilesPacked), four per round
+        const lds_u8p wbuf = (lds_u8p)smemRaw + kBufBase + wv * (uint32_t)kCrcMixBuf;
+        const uint64_t stride = (uint64_t)gridDim.x * PW * NP;
+        const uint32_t nseg = (nd + (tb ? 1u : 0u) + SD - 1u) / SD;
+        const uint32_t qRow = lm.live ? (uint32_t)lm.q : 0u;
+        // segment `seg` of the 84 rows that start at tile `tb0`: chunk jc (0..5) of row n -> LDS 96 n + 16 jc
+        auto stage = [&](uint64_t tb0, uint32_t seg) __attribute__((always_inline)) {
+            const uint8_t *region = data + tb0 * IPW * (uint64_t)blockLen;
+            const uint32_t regLow = (uint32_t)reinterpret_cast<uintptr_t>(region) & 15u;
+            uint32_t n = (uint32_t)lm.lane / 6u, jc = (uint32_t)lm.lane - 6u * n;
+#pragma unroll
+            for (int m = 0; m < kCrcMixPieces; ++m) {
+                const uint32_t rowOff = n * blockLen + regLow;       // the row's first byte, from the region's 16-byte floor
+                const uint32_t o = rowOff + 4u * SD * seg;           // the segment's first byte
+                const uint32_t src = (o & ~15u) + 16u * jc;
+                const uint32_t end = min(o + 4u * SD + 4u, rowOff + blockLen);
+                if (n < (uint32_t)kCrcMixRows && src < end)
+                    __builtin_amdgcn_global_load_lds((glb_u32p)(uintptr_t)(region - regLow + src),
+                                                     (__attribute__((address_space(3))) uint32_t *)(wbuf + m * 1024), 16, 0, 0);
+                n += 10u, jc += 4u; // 64 = 10 * 6 + 4
+                if (jc >= 6u)
+                    jc -= 6u, n += 1u;
+            }
+        };
+        uint64_t tileBase = ((uint64_t)blockIdx.x * PW + wv) * NP;
+        if (tileBase < ntilesPacked)
+            stage(tileBase, 0u);
+        for (; tileBase < ntilesPacked; tileBase += stride) {
+            const uint8_t *region = data + tileBase * IPW * (uint64_t)blockLen;
+            const uint32_t regLow = (uint32_t)reinterpret_cast<uintptr_t>(region) & 15u;
+            lds_u32p lp[NP];
+            uint32_t sel[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const uint32_t nrow = (uint32_t)(IPW * k) + qRow;
+                const uint32_t b = nrow * (uint32_t)kCrcMixPitch + ((nrow * blockLen + regLow) & 15u);
+                lp[k] = (lds_u32p)(wbuf + (b & ~3u));
+                sel[k] = 0x03020100u + 0x01010101u * (b & 3u);
+            }
+            uint32_t H = 0xffffffffu, L = 0xffffffffu;
+            for (uint32_t seg = 0; seg < nseg; ++seg) {
+                uint32_t cur[NP][SD + 1];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the segment has landed
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+#pragma unroll
+                    for (int i = 0; i <= SD; ++i)
+                        cur[k][i] = lp[k][i];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // ... and is in registers: the buffer is free for the next one
+                if (seg + 1u < nseg)
+                    stage(tileBase, seg + 1u);
+                else if (tileBase + stride < ntilesPacked)
+                    stage(tileBase + stride, 0u);
+#pragma unroll
+                for (int i = 0; i < SD; ++i) {
+                    const uint32_t g = seg * SD + (uint32_t)i; // row dword
+                    const uint32_t nbytes = g < nd ? 4u : (g == nd ? tb : 0u);
+                    if (nbytes == 0u)
+                        break;
+                    uint32_t e[NP];
+#pragma unroll
+                    for (int k = 0; k < NP; ++k)
+                        e[k] = __builtin_amdgcn_perm(cur[k][i + 1], cur[k][i], sel[k]);
+                    const uint32_t a01 = __builtin_amdgcn_perm(e[1], e[0], 0x05010400u), a23 = __builtin_amdgcn_perm(e[3], e[2], 0x05010400u);
+                    const uint32_t b01 = __builtin_amdgcn_perm(e[1], e[0], 0x07030602u), b23 = __builtin_amdgcn_perm(e[3], e[2], 0x07030602u);
+                    crc16_swar_step(H, L, __builtin_amdgcn_perm(a23, a01, 0x05040100u));
+                    if (nbytes >= 2u)
+                        crc16_swar_step(H, L, __builtin_amdgcn_perm(a23, a01, 0x07060302u));
+                    if (nbytes >= 3u)
+                        crc16_swar_step(H, L, __builtin_amdgcn_perm(b23, b01, 0x05040100u));
+                    if (nbytes == 4u)
+                        crc16_swar_step(H, L, __builtin_amdgcn_perm(b23, b01, 0x07060302u));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+                finishTile(tileBase + k, (((H >> (8 * k)) & 0xffu) << 8) | ((L >> (8 * k)) & 0xffu));
+        }
+    } else if constexpr (TW > 0) {
+        // ---- lookup waves: tiles [ntilesPacked, ntiles), one per round (the walk of crc16_stream_kernel<3, 1, false>)
+        const uint32_t nbFull = nd >> 4, R = nd & 15u;
+        const uint32_t nChunks = (nd + (tb ? 1u : 0u) + 1u + 3u) >> 2;
+        const uint64_t stride = (uint64_t)gridDim.x * TW;
+#ifdef CRC_MIX_PRIO
+        __builtin_amdgcn_s_setprio(3); // the lookup chain is latency-bound: its few VALU instructions go first
+#endif
+        for (uint64_t tile = ntilesPacked + (uint64_t)blockIdx.x * TW + (wv - PW); tile < ntiles; tile += stride) {
+            const bool slow = tile >= ntilesWalk || (ft.range && __builtin_amdgcn_readfirstlane(ft.range[tile].y) != 0u);
+            const uint64_t item = tile * IPW + (uint64_t)lm.q;
+            const bool live = lm.live && item < nblocksData;
+            uint32_t crc = 0xFFFFu;
+            if (!slow) {
+                const uint8_t *row = data + (live ? item : 0) * (uint64_t)blockLen;
+                const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(row) & 3u);
+                const uint8_t *p = row - sh;
+                const uint32_t sel = crc_perm_sel(sh);
+                uint32_t cur[16], nxt[16];
+#define CRCM_CHUNK(dst, bt, v)                                                                               \
+    do {                                                                                                     \
+        const uint4 q__ = *reinterpret_cast<const uint4 *>(p + (size_t)(bt) * 64 + 16 * (v));                \
+        dst[4 * (v)] = q__.x, dst[4 * (v) + 1] = q__.y, dst[4 * (v) + 2] = q__.z, dst[4 * (v) + 3] = q__.w;  \
+    } while (0)
+#define CRCM_LOAD_GUARDED(dst, bt) _Pragma("unroll") for (int v = 0; v < 4; ++v) if (4u * (bt) + (uint32_t)v < nChunks) CRCM_CHUNK(dst, bt, v)
+#define CRCM_LOAD(dst, bt) _Pragma("unroll") for (int v = 0; v < 4; ++v) CRCM_CHUNK(dst, bt, v)
+                if (nbFull) {
+                    CRCM_LOAD(cur, 0u);
+                } else {
+                    CRCM_LOAD_GUARDED(cur, 0u);
+                }
+                for (uint32_t b = 0; b < nbFull; ++b) {
+                    if (b + 1u < nbFull) {
+                        CRCM_LOAD(nxt, b + 1u);
+                    } else {
+                        CRCM_LOAD_GUARDED(nxt, b + 1u);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint32_t e = crc_be32(i < 15 ? cur[(i + 1) & 15] : nxt[0], cur[i], sel);
+                        crc = T[crc ^ (e >> 16)];
+                        crc = T[crc ^ (e & 0xffffu)];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        cur[i] = nxt[i];
+                }
+                if (R | tb) {
+                    if (4u * (nbFull + 1u) < nChunks)
+                        nxt[0] = *reinterpret_cast<const uint32_t *>(p + (size_t)(nbFull + 1u) * 64);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if ((uint32_t)i < R) {
+                            const uint32_t e = crc_be32(i < 15 ? cur[(i + 1) & 15] : nxt[0], cur[i], sel);
+                            crc = T[crc ^ (e >> 16)];
+                            crc = T[crc ^ (e & 0xffffu)];
+                        } else if ((uint32_t)i == R && tb) {
+                            const uint32_t e = crc_be32(i < 15 ? cur[(i + 1) & 15] : nxt[0], cur[i], sel);
+                            if (tb >= 2u)
+                                crc = T[crc ^ (e >> 16)];
+                            if (tb & 1u)
+                                crc = crc16_byte(crc, tb == 1u ? e >> 24 : (e >> 8) & 0xffu);
+                        }
+                    }
+                }
+#undef CRCM_LOAD
+#undef CRCM_LOAD_GUARDED
+#undef CRCM_CHUNK
+            }
+            finishTile(tile, crc);
         }
     }
     block_tally(tl.miss, tl.syncs, detItems, sCnt, ctr, blockIdx.x);

@@ -813,6 +813,40 @@ def test_crc16_stream_prefix_and_linearity(eng, orc):
     assert (ca[: pre.shape[0]] == exp).all()
 
 
+@pytest.fixture(scope="module")
+def crc_probe(tmp_path_factory):
+    """tools/crc_hyb_probe: the binary that travelled with the tree, or one compile per session"""
+    import os
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "crc_hyb_probe")
+    if os.path.exists(exe) and os.access(exe, os.X_OK):
+        return exe
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    exe = str(tmp_path_factory.mktemp("crcprobe") / "crc_hyb_probe")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-o", exe, os.path.join(root, "tools", "crc_hyb_probe.hip")], check=True,
+                   capture_output=True, timeout=900)
+    return exe
+
+
+@pytest.mark.parametrize("block_len", [255, 256, 161])
+def test_crc16_lookup_free_walks_identical_with_the_shipped_kernel(crc_probe, block_len):
+    """Round 6's other formulation of the stream walk (crc16_hybrid_kernel / crc16_packed_kernel / crc16_mixed_kernel<PW> in crc16_kernel.hip:
+    the reference recurrence, crc16.c:26-28, on four blocks per register; measured slower and not instantiated by the library,
+    profiles/r06_crc16_hybrid.txt): tools/crc_hyb_probe builds them from the library's own source and compares every word of a 2^18-block TMR
+    stream with crc16_stream_kernel's and a sample with the recurrence on the host; its exit status is the verdict."""
+    import subprocess
+
+    p = subprocess.run([crc_probe, str(block_len), "18", "1", "1"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
+    assert "MISMATCH" not in p.stdout and p.stdout.count("identical") >= 13, p.stdout[-3000:]
+    assert "shipped kernel 0 wrong" in p.stdout and ") 0 wrong" in p.stdout, p.stdout[-500:]
+
+
 # ------------------------------------------------------------------------------------------------ boundary
 def test_reference_named_host_calls(eng, orc, golden):
     """The single-call shims carry the reference's data contract (host buffers, in-place key schedule)."""
