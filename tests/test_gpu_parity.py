@@ -3166,14 +3166,18 @@ def test_campaign_uniform_register_file_mm256():
     and how to read them: docs/design/campaign.md (ONE table; round 6: TMR on mm_mfma_blk4_kernel 97.5 % with the cloned staging loads -- the
     default --, 93.4 % without, scalar class counted as errors; the reference's MSP430 table, docs/source/results/msp430.rst:14: unmitigated
     84.0 %, -TMR 99.6 %, -TMR -countErrors 95.0 %)."""
-    recs, t = _uniform_campaign(["-m", "TMR", "-t", "1280"])
-    _, c = _uniform_campaign(["-m", "TMR", "-t", "1280", "--clone-staging"])
-    _, u = _uniform_campaign(["-m", "NONE", "-t", "1280"])
+    # 640 runs each and a short leash on the children (this process has torch and the device warm): an upset that turns a loop bound into a long
+    # walk hangs its child until the timeout, and which draws do that changes with every build's register allocation -- at 1280 runs and the
+    # campaign's own timeouts (250 s for the first child, 86 for the others) one build's draws cost this test 19 of the suite's 23 minutes
+    quick = ["-t", "640", "--child-timeout", "25"]
+    recs, t = _uniform_campaign(["-m", "TMR"] + quick)
+    _, c = _uniform_campaign(["-m", "TMR", "--clone-staging"] + quick)
+    _, u = _uniform_campaign(["-m", "NONE"] + quick)
     for s in (t, c, u):
-        assert s["runs"] == 1280 == s["success"] + s["errors"] + s["faults"] + s["invalids"] and s["invalids"] <= 3, s
+        assert s["runs"] == 640 == s["success"] + s["errors"] + s["faults"] + s["invalids"] and s["invalids"] <= 3, s
         assert s["scalar_upsets_not_executed_counted_as_errors"] >= 1  # (s0..s101 and the spill registers' lanes: ~1.4 % of the state)
     assert {r["class"] for r in recs} <= {"success", "fault", "error", "invalid"} and all(0 <= r["target"]["reg"] < 256 for r in recs)
-    assert t["coverage_pct"] > 90.0 and t["faults"] > 500          # (93.4 % at 5000 runs; 58 % of the upsets are out-voted and counted)
+    assert t["coverage_pct"] > 90.0 and t["faults"] > 250          # (93.4 % at 5000 runs; 58 % of the upsets are out-voted and counted)
     assert c["coverage_pct"] > 95.0 and c["coverage_pct"] > t["coverage_pct"] and c["clone_staging"]  # (97.5 % at 5000 runs)
     assert u["faults"] == 0 and u["coverage_pct"] < t["coverage_pct"] - 3.0, (u["coverage_pct"], t["coverage_pct"])
 

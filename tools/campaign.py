@@ -744,15 +744,22 @@ def run_uniform_campaign(a, eng=None):
         children += 1
         # (a child that an upset takes down must not leave a core file behind: with 12 GB of device memory mapped each one is tens of GB, and
         # the scalar-class runs of --sgpr run filled a 79 GB disk in one campaign)
+        dbg = os.environ.get("COAST_CAMPAIGN_DEBUG", "")  # development: "t" = per-child wall time and exit status on stderr; "e" = children keep the parent's environment
+        tc = time.perf_counter()
         proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--preg-child", "-"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
-                                preexec_fn=_no_core_files, env=dict(os.environ, HSA_ENABLE_COREDUMP="0"))
+                                preexec_fn=_no_core_files, env=dict(os.environ) if "e" in dbg else dict(os.environ, HSA_ENABLE_COREDUMP="0"))
         try:
             # (a launch takes a tenth of a second; the first child of a fresh box pages torch in for a minute or two.  A child that hangs --
             # an upset that turns a loop bound into a long walk -- is cut and its launch halved like a crashed one's)
-            out, _ = proc.communicate(spec, timeout=(240 if children == 1 else 75) + len(todo))
+            # (--child-timeout T: a caller whose own process has torch and the device warm -- the test suite -- cuts a hung child after
+            # T + one second per launch; a campaign's three or four hangs otherwise cost it 250 + 3 x 86 s)
+            base = a.child_timeout if a.child_timeout else (240 if children == 1 else 75)
+            out, _ = proc.communicate(spec, timeout=base + len(todo))
         except subprocess.TimeoutExpired:
             proc.kill()
             out, _ = proc.communicate()
+        if "t" in dbg:
+            print("child %d: %d launches, %.1f s, exit %s" % (children, len(todo), time.perf_counter() - tc, proc.returncode), file=sys.stderr, flush=True)
         started, done = None, set()
         for line in out.splitlines():
             w = line.split(" ", 2)
@@ -929,6 +936,9 @@ def parse(argv=None):
                     help="--reg-model uniform -m TMR: the matrix-core kernel whose register file is drawn from -- mm_mfma_blk4_kernel (128-row panel, "
                          "the library's TMR default since round 6) or mm_mfma_blk3_kernel (64-row panel, rounds 4-5; always the DWC / unprotected kernel)")
     ap.add_argument("--preg-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--child-timeout", type=int, default=0,
+                    help="--reg-model uniform: seconds (+ one per launch) before a child process is taken for hung and its launch halved "
+                         "(default: 240 for the first child of a run -- a fresh box pages torch in --, 75 for the others)")
     ap.add_argument("--counters-in-sor", action="store_true",
                     help="registers: run with COAST_F_BRANCH_SYNC | COAST_F_ADDR_SYNC (the loop counters replica-private, their branch conditions "
                          "and GEP offsets voted) and aim every upset at a loop counter")
