@@ -93,6 +93,26 @@ __global__ void aes_tables_kernel()
     }
 }
 
+// The LDS images of the persistent kernels' bank-replicated tables (layout: aes128_enc_rep_kernel / aes128_dec_rep_kernel below), built once per
+// device behind aes_tables_kernel: a workgroup fills its LDS with a straight 16-byte copy of the image (4 / 8 pieces per thread, coalesced,
+// L2-resident) instead of assembling it from the five tables word by word -- 16 dependent-latency iterations per thread, with a divergent
+// branch per iteration in the decryption kernel: a launch with nothing to do took 9.8 / 15.0 us (profiles/r06_aes_fixed_cost.txt).
+__device__ uint32_t gAesEncImage[65536 / 4];     // block {Te_0..Te_3}: entry v = row v of 256 B, slot r at 64 r, copy c at 4 c
+__device__ uint32_t gAesDecImage[2 * 65536 / 4]; // block 0 {Td_0..Td_3}; block 1: pairs {Tis_0[v], S[v] x 4} at 8 c, rsbox[v] x 4 at 128 + 4 c
+__global__ void aes_images_kernel() // 64 workgroups x 256 threads: thread = one dword of a 64 KiB block
+{
+    const uint32_t d = blockIdx.x * 256u + threadIdx.x; // dword of the block
+    const uint32_t v = d >> 6, w = d & 63u;              // row (entry value), dword inside the row
+    gAesEncImage[d] = gAesTe[w >> 4][v];
+    gAesDecImage[d] = gAesTd[w >> 4][v];
+    uint32_t x = 0u;
+    if (w < 32u)
+        x = (w & 1u) ? (uint32_t)gAesSbox[v] * 0x01010101u : gAesTis[0][v];
+    else if (w < 48u)
+        x = (uint32_t)gAesRsbox[v] * 0x01010101u;
+    gAesDecImage[16384u + d] = x;
+}
+
 __device__ __forceinline__ uint32_t xtime(uint32_t v) { return ((v << 1) ^ ((v & 0x80u) ? 0x1bu : 0u)) & 0xffu; } // :88-99
 
 __device__ __forceinline__ void aes_mix_col(uint32_t *c, bool inverse) // :168-185
@@ -684,11 +704,12 @@ __global__ __launch_bounds__(kAesRepThreads) __attribute__((amdgpu_waves_per_eu(
         if (ft.range)
             fr0 = ft.range[tile0];
     }
-    { // a wave writes whole rows: lane = (slot r, copy c) -- 64 consecutive dwords, two lanes per bank (free for ds_write_b32)
-        const int c = tid & (kAesCopies - 1), r = (tid >> 4) & 3, v0 = (tid >> 6) * 16;
+    { // the table block: row v = entry v, slot r at 64 r, copy c at 4 c -- a straight copy of the image aes_images_kernel built (4 pieces per thread)
+        const uint4 *src = reinterpret_cast<const uint4 *>(gAesEncImage);
+        uint4 *dst = reinterpret_cast<uint4 *>(smemAes);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            *reinterpret_cast<uint32_t *>(smemAes + (v0 + i) * kAesRowBytes + r * 64 + c * 4) = gAesTe[r][v0 + i];
+        for (int i = 0; i < kAesBlockBytes / 16 / kAesRepThreads; ++i)
+            dst[i * kAesRepThreads + tid] = src[i * kAesRepThreads + tid];
     }
     if (tid < 4)
         sCnt[tid] = 0;
@@ -845,19 +866,13 @@ __global__ __launch_bounds__(kAesRepThreads) void aes128_dec_rep_kernel(uint8_t 
         if (ft.range)
             frN = ft.range[tile0];
     }
-    { // block 0: Td_0..3; block 1: {Tis_0[v], S[v] x 4} pairs in slots 0-1, rsbox[v] x 4 in slot 2.  A wave writes whole rows:
-      // lane = (slot r, copy c); in block 1 slot group 0 writes the pairs, group 1 the rsbox dwords
-        const int c = tid & (kAesCopies - 1), r = (tid >> 4) & 3, v0 = (tid >> 6) * 16;
+    { // block 0: Td_0..3; block 1: {Tis_0[v], S[v] x 4} pairs in slots 0-1 (8 bytes per copy), rsbox[v] x 4 in slot 2 -- a straight copy of the
+      // image aes_images_kernel built (8 pieces per thread)
+        const uint4 *src = reinterpret_cast<const uint4 *>(gAesDecImage);
+        uint4 *dst = reinterpret_cast<uint4 *>(smemAes);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int v = v0 + i;
-            uint8_t *row0 = smemAes + v * kAesRowBytes, *row1 = row0 + kAesBlockBytes;
-            *reinterpret_cast<uint32_t *>(row0 + r * 64 + c * 4) = gAesTd[r][v];
-            if (r == 0)
-                *reinterpret_cast<uint2 *>(row1 + c * 8) = make_uint2(gAesTis[0][v], (uint32_t)gAesSbox[v] * 0x01010101u);
-            else if (r == 1)
-                *reinterpret_cast<uint32_t *>(row1 + 128 + c * 4) = (uint32_t)gAesRsbox[v] * 0x01010101u;
-        }
+        for (int i = 0; i < 2 * kAesBlockBytes / 16 / kAesRepThreads; ++i)
+            dst[i * kAesRepThreads + tid] = src[i * kAesRepThreads + tid];
     }
     if (tid < 4)
         sCnt[tid] = 0;
