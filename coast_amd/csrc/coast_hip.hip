@@ -125,8 +125,8 @@ int fail(coast_ctx *ctx, int code, const char *fmt, ...)
                         __LINE__);                                                                            \
     } while (0)
 
-// the counter slots, and behind them the ticket word of the kernels that fold the slots themselves (Counters::ticket)
-constexpr size_t kSlotBytes = sizeof(unsigned long long) * ((size_t)kCounterSlots * kSlotStride + 8);
+// the counter slots, and behind them the ticket words (kTicketWords: top + group tickets) of the kernels that fold the slots themselves (Counters::ticket)
+constexpr size_t kSlotBytes = sizeof(unsigned long long) * (size_t)kCounterSlots * kSlotStride + sizeof(uint32_t) * (size_t)kTicketWords;
 uint32_t *ticket_of(coast_ctx *c) { return reinterpret_cast<uint32_t *>(c->dSlots + (size_t)kCounterSlots * kSlotStride); }
 unsigned long long *totals_of(coast_ctx *c) { return c->dBound ? c->dBound : c->dTotals; }
 

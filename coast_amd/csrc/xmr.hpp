@@ -34,8 +34,14 @@ struct Counters {
     // totals itself -- no reduce_counters_kernel behind the launch, one dependent dispatch less per step.  Null everywhere else.
     uint32_t foldLaunches;      // what the fold adds to totals[3]: the launches since the last fold, this one included
     unsigned long long *totals; // {errors, syncs, dwc_items, launches}
-    uint32_t *ticket;           // workgroups that have left; the last one sets it back to 0
+    uint32_t *ticket;           // kTicketWords words: the top ticket and kTicketGroups group tickets, a 128-byte line each (block_fold)
 };
+// block_fold's completion count is two-level: a workgroup draws the ticket of its group (blockIdx.x % kTicketGroups), the last one of a group
+// draws the top ticket, the last of those folds.  Same-address device-scope atomics retire at ~10 ns each (tools/aes_fixed_probe.hip): one
+// word for 256 / 512 workgroups that leave together was 2.7 / 5.2 us of every launch; 16 lines take 16-32 arrivals each, side by side.
+constexpr uint32_t kTicketGroups = 16;
+constexpr uint32_t kTicketStride = 32; // uint32 words between two tickets: one 128-byte line each
+constexpr uint32_t kTicketWords = (1 + kTicketGroups) * kTicketStride;
 constexpr uint32_t kFlagNoStoreDataSync = 1u; // == COAST_F_NO_STORE_DATA_SYNC
 constexpr uint32_t kFlagBranchSync = 2u;      // == COAST_F_BRANCH_SYNC: loop / byte counters are replica-private, their branch conditions voted
 constexpr uint32_t kFlagAddrSync = 4u;        // == COAST_F_ADDR_SYNC: GEP offsets built from them are voted ...
@@ -245,7 +251,7 @@ __device__ __forceinline__ void block_tally(uint32_t miss, uint32_t syncs, uint3
 }
 
 // The counter fold inside the protected kernel (Counters::totals set): every workgroup calls this behind block_tally, all threads.  The
-// workgroup's slot atomics are released in front of its ticket; the workgroup that draws the last ticket reads and clears every slot with
+// workgroup's slot atomics are released in front of its ticket (two-level: kTicketGroups); the workgroup that draws the last ticket reads and clears every slot with
 // atomics (the slots were written with atomics from every XCD: the exchange runs where they ran), sums them per wave and adds the sums to
 // the totals.  `slotKey`: block_tally's; `s_flag`: one uint32 of LDS nobody else writes between block_tally's barrier and the kernel's end.
 __device__ __forceinline__ void block_fold(const Counters &ctr, uint32_t slotKey, uint32_t *s_flag)
@@ -265,7 +271,19 @@ __device__ __forceinline__ void block_fold(const Counters &ctr, uint32_t slotKey
         // acknowledges them --, so the order holds twice over.)
         const unsigned long long r = atomicExch(mine + 3, 0ull);
         asm volatile("s_waitcnt vmcnt(0)" ::"v"(r) : "memory");
-        *s_flag = atomicAdd(ctr.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+        // two-level ticket: group g = blockIdx.x % kTicketGroups holds the workgroups g, g + 16, ...; whoever sees the group complete clears
+        // the group's word (nobody of this launch touches it again) and draws the top ticket.  The order argument is transitive: every
+        // member's slot atomics were acknowledged in front of its group ticket, the group's last ticket in front of the top one.
+        const uint32_t g = blockIdx.x % kTicketGroups;
+        const uint32_t members = (gridDim.x - g + kTicketGroups - 1u) / kTicketGroups;
+        const uint32_t groups = gridDim.x < kTicketGroups ? gridDim.x : kTicketGroups;
+        uint32_t *gt = ctr.ticket + (size_t)kTicketStride * (1u + g);
+        uint32_t last = 0u;
+        if (atomicAdd(gt, 1u) == members - 1u) {
+            atomicExch(gt, 0u);
+            last = atomicAdd(ctr.ticket, 1u) == groups - 1u ? 1u : 0u;
+        }
+        *s_flag = last;
     }
     __syncthreads();
     if (*s_flag == 0u)

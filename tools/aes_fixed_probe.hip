@@ -100,8 +100,8 @@ int main()
     CK(hipMalloc((void **)&image, 128 * 1024));
     CK(hipMemset(image, 1, 128 * 1024));
     CK(hipMalloc((void **)&sink, 64));
-    CK(hipMalloc((void **)&ticket, 64));
-    CK(hipMemset(ticket, 0, 64));
+    CK(hipMalloc((void **)&ticket, kTicketWords * 4));
+    CK(hipMemset(ticket, 0, kTicketWords * 4));
     CK(hipMalloc((void **)&slots, kCounterSlots * kSlotStride * 8));
     CK(hipMemset(slots, 0, kCounterSlots * kSlotStride * 8));
     CK(hipMalloc((void **)&totals, 64));
