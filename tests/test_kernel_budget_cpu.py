@@ -210,6 +210,30 @@ def test_in_kernel_counter_fold_orders_by_atomics_not_by_an_l2_write_back(compil
         assert "s_waitcnt vmcnt(0)" in b[i_line:i_ticket], name
 
 
+def test_counter_fold_ticket_is_two_level(compiled):
+    """round 6, block_fold's completion count (xmr.hpp): one returning add on the workgroup's GROUP word, and only behind it -- for the group's
+    last workgroup -- the reset of that word and the returning add on the top word.  One word for every workgroup cost 2.7 / 5.2 us per launch
+    (same-address device-scope atomics retire at ~10 ns each: profiles/r06_aes_two_level_ticket.txt).  The arithmetic the kernel uses to find a
+    group's size must count every workgroup exactly once for any grid, and the host must allocate the words the kernel addresses."""
+    src = open(os.path.join(CSRC, "xmr.hpp")).read()
+    groups = int(re.search(r"constexpr uint32_t kTicketGroups = (\d+);", src).group(1))
+    stride = int(re.search(r"constexpr uint32_t kTicketStride = (\d+);", src).group(1))
+    assert "kTicketWords = (1 + kTicketGroups) * kTicketStride" in src and stride * 4 >= 128  # a 128-byte line per ticket
+    assert "(gridDim.x - g + kTicketGroups - 1u) / kTicketGroups" in src and "gridDim.x < kTicketGroups ? gridDim.x : kTicketGroups" in src
+    for grid in list(range(1, 70)) + [255, 256, 257, 300, 511, 512, 513, 1024]:
+        members = [(grid - g + groups - 1) // groups for g in range(min(groups, grid))]
+        assert all(m >= 1 for m in members) and sum(members) == grid, grid
+        assert members == [len(range(g, grid, groups)) for g in range(min(groups, grid))], grid
+    host = open(os.path.join(CSRC, "coast_hip.hip")).read()
+    assert "sizeof(uint32_t) * (size_t)kTicketWords" in host  # kSlotBytes: slots + ticket words, cleared together at create / reset
+    _, bodies = compiled
+    for name in ("void coast::aes128_enc_rep_kernel<2>", "void coast::aes128_dec_rep_kernel<2>"):
+        b = _find(bodies, name)
+        adds = [m.start() for m in re.finditer(r"global_atomic_add v\d+, .* sc0", b)]
+        swap = b.find("global_atomic_swap v")
+        assert len(adds) == 2 and adds[0] < swap < adds[1], (name, adds, swap)  # group ticket, the group word's reset, top ticket
+
+
 def test_bench_lookup_counts_match_the_compiled_kernels():
     import importlib.util
 
